@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE's own hot-path modules.
+
+Runs ONLY in the build container (needs /root/reference; the GPU box has none):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+It imports ``dmm.modules.match_model``, ``dmm.utils.match_helper`` and
+``dmm.modules.submodules.relax_match`` from /root/reference (torch CPU, fp32), feeds them the
+build-owned seeded inputs of ``dmm_net_amd.synth`` (plus hand-made edge cases) and stores
+inputs-by-seed + expected outputs as small ``.npz`` fixtures next to this script.  The fixtures
+are data only -- no reference source text is stored.  Groups follow SURVEY.md section 8c:
+
+  G1 solver known-answer test of the reference's own self-test (relax_match.py:108-119)
+  G2 config 1 (P=8, O=3, 64x64): every intermediate, is_test 0/1, four iteration settings,
+     + targets -> gt_iou / gt_matched / cost_loss
+  G3 pad path P <= O
+  G4 config 2 / config 5 shapes at 255x255: [M,N]-sized tables + checksums of the big output
+  G5 edge cases (empty masks, 0.5 pixels, ties, no-column-minimum rows, zero sim, zero features)
+  G6 backward of the layer wrt the features
+  G8 the DMM_Model per-video harness steps (dmm_model.py:115-141) re-executed around the imported
+     MatchModel (DMM_Model itself needs maskrcnn_benchmark and cannot be imported)
+"""
+import os
+import sys
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from dmm.modules.match_model import MatchModel  # noqa: E402  (reference)
+from dmm.modules.submodules.relax_match import relax_matching  # noqa: E402  (reference)
+from dmm.utils import match_helper  # noqa: E402  (reference)
+from scipy.optimize import linear_sum_assignment  # noqa: E402
+
+from dmm_net_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def cfg(max_iter, proj_iter, lr=0.1, w=0.3, algo="relax"):
+    return {"matching": {"algo": algo}, "relax_max_iter": max_iter, "relax_proj_iter": proj_iter,
+            "relax_learning_rate": lr, "score_weight": w}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def int_tables(pm, tm):
+    a = T(pm).flatten(1) > 0.5
+    b = T(tm).flatten(1) > 0.5
+    inter = (b[:, None, :] & a[None, :, :]).sum(-1).to(torch.int32)
+    return inter.numpy(), a.sum(1).to(torch.int32).numpy(), b.sum(1).to(torch.int32).numpy()
+
+
+def run_layer(fr, max_iter, proj_iter, is_test, lr=0.1, w=0.3, with_targets=False, full=True):
+    """Run the reference layer piecewise so every intermediate is captured."""
+    model = MatchModel(cfg(max_iter, proj_iter, lr, w), is_test)
+    pf, tf = T(fr.proposed_feature), T(fr.template_feature)
+    pm, tm, sc = T(fr.proposed_mask), T(fr.mask_last_occurence), T(fr.proposal_score)
+    tg = T(fr.targets) if with_targets else None
+    out = {}
+    with torch.no_grad():
+        feats = {"proposed": pf, "template": [tf]}
+        masks = {"proposed": pm, "template": tm}
+        sim, n_prop, n_tplt, mloss = model.compute_cost_matrix(feats, masks, {"proposal_score": sc}, tg)
+        cosv = match_helper.get_cosine_score(tf, pf)
+        P, O = pm.shape[0], tm.shape[0]
+        iou = match_helper.compute_iou_binary_mask_2D(
+            pm.view(P, -1).expand(O, -1, -1).contiguous().view(O * P, -1),
+            tm.contiguous().view(O, 1, -1).expand(-1, P, -1).contiguous().view(O * P, -1)).view(O, P)
+        out.update(cos=cosv.numpy(), iou=iou.numpy(), sim=sim.numpy())
+        if with_targets:
+            out["cost_loss"] = np.float32(mloss["cost_loss"].item())
+            bp = pm > 0.5
+            gt_iou = match_helper.compute_iou_binary_mask_2D(
+                bp.view(P, -1).expand(O, -1, -1).contiguous().view(O * P, -1),
+                tg.contiguous().view(O, 1, -1).expand(-1, P, -1).contiguous().view(O * P, -1)).view(O, P)
+            gt_matched = relax_matching(-gt_iou, max_iter=0, proj_iter=0, lr=0)[0]
+            out.update(gt_iou=gt_iou.numpy(), gt_matched=gt_matched.numpy())
+        # pad + solver exactly as match_with_first_frame does (match_model.py:107-121)
+        if sim.shape[1] <= sim.shape[0]:
+            simp = sim.new_zeros((sim.shape[0], sim.shape[0] + 1))
+            simp[:, :sim.shape[1]] = sim
+        else:
+            simp = sim
+        X, cost, X_list, _ = relax_matching(-simp, max_iter=max_iter, proj_iter=proj_iter, lr=lr)
+        R = sum(X_list) / len(X_list)
+        out.update(X_final=X.numpy(), cost=np.asarray(cost, np.float32), n_xlist=np.int32(len(X_list)),
+                   R=R.numpy(), X0=X_list[0].numpy())
+        if full:
+            out["xlist"] = torch.stack(X_list).numpy()
+        fo, ms, ds, logic, Rb = model.match_with_first_frame(sim, n_prop, n_tplt, pm.float(), sc, tm)
+        out.update(match_score=ms.numpy(), det_score=ds.numpy(), logic=logic.numpy(), Rb=Rb.numpy())
+        # the public forward (5-tuple) must agree with the piecewise run
+        f5 = model(pf, pm, [tf], tm, sc, tg)
+        assert torch.equal(f5[0], fo) and torch.equal(f5[1], ms) and torch.equal(f5[2], ds)
+        assert f5[3] is f5[0]
+        if full:
+            out["full_outmask"] = fo.numpy()
+        else:
+            fo64 = fo.double()
+            out["outmask_sum"] = fo64.flatten(1).sum(1).numpy()
+            out["outmask_sample"] = fo.flatten(1)[:, ::997].numpy()
+        out["argmax"] = R.argmax(1).to(torch.int32).numpy()
+    inter, ap, at = int_tables(fr.proposed_mask, fr.mask_last_occurence)
+    iou_chk = torch.from_numpy(inter).float() / ((torch.from_numpy(ap)[None, :] + torch.from_numpy(at)[:, None]
+                                                   - torch.from_numpy(inter)).float() + 1e-6)
+    assert torch.equal(iou_chk, T(out["iou"])), "integer tables disagree with the reference's iou"
+    out.update(inter=inter, area_p=ap, area_t=at)
+    return out
+
+
+def save(name, d):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(d)} arrays)")
+
+
+def flat(prefix, d):
+    return {f"{prefix}/{k}": v for k, v in d.items()}
+
+
+# ------------------------------------------------------------------------------------------ G1
+def g1():
+    cost = np.array([[4, 1, 3], [2, 0, 5], [3, 2, 2]])
+    r, c = linear_sum_assignment(cost)
+    C = torch.from_numpy(cost).float()
+    X, costs, X_list, inner = relax_matching(C, max_iter=100, proj_iter=100, lr=0.1)
+    d = dict(C=C.numpy(), hungarian_cols=c.astype(np.int32), X_final=X.numpy(),
+             n_xlist=np.int32(len(X_list)), R=(sum(X_list) / len(X_list)).numpy(),
+             cost=np.asarray(costs, np.float32), xlist=torch.stack(X_list).numpy(),
+             max_iter=np.int32(100), proj_iter=np.int32(100), lr=np.float32(0.1))
+    # more solver-only KATs on random costs, with and without early exits
+    rng = np.random.Generator(np.random.PCG64(77))
+    k = 0
+    for (n, m, mi, pi) in [(3, 8, 20, 5), (10, 50, 20, 5), (10, 50, 40, 5), (5, 50, 10, 5), (20, 200, 20, 5),
+                           (4, 5, 400, 50), (10, 50, 400, 50), (2, 3, 100, 100), (6, 7, 60, 1)]:
+        Cn = -rng.random((n, m), dtype=np.float32)
+        X, costs, X_list, inner = relax_matching(T(Cn), max_iter=mi, proj_iter=pi, lr=0.1)
+        d.update(flat(f"rand{k}", dict(C=Cn, X_final=X.numpy(), n_xlist=np.int32(len(X_list)),
+                                      R=(sum(X_list) / len(X_list)).numpy(), cost=np.asarray(costs, np.float32),
+                                      max_iter=np.int32(mi), proj_iter=np.int32(pi), lr=np.float32(0.1),
+                                      n_inner_last=np.int32(len(inner)))))
+        k += 1
+    d["n_rand"] = np.int32(k)
+    save("g1_solver_kat", d)
+
+
+# ------------------------------------------------------------------------------------------ G2
+ITER_SETTINGS = [(10, 5), (40, 5), (20, 5), (0, 0)]
+
+
+def g2():
+    d = {}
+    for kind in ("structured", "uniform"):
+        fr = synth.make_config_frame(1, kind=kind, with_targets=True)
+        d[f"{kind}/checksum"] = np.array(fr.checksum())
+        for is_test in (0, 1):
+            for (mi, pi) in ITER_SETTINGS:
+                o = run_layer(fr, mi, pi, is_test, with_targets=True)
+                d.update(flat(f"{kind}/t{is_test}/i{mi}_{pi}", o))
+    save("g2_config1", d)
+
+
+# ------------------------------------------------------------------------------------------ G3
+def g3():
+    d = {}
+    for (P, O) in [(3, 5), (1, 1), (5, 5), (2, 1), (1, 4)]:
+        fr = synth.make_frame(P, O, 64, 64, 512, seed=synth.BASE_SEED + 100 + 10 * P + O, kind="structured",
+                              with_targets=True)
+        d[f"p{P}o{O}/checksum"] = np.array(fr.checksum())
+        for is_test in (0, 1):
+            o = run_layer(fr, 20, 5, is_test, with_targets=True)
+            d.update(flat(f"p{P}o{O}/t{is_test}", o))
+    save("g3_pad", d)
+
+
+# ------------------------------------------------------------------------------------------ G4
+def g4():
+    d = {}
+    for ci in (2, 5):
+        for kind in ("structured", "uniform"):
+            fr = synth.make_config_frame(ci, kind=kind)
+            d[f"c{ci}/{kind}/checksum"] = np.array(fr.checksum())
+            for is_test in (1, 0):
+                if ci == 5 and is_test == 0:
+                    continue
+                o = run_layer(fr, 20, 5, is_test, full=False)
+                d.update(flat(f"c{ci}/{kind}/t{is_test}", o))
+            if ci == 2:
+                o = run_layer(fr, 40, 5, 1, full=False)
+                d.update(flat(f"c{ci}/{kind}/eval40", o))
+    save("g4_big", d)
+
+
+# ------------------------------------------------------------------------------------------ G5
+def g5():
+    d = {}
+    rng = np.random.Generator(np.random.PCG64(55))
+    H = W = 16
+    D = 32
+
+    def base(P, O):
+        fr = synth.make_frame(P, O, H, W, D, seed=5000 + 10 * P + O, kind="uniform")
+        return fr
+
+    cases = {}
+    # (a) all-zero masks -> union 0 -> iou 0
+    fr = base(6, 3)
+    fr.proposed_mask[:] = 0
+    fr.mask_last_occurence[:] = 0
+    cases["zero_masks"] = fr
+    # (b) pixels exactly 0.5 are NOT set (strict >)
+    fr = base(6, 3)
+    fr.proposed_mask[:] = np.where(rng.random(fr.proposed_mask.shape) < 0.5, 0.5, 0.75).astype(np.float32)
+    fr.mask_last_occurence[:] = np.where(rng.random(fr.mask_last_occurence.shape) < 0.5, 0.5,
+                                         np.nextafter(np.float32(0.5), np.float32(1))).astype(np.float32)
+    cases["half_pixels"] = fr
+    # (c) duplicate proposals (argmin ties) and duplicate templates
+    fr = base(6, 3)
+    fr.proposed_mask[3] = fr.proposed_mask[1]
+    fr.proposed_feature[3] = fr.proposed_feature[1]
+    fr.mask_last_occurence[2] = fr.mask_last_occurence[0]
+    fr.template_feature[2] = fr.template_feature[0]
+    cases["duplicates"] = fr
+    # (d) a template that owns no column minimum (its sim is the lowest everywhere) -> picks col 0
+    fr = base(6, 3)
+    fr.mask_last_occurence[1] = 0
+    fr.template_feature[1] = -fr.proposed_feature.mean(0)
+    cases["no_col_min"] = fr
+    # (e) all-zero sim: zero features and empty masks -> outer exit at it=0 (cost[0]==cost[1]==0)
+    fr = base(6, 3)
+    fr.proposed_mask[:] = 0
+    fr.proposed_feature[:] = 0
+    cases["zero_sim"] = fr
+    # (f) zero-norm feature rows (eps clamp), rest generic
+    fr = base(6, 3)
+    fr.proposed_feature[2] = 0
+    fr.template_feature[0] = 0
+    cases["zero_feature_rows"] = fr
+    # (g) tiny-norm features (norm below eps = 1e-8)
+    fr = base(6, 3)
+    fr.proposed_feature[4] = np.float32(1e-12)
+    cases["tiny_feature_rows"] = fr
+    # (h) full masks (everything set)
+    fr = base(6, 3)
+    fr.proposed_mask[:] = 1
+    fr.mask_last_occurence[:] = 1
+    cases["full_masks"] = fr
+    # (i) odd plane size, single pixel row
+    fr = synth.make_frame(5, 2, 1, 7, D, seed=5999, kind="uniform")
+    cases["tiny_plane"] = fr
+    for name, fr in cases.items():
+        d.update(flat(f"{name}/in", dict(pm=fr.proposed_mask, tm=fr.mask_last_occurence, pf=fr.proposed_feature,
+                                         tf=fr.template_feature, sc=fr.proposal_score)))
+        for is_test in (0, 1):
+            o = run_layer(fr, 20, 5, is_test)
+            d.update(flat(f"{name}/t{is_test}", o))
+    d["names"] = np.array(sorted(cases.keys()))
+    save("g5_edge", d)
+
+
+# ------------------------------------------------------------------------------------------ G6
+def g6():
+    d = {}
+    for name, (P, O, mi, pi, is_test) in {"c1_train": (8, 3, 10, 5, 0), "c1_test": (8, 3, 20, 5, 1),
+                                           "pad": (3, 5, 10, 5, 0), "mid": (20, 5, 10, 5, 0)}.items():
+        fr = synth.make_frame(P, O, 64, 64, 512, seed=synth.BASE_SEED + 600 + P + O, kind="structured",
+                              with_targets=True)
+        d[f"{name}/checksum"] = np.array(fr.checksum())
+        d[f"{name}/shape"] = np.array([P, O, 64, 64, 512, mi, pi, is_test], np.int32)
+        model = MatchModel(cfg(mi, pi), is_test)
+        pf = T(fr.proposed_feature).requires_grad_(True)
+        tf = T(fr.template_feature).requires_grad_(True)
+        gen = torch.Generator().manual_seed(7)
+        wmask = torch.rand((O, 64, 64), generator=gen)
+        wms, wds = torch.rand(O, generator=gen), torch.rand(O, generator=gen)
+        fo, ms, ds, _, loss = model(pf, T(fr.proposed_mask), [tf], T(fr.mask_last_occurence),
+                                    T(fr.proposal_score), T(fr.targets))
+        total = (fo * wmask).sum() + (ms * wms).sum() + (ds * wds).sum() + 3.0 * loss["cost_loss"]
+        total.backward()
+        d.update(flat(name, dict(wmask=wmask.numpy(), wms=wms.numpy(), wds=wds.numpy(),
+                                 total=np.float32(total.item()), cost_loss=np.float32(loss["cost_loss"].item()),
+                                 grad_pf=pf.grad.numpy(), grad_tf=tf.grad.numpy(),
+                                 full_outmask=fo.detach().numpy())))
+    save("g6_backward", d)
+
+
+# ------------------------------------------------------------------------------------------ G8
+def g8():
+    """Steps of DMM_Model.forward / .inference (dmm_model.py:48-158) around the imported layer."""
+    d = {}
+    B, F, P, H, W, D = 3, 5, 8, 32, 32, 64
+    n_valid = [0, 2, 5]
+    rng = np.random.Generator(np.random.PCG64(88))
+    mask_last = np.zeros((B, F, H, W), np.float32)
+    tplt_feat = np.zeros((B, F, D), np.float32)
+    targets = np.zeros((B, F, H, W), np.float32)
+    valid = np.zeros((B, F), np.float32)
+    frames = []
+    for b in range(B):
+        fr = synth.make_frame(P, F, H, W, D, seed=8800 + b, kind="structured", with_targets=True)
+        frames.append(fr)
+        O = n_valid[b]
+        valid[b, :O] = 1
+        mask_last[b, :O] = fr.mask_last_occurence[:O]
+        mask_last[b, O:] = rng.random((F - O, H, W), dtype=np.float32) * 0.1   # stale junk in invalid slots
+        tplt_feat[b] = fr.template_feature
+        targets[b, :O] = fr.targets[:O]
+    for mode in ("train", "test"):
+        is_test = int(mode == "test")
+        layer = MatchModel(cfg(10, 5), is_test)
+        out_mask, out_last, losses = [], [], []
+        with torch.no_grad():
+            for b in range(B):
+                tv = T(valid[b])
+                O = int(tv.sum().item())
+                ml = T(mask_last[b])
+                if O == 0:
+                    out_mask.append(ml.new_zeros(F, H, W))
+                    out_last.append(ml)
+                    losses.append(0.0)
+                    continue
+                FF = torch.diag(tv).float()
+                OF = FF[:O, :]
+                tfv = [torch.mm(OF, T(tplt_feat[b]).view(F, -1)).view(O, D)]
+                fo, ms, ds, newm, loss = layer(T(frames[b].proposed_feature), T(frames[b].proposed_mask), tfv,
+                                               ml[:O].view(O, H, W), T(frames[b].proposal_score),
+                                               targets=None if is_test else T(targets[b, :O]))
+                FO = OF.t()
+                out_mask.append(torch.mm(FO, fo.view(O, -1)).view(F, H, W))
+                out_last.append(torch.mm(FO, newm.view(O, -1)).view(F, H, W))
+                losses.append(float(loss["cost_loss"]) if len(loss) > 0 else 0.0)
+        d[f"{mode}/output_mask"] = torch.stack(out_mask).numpy()
+        d[f"{mode}/out_mask_last"] = torch.stack(out_last).numpy()
+        d[f"{mode}/losses"] = np.asarray(losses, np.float32)
+    d.update(mask_last=mask_last, tplt_feat=tplt_feat, targets=targets, valid=valid,
+             shape=np.array([B, F, P, H, W, D], np.int32), n_valid=np.array(n_valid, np.int32))
+    for b, fr in enumerate(frames):
+        d[f"frame{b}/checksum"] = np.array(fr.checksum())
+    save("g8_harness", d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    for w in which:
+        globals()[w]()

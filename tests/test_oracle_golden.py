@@ -1,0 +1,148 @@
+"""Pin the CPU oracle (oracle/dmm_oracle.c) to the reference's golden vectors (CPU only).
+
+The oracle restates the summation order of the torch CPU kernels the goldens were captured
+with, so everything except the training-mode ``torch.mm`` mask mix is required to be BIT EXACT:
+integer tables, iou, cosine, sim, every solver iterate, iteration counts, R, logic, scores.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden
+from dmm_net_amd import synth
+
+TOL = 2e-6
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size:
+        err = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
+        assert err <= tol, err
+
+
+def check_layer(fr, g, max_iter, proj_iter, is_test, big=False):
+    o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                             fr.proposal_score, max_iter=max_iter, proj_iter=proj_iter, is_test=is_test)
+    assert np.array_equal(o["inter"], g["inter"])
+    assert np.array_equal(o["area_p"], g["area_p"]) and np.array_equal(o["area_t"], g["area_t"])
+    iou = oracle.iou_from_counts(o["inter"], o["area_p"], o["area_t"])
+    assert np.array_equal(iou, g["iou"]), "iou must be bit exact"
+    assert np.array_equal(o["cos"], g["cos"]), np.abs(o["cos"] - g["cos"]).max()
+    assert np.array_equal(o["sim"], g["sim"])
+    assert o["iters"] + 1 == int(g["n_xlist"])
+    assert np.array_equal(o["R"], g["R"]), np.abs(o["R"] - g["R"]).max()
+    assert np.array_equal(o["R"].argmax(1), g["argmax"])
+    assert np.array_equal(o["logic"], g["logic"])
+    assert np.array_equal(o["Rb"], g["Rb"])
+    assert np.array_equal(o["match_score"], g["match_score"])
+    assert np.array_equal(o["det_score"], g["det_score"]), np.abs(o["det_score"] - g["det_score"]).max()
+    if big:
+        close(o["full_outmask"].reshape(o["full_outmask"].shape[0], -1)[:, ::997], g["outmask_sample"], 1e-5)
+        s = o["full_outmask"].astype(np.float64).reshape(o["full_outmask"].shape[0], -1).sum(1)
+        assert np.allclose(s, g["outmask_sum"], rtol=1e-6, atol=1e-3)
+    elif is_test:
+        assert np.array_equal(o["full_outmask"], g["full_outmask"])
+    else:
+        close(o["full_outmask"], g["full_outmask"], 1e-5)
+    return o
+
+
+# ------------------------------------------------------------------------------------------ G1
+def test_g1_reference_selftest_kat():
+    g = golden("g1_solver_kat")
+    r = oracle.relax(g["C"], int(g["max_iter"]), int(g["proj_iter"]), float(g["lr"]), want_xlist=True)
+    assert r["iters"] + 1 == int(g["n_xlist"]) == 58
+    assert np.array_equal(r["X"], g["X_final"])
+    assert np.array_equal(r["R"], g["R"])
+    assert np.array_equal(r["cost"], g["cost"])
+    assert np.array_equal(r["xlist"], g["xlist"])
+    # rounds to the Hungarian permutation (relax_match.py:109-116)
+    assert np.array_equal(np.round(r["X"]).argmax(1), g["hungarian_cols"])
+    assert np.array_equal(oracle.hungarian(g["C"]).argmax(1), g["hungarian_cols"])
+
+
+def test_g1_random_costs():
+    g = golden("g1_solver_kat")
+    for k in range(int(g["n_rand"])):
+        c = g.group(f"rand{k}")
+        r = oracle.relax(c["C"], int(c["max_iter"]), int(c["proj_iter"]), float(c["lr"]))
+        assert r["iters"] + 1 == int(c["n_xlist"]), (k, r["iters"], int(c["n_xlist"]))
+        assert np.array_equal(r["X"], c["X_final"]), k
+        assert np.array_equal(r["R"], c["R"]), k
+        assert np.array_equal(r["cost"], c["cost"]), k
+
+
+# ------------------------------------------------------------------------------------------ G2
+@pytest.mark.parametrize("kind", ["structured", "uniform"])
+def test_g2_config1(kind):
+    g = golden("g2_config1")
+    fr = synth.make_config_frame(1, kind=kind, with_targets=True)
+    assert fr.checksum() == str(g[f"{kind}/checksum"])
+    for is_test in (0, 1):
+        for (mi, pi) in [(10, 5), (40, 5), (20, 5), (0, 0)]:
+            c = g.group(f"{kind}/t{is_test}/i{mi}_{pi}")
+            o = check_layer(fr, c, mi, pi, is_test)
+            # greedy init + every pre-projection iterate
+            C = np.zeros_like(o["R"])
+            C[:, :o["sim"].shape[1]] = -c["sim"]
+            r = oracle.relax(C, mi, pi, 0.1, want_xlist=True)
+            assert np.array_equal(r["xlist"], c["xlist"])
+            assert np.array_equal(r["xlist"][0], c["X0"])
+            assert np.array_equal(r["X"], c["X_final"])
+            loss, gi, go = oracle.matching_loss(fr.proposed_mask, fr.targets, o["cos"])
+            assert np.array_equal(gi, c["gt_iou"])
+            assert np.array_equal(go, c["gt_matched"])
+            assert np.float32(loss) == c["cost_loss"], (loss, c["cost_loss"])
+
+
+# ------------------------------------------------------------------------------------------ G3
+@pytest.mark.parametrize("P,O", [(3, 5), (1, 1), (5, 5), (2, 1), (1, 4)])
+def test_g3_pad(P, O):
+    g = golden("g3_pad")
+    fr = synth.make_frame(P, O, 64, 64, 512, seed=synth.BASE_SEED + 100 + 10 * P + O, kind="structured",
+                          with_targets=True)
+    assert fr.checksum() == str(g[f"p{P}o{O}/checksum"])
+    for is_test in (0, 1):
+        c = g.group(f"p{P}o{O}/t{is_test}")
+        o = check_layer(fr, c, 20, 5, is_test)
+        assert o["R"].shape[1] == max(P, O + 1)
+        loss, gi, go = oracle.matching_loss(fr.proposed_mask, fr.targets, o["cos"])
+        assert np.array_equal(go, c["gt_matched"])
+        assert np.float32(loss) == c["cost_loss"], (loss, c["cost_loss"])
+
+
+# ------------------------------------------------------------------------------------------ G4
+@pytest.mark.parametrize("ci,kind", [(2, "structured"), (2, "uniform"), (5, "structured"), (5, "uniform")])
+def test_g4_big(ci, kind):
+    g = golden("g4_big")
+    fr = synth.make_config_frame(ci, kind=kind)
+    assert fr.checksum() == str(g[f"c{ci}/{kind}/checksum"])
+    check_layer(fr, g.group(f"c{ci}/{kind}/t1"), 20, 5, 1, big=True)
+    if ci == 2:
+        check_layer(fr, g.group(f"c{ci}/{kind}/t0"), 20, 5, 0, big=True)
+        check_layer(fr, g.group(f"c{ci}/{kind}/eval40"), 40, 5, 1, big=True)
+
+
+# ------------------------------------------------------------------------------------------ G5
+def test_g5_edge_cases():
+    g = golden("g5_edge")
+    for name in [str(n) for n in g["names"]]:
+        i = g.group(f"{name}/in")
+        fr = synth.Frame(i["pm"], i["tm"], i["pf"], i["tf"], i["sc"], None, None)
+        for is_test in (0, 1):
+            c = g.group(f"{name}/t{is_test}")
+            o = check_layer(fr, c, 20, 5, is_test)
+            if name == "zero_sim":
+                assert o["iters"] == 1      # outer exit at it=0: cost[0]==cost[1]==0
+            if name in ("zero_masks", "zero_sim"):
+                assert not o["inter"].any()
+
+
+def test_greedy_init_semantics():
+    # first-argmin ties and the "row without a column minimum picks column 0" rule
+    C = np.array([[-1.0, -1.0, -0.5], [-1.0, -1.0, -0.5], [-0.2, -0.1, -0.4]], np.float32)
+    assert list(oracle.greedy_init(C)) == [0, 0, 0]
+    C = np.array([[-0.9, -0.1, -0.2], [-0.1, -0.8, -0.3]], np.float32)
+    assert list(oracle.greedy_init(C)) == [0, 1]
