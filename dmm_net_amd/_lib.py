@@ -1,0 +1,92 @@
+"""Loader for libdmm_match.so (the gfx950 HIP library) through its C ABI (include/dmm_match.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C dmm_net_amd/csrc``) and
+loaded with ctypes.  There is NO fallback: if the library is missing or a call fails, the product
+raises -- nothing here ever routes to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmm_match.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DMM_OK = 0
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+MAX_TEMPLATES = 32
+MAX_PROPOSALS = 256
+
+# every symbol include/dmm_match.h declares
+SYMBOLS = (
+    "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
+    "dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    "dmm_mask_mix", "dmm_workspace_bytes", "dmm_match_forward",
+)
+
+_lib = None
+
+
+class DmmError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into dmm_net_amd/libdmm_match.so (hipcc cross-compiles)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    if not os.path.exists(LIB_PATH):
+        raise DmmError("build did not produce " + LIB_PATH)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the HIP extension is mandatory; there is no CPU fallback)")
+    import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+    L = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(L, s):
+            raise DmmError(f"{LIB_PATH} does not export {s}")
+    c_int, c_float, c_i64, vp, sz = ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    L.dmm_abi_version.restype = c_int
+    L.dmm_status_string.restype = ctypes.c_char_p
+    L.dmm_status_string.argtypes = [c_int]
+    L.dmm_last_hip_error.restype = c_int
+    L.dmm_build_info.restype = ctypes.c_char_p
+    L.dmm_iou_counts.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, vp, vp,
+                                 vp, vp, vp, vp]
+    L.dmm_feature_normalize_f32.argtypes = [vp, c_i64, c_int, vp, vp, vp]
+    L.dmm_relax_match_f32.argtypes = [vp, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int,
+                                      c_int, c_float, c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dmm_relax_solve_f32.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_float, vp, vp, vp, vp, vp]
+    L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
+                               c_i64, vp]
+    L.dmm_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    L.dmm_workspace_bytes.restype = sz
+    L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
+                                    c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
+                                    vp, vp, vp, vp, sz, vp]
+    for f in ("dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+              "dmm_mask_mix", "dmm_match_forward"):
+        getattr(L, f).restype = c_int
+    if L.dmm_abi_version() != 1:
+        raise DmmError("libdmm_match.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != DMM_OK:
+        L = load()
+        msg = L.dmm_status_string(rc).decode()
+        extra = f" (hipError {L.dmm_last_hip_error()})" if rc == 3 else ""
+        raise DmmError(f"{what}: {msg}{extra}")

@@ -1,0 +1,93 @@
+// dmm_api.hip -- C-ABI glue of libdmm_match.so: status/reporting and the fused forward entry point
+// that chains the four kernels of MatchModel.forward (dmm/modules/match_model.py:24-47) on one stream.
+#include "dmm_common.h"
+
+namespace dmm {
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    int32_t *inter, *area_p, *area_t;
+    float *featn_p, *featn_t, *sim, *Rb;
+    size_t bytes;
+};
+
+static Workspace carve(void *base, int B, int N, int M, int D) {
+    const int Pp = N > M ? N : M + 1;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        void *p = base ? (void *)((char *)base + off) : nullptr;
+        off += align_up(n, 256);
+        return p;
+    };
+    // inter | area_p | area_t back to back: dmm_iou_counts clears them with one memset
+    w.inter = (int32_t *)take(sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M));
+    w.area_p = w.inter ? w.inter + (size_t)B * M * N : nullptr;
+    w.area_t = w.area_p ? w.area_p + (size_t)B * N : nullptr;
+    w.featn_p = (float *)take(sizeof(float) * (size_t)B * N * D);
+    w.featn_t = (float *)take(sizeof(float) * (size_t)B * M * D);
+    w.sim = (float *)take(sizeof(float) * (size_t)B * M * N);
+    w.Rb = (float *)take(sizeof(float) * (size_t)B * M * Pp);
+    w.bytes = off;
+    return w;
+}
+}  // namespace dmm
+
+extern "C" int dmm_abi_version(void) { return DMM_ABI_VERSION; }
+
+extern "C" const char *dmm_status_string(int status) {
+    switch (status) {
+        case DMM_OK: return "ok";
+        case DMM_ERR_BAD_ARG: return "bad argument";
+        case DMM_ERR_UNSUPPORTED: return "shape outside the compiled kernel envelope";
+        case DMM_ERR_LAUNCH: return "HIP launch/runtime error (see dmm_last_hip_error)";
+        case DMM_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int dmm_last_hip_error(void) { return dmm::g_last_hip_error; }
+
+extern "C" const char *dmm_build_info(void) { return "libdmm_match gfx950 (CDNA4, wave64) abi " "1"; }
+
+extern "C" size_t dmm_workspace_bytes(int B, int N, int M, int D) {
+    if (B <= 0 || N <= 0 || M <= 0 || D < 0) return 0;
+    return dmm::carve(nullptr, B, N, M, D).bytes;
+}
+
+extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int mask_dtype, const float *feat_p,
+                                 const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,
+                                 int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                                 const int32_t *m_valid, float score_weight, int max_iter, int proj_iter, float lr,
+                                 int is_test, float *full_outmask, float *match_score, float *det_score,
+                                 float *sim_out, float *R_out, float *Rb_out, int32_t *iters_out, void *workspace,
+                                 size_t workspace_bytes, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    if (!masks_p || !masks_t || !feat_p || !feat_t || !score_p || !full_outmask || !match_score || !det_score ||
+        !workspace)
+        return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    dmm::Workspace w = dmm::carve(workspace, B, N, M, D);
+    if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
+    int rc = dmm_iou_counts(masks_p, masks_t, mask_dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid,
+                            w.inter, w.area_p, w.area_t, stream);
+    if (rc != DMM_OK) return rc;
+    rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
+    if (rc != DMM_OK) return rc;
+    rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
+    if (rc != DMM_OK) return rc;
+    float *sim = sim_out ? sim_out : w.sim;
+    float *Rb = Rb_out ? Rb_out : w.Rb;
+    rc = dmm_relax_match_f32(w.featn_t, w.featn_p, D, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid,
+                             score_weight, max_iter, proj_iter, lr, is_test, nullptr, sim, R_out, Rb, match_score,
+                             det_score, iters_out, nullptr, stream);
+    if (rc != DMM_OK) return rc;
+    return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                        (int64_t)M * HW, HW, stream);
+}

@@ -1,0 +1,139 @@
+// dmm_common.h -- device helpers shared by the gfx950 kernels of libdmm_match.so.
+// CDNA4 only: 64-lane wavefronts, GFX9 DPP controls (row_bcast15/31), no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmm_match.h"
+
+namespace dmm {
+
+constexpr int kWave = 64;
+
+// 16-byte vectors that are only guaranteed 4-byte aligned: a 255x255 fp32 plane is 260100 B,
+// so odd planes start 4/8/12 B off a 16-B boundary.  gfx950 global_load/store_dwordx4 only
+// need dword alignment; the aligned(4) typedef makes hipcc emit them instead of 4 dword ops.
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t uint2u __attribute__((ext_vector_type(2), aligned(2)));  // 4 x 16-bit, 2-B aligned
+typedef _Float16 half4u __attribute__((ext_vector_type(4), aligned(2)));
+// 16-bit storage tags for mask planes (IEEE half / bfloat16); arithmetic is always fp32
+struct f16_t { _Float16 v; };
+struct bf16_t { uint16_t v; };
+
+// ---- DPP cross-lane primitives -------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v, int old) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // row_half_mirror
+constexpr int DPP_MIRROR = 0x140;      // row_mirror
+constexpr int DPP_BCAST15 = 0x142;     // row_bcast:15
+constexpr int DPP_BCAST31 = 0x143;     // row_bcast:31
+
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Sum over the 64 lanes, fixed tree order, result broadcast (wave-uniform).
+// ((l, l^1), (.., ^2), half-mirror, mirror) inside each 16-lane row, then rows 0+1, 2+3, (01)+(23).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = v + dpp_f32<DPP_XOR1>(v);
+    v = v + dpp_f32<DPP_XOR2>(v);
+    v = v + dpp_f32<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f32<DPP_MIRROR>(v);
+    v = v + dpp_f32<DPP_BCAST15, 0xA>(v);
+    v = v + dpp_f32<DPP_BCAST31, 0xC>(v);
+    return readlane_f32(v, 63);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    // max needs the identity in disabled rows: use `old = v` so a disabled row keeps its value.
+    auto step = [](float x, float y) { return x > y ? x : y; };
+    v = step(v, dpp_f32<DPP_XOR1>(v));
+    v = step(v, dpp_f32<DPP_XOR2>(v));
+    v = step(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = step(v, dpp_f32<DPP_MIRROR>(v));
+    float t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_BCAST15, 0xA, 0xF, false));
+    v = step(v, t);
+    t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_BCAST31, 0xC, 0xF, false));
+    v = step(v, t);
+    return readlane_f32(v, 63);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+    auto step = [](float x, float y) { return x < y ? x : y; };
+    v = step(v, dpp_f32<DPP_XOR1>(v));
+    v = step(v, dpp_f32<DPP_XOR2>(v));
+    v = step(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = step(v, dpp_f32<DPP_MIRROR>(v));
+    float t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_BCAST15, 0xA, 0xF, false));
+    v = step(v, t);
+    t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_BCAST31, 0xC, 0xF, false));
+    v = step(v, t);
+    return readlane_f32(v, 63);
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    auto step = [](int x, int y) { return x < y ? x : y; };
+    v = step(v, dpp_i32<DPP_XOR1>(v, v));
+    v = step(v, dpp_i32<DPP_XOR2>(v, v));
+    v = step(v, dpp_i32<DPP_HALF_MIRROR>(v, v));
+    v = step(v, dpp_i32<DPP_MIRROR>(v, v));
+    v = step(v, dpp_i32<DPP_BCAST15, 0xA>(v, v));
+    v = step(v, dpp_i32<DPP_BCAST31, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---- mask element loads: 4 consecutive pixels as fp32 ---------------------------------------
+template <typename T> struct MaskIO;
+template <> struct MaskIO<float> {
+    static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
+        float4u t = *reinterpret_cast<const float4u *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+};
+template <> struct MaskIO<f16_t> {
+    static __device__ __forceinline__ void load4(const f16_t *p, float (&v)[4]) {
+        half4u t = *reinterpret_cast<const half4u *>(p);
+        v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+    }
+    static __device__ __forceinline__ float load1(const f16_t *p) { return (float)p->v; }
+};
+template <> struct MaskIO<bf16_t> {
+    static __device__ __forceinline__ void load4(const bf16_t *p, float (&v)[4]) {
+        uint2u t = *reinterpret_cast<const uint2u *>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+    }
+    static __device__ __forceinline__ float load1(const bf16_t *p) { return __uint_as_float(((uint32_t)p->v) << 16); }
+};
+
+}  // namespace dmm
+
+// ---- host side ------------------------------------------------------------------------------
+namespace dmm {
+void set_last_hip_error(int e);
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_hip_error((int)e);
+        return DMM_ERR_LAUNCH;
+    }
+    return DMM_OK;
+}
+#define DMM_HIP_TRY(expr)                                  \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            ::dmm::set_last_hip_error((int)_e);            \
+            return DMM_ERR_LAUNCH;                         \
+        }                                                  \
+    } while (0)
+}  // namespace dmm

@@ -1,0 +1,264 @@
+// dmm_cost.hip -- pairwise binary-mask intersection / area tables on gfx950.
+//
+// Replaces compute_iou_binary_mask_2D over the expanded [O*P, HW] tensors of the reference
+// (dmm/utils/match_helper.py:9-28, called from dmm/modules/match_model.py:83-89 and from
+// compute_matching_loss, match_helper.py:34-43).  The reference materialises two O*P*HW fp32
+// copies; here every mask plane is read from HBM exactly once.
+//
+// Roofline: HBM.  Algorithmic bytes per frame = (N+M)*HW*sizeof(elem) (+ 4*M*N table).
+//
+// Mapping (one workgroup = 4 independent waves, one frame, a contiguous range of 256-pixel chunks):
+//   * a wave loads one 256-pixel chunk of a plane with ONE dwordx4 per lane (1 KiB / wave
+//     instruction, coalesced), thresholds `> 0.5` and bit-packs through 4 v_cmp -> 64-bit
+//     lane masks (the hardware transposer): word k holds pixels 4*lane+k;
+//   * the 64-bit words are parked in lane `plane` of 8 VGPRs with a lane-select (v_cndmask on
+//     lane == plane; proposal n -> lane n of group n/64, template m -> lane m of the template set),
+//     so the whole bit tile of a chunk lives in registers -- no LDS, no barriers in the streaming loop;
+//   * pair phase: lane = proposal, scalar loop over templates: v_readlane the template word
+//     into SGPRs, v_and + v_bcnt accumulate popc(P & T) into acc[m] (registers);
+//   * epilogue: the 4 waves fold their integer partials with LDS atomics, then one global
+//     atomicAdd per table entry and workgroup (integers: result independent of order).
+// VALU work is ~8 % of the HBM time of a chunk; the kernel is a pure stream.
+#include "dmm_common.h"
+
+namespace dmm {
+
+constexpr int kChunk = 256;   // pixels per wave step (64 lanes x 4)
+constexpr int kUnroll = 8;    // plane loads in flight per wave (8 KiB)
+constexpr int kCostThreads = 256;
+
+template <typename T, bool TAIL>
+__device__ __forceinline__ void load_pixels(const T *plane, int x, int HW, float (&v)[4]) {
+    if (!TAIL) {
+        MaskIO<T>::load4(plane + x, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+    }
+}
+
+// Bit tile of one group of <= 64 planes for one chunk: lane p holds words k=0..3 of plane p.
+struct BitTile {
+    int lo[4], hi[4];
+};
+
+template <typename T, bool TAIL>
+__device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t plane_stride, int nplanes,
+                                          int x, int HW) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
+    for (int p0 = 0; p0 < nplanes; p0 += kUnroll) {
+        float v[kUnroll][4];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            // clamp: planes past the end re-read the last one; they land in lanes that are never read
+            int p = p0 + u < nplanes ? p0 + u : nplanes - 1;
+            load_pixels<T, TAIL>(base + (int64_t)p * plane_stride, x, HW, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int p = p0 + u;
+            if (p < nplanes) {
+                const bool mine = lane == p;   // park the words of plane p in lane p
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long b = __ballot(v[u][k] > 0.5f);
+                    w.lo[k] = mine ? (int)(unsigned)b : w.lo[k];
+                    w.hi[k] = mine ? (int)(unsigned)(b >> 32) : w.hi[k];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int NG, bool TAIL>
+__device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, int64_t sp_n, int64_t st_m, int Nb, int Mb,
+                                              int x, int HW, unsigned (&acc)[NG][MT], unsigned (&area_p)[NG],
+                                              unsigned &area_t) {
+    BitTile tw;
+    fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x, HW);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int nn = Nb - g * kWave;
+        if (nn <= 0) break;
+        if (nn > kWave) nn = kWave;
+        BitTile pw;
+        fill_tile<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x, HW);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) area_p[g] += __builtin_popcount(pw.lo[k]) + __builtin_popcount(pw.hi[k]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < Mb) {
+                unsigned a = acc[g][m];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int tl = __builtin_amdgcn_readlane(tw.lo[k], m);
+                    int th = __builtin_amdgcn_readlane(tw.hi[k], m);
+                    a += __builtin_popcount(pw.lo[k] & tl) + __builtin_popcount(pw.hi[k] & th);
+                }
+                acc[g][m] = a;
+            }
+        }
+    }
+}
+
+// grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
+// Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
+template <typename T, int MT, int NG>
+__global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
+    const T *__restrict__ masks_p, const T *__restrict__ masks_t, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
+    int64_t st_b, int64_t st_m, const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid,
+    int32_t *__restrict__ inter, int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int n0, int m0,
+    int chunks_per_wg, int write_area_p, int write_area_t) {
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    Nb = min(Nb - n0, NG * kWave);
+    Mb = min(Mb - m0, MT);
+    if (Nb <= 0 || Mb <= 0) return;
+    const T *Pb = masks_p + (int64_t)b * sp_b + (int64_t)n0 * sp_n;
+    const T *Tb = masks_t + (int64_t)b * st_b + (int64_t)m0 * st_m;
+
+    unsigned acc[NG][MT];
+    unsigned ap[NG];
+    unsigned at = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        ap[g] = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[g][m] = 0;
+    }
+
+    const int full_chunks = HW / kChunk;
+    const int nchunks = (HW + kChunk - 1) / kChunk;
+    const int c_begin = blockIdx.x * chunks_per_wg;
+    const int c_end = min(nchunks, c_begin + chunks_per_wg);
+    for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
+        const int x = c * kChunk + lane * 4;
+        if (c < full_chunks)
+            process_chunk<T, MT, NG, false>(Pb, Tb, sp_n, st_m, Nb, Mb, x, HW, acc, ap, at);
+        else
+            process_chunk<T, MT, NG, true>(Pb, Tb, sp_n, st_m, Nb, Mb, x, HW, acc, ap, at);
+    }
+
+    // fold the 4 waves (integer LDS atomics), then one global atomic per entry
+    __shared__ unsigned red[(MT + 1) * NG * kWave + kWave];
+    unsigned *red_at = red + (MT + 1) * NG * kWave;
+    for (int i = threadIdx.x; i < (MT + 1) * NG * kWave + kWave; i += kCostThreads) red[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int col = g * kWave + lane;
+        if (col < Nb) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (m < Mb && acc[g][m]) atomicAdd(&red[m * NG * kWave + col], acc[g][m]);
+            if (ap[g]) atomicAdd(&red[MT * NG * kWave + col], ap[g]);
+        }
+    }
+    if (lane < Mb && at) atomicAdd(&red_at[lane], at);
+    __syncthreads();
+    int32_t *inter_b = inter + (int64_t)b * M * N;
+    for (int i = threadIdx.x; i < MT * NG * kWave; i += kCostThreads) {
+        const int m = i / (NG * kWave), col = i % (NG * kWave);
+        if (m < Mb && col < Nb && red[i]) atomicAdd(&inter_b[(int64_t)(m0 + m) * N + n0 + col], (int)red[i]);
+    }
+    if (write_area_p)
+        for (int col = threadIdx.x; col < Nb; col += kCostThreads)
+            if (red[MT * NG * kWave + col]) atomicAdd(&area_p[(int64_t)b * N + n0 + col], (int)red[MT * NG * kWave + col]);
+    if (write_area_t && threadIdx.x < Mb && red_at[threadIdx.x])
+        atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);
+}
+
+template <typename T, int MT, int NG>
+static int launch_tile(const T *masks_p, const T *masks_t, int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
+                       int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, int32_t *inter,
+                       int32_t *area_p, int32_t *area_t, int n0, int m0, int wap, int wat, hipStream_t stream) {
+    const int nchunks = (HW + kChunk - 1) / kChunk;
+    // >= ~2048 workgroups in flight (8 per CU), at least 1 chunk per wave step
+    int splits = (2048 + B - 1) / B;
+    const int max_splits = (nchunks + 3) / 4;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int chunks_per_wg = (nchunks + splits - 1) / splits;
+    splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
+    dim3 grid(splits, B);
+    hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, N, M, HW,
+                       sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter, area_p, area_t, n0, m0, chunks_per_wg, wap,
+                       wat);
+    return check_launch();
+}
+
+template <typename T>
+static int iou_counts_typed(const T *masks_p, const T *masks_t, int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
+                            int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, int32_t *inter,
+                            int32_t *area_p, int32_t *area_t, hipStream_t stream) {
+    if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
+        // the three tables are one contiguous block (dmm_match_forward's workspace): one memset node
+        DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
+    } else {
+        DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)B * M * N, stream));
+        DMM_HIP_TRY(hipMemsetAsync(area_p, 0, sizeof(int32_t) * (size_t)B * N, stream));
+        DMM_HIP_TRY(hipMemsetAsync(area_t, 0, sizeof(int32_t) * (size_t)B * M, stream));
+    }
+    if (HW == 0) return DMM_OK;
+    // Tile the (N, M) table over the compiled envelopes; one launch covers N <= 256, M <= 32.
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int mt = M - m0 < 32 ? M - m0 : 32;
+        for (int n0 = 0; n0 < N; n0 += 256) {
+            const int nt = N - n0 < 256 ? N - n0 : 256;
+            const int wap = (m0 == 0), wat = (n0 == 0);
+            int rc;
+#define DMM_COST_CASE(MT_, NG_)                                                                                   \
+    rc = launch_tile<T, MT_, NG_>(masks_p, masks_t, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter, \
+                                  area_p, area_t, n0, m0, wap, wat, stream)
+            if (nt <= 64) {
+                if (mt <= 8) DMM_COST_CASE(8, 1);
+                else if (mt <= 16) DMM_COST_CASE(16, 1);
+                else DMM_COST_CASE(32, 1);
+            } else if (nt <= 128) {
+                if (mt <= 8) DMM_COST_CASE(8, 2);
+                else if (mt <= 16) DMM_COST_CASE(16, 2);
+                else DMM_COST_CASE(32, 2);
+            } else {
+                if (mt <= 8) DMM_COST_CASE(8, 4);
+                else if (mt <= 16) DMM_COST_CASE(16, 4);
+                else DMM_COST_CASE(32, 4);
+            }
+#undef DMM_COST_CASE
+            if (rc != DMM_OK) return rc;
+        }
+    }
+    return DMM_OK;
+}
+
+}  // namespace dmm
+
+extern "C" int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW,
+                              int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                              const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                              dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || N == 0 || M == 0) return DMM_OK;
+    if (!masks_p || !masks_t || !inter || !area_p || !area_t) return DMM_ERR_BAD_ARG;
+    if (sp_n < HW || st_m < HW) return DMM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case DMM_F32:
+            return dmm::iou_counts_typed<float>((const float *)masks_p, (const float *)masks_t, B, N, M, HW, sp_b, sp_n,
+                                                st_b, st_m, n_valid, m_valid, inter, area_p, area_t, s);
+        case DMM_F16:
+            return dmm::iou_counts_typed<dmm::f16_t>((const dmm::f16_t *)masks_p, (const dmm::f16_t *)masks_t, B, N, M, HW, sp_b,
+                                                 sp_n, st_b, st_m, n_valid, m_valid, inter, area_p, area_t, s);
+        case DMM_BF16:
+            return dmm::iou_counts_typed<dmm::bf16_t>((const dmm::bf16_t *)masks_p, (const dmm::bf16_t *)masks_t, B,
+                                                       N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter,
+                                                       area_p, area_t, s);
+        default:
+            return DMM_ERR_BAD_ARG;
+    }
+}

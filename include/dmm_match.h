@@ -1,0 +1,152 @@
+/*
+ * dmm_match.h -- C ABI of libdmm_match.so: the MI355X (gfx950) implementation of DMM-Net's
+ * differentiable mask-matching layer.
+ *
+ * Drop-in boundary.  The reference (ZENGXH/DMM_Net) is pure Python; its matching layer is
+ *   dmm/modules/match_model.py:13-152   class MatchModel (forward :24-47)
+ *   dmm/utils/match_helper.py:9-64      pairwise mask IoU, cosine, matching loss
+ *   dmm/modules/submodules/relax_match.py:9-105   relax_matching (PGD + Dykstra projections)
+ * and it reaches native code only through torch ops.  The entry points below are what a
+ * ctypes / cpp_extension binding of that layer calls instead of those torch ops; each one
+ * names the reference lines it replaces.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, sizes, element strides, a hipStream_t passed as void*;
+ *    no torch types, no exceptions; every function returns a dmm_status (0 = ok);
+ *  - nothing is allocated: outputs and workspace are caller provided (dmm_workspace_bytes);
+ *  - everything is enqueued on `stream` and is hipGraph-capturable (no host syncs);
+ *  - batched: B independent frames per call.  B = 1 reproduces one reference call;
+ *    N = proposals (reference "P"), M = templates (reference "O"), Pp = max(N, M+1) is the
+ *    padded solver width (match_model.py:109-113), HW = H*W pixels of one mask plane;
+ *  - ragged batches: n_valid[B] / m_valid[B] (device int32, may be NULL) give the number of
+ *    live proposals / templates of each frame (<= N, <= M); tables keep the N/M/Pp strides;
+ *    frames with m_valid == 0 or n_valid == 0 produce zeros (dmm_model.py:118-122);
+ *  - a mask plane is H*W contiguous elements; planes / frames may be strided (in elements);
+ *  - integer results are bit exact w.r.t. the reference; fp32 results follow the reference's
+ *    op order with fp contraction disabled (sums use a fixed tree order).
+ */
+#ifndef DMM_MATCH_H
+#define DMM_MATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMM_ABI_VERSION 1
+
+typedef enum dmm_status {
+    DMM_OK = 0,
+    DMM_ERR_BAD_ARG = 1,      /* null pointer / negative size / inconsistent shape */
+    DMM_ERR_UNSUPPORTED = 2,  /* shape outside the compiled kernel envelope          */
+    DMM_ERR_LAUNCH = 3,       /* HIP reported an error; see dmm_last_hip_error()     */
+    DMM_ERR_WORKSPACE = 4     /* workspace too small                                 */
+} dmm_status;
+
+typedef enum dmm_dtype { DMM_F32 = 0, DMM_F16 = 1, DMM_BF16 = 2 } dmm_dtype;
+
+typedef void *dmm_stream_t; /* hipStream_t */
+
+#define DMM_API __attribute__((visibility("default")))
+
+/* Limits of the compiled kernels (dmm_relax_* / dmm_mask_mix_*).  dmm_iou_counts_* tiles
+ * internally and accepts any N, M. */
+#define DMM_MAX_TEMPLATES 32  /* M  */
+#define DMM_MAX_PROPOSALS 256 /* Pp */
+
+DMM_API int dmm_abi_version(void);
+DMM_API const char *dmm_status_string(int status);
+DMM_API int dmm_last_hip_error(void);         /* hipError_t of the last DMM_ERR_LAUNCH on this thread */
+DMM_API const char *dmm_build_info(void);     /* "gfx950 ..." */
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) Pairwise binary-mask intersection / area tables.
+ * Replaces compute_iou_binary_mask_2D over the expanded [O*P, HW] tensors
+ * (match_helper.py:9-28 as called from match_model.py:83-89, and from
+ * compute_matching_loss match_helper.py:34-43 with masks_t = targets).
+ *   a = x > 0.5 (strict);  inter[b,m,n] = |T_m & P_n|;  area_p[b,n] = |P_n|;  area_t[b,m] = |T_m|
+ * (union = area_p + area_t - inter).  Outputs are int32 and are overwritten.
+ * masks_p: N planes per frame, plane stride sp_n, frame stride sp_b (elements);
+ * masks_t: M planes per frame, strides st_m / st_b.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW,
+                   int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
+                   const int32_t *n_valid, const int32_t *m_valid,
+                   int32_t *inter /*[B,M,N]*/, int32_t *area_p /*[B,N]*/, int32_t *area_t /*[B,M]*/,
+                   dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) Row-normalise feature vectors: out[r,:] = in[r,:] / max(||in[r,:]||_2, 1e-8).
+ * First half of F.cosine_similarity as get_cosine_score uses it (match_helper.py:51-64).
+ * Also returns the clamped norms (needed by the backward).  rows = B*N or B*M.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, float *out /*[rows,D]*/,
+                              float *norms /*[rows] or NULL*/, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Similarity + relaxed assignment + scores, one frame per wave(-group), solver state
+ * resident in registers for all iterations.  Replaces, per frame:
+ *   cos[m,n] = <tn_m, pn_n>                               match_helper.py:59-63 (second half)
+ *   iou = inter / (union + 1e-6);  sim = (1-w)*cos + w*iou             match_model.py:89-90
+ *   pad to [M, Pp];  C = -sim_pad                                      match_model.py:107-116
+ *   relax_matching(C, max_iter, proj_iter, lr) and R = mean(X_list)
+ *                                       relax_match.py:36-105, match_model.py:118-121
+ *   logic = (R == rowmax) if is_test else (R > 0.01);  Rb = R*logic    match_model.py:124-130
+ *   match_score = max_p clamp(R,0,1)*sim_pad;  det_score = sum_p score_p*Rb     :146-147
+ * featn_t [B,M,D] / featn_p [B,N,D] are the normalised features of (2).
+ * Outputs: cos (may be NULL) [B,M,N], sim [B,M,N], R / Rb [B,M,Pp], match_score /
+ * det_score [B,M], iters [B] = executed outer iterations (len(X_list)-1), X_final (may be
+ * NULL) [B,M,Pp].  Requires M <= DMM_MAX_TEMPLATES and Pp <= DMM_MAX_PROPOSALS.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_relax_match_f32(const float *featn_t, const float *featn_p, int D,
+                        const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
+                        const float *score_p /*[B,N]*/, int B, int N, int M,
+                        const int32_t *n_valid, const int32_t *m_valid,
+                        float score_weight, int max_iter, int proj_iter, float lr, int is_test,
+                        float *cos_out, float *sim_out, float *R_out, float *Rb_out,
+                        float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                        dmm_stream_t stream);
+
+/* Solver only, on a caller-provided cost matrix C [B,n,m] (relax_matching itself,
+ * relax_match.py:36-105): X_final, R = mean(X_list), cost list [B,max_iter+1] (may be NULL),
+ * iters [B].  n <= DMM_MAX_TEMPLATES, m <= DMM_MAX_PROPOSALS. */
+DMM_API int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_iter, int proj_iter, float lr,
+                        float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
+                        dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) Assignment-weighted mask mix: full_outmask[b,m,:] = sum_n Rb[b,m,n] * masks_p[b,n,:]
+ * (torch.mm at match_model.py:144; padded columns n >= N carry zero planes, :134-142).
+ * Only planes with a non-zero weight are read (in test mode <= M planes per frame).
+ * Rb is [B,M,Pp] with row stride Pp.  out: [B,M,HW] fp32, strides so_b / so_m (elements).
+ * Rows m >= m_valid[b] are zero filled.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                 int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                 float *out, int64_t so_b, int64_t so_m, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) The whole forward of MatchModel for B frames (match_model.py:24-47, targets=None):
+ * (1) -> (2) -> (3) -> (4) on `stream`, intermediates in `workspace`.
+ * Outputs as in (3)/(4).  workspace >= dmm_workspace_bytes(B, N, M, D).
+ * ------------------------------------------------------------------------------------------- */
+DMM_API size_t dmm_workspace_bytes(int B, int N, int M, int D);
+
+DMM_API int dmm_match_forward(const void *masks_p, const void *masks_t, int mask_dtype,
+                      const float *feat_p /*[B,N,D]*/, const float *feat_t /*[B,M,D]*/,
+                      const float *score_p /*[B,N]*/, int B, int N, int M, int HW, int D,
+                      int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
+                      const int32_t *n_valid, const int32_t *m_valid,
+                      float score_weight, int max_iter, int proj_iter, float lr, int is_test,
+                      float *full_outmask /*[B,M,HW]*/, float *match_score /*[B,M]*/,
+                      float *det_score /*[B,M]*/, float *sim_out /*[B,M,N] or NULL*/,
+                      float *R_out /*[B,M,Pp] or NULL*/, float *Rb_out /*[B,M,Pp] or NULL*/,
+                      int32_t *iters_out /*[B] or NULL*/,
+                      void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMM_MATCH_H */

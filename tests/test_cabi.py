@@ -1,0 +1,61 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/dmm_match.h declares.
+(No compute calls here: those are the -m gpu tests.)"""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from dmm_net_amd import _lib
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dmm_match.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/dmm_match.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms, "dmm_net_amd/_lib.py binds a different symbol set than the header declares"
+
+
+def test_load_and_status_strings():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.load()
+    assert L.dmm_abi_version() == 1
+    assert L.dmm_status_string(0) == b"ok"
+    assert b"gfx950" in L.dmm_build_info()
+    assert L.dmm_workspace_bytes(4, 50, 10, 512) > 4 * (50 + 10) * 512 * 4
+    assert L.dmm_workspace_bytes(0, 50, 10, 512) == 0
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before anything touches the device."""
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.load()
+    assert L.dmm_iou_counts(None, None, 0, 1, 4, 2, 16, 64, 16, 32, 16, None, None, None, None, None, None) == 1
+    assert L.dmm_iou_counts(None, None, 0, -1, 4, 2, 16, 64, 16, 32, 16, None, None, None, None, None, None) == 1
+    assert L.dmm_iou_counts(None, None, 0, 0, 4, 2, 16, 64, 16, 32, 16, None, None, None, None, None, None) == 0
+    # M beyond the compiled solver envelope
+    one = ctypes.c_void_p(8)
+    assert L.dmm_relax_solve_f32(one, 1, 33, 40, 1, 1, 0.1, one, one, None, one, None) == 2
+    assert L.dmm_relax_solve_f32(one, 1, 3, 257, 1, 1, 0.1, one, one, None, one, None) == 2
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never reach into oracle/ (CPU fallback would void parity)."""
+    pkg = os.path.join(ROOT, "dmm_net_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), fn
+                assert "dmm_oracle" not in src, fn
