@@ -93,7 +93,7 @@ def main():
     counts = torch.empty((B * M * N + B * N + B * M,), **i32)    # inter | area_p | area_t, one memset
     inter, ap, at = counts[:B * M * N], counts[B * M * N:B * M * N + B * N], counts[B * M * N + B * N:]
     pn, tn = torch.empty_like(pf), torch.empty_like(tf)
-    sim, Rb = torch.empty((B, M, N), **f32), torch.empty((B, M, Pp), **f32)
+    cosv, sim, Rb = torch.empty((B, M, N), **f32), torch.empty((B, M, N), **f32), torch.empty((B, M, Pp), **f32)
     ms, ds = torch.empty((B, M), **f32), torch.empty((B, M), **f32)
     iters = torch.empty((B,), **i32)
     full = torch.empty((B, M, H, W), **f32)
@@ -110,8 +110,9 @@ def main():
             ev[k][1].record()
         rc |= L.dmm_feature_normalize_f32(P(pf), B * N, D, P(pn), None, stream)
         rc |= L.dmm_feature_normalize_f32(P(tf), B * M, D, P(tn), None, stream)
-        rc |= L.dmm_relax_match_f32(P(tn), P(pn), D, P(inter), P(ap), P(at), P(sc), B, N, M, None, None, 0.3, 20, 5, 0.1,
-                                    1, None, P(sim), None, P(Rb), P(ms), P(ds), P(iters), None, stream)
+        rc |= L.dmm_cosine_f32(P(tn), P(pn), B, N, M, D, None, None, P(cosv), stream)
+        rc |= L.dmm_relax_match_f32(P(cosv), P(inter), P(ap), P(at), P(sc), B, N, M, None, None, 0.3, 20, 5, 0.1, 1,
+                                    P(sim), None, P(Rb), P(ms), P(ds), P(iters), None, stream)
         rc |= L.dmm_mask_mix(P(Rb), P(pm), 0, B, N, M, Pp, HW, N * HW, HW, None, None, P(full), M * HW, HW, stream)
         if rc:
             raise RuntimeError(f"libdmm_match call failed: {rc}")

@@ -22,7 +22,7 @@ MAX_PROPOSALS = 256
 # every symbol include/dmm_match.h declares
 SYMBOLS = (
     "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
-    "dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    "dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_mask_mix", "dmm_workspace_bytes", "dmm_match_forward",
 )
 
@@ -65,8 +65,9 @@ def load():
     L.dmm_iou_counts.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, vp, vp,
                                  vp, vp, vp, vp]
     L.dmm_feature_normalize_f32.argtypes = [vp, c_i64, c_int, vp, vp, vp]
-    L.dmm_relax_match_f32.argtypes = [vp, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int,
-                                      c_int, c_float, c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dmm_cosine_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
+    L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,
+                                      c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dmm_relax_solve_f32.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_float, vp, vp, vp, vp, vp]
     L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
                                c_i64, vp]
@@ -75,7 +76,7 @@ def load():
     L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                     c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]
-    for f in ("dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    for f in ("dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward"):
         getattr(L, f).restype = c_int
     if L.dmm_abi_version() != 1:

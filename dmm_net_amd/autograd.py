@@ -47,8 +47,9 @@ class _MatchLayerFn(torch.autograd.Function):
         inter, ap, at = ops.iou_counts(pm_b, tm_b)
         pn, pnorm = ops.feature_normalize(pf.unsqueeze(0), want_norms=True)
         tn, tnorm = ops.feature_normalize(tf.unsqueeze(0), want_norms=True)
-        r = ops.relax_match(tn, pn, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=max_iter,
-                            proj_iter=proj_iter, lr=lr, is_test=is_test, want_cos=True)
+        cos = ops.cosine(tn, pn)
+        r = ops.relax_match(cos, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=max_iter,
+                            proj_iter=proj_iter, lr=lr, is_test=is_test)
         full = ops.mask_mix(r["Rb"], pm_b)
         cost_loss = pf.new_zeros(())
         gt = None
@@ -59,7 +60,7 @@ class _MatchLayerFn(torch.autograd.Function):
             union = (gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6
             gt_iou = gi.float() / union
             gt = _greedy_onehot(-gt_iou)
-            diff = r["cos"] - gt
+            diff = cos - gt
             cost_loss = (diff * diff).mean()
         ctx.save_for_backward(pn, tn, pnorm, tnorm, r["sim"], r["R"], r["Rb"], sc, pm, gt if gt is not None else pn)
         ctx.has_targets = targets is not None
@@ -100,8 +101,9 @@ def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
     inter, ap, at = ops.iou_counts(pm_b, tm_b)
     pn = ops.feature_normalize(pf.unsqueeze(0))
     tn = ops.feature_normalize(tf.unsqueeze(0))
-    r = ops.relax_match(tn, pn, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=0, proj_iter=0,
-                        lr=0.0, is_test=is_test, want_cos=True)
+    cos = ops.cosine(tn, pn)
+    r = ops.relax_match(cos, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=0, proj_iter=0,
+                        lr=0.0, is_test=is_test)
     sim = r["sim"][0]
     Pp = ops.padded_width(P, O)
     simp = sim.new_zeros((O, Pp))
@@ -120,5 +122,5 @@ def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
         gi, gap, gat = ops.iou_counts(pm_b, targets.unsqueeze(0).to(pm.dtype))
         gt_iou = gi.float() / ((gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6)
         gt = _greedy_onehot(-gt_iou)
-        loss = ((r["cos"] - gt) ** 2).mean()
+        loss = ((cos - gt) ** 2).mean()
     return full, ms, ds, loss

@@ -10,7 +10,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct Workspace {
     int32_t *inter, *area_p, *area_t;
-    float *featn_p, *featn_t, *sim, *Rb;
+    float *featn_p, *featn_t, *cosv, *sim, *Rb;
     size_t bytes;
 };
 
@@ -29,6 +29,7 @@ static Workspace carve(void *base, int B, int N, int M, int D) {
     w.area_t = w.area_p ? w.area_p + (size_t)B * N : nullptr;
     w.featn_p = (float *)take(sizeof(float) * (size_t)B * N * D);
     w.featn_t = (float *)take(sizeof(float) * (size_t)B * M * D);
+    w.cosv = (float *)take(sizeof(float) * (size_t)B * M * N);
     w.sim = (float *)take(sizeof(float) * (size_t)B * M * N);
     w.Rb = (float *)take(sizeof(float) * (size_t)B * M * Pp);
     w.bytes = off;
@@ -84,9 +85,11 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
     if (rc != DMM_OK) return rc;
     float *sim = sim_out ? sim_out : w.sim;
     float *Rb = Rb_out ? Rb_out : w.Rb;
-    rc = dmm_relax_match_f32(w.featn_t, w.featn_p, D, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid,
-                             score_weight, max_iter, proj_iter, lr, is_test, nullptr, sim, R_out, Rb, match_score,
-                             det_score, iters_out, nullptr, stream);
+    rc = dmm_cosine_f32(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, stream);
+    if (rc != DMM_OK) return rc;
+    rc = dmm_relax_match_f32(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid, score_weight,
+                             max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,
+                             nullptr, stream);
     if (rc != DMM_OK) return rc;
     return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
                         (int64_t)M * HW, HW, stream);

@@ -90,6 +90,71 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---- row-batched reductions: CNT independent values reduced with their DPP trees INTERLEAVED
+// (step-major), so the 2-wait-state DPP hazards and the add latency of one tree are filled by the
+// others.  Results are wave-uniform.  Same tree order as wave_sum / wave_max / wave_min.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep_f32(float v) {   // disabled rows keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_full_f32(float v) {   // full row mask, every source lane valid
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CNT>
+__device__ __forceinline__ void wave_sum_rows(float (&v)[CNT]) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_full_f32<DPP_XOR1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_full_f32<DPP_XOR2>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_full_f32<DPP_HALF_MIRROR>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_full_f32<DPP_MIRROR>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_f32<DPP_BCAST15, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = v[i] + dpp_f32<DPP_BCAST31, 0xC>(v[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = readlane_f32(v[i], 63);
+}
+template <int CNT, typename OP>
+__device__ __forceinline__ void wave_fold_rows(float (&v)[CNT], OP op) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_full_f32<DPP_XOR1>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_full_f32<DPP_XOR2>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_full_f32<DPP_HALF_MIRROR>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_full_f32<DPP_MIRROR>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_keep_f32<DPP_BCAST15, 0xA>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = op(v[i], dpp_keep_f32<DPP_BCAST31, 0xC>(v[i]));
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = readlane_f32(v[i], 63);
+}
+struct op_fmax { __device__ __forceinline__ float operator()(float a, float b) const { return a > b ? a : b; } };
+struct op_fmin { __device__ __forceinline__ float operator()(float a, float b) const { return a < b ? a : b; } };
+template <int CNT> __device__ __forceinline__ void wave_max_rows(float (&v)[CNT]) { wave_fold_rows<CNT>(v, op_fmax()); }
+template <int CNT> __device__ __forceinline__ void wave_min_rows(float (&v)[CNT]) { wave_fold_rows<CNT>(v, op_fmin()); }
+template <int CNT>
+__device__ __forceinline__ void wave_min_rows_i32(int (&v)[CNT]) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) v[i] = wave_min_i32(v[i]);
+}
+
+// a / b for a loop-invariant b with rcp = RN(1/b): q0 = a*rcp, r = fma(-q0, b, a), q = fma(r, rcp, q0).
+// Markstein's correction: the result equals the IEEE-754 correctly rounded a / b (what the reference's
+// `/ X.shape[k]` computes).  Checked exhaustively enough for b = 1..256 over 5e8 operands by the
+// oracle's dmmo_check_div_by_const (tests/test_host_logic.py); a, b are never denormal here.
+__device__ __forceinline__ float div_by_const(float a, float b, float rcp) {
+    const float q0 = a * rcp;
+    const float r = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(r, rcp, q0);
+}
+
 // ---- mask element loads: 4 consecutive pixels as fp32 ---------------------------------------
 template <typename T> struct MaskIO;
 template <> struct MaskIO<float> {

@@ -1,0 +1,160 @@
+// dmm_cosine.hip -- feature similarity of the matching layer on gfx950.
+//
+// Replaces get_cosine_score (reference dmm/utils/match_helper.py:51-64): F.cosine_similarity over the
+// D axis of the expanded [O, D, P] tensors.  Under the torch (2.10) semantics the goldens were captured
+// with, each vector is divided by max(||v||, 1e-8) first and the products are then summed over D:
+//     cos[o, p] = sum_d (q[o,d] / qn[o]) * (k[p,d] / kn[p]).
+// Both stages follow the summation order of the reference's torch CPU kernels (dmm_torch_order.h), so
+// the table is bit exact against the reference -- it feeds the solver, whose exit tests are sensitive to
+// the last ulp.  Work is tiny (M*N*D = 256 kFLOP per frame at the BASELINE config); the kernels are laid
+// out for exactness first, parallelism across frames second.
+#include "dmm_torch_order.h"
+
+namespace dmm {
+
+// ---------------------------------------------------------------------------------------------
+// out[r,:] = in[r,:] / max(||in[r,:]||_2, 1e-8); one aligned 8-lane group per row (8 rows per wave),
+// the group plays the 8 AVX2 lanes of ATen's 2-norm fast path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__restrict__ in, int64_t rows, int D,
+                                                                float *__restrict__ out, float *__restrict__ norms) {
+    const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int l = threadIdx.x & 7;
+    const bool valid = r < rows;
+    const float *x = in + (valid ? r : 0) * D;
+    float nr = torder::norm2_group8(D, l, [&](long i) { return x[i]; });
+    nr = nr > 1e-8f ? nr : 1e-8f;                           // clamp_min(eps)
+    nr = __shfl(nr, (threadIdx.x & 63) & ~7);               // group lane 0 -> its 8 lanes
+    if (!valid) return;
+    for (int d = l; d < D; d += 8) out[r * D + d] = x[d] / nr;
+    if (norms && l == 0) norms[r] = nr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cos[b,m,n] = sum_d RN(tn[b,m,d] * pn[b,n,d]) in the order ATen reduces the contiguous [D, N] slab of
+// products over its rows: column n < outer_class_bound(N) by one cascade chain, the others by the
+// ILP-4 row_sum.  grid = (M, B); thread n owns proposal column n; the proposal rows are staged through
+// LDS in D-chunks (coalesced row loads, conflict-free padded column reads).  N == 1 degenerates to a
+// contiguous (inner) reduction in torch; it is handled by an 8-lane group through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCosMaxD1 = 4096;   // D limit of the N == 1 path (LDS staging)
+constexpr int kCosDC = 64;        // D-chunk staged per step: N x (64+1) floats <= 66.6 KB at N = 256
+
+__global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ featn_t, const float *__restrict__ featn_p,
+                                                     int N, int M, int D, const int32_t *__restrict__ n_valid,
+                                                     const int32_t *__restrict__ m_valid, float *__restrict__ cos_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y, m = blockIdx.x;
+    const int Nb = n_valid ? n_valid[b] : N;
+    const int Mb = m_valid ? m_valid[b] : M;
+    float *o = cos_out + ((int64_t)b * M + m) * N;
+    if (m >= Mb || Nb <= 0) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) o[n] = 0.0f;
+        return;
+    }
+    const float *q = featn_t + ((int64_t)b * M + m) * D;
+    const float *kbase = featn_p + (int64_t)b * N * D;
+    if (Nb == 1) {
+        float *prod = lds;                                   // [D]
+        for (int d = threadIdx.x; d < D; d += blockDim.x) prod[d] = q[d] * kbase[d];
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const float s = torder::inner_sum_group8(D, threadIdx.x, [&](long i) { return prod[i]; });
+            if (threadIdx.x == 0) o[0] = s;
+        }
+        for (int n = 1 + threadIdx.x; n < N; n += blockDim.x) o[n] = 0.0f;
+        return;
+    }
+    float *q_s = lds;                                        // [kCosDC]
+    float *tp = lds + kCosDC;                                // [Nb][kCosDC + 1]
+    const int n = threadIdx.x;
+    const bool live = n < Nb;
+    const bool class_a = n < torder::outer_class_bound(Nb);
+    torder::Cascade ca, c0, c1, c2, c3;
+    const long g4 = D / 4;
+    ca.init(D);
+    c0.init(g4); c1.init(g4); c2.init(g4); c3.init(g4);
+    float rem[3] = {0.0f, 0.0f, 0.0f};
+    for (int d0 = 0; d0 < D; d0 += kCosDC) {
+        const int dc = min(kCosDC, D - d0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < Nb * dc; i += blockDim.x) {
+            const int r = i / dc, c = i - r * dc;
+            tp[r * (kCosDC + 1) + c] = kbase[(int64_t)r * D + d0 + c];
+        }
+        if (threadIdx.x < dc) q_s[threadIdx.x] = q[d0 + threadIdx.x];
+        __syncthreads();
+        if (live) {
+            const float *row = tp + n * (kCosDC + 1);
+            if (class_a) {
+                for (int dd = 0; dd < dc; ++dd) ca.push(q_s[dd] * row[dd]);
+            } else {
+                for (int dd = 0; dd < dc; ++dd) {
+                    const long d = d0 + dd;
+                    const float p = q_s[dd] * row[dd];
+                    if (d < 4 * g4) {
+                        switch (d & 3) {
+                            case 0: c0.push(p); break;
+                            case 1: c1.push(p); break;
+                            case 2: c2.push(p); break;
+                            default: c3.push(p); break;
+                        }
+                    } else {
+                        rem[d - 4 * g4] = p;
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        float r;
+        if (class_a) {
+            r = ca.finish();
+        } else {
+            r = c0.finish();
+            const float p1 = c1.finish(), p2 = c2.finish(), p3 = c3.finish();
+            for (long i = 4 * g4; i < D; ++i) r = r + rem[i - 4 * g4];
+            r = r + p1;
+            r = r + p2;
+            r = r + p3;
+        }
+        o[n] = r;
+    }
+    for (int j = Nb + threadIdx.x; j < N; j += blockDim.x) o[j] = 0.0f;
+}
+
+}  // namespace dmm
+
+extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, float *out, float *norms,
+                                         dmm_stream_t stream) {
+    if (rows < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (rows == 0 || D == 0) return DMM_OK;
+    if (!in || !out) return DMM_ERR_BAD_ARG;
+    const int64_t blocks = (rows + 31) / 32;
+    hipLaunchKernelGGL(dmm::feature_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in,
+                       rows, D, out, norms);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B, int N, int M, int D,
+                              const int32_t *n_valid, const int32_t *m_valid, float *cos_out, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || N == 0 || M == 0) return DMM_OK;
+    if (!featn_t || !featn_p || !cos_out) return DMM_ERR_BAD_ARG;
+    if (N > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
+    const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+    size_t lds = sizeof(float) * ((size_t)dmm::kCosDC + (size_t)N * (dmm::kCosDC + 1));
+    if (N == 1 || n_valid) {
+        const size_t l1 = sizeof(float) * (size_t)D;
+        lds = l1 > lds ? l1 : lds;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(dmm::cosine_kernel, dim3(M, B), dim3(threads), lds, (hipStream_t)stream, featn_t, featn_p, N, M,
+                       D, n_valid, m_valid, cos_out);
+    return dmm::check_launch();
+}

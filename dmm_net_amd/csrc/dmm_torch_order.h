@@ -1,0 +1,162 @@
+// dmm_torch_order.h -- fp32 reductions in the SUMMATION ORDER of the reference's torch CPU kernels.
+//
+// Why: relax_matching's early exits compare fp32 norms for exact equality (reference
+// dmm/modules/submodules/relax_match.py:88-89, :96-98).  Once the iteration has converged, whether
+// the exit fires at step k or k+2 depends on the last ulp of the row / column sums, and
+// R = mean(X_list) then moves by ~|X* - R| / k (1e-2, not 1e-5).  The golden vectors were captured
+// from the reference on torch 2.10 CPU, whose reductions are ATen's cascade sums (AVX2 dispatch, 8 fp32
+// lanes; third-party arithmetic: aten/src/ATen/native/cpu/SumKernel.cpp `cascade_sum`,
+// ReduceOpsKernel.cpp norm fast path).  oracle/dmm_oracle.c restates those orders and is bit exact
+// against every golden; the device routines below follow the same orders, so the HIP solver and cosine
+// are bit exact too (tests/test_gpu_parity.py).  All adds/muls here are single IEEE ops (the library
+// is compiled with -ffp-contract=off); explicit __builtin_fmaf marks the fused ones.
+#pragma once
+#include "dmm_common.h"
+
+namespace dmm {
+namespace torder {
+
+constexpr int TV = 8;   // Vectorized<float>::size() under the AVX2 dispatch
+
+__device__ __forceinline__ int ceil_log2(long x) {
+    int l = 0;
+    while ((1L << l) < x) ++l;
+    return x <= 1 ? 0 : l;
+}
+
+// One accumulator chain of ATen's multi_row_sum (4 cascade levels, level_step = 2^lp rows).
+struct Cascade {
+    float a0, a1, a2, a3;
+    int lp;
+    long i;
+    __device__ __forceinline__ void init(long size) {
+        a0 = a1 = a2 = a3 = 0.0f;
+        i = 0;
+        const int l = ceil_log2(size) / 4;
+        lp = l > 4 ? l : 4;
+    }
+    __device__ __forceinline__ void push(float v) {
+        a0 = a0 + v;
+        ++i;
+        const long mask = (1L << lp) - 1;
+        if ((i & mask) == 0) {   // a full level_step block just completed
+            a1 = a1 + a0; a0 = 0.0f;
+            if ((i & (mask << lp)) != 0) return;
+            a2 = a2 + a1; a1 = 0.0f;
+            if ((i & (mask << (2 * lp))) != 0) return;
+            a3 = a3 + a2; a2 = 0.0f;
+        }
+    }
+    __device__ __forceinline__ float finish() {
+        a0 = a0 + a1;
+        a0 = a0 + a2;
+        a0 = a0 + a3;
+        return a0;
+    }
+};
+
+// row_sum of `size` scalar items x(i): 4-way ILP split, remainder to chain 0, then 0+1+2+3.
+template <typename F>
+__device__ __forceinline__ float row_sum_scalar(long size, F x) {
+    Cascade c0, c1, c2, c3;
+    const long g = size / 4;
+    c0.init(g); c1.init(g); c2.init(g); c3.init(g);
+    for (long q = 0; q < g; ++q) {
+        c0.push(x(4 * q)); c1.push(x(4 * q + 1)); c2.push(x(4 * q + 2)); c3.push(x(4 * q + 3));
+    }
+    float p0 = c0.finish();
+    const float p1 = c1.finish(), p2 = c2.finish(), p3 = c3.finish();
+    for (long i = 4 * g; i < size; ++i) p0 = p0 + x(i);
+    p0 = p0 + p1;
+    p0 = p0 + p2;
+    p0 = p0 + p3;
+    return p0;
+}
+
+// Column class of ATen's outer sum over the rows of a contiguous [rows, m] matrix: columns below the
+// returned bound are reduced by multi_row_sum (one cascade chain), the rest by row_sum (ILP-4).
+__device__ __forceinline__ int outer_class_bound(int m) { return m >= TV ? 32 * (m / 32) : 4 * (m / 4); }
+
+// Sum over `size` values x(i) of ONE column of such a matrix.
+template <typename F>
+__device__ __forceinline__ float outer_sum_col(long size, bool class_a, F x) {
+    if (class_a) {
+        Cascade c;
+        c.init(size);
+        for (long i = 0; i < size; ++i) c.push(x(i));
+        return c.finish();
+    }
+    return row_sum_scalar(size, x);
+}
+
+// DPP row_shl:K -- lane i reads lane i+K of its 16-lane row (K <= 7 keeps an 8-lane group inside it).
+template <int K>
+__device__ __forceinline__ float shl_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + K, 0xF, 0xF, false));
+}
+// acc + v[group lane 0] + v[1] + ... + v[7] in that order; valid in lane 0 of every aligned 8-lane group.
+__device__ __forceinline__ float add_group8_seq(float acc, float v) {
+    acc = acc + v;
+    acc = acc + shl_f32<1>(v);
+    acc = acc + shl_f32<2>(v);
+    acc = acc + shl_f32<3>(v);
+    acc = acc + shl_f32<4>(v);
+    acc = acc + shl_f32<5>(v);
+    acc = acc + shl_f32<6>(v);
+    acc = acc + shl_f32<7>(v);
+    return acc;
+}
+
+// Inner (contiguous) sum of x[0..n) in ATen's vectorized_inner_sum order, computed by an aligned group of
+// 8 lanes (l = lane & 7); the result is valid in the group's lane 0.  x(i) must be readable by all 8 lanes.
+template <typename F>
+__device__ __forceinline__ float inner_sum_group8(long n, int l, F x) {
+    if (n < TV) return row_sum_scalar(n, x);           // scalar_inner_sum (every lane computes the same)
+    const long vs = n / TV, g = vs / 4;
+    Cascade c0, c1, c2, c3;
+    c0.init(g); c1.init(g); c2.init(g); c3.init(g);
+    for (long q = 0; q < g; ++q) {
+        c0.push(x(TV * (4 * q) + l)); c1.push(x(TV * (4 * q + 1) + l));
+        c2.push(x(TV * (4 * q + 2) + l)); c3.push(x(TV * (4 * q + 3) + l));
+    }
+    float p0 = c0.finish();
+    const float p1 = c1.finish(), p2 = c2.finish(), p3 = c3.finish();
+    for (long i = 4 * g; i < vs; ++i) p0 = p0 + x(TV * i + l);
+    p0 = p0 + p1;
+    p0 = p0 + p2;
+    p0 = p0 + p3;                                       // vec[l]
+    float acc = 0.0f;
+    for (long k = vs * TV; k < n; ++k) acc = acc + x(k);
+    return add_group8_seq(acc, p0);
+}
+
+// ||x[0..n)||_2 in the order of ATen's 2-norm fast path: 8 fma lanes, lanes added in order, tail in groups
+// of 4 (square rounded, then added), final < 4 remainder fused.  Computed by an aligned 8-lane group,
+// valid in its lane 0.
+template <typename F>
+__device__ __forceinline__ float norm2_group8(long n, int l, F x) {
+    float a = 0.0f;
+    const long nv = n - (n % TV);
+    for (long d = 0; d < nv; d += TV) {
+        const float v = x(d + l);
+        a = __builtin_fmaf(v, v, a);
+    }
+    float b = add_group8_seq(0.0f, a);                  // 0 + a0 is exact; then + a1 ... + a7
+    long d = nv;
+    for (; n - d >= 4; d += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = x(d + q);
+            const float sq = v * v;
+            b = b + sq;
+        }
+    }
+    for (; d < n; ++d) {
+        const float v = x(d);
+        b = __builtin_fmaf(v, v, b);
+    }
+    return __builtin_sqrtf(b);
+}
+
+}  // namespace torder
+}  // namespace dmm

@@ -78,27 +78,40 @@ def feature_normalize(x: torch.Tensor, want_norms: bool = False):
     return (out, norms) if want_norms else out
 
 
-def relax_match(featn_t, featn_p, inter, area_p, area_t, score_p, *, score_weight, max_iter, proj_iter, lr,
-                is_test, n_valid=None, m_valid=None, want_cos=False, want_x=False):
-    """Similarity + relaxed assignment + scores for B frames.  Returns a dict of tensors."""
-    _need_gpu(featn_t, featn_p, inter)
+def cosine(featn_t: torch.Tensor, featn_p: torch.Tensor, n_valid=None, m_valid=None) -> torch.Tensor:
+    """cos [B,M,N] of normalised rows featn_t [B,M,D], featn_p [B,N,D] (match_helper.py:59-63)."""
+    _need_gpu(featn_t, featn_p)
+    featn_t, featn_p = featn_t.contiguous().float(), featn_p.contiguous().float()
     B, M, D = featn_t.shape
     N = featn_p.shape[1]
+    out = torch.empty((B, M, N), dtype=torch.float32, device=featn_t.device)
+    with torch.cuda.device(featn_t.device):
+        rc = _lib.load().dmm_cosine_f32(_ptr(featn_t), _ptr(featn_p), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
+                                        _ptr(out), _stream(featn_t))
+    _lib.check(rc, "dmm_cosine_f32")
+    return out
+
+
+def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test,
+                n_valid=None, m_valid=None, want_x=False):
+    """Similarity mix + relaxed assignment + scores for B frames.  cos [B,M,N] = feature_sim.
+    Returns dict(sim, R, Rb, match_score, det_score, iters, X)."""
+    _need_gpu(cos, inter)
+    B, M, N = cos.shape
     Pp = padded_width(N, M)
-    dev = featn_t.device
+    dev = cos.device
     f32 = dict(dtype=torch.float32, device=dev)
     out = dict(sim=torch.empty((B, M, N), **f32), R=torch.empty((B, M, Pp), **f32), Rb=torch.empty((B, M, Pp), **f32),
                match_score=torch.empty((B, M), **f32), det_score=torch.empty((B, M), **f32),
                iters=torch.empty((B,), dtype=torch.int32, device=dev),
-               cos=torch.empty((B, M, N), **f32) if want_cos else None,
                X=torch.empty((B, M, Pp), **f32) if want_x else None)
-    featn_t, featn_p, score_p = featn_t.contiguous(), featn_p.contiguous(), score_p.contiguous().float()
+    cos, score_p = cos.contiguous().float(), score_p.contiguous().float()
     with torch.cuda.device(dev):
         rc = _lib.load().dmm_relax_match_f32(
-            _ptr(featn_t), _ptr(featn_p), D, _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M,
-            _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test),
-            _ptr(out["cos"]), _ptr(out["sim"]), _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]),
-            _ptr(out["det_score"]), _ptr(out["iters"]), _ptr(out["X"]), _stream(featn_t))
+            _ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
+            float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
+            _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]), _ptr(out["det_score"]), _ptr(out["iters"]),
+            _ptr(out["X"]), _stream(cos))
     _lib.check(rc, "dmm_relax_match_f32")
     return out
 

@@ -86,28 +86,35 @@ DMM_API int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, floa
                               float *norms /*[rows] or NULL*/, dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * (3) Similarity + relaxed assignment + scores, one frame per wave(-group), solver state
+ * (2b) Cosine table of normalised rows: cos[b,m,n] = <featn_t[b,m,:], featn_p[b,n,:]>
+ * (second half of F.cosine_similarity, match_helper.py:59-63; == MatchModel's feature_sim for a
+ * single template-feature entry, match_model.py:71-76).  featn_* come from (2).  M <= 32.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_cosine_f32(const float *featn_t /*[B,M,D]*/, const float *featn_p /*[B,N,D]*/, int B, int N, int M,
+                           int D, const int32_t *n_valid, const int32_t *m_valid, float *cos_out /*[B,M,N]*/,
+                           dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Similarity mix + relaxed assignment + scores, one frame per wave(-group), solver state
  * resident in registers for all iterations.  Replaces, per frame:
- *   cos[m,n] = <tn_m, pn_n>                               match_helper.py:59-63 (second half)
- *   iou = inter / (union + 1e-6);  sim = (1-w)*cos + w*iou             match_model.py:89-90
+ *   iou = inter / (union + 1e-6);  sim = (1-w)*feature_sim + w*iou      match_model.py:89-90
  *   pad to [M, Pp];  C = -sim_pad                                      match_model.py:107-116
  *   relax_matching(C, max_iter, proj_iter, lr) and R = mean(X_list)
  *                                       relax_match.py:36-105, match_model.py:118-121
  *   logic = (R == rowmax) if is_test else (R > 0.01);  Rb = R*logic    match_model.py:124-130
  *   match_score = max_p clamp(R,0,1)*sim_pad;  det_score = sum_p score_p*Rb     :146-147
- * featn_t [B,M,D] / featn_p [B,N,D] are the normalised features of (2).
- * Outputs: cos (may be NULL) [B,M,N], sim [B,M,N], R / Rb [B,M,Pp], match_score /
- * det_score [B,M], iters [B] = executed outer iterations (len(X_list)-1), X_final (may be
- * NULL) [B,M,Pp].  Requires M <= DMM_MAX_TEMPLATES and Pp <= DMM_MAX_PROPOSALS.
+ * cos_in [B,M,N] is feature_sim (from (2b)).
+ * Outputs: sim [B,M,N], R (may be NULL) / Rb [B,M,Pp], match_score / det_score [B,M],
+ * iters (may be NULL) [B] = executed outer iterations (len(X_list)-1), X_final (may be NULL)
+ * [B,M,Pp].  Requires M <= DMM_MAX_TEMPLATES and Pp <= DMM_MAX_PROPOSALS.
  * ------------------------------------------------------------------------------------------- */
-DMM_API int dmm_relax_match_f32(const float *featn_t, const float *featn_p, int D,
-                        const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
-                        const float *score_p /*[B,N]*/, int B, int N, int M,
-                        const int32_t *n_valid, const int32_t *m_valid,
-                        float score_weight, int max_iter, int proj_iter, float lr, int is_test,
-                        float *cos_out, float *sim_out, float *R_out, float *Rb_out,
-                        float *match_score, float *det_score, int32_t *iters_out, float *X_final,
-                        dmm_stream_t stream);
+DMM_API int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                const int32_t *area_t, const float *score_p /*[B,N]*/, int B, int N, int M,
+                                const int32_t *n_valid, const int32_t *m_valid,
+                                float score_weight, int max_iter, int proj_iter, float lr, int is_test,
+                                float *sim_out, float *R_out, float *Rb_out,
+                                float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                dmm_stream_t stream);
 
 /* Solver only, on a caller-provided cost matrix C [B,n,m] (relax_matching itself,
  * relax_match.py:36-105): X_final, R = mean(X_list), cost list [B,max_iter+1] (may be NULL),

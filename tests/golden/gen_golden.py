@@ -18,6 +18,7 @@ are data only -- no reference source text is stored.  Groups follow SURVEY.md se
   G4 config 2 / config 5 shapes at 255x255: [M,N]-sized tables + checksums of the big output
   G5 edge cases (empty masks, 0.5 pixels, ties, no-column-minimum rows, zero sim, zero features)
   G6 backward of the layer wrt the features
+  G7 solver-only and cosine-only known answers on many [n, m] / (O, P, D) shapes (pins the reduction order)
   G8 the DMM_Model per-video harness steps (dmm_model.py:115-141) re-executed around the imported
      MatchModel (DMM_Model itself needs maskrcnn_benchmark and cannot be imported)
 """
@@ -153,6 +154,44 @@ def g1():
         k += 1
     d["n_rand"] = np.int32(k)
     save("g1_solver_kat", d)
+
+
+def g7():
+    """Solver-only KATs on many [n, m] shapes: pins the reduction order of the torch CPU build the
+    goldens come from (AVX2 cascade sums) for every kernel envelope, incl. early exits."""
+    rng = np.random.Generator(np.random.PCG64(707))
+    d = {}
+    shapes = [(1, 2), (1, 9), (2, 3), (3, 4), (4, 5), (5, 6), (7, 8), (3, 7), (8, 9), (9, 10), (10, 11), (5, 16),
+              (5, 31), (5, 32), (5, 33), (10, 40), (10, 48), (10, 63), (10, 64), (12, 65), (15, 100), (16, 17),
+              (16, 128), (17, 129), (20, 21), (20, 200), (24, 255), (31, 256), (32, 33), (32, 256), (10, 50)]
+    k = 0
+    for (n, m) in shapes:
+        for (mi, pi) in ((12, 4), (60, 8)):
+            if n * m > 4000 and mi > 12:
+                continue
+            Cn = -rng.random((n, m), dtype=np.float32)
+            if k % 3 == 1:
+                Cn = (Cn * np.float32(0.2)).astype(np.float32)
+            X, costs, X_list, inner = relax_matching(T(Cn), max_iter=mi, proj_iter=pi, lr=0.1)
+            d.update(flat(f"k{k}", dict(C=Cn, X_final=X.numpy(), n_xlist=np.int32(len(X_list)),
+                                       R=(sum(X_list) / len(X_list)).numpy(), cost=np.asarray(costs, np.float32),
+                                       max_iter=np.int32(mi), proj_iter=np.int32(pi), lr=np.float32(0.1))))
+            k += 1
+    d["n"] = np.int32(k)
+    # cosine tables on several (O, P, D) incl. the degenerate P == 1 layout and ragged D
+    j = 0
+    for (O, P, D) in [(3, 8, 512), (10, 50, 512), (5, 3, 64), (2, 7, 33), (1, 1, 16), (4, 1, 512), (1, 5, 40),
+                      (20, 200, 512), (6, 33, 100), (7, 64, 256), (3, 65, 1024), (2, 40, 8), (2, 9, 7)]:
+        q = rng.standard_normal((O, D), dtype=np.float32)
+        kf = rng.standard_normal((P, D), dtype=np.float32)
+        if j == 2:
+            q[0] = 0
+            kf[1] = np.float32(1e-12)
+        c = match_helper.get_cosine_score(T(q), T(kf)).numpy()
+        d.update(flat(f"cos{j}", dict(q=q, k=kf, cos=c)))
+        j += 1
+    d["n_cos"] = np.int32(j)
+    save("g7_shapes", d)
 
 
 # ------------------------------------------------------------------------------------------ G2
@@ -351,6 +390,6 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

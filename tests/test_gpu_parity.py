@@ -1,7 +1,10 @@
 """GPU parity: the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
 
-Bars: integer tables bit exact; fp32 tables within 1e-5 of the reference (north_star), argmax and
-executed-iteration counts identical; test-mode mask mix bit exact w.r.t. R (single product).
+Bars.  Integer tables: bit exact.  fp32 tables (cosine, sim, every solver output, executed-iteration
+counts incl. the data-dependent early exits, R, logic, Rb, match/det scores): BIT EXACT -- the kernels
+follow the reference's torch-CPU summation order (dmm_torch_order.h).  Mask mix: bit exact in test mode
+(single product per pixel), within 1e-5 in train mode (torch.mm's blocked order is not restated).
+north_star's bar (assignment within 1e-5, argmax identical) is implied.
 """
 import numpy as np
 import pytest
@@ -44,11 +47,13 @@ def run_frame(fr, max_iter, proj_iter, is_test):
     inter, ap, at = ops.iou_counts(pm, tm)
     pn = ops.feature_normalize(dev(fr.proposed_feature)[None])
     tn = ops.feature_normalize(dev(fr.template_feature)[None])
-    r = ops.relax_match(tn, pn, inter, ap, at, dev(fr.proposal_score)[None], score_weight=0.3, max_iter=max_iter,
-                        proj_iter=proj_iter, lr=0.1, is_test=is_test, want_cos=True, want_x=True)
+    cos = ops.cosine(tn, pn)
+    r = ops.relax_match(cos, inter, ap, at, dev(fr.proposal_score)[None], score_weight=0.3, max_iter=max_iter,
+                        proj_iter=proj_iter, lr=0.1, is_test=is_test, want_x=True)
     full = ops.mask_mix(r["Rb"], pm)
     torch.cuda.synchronize()
     out = {k: (v[0].cpu().numpy() if v is not None else None) for k, v in r.items()}
+    out["cos"] = cos[0].cpu().numpy()
     out.update(inter=inter[0].cpu().numpy(), area_p=ap[0].cpu().numpy(), area_t=at[0].cpu().numpy(),
                full_outmask=full[0].cpu().numpy())
     return out
@@ -57,21 +62,27 @@ def run_frame(fr, max_iter, proj_iter, is_test):
 def check_against_golden(o, g, is_test, big=False):
     assert np.array_equal(o["inter"], g["inter"])
     assert np.array_equal(o["area_p"], g["area_p"]) and np.array_equal(o["area_t"], g["area_t"])
-    close(o["cos"], g["cos"], 2e-6)
-    close(o["sim"], g["sim"], 2e-6)
+    assert np.array_equal(o["cos"], g["cos"]), np.abs(o["cos"] - g["cos"]).max()
+    assert np.array_equal(o["sim"], g["sim"]), np.abs(o["sim"] - g["sim"]).max()
     assert int(o["iters"]) + 1 == int(g["n_xlist"])
-    close(o["R"], g["R"])
+    assert np.array_equal(o["R"], g["R"]), np.abs(o["R"] - g["R"]).max()
     assert np.array_equal(o["R"].argmax(1), g["argmax"]), "argmax must be identical"
-    close(o["Rb"], g["Rb"])
-    assert np.array_equal((o["Rb"] != 0), (g["Rb"] != 0)), "logic mask must be identical"
-    close(o["match_score"], g["match_score"])
-    close(o["det_score"], g["det_score"])
+    assert np.array_equal(o["Rb"], g["Rb"])
+    assert np.array_equal((o["Rb"] != 0), (g["logic"] != 0) & (g["Rb"] != 0))
+    assert np.array_equal(o["match_score"], g["match_score"])
+    assert np.array_equal(o["det_score"], g["det_score"]), np.abs(o["det_score"] - g["det_score"]).max()
     if "X_final" in g:
-        close(o["X"], g["X_final"])
+        assert np.array_equal(o["X"], g["X_final"])
     if big:
-        close(o["full_outmask"].reshape(o["full_outmask"].shape[0], -1)[:, ::997], g["outmask_sample"])
+        samp = o["full_outmask"].reshape(o["full_outmask"].shape[0], -1)[:, ::997]
+        if is_test:
+            assert np.array_equal(samp, g["outmask_sample"])
+        else:
+            close(samp, g["outmask_sample"])
         s = o["full_outmask"].astype(np.float64).reshape(o["full_outmask"].shape[0], -1).sum(1)
-        assert np.allclose(s, g["outmask_sum"], rtol=1e-5, atol=1e-2)
+        assert np.allclose(s, g["outmask_sum"], rtol=1e-6, atol=1e-3)
+    elif is_test:
+        assert np.array_equal(o["full_outmask"], g["full_outmask"])
     else:
         close(o["full_outmask"], g["full_outmask"])
 
@@ -122,17 +133,15 @@ def test_iou_counts_batched_strided_ragged():
 
 # ------------------------------------------------------------------------------------ solver
 def test_g1_kat_solver():
+    """The reference's own self-test (relax_match.py:108-119): exits at step 57 on the reference; so do we."""
     g = golden("g1_solver_kat")
     r = ops.relax_solve(dev(g["C"])[None], 100, 100, 0.1)
     X = r["X"][0].cpu().numpy()
-    # the reference's own self-test criterion: the relaxed solution is the Hungarian permutation
     assert np.array_equal(np.round(X).argmax(1), g["hungarian_cols"])
-    close(X, g["X_final"])                       # same fixed point
-    # the exit step (57 on the reference's CPU build) is chaotic in the last ulp of the cost norm:
-    # require a converged exit well before max_iter and the same cost plateau
-    it = int(r["iters"][0])
-    assert 30 <= it < 100
-    close(r["cost"][0, it], g["cost"][-1], 2e-5)
+    assert int(r["iters"][0]) + 1 == int(g["n_xlist"]) == 58
+    assert np.array_equal(X, g["X_final"])
+    assert np.array_equal(r["R"][0].cpu().numpy(), g["R"])
+    assert np.array_equal(r["cost"][0, :58].cpu().numpy(), g["cost"])
 
 
 def test_g1_random_costs_solver():
@@ -141,25 +150,49 @@ def test_g1_random_costs_solver():
         c = g.group(f"rand{k}")
         mi, pi = int(c["max_iter"]), int(c["proj_iter"])
         r = ops.relax_solve(dev(c["C"])[None], mi, pi, float(c["lr"]))
-        full_run = int(c["n_xlist"]) == mi + 1
-        if full_run:                                  # no early exit on the reference: must match step for step
-            assert int(r["iters"][0]) == mi, k
-            close(r["R"][0], c["R"])
-            close(r["cost"][0], c["cost"], 2e-5)
-        close(r["X"][0], c["X_final"], 2e-5)
+        it = int(r["iters"][0])
+        assert it + 1 == int(c["n_xlist"]), (k, c["C"].shape, it, int(c["n_xlist"]))
+        assert np.array_equal(r["X"][0].cpu().numpy(), c["X_final"]), k
+        assert np.array_equal(r["R"][0].cpu().numpy(), c["R"]), k
+        assert np.array_equal(r["cost"][0, :it + 1].cpu().numpy(), c["cost"]), k
+
+
+def test_g7_solver_shapes_bit_exact():
+    """Every kernel envelope (exact-row and guarded instantiations, 1/2/4 waves) incl. early exits."""
+    g = golden("g7_shapes")
+    for k in range(int(g["n"])):
+        c = g.group(f"k{k}")
+        mi, pi = int(c["max_iter"]), int(c["proj_iter"])
+        r = ops.relax_solve(dev(c["C"])[None], mi, pi, float(c["lr"]))
+        it = int(r["iters"][0])
+        assert it + 1 == int(c["n_xlist"]), (k, c["C"].shape, it, int(c["n_xlist"]))
+        assert np.array_equal(r["X"][0].cpu().numpy(), c["X_final"]), (k, c["C"].shape)
+        assert np.array_equal(r["R"][0].cpu().numpy(), c["R"]), (k, c["C"].shape)
+        assert np.array_equal(r["cost"][0, :it + 1].cpu().numpy(), c["cost"]), (k, c["C"].shape)
+
+
+def test_g7_cosine_shapes_bit_exact():
+    g = golden("g7_shapes")
+    for j in range(int(g["n_cos"])):
+        c = g.group(f"cos{j}")
+        tn = ops.feature_normalize(dev(c["q"])[None])
+        pn = ops.feature_normalize(dev(c["k"])[None])
+        out = ops.cosine(tn, pn)[0].cpu().numpy()
+        assert np.array_equal(out, c["cos"]), (j, c["q"].shape, c["k"].shape, np.abs(out - c["cos"]).max())
 
 
 def test_solver_batch_matches_oracle():
+    """Batched launch, random costs: bit exact against the oracle frame by frame."""
     rng = np.random.Generator(np.random.PCG64(11))
     for (n, m, mi, pi) in [(3, 4, 20, 5), (10, 50, 20, 5), (10, 50, 40, 5), (5, 64, 10, 5), (20, 200, 20, 5),
-                           (32, 256, 5, 3), (1, 2, 20, 5), (16, 65, 10, 5), (9, 128, 10, 2)]:
+                           (32, 256, 5, 3), (1, 2, 20, 5), (16, 65, 10, 5), (9, 128, 10, 2), (13, 7, 30, 5)]:
         C = -rng.random((6, n, m), dtype=np.float32)
         r = ops.relax_solve(dev(C), mi, pi, 0.1)
         for b in range(C.shape[0]):
             o = oracle.relax(C[b], mi, pi, 0.1)
             assert int(r["iters"][b]) == o["iters"], (n, m, b)
-            close(r["R"][b], o["R"])
-            close(r["X"][b], o["X"])
+            assert np.array_equal(r["R"][b].cpu().numpy(), o["R"]), (n, m, b)
+            assert np.array_equal(r["X"][b].cpu().numpy(), o["X"]), (n, m, b)
 
 
 # ------------------------------------------------------------------------------------ whole layer
@@ -213,8 +246,8 @@ def test_matchmodel_dropin_forward(is_test):
                                   dev(fr.mask_last_occurence), dev(fr.proposal_score), dev(fr.targets))
     assert fo2 is fo                                    # the reference returns full_outmask twice (:47)
     close(fo, c["full_outmask"])
-    close(ms, c["match_score"])
-    close(ds, c["det_score"])
+    assert np.array_equal(ms.detach().cpu().numpy(), c["match_score"])
+    assert np.array_equal(ds.detach().cpu().numpy(), c["det_score"])
     assert abs(float(loss["cost_loss"]) - float(c["cost_loss"])) < 1e-6
     fo, ms, ds, _, loss = model(dev(fr.proposed_feature), dev(fr.proposed_mask), [dev(fr.template_feature)],
                                 dev(fr.mask_last_occurence), dev(fr.proposal_score), None)
@@ -260,7 +293,7 @@ def test_full_size_batch_properties():
     R, Rb = plan.R.cpu().numpy(), plan.Rb.cpu().numpy()
     # (1) frames are independent: frame 0 of the batch == the golden single-frame result
     g = golden("g4_big").group("c2/structured/t1")
-    close(R[0], g["R"])
+    assert np.array_equal(R[0], g["R"])
     assert np.array_equal(R[0].argmax(1), g["argmax"])
     # (2) planted assignment recovered on every frame, one selected proposal per template
     for b in range(B):

@@ -146,3 +146,26 @@ def test_greedy_init_semantics():
     assert list(oracle.greedy_init(C)) == [0, 0, 0]
     C = np.array([[-0.9, -0.1, -0.2], [-0.1, -0.8, -0.3]], np.float32)
     assert list(oracle.greedy_init(C)) == [0, 1]
+
+
+# ------------------------------------------------------------------------------------------ G7
+def test_g7_solver_shapes_bit_exact():
+    g = golden("g7_shapes")
+    early = 0
+    for k in range(int(g["n"])):
+        c = g.group(f"k{k}")
+        r = oracle.relax(c["C"], int(c["max_iter"]), int(c["proj_iter"]), float(c["lr"]))
+        assert r["iters"] + 1 == int(c["n_xlist"]), (k, c["C"].shape)
+        assert np.array_equal(r["X"], c["X_final"]), (k, c["C"].shape)
+        assert np.array_equal(r["R"], c["R"]), (k, c["C"].shape)
+        assert np.array_equal(r["cost"], c["cost"]), (k, c["C"].shape)
+        early += int(int(c["n_xlist"]) < int(c["max_iter"]) + 1)
+    assert early > 0          # the set exercises the early-exit branch too
+
+
+def test_g7_cosine_shapes_bit_exact():
+    g = golden("g7_shapes")
+    for j in range(int(g["n_cos"])):
+        c = g.group(f"cos{j}")
+        out = oracle.cosine(c["q"], c["k"])
+        assert np.array_equal(out, c["cos"]), (j, c["q"].shape, c["k"].shape, np.abs(out - c["cos"]).max())

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Per-stage timing of the matching layer on the GPU (HIP events on torch's current stream).
+usage: python tools/stage_timing.py [B ...]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dmm_net_amd import ops, synth
+
+dev = "cuda:0"
+c = synth.CONFIGS[2]
+N, M, H, W, D = c["P"], c["O"], c["H"], c["W"], c["D"]
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+for B in [int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]:
+    g = torch.Generator(device=dev).manual_seed(1)
+    pm = torch.rand((B, N, H, W), generator=g, device=dev)
+    tm = torch.rand((B, M, H, W), generator=g, device=dev)
+    pf = torch.randn((B, N, D), generator=g, device=dev)
+    tf = torch.randn((B, M, D), generator=g, device=dev)
+    sc = torch.rand((B, N), generator=g, device=dev)
+    inter, ap, at = ops.iou_counts(pm, tm)
+    pn, tn = ops.feature_normalize(pf), ops.feature_normalize(tf)
+    cos = ops.cosine(tn, pn)
+    r = ops.relax_match(cos, inter, ap, at, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
+    C = -r["sim"]
+    t_cost = timeit(lambda: ops.iou_counts(pm, tm))
+    t_norm = timeit(lambda: (ops.feature_normalize(pf), ops.feature_normalize(tf)))
+    t_cos = timeit(lambda: ops.cosine(tn, pn))
+    t_relax = timeit(lambda: ops.relax_match(cos, inter, ap, at, sc, score_weight=0.3, max_iter=20, proj_iter=5,
+                                             lr=0.1, is_test=1))
+    t_relax0 = timeit(lambda: ops.relax_match(cos, inter, ap, at, sc, score_weight=0.3, max_iter=0, proj_iter=0,
+                                              lr=0.1, is_test=1))
+    t_solve = timeit(lambda: ops.relax_solve(C, 20, 5, 0.1))
+    t_solve0 = timeit(lambda: ops.relax_solve(C, 0, 0, 0.1))
+    t_mix = timeit(lambda: ops.mask_mix(r["Rb"], pm))
+    gb = B * (N + M) * H * W * 4 / 1e9
+    print(f"B={B:5d} cost {t_cost:8.1f}us ({gb / t_cost * 1e6:7.0f} GB/s)  norm {t_norm:6.1f} cos {t_cos:6.1f}  relax_match {t_relax:7.1f} "
+          f"(iters=0: {t_relax0:6.1f})  solve-only {t_solve:7.1f} (init only {t_solve0:6.1f})  "
+          f"mix {t_mix:7.1f} ({B * 2 * M * H * W * 4 / t_mix / 1e3:6.0f} GB/s)", flush=True)
+    del pm, tm
+    torch.cuda.empty_cache()
