@@ -40,68 +40,105 @@ __global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__r
 constexpr int kCosMaxD1 = 4096;   // D limit of the N == 1 path (LDS staging)
 constexpr int kCosDC = 64;        // D-chunk staged per step: N x (64+1) floats <= 66.6 KB at N = 256
 
+// block = 256 threads = `slots` template rows of TPM = 64*ceil(N/64) threads each; grid = (ceil(M/slots), B).
+// All slots of a block share the staged proposal tile.
 __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ featn_t, const float *__restrict__ featn_p,
-                                                     int N, int M, int D, const int32_t *__restrict__ n_valid,
+                                                     int N, int M, int D, int tpm, const int32_t *__restrict__ n_valid,
                                                      const int32_t *__restrict__ m_valid, float *__restrict__ cos_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.y, m = blockIdx.x;
+    const int b = blockIdx.y;
+    const int slots = 256 / tpm;
+    const int slot = threadIdx.x / tpm, n = threadIdx.x - slot * tpm;
+    const int m = blockIdx.x * slots + slot;
     const int Nb = n_valid ? n_valid[b] : N;
     const int Mb = m_valid ? m_valid[b] : M;
-    float *o = cos_out + ((int64_t)b * M + m) * N;
-    if (m >= Mb || Nb <= 0) {
-        for (int n = threadIdx.x; n < N; n += blockDim.x) o[n] = 0.0f;
-        return;
-    }
-    const float *q = featn_t + ((int64_t)b * M + m) * D;
+    const bool row_live = m < Mb && Nb > 0;
+    float *o = cos_out + ((int64_t)b * M + (m < M ? m : 0)) * N;
     const float *kbase = featn_p + (int64_t)b * N * D;
-    if (Nb == 1) {
-        float *prod = lds;                                   // [D]
-        for (int d = threadIdx.x; d < D; d += blockDim.x) prod[d] = q[d] * kbase[d];
-        __syncthreads();
-        if (threadIdx.x < 8) {
-            const float s = torder::inner_sum_group8(D, threadIdx.x, [&](long i) { return prod[i]; });
-            if (threadIdx.x == 0) o[0] = s;
+    const float *q = featn_t + ((int64_t)b * M + (m < M ? m : 0)) * D;
+    if (Nb <= 1) {                                           // uniform per block
+        if (Nb == 1) {
+            float *prod = lds + slot * D;                    // [slots][D]
+            if (row_live)
+                for (int d = n; d < D; d += tpm) prod[d] = q[d] * kbase[d];
+            __syncthreads();
+            if (row_live && n < 8) {
+                const float s = torder::inner_sum_group8(D, n, [&](long i) { return prod[i]; });
+                if (n == 0) o[0] = s;
+            }
         }
-        for (int n = 1 + threadIdx.x; n < N; n += blockDim.x) o[n] = 0.0f;
+        if (m < M)
+            for (int j = (row_live ? 1 : 0) + n; j < N; j += tpm) o[j] = 0.0f;
         return;
     }
-    float *q_s = lds;                                        // [kCosDC]
-    float *tp = lds + kCosDC;                                // [Nb][kCosDC + 1]
-    const int n = threadIdx.x;
-    const bool live = n < Nb;
+    float *q_s = lds;                                        // [slots][kCosDC]
+    float *tp = lds + slots * kCosDC;                        // [Nb][kCosDC + 1]
+    const bool live = row_live && n < Nb;
     const bool class_a = n < torder::outer_class_bound(Nb);
     torder::Cascade ca, c0, c1, c2, c3;
     const long g4 = D / 4;
     ca.init(D);
     c0.init(g4); c1.init(g4); c2.init(g4); c3.init(g4);
+    const bool fast_ok = ca.lp == 4 && c0.lp == 4;           // level_step == 16 everywhere
     float rem[3] = {0.0f, 0.0f, 0.0f};
     for (int d0 = 0; d0 < D; d0 += kCosDC) {
         const int dc = min(kCosDC, D - d0);
         __syncthreads();
-        for (int i = threadIdx.x; i < Nb * dc; i += blockDim.x) {
-            const int r = i / dc, c = i - r * dc;
-            tp[r * (kCosDC + 1) + c] = kbase[(int64_t)r * D + d0 + c];
+        if (dc == kCosDC && (D & 3) == 0) {                  // 16 float4 per row chunk, coalesced 256 B rows
+            for (int i = threadIdx.x; i < Nb * 16; i += 256) {
+                const int r = i >> 4, c4 = (i & 15) * 4;
+                const float4u v = *reinterpret_cast<const float4u *>(kbase + (int64_t)r * D + d0 + c4);
+                float *dst = tp + r * (kCosDC + 1) + c4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < Nb * dc; i += 256) {
+                const int r = i / dc, c = i - r * dc;
+                tp[r * (kCosDC + 1) + c] = kbase[(int64_t)r * D + d0 + c];
+            }
         }
-        if (threadIdx.x < dc) q_s[threadIdx.x] = q[d0 + threadIdx.x];
+        if (n < dc && m < M) q_s[slot * kCosDC + n] = q[d0 + n];   // tpm >= 64 >= dc
         __syncthreads();
-        if (live) {
-            const float *row = tp + n * (kCosDC + 1);
+        if (!live) continue;
+        const float *row = tp + n * (kCosDC + 1);
+        const float *qq = q_s + slot * kCosDC;
+        if (dc == kCosDC && fast_ok) {
             if (class_a) {
-                for (int dd = 0; dd < dc; ++dd) ca.push(q_s[dd] * row[dd]);
-            } else {
-                for (int dd = 0; dd < dc; ++dd) {
-                    const long d = d0 + dd;
-                    const float p = q_s[dd] * row[dd];
-                    if (d < 4 * g4) {
-                        switch (d & 3) {
-                            case 0: c0.push(p); break;
-                            case 1: c1.push(p); break;
-                            case 2: c2.push(p); break;
-                            default: c3.push(p); break;
-                        }
-                    } else {
-                        rem[d - 4 * g4] = p;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    float a = ca.a0;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) a = a + qq[16 * blk + t] * row[16 * blk + t];
+                    ca.a0 = a;
+                    ca.block16_done();
+                }
+            } else {                                          // 64 consecutive d = 16 per ILP chain (d0 % 64 == 0)
+                float a0 = c0.a0, a1 = c1.a0, a2 = c2.a0, a3 = c3.a0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    a0 = a0 + qq[4 * t] * row[4 * t];
+                    a1 = a1 + qq[4 * t + 1] * row[4 * t + 1];
+                    a2 = a2 + qq[4 * t + 2] * row[4 * t + 2];
+                    a3 = a3 + qq[4 * t + 3] * row[4 * t + 3];
+                }
+                c0.a0 = a0; c1.a0 = a1; c2.a0 = a2; c3.a0 = a3;
+                c0.block16_done(); c1.block16_done(); c2.block16_done(); c3.block16_done();
+            }
+        } else if (class_a) {
+            for (int dd = 0; dd < dc; ++dd) ca.push(qq[dd] * row[dd]);
+        } else {
+            for (int dd = 0; dd < dc; ++dd) {
+                const long d = d0 + dd;
+                const float p = qq[dd] * row[dd];
+                if (d < 4 * g4) {
+                    switch (d & 3) {
+                        case 0: c0.push(p); break;
+                        case 1: c1.push(p); break;
+                        case 2: c2.push(p); break;
+                        default: c3.push(p); break;
                     }
+                } else {
+                    rem[d - 4 * g4] = p;
                 }
             }
         }
@@ -120,7 +157,13 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ f
         }
         o[n] = r;
     }
-    for (int j = Nb + threadIdx.x; j < N; j += blockDim.x) o[j] = 0.0f;
+    if (m < M) {
+        if (row_live) {
+            for (int j = Nb + n; j < N; j += tpm) o[j] = 0.0f;
+        } else {
+            for (int j = n; j < N; j += tpm) o[j] = 0.0f;
+        }
+    }
 }
 
 }  // namespace dmm
@@ -143,18 +186,20 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (!featn_t || !featn_p || !cos_out) return DMM_ERR_BAD_ARG;
     if (N > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
     if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
-    const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
-    size_t lds = sizeof(float) * ((size_t)dmm::kCosDC + (size_t)N * (dmm::kCosDC + 1));
+    const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+    const int slots = 256 / tpm;
+    size_t lds = sizeof(float) * ((size_t)slots * dmm::kCosDC + (size_t)N * (dmm::kCosDC + 1));
     if (N == 1 || n_valid) {
-        const size_t l1 = sizeof(float) * (size_t)D;
+        const size_t l1 = sizeof(float) * (size_t)D * slots;
         lds = l1 > lds ? l1 : lds;
     }
+    if (lds > 160 * 1024) return DMM_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(dmm::cosine_kernel, dim3(M, B), dim3(threads), lds, (hipStream_t)stream, featn_t, featn_p, N, M,
-                       D, n_valid, m_valid, cos_out);
+    hipLaunchKernelGGL(dmm::cosine_kernel, dim3((M + slots - 1) / slots, B), dim3(256), lds, (hipStream_t)stream,
+                       featn_t, featn_p, N, M, D, tpm, n_valid, m_valid, cos_out);
     return dmm::check_launch();
 }

@@ -13,6 +13,8 @@ namespace dmm {
 
 constexpr int kMixThreads = 256;
 
+constexpr int kMixUnroll = 8;    // plane loads in flight per thread
+
 // grid = (pixel blocks, B); each thread owns 4 consecutive pixels per step.
 template <typename T, int MT>
 __global__ __launch_bounds__(kMixThreads) void mask_mix_kernel(const float *__restrict__ Rb, const T *__restrict__ masks_p,
@@ -23,6 +25,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_kernel(const float *__re
                                                                int steps_per_wg) {
     __shared__ float w_s[MT * DMM_MAX_PROPOSALS];   // compacted weights [list pos][m]
     __shared__ int col_s[DMM_MAX_PROPOSALS];        // proposal index of each list entry
+    __shared__ unsigned rows_s[DMM_MAX_PROPOSALS];  // bit m set <=> weight [pos][m] != 0
     __shared__ int cnt_s;
     const int b = blockIdx.y;
     int Nb = n_valid ? n_valid[b] : N;
@@ -31,19 +34,18 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_kernel(const float *__re
     const float *Rb_b = Rb + (int64_t)b * M * Pp;
 
     // Build the list of proposal planes that carry any non-zero weight (ascending n).
-    if (threadIdx.x == 0) cnt_s = 0;
-    __syncthreads();
     if (threadIdx.x < 64) {          // one wave scans the columns in order: ballot keeps it sorted
         int base = 0;
         for (int n0 = 0; n0 < Nb; n0 += 64) {
             const int n = n0 + threadIdx.x;
-            bool any = false;
+            unsigned rows = 0;
             if (n < Nb)
-                for (int m = 0; m < Mb; ++m) any |= (Rb_b[(int64_t)m * Pp + n] != 0.0f);
-            const unsigned long long bal = __ballot(any);
-            if (any) {
+                for (int m = 0; m < Mb; ++m) rows |= (Rb_b[(int64_t)m * Pp + n] != 0.0f) ? (1u << m) : 0u;
+            const unsigned long long bal = __ballot(rows != 0);
+            if (rows) {
                 const int pos = base + __builtin_popcountll(bal & ((1ull << threadIdx.x) - 1ull));
                 col_s[pos] = n;
+                rows_s[pos] = rows;
                 for (int m = 0; m < MT; ++m) w_s[pos * MT + m] = m < Mb ? Rb_b[(int64_t)m * Pp + n] : 0.0f;
             }
             base += __builtin_popcountll(bal);
@@ -60,31 +62,42 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_kernel(const float *__re
     const int s_end = min(nsteps, s_begin + steps_per_wg);
     for (int s = s_begin; s < s_end; ++s) {
         const int x = (s * kMixThreads + threadIdx.x) * 4;
-        if (x >= HW) break;
+        const bool in = x < HW;
         const bool full = x + 3 < HW;
         float acc[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[m][k] = 0.0f;
-        for (int e = 0; e < cnt; ++e) {
-            const T *plane = Pb + (int64_t)col_s[e] * sp_n;
-            float v[4];
-            if (full) {
-                MaskIO<T>::load4(plane + x, v);
-            } else {
+        for (int e0 = 0; e0 < cnt; e0 += kMixUnroll) {
+            float v[kMixUnroll][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = x + k < HW ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+            for (int u = 0; u < kMixUnroll; ++u) {
+                const int e = e0 + u < cnt ? e0 + u : cnt - 1;       // clamp: extra loads hit the same plane
+                const T *plane = Pb + (int64_t)col_s[e] * sp_n;
+                if (full) {
+                    MaskIO<T>::load4(plane + x, v[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = (in && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                }
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float w = w_s[e * MT + m];
-                if (w != 0.0f) {                 // wave-uniform
+            for (int u = 0; u < kMixUnroll; ++u) {
+                if (e0 + u < cnt) {                                   // wave-uniform
+                    const unsigned rows = rows_s[e0 + u];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[m][k] = __builtin_fmaf(w, v[k], acc[m][k]);
+                    for (int m = 0; m < MT; ++m) {
+                        if (rows & (1u << m)) {                       // wave-uniform
+                            const float w = w_s[(e0 + u) * MT + m];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[m][k] = __builtin_fmaf(w, v[u][k], acc[m][k]);
+                        }
+                    }
                 }
             }
         }
+        if (!in) continue;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             if (m < M) {                          // rows >= Mb are written as zeros

@@ -111,7 +111,7 @@ __device__ __forceinline__ void row_sums_torch_order(const float *xbuf, int n, i
     const int l = threadIdx.x & 7;
     for (int r = threadIdx.x >> 3; r < n; r += 8 * NG) {
         const float *x = xbuf + r * m;
-        const float s = torder::inner_sum_group8(m, l, [&](long i) { return x[i]; });
+        const float s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });   // m <= 256
         if (l == 0) rsbuf[r] = s;
     }
     __syncthreads();                                   // rsbuf complete, xbuf free again

@@ -47,6 +47,15 @@ struct Cascade {
             a3 = a3 + a2; a2 = 0.0f;
         }
     }
+    // after the caller added exactly 16 values to a0 itself (lp == 4 only: level_step == 16)
+    __device__ __forceinline__ void block16_done() {
+        i += 16;
+        a1 = a1 + a0; a0 = 0.0f;
+        if ((i & 0xF0L) != 0) return;
+        a2 = a2 + a1; a1 = 0.0f;
+        if ((i & 0xF00L) != 0) return;
+        a3 = a3 + a2; a2 = 0.0f;
+    }
     __device__ __forceinline__ float finish() {
         a0 = a0 + a1;
         a0 = a0 + a2;
@@ -130,6 +139,31 @@ __device__ __forceinline__ float inner_sum_group8(long n, int l, F x) {
     return add_group8_seq(acc, p0);
 }
 
+// Same as inner_sum_group8 for n < 512 (no cascade level is ever reached: the solver's rows, n <= 256):
+// plain sequential chains, no per-element bookkeeping.
+template <typename F>
+__device__ __forceinline__ float inner_sum_group8_small(int n, int l, F x) {
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    if (n < TV) {                                       // scalar_inner_sum: ILP-4 over single elements
+        const int g = n >> 2;
+        for (int q = 0; q < g; ++q) { p0 = p0 + x(4 * q); p1 = p1 + x(4 * q + 1); p2 = p2 + x(4 * q + 2); p3 = p3 + x(4 * q + 3); }
+        for (int i = 4 * g; i < n; ++i) p0 = p0 + x(i);
+        p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+        return p0;
+    }
+    const int vs = n >> 3, g = vs >> 2;
+    for (int q = 0; q < g; ++q) {
+        const float v0 = x(TV * (4 * q) + l), v1 = x(TV * (4 * q + 1) + l), v2 = x(TV * (4 * q + 2) + l),
+                    v3 = x(TV * (4 * q + 3) + l);
+        p0 = p0 + v0; p1 = p1 + v1; p2 = p2 + v2; p3 = p3 + v3;
+    }
+    for (int i = 4 * g; i < vs; ++i) p0 = p0 + x(TV * i + l);
+    p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;           // vec[l]
+    float acc = 0.0f;
+    for (int k = vs * TV; k < n; ++k) acc = acc + x(k);
+    return add_group8_seq(acc, p0);
+}
+
 // ||x[0..n)||_2 in the order of ATen's 2-norm fast path: 8 fma lanes, lanes added in order, tail in groups
 // of 4 (square rounded, then added), final < 4 remainder fused.  Computed by an aligned 8-lane group,
 // valid in its lane 0.
@@ -137,8 +171,16 @@ template <typename F>
 __device__ __forceinline__ float norm2_group8(long n, int l, F x) {
     float a = 0.0f;
     const long nv = n - (n % TV);
-    for (long d = 0; d < nv; d += TV) {
-        const float v = x(d + l);
+    long d4 = 0;
+    for (; d4 + 4 * TV <= nv; d4 += 4 * TV) {           // 4 independent loads in flight, fmas stay in order
+        const float v0 = x(d4 + l), v1 = x(d4 + TV + l), v2 = x(d4 + 2 * TV + l), v3 = x(d4 + 3 * TV + l);
+        a = __builtin_fmaf(v0, v0, a);
+        a = __builtin_fmaf(v1, v1, a);
+        a = __builtin_fmaf(v2, v2, a);
+        a = __builtin_fmaf(v3, v3, a);
+    }
+    for (; d4 < nv; d4 += TV) {
+        const float v = x(d4 + l);
         a = __builtin_fmaf(v, v, a);
     }
     float b = add_group8_seq(0.0f, a);                  // 0 + a0 is exact; then + a1 ... + a7

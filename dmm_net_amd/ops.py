@@ -148,41 +148,123 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
 
 
 class ForwardPlan:
-    """Pre-allocated outputs + workspace for the fused forward of B same-shaped frames
-    (``dmm_match_forward``): one ctypes call per batch, nothing allocated in the timed region."""
+    """Pre-allocated forward of B same-shaped frames: nothing is allocated or synchronised per call.
 
-    def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False):
+    Two execution shapes:
+
+    * ``pipeline=False`` -- one ``dmm_match_forward`` C call, all kernels back to back on the current stream;
+    * ``pipeline=True``  -- "streaming lane + latency lane".  The batch is split in two halves A, B.  The
+      current stream runs only the HBM-bound kernels, serialised at full bandwidth:
+      cost(A) -> cost(B) -> mix(A) -> mix(B).  A side stream runs the latency-bound ones:
+      normalise + cosine (all frames) -> solver(A) (after cost(A)) -> solver(B) (after cost(B)).
+      solver(A) hides under cost(B), solver(B) under mix(A); HIP events carry the dependencies, there is no
+      host synchronisation, and every output is complete in current-stream order when ``run`` returns.
+    """
+
+    def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
         self.mask_dtype = mask_dtype
+        self.pipeline = (B >= 64) if pipeline is None else bool(pipeline)
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.ws_bytes = int(L.dmm_workspace_bytes(B, N, M, D))
-        self.workspace = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
         self.full_outmask = torch.empty((B, M, H, W), **f32)
         self.match_score = torch.empty((B, M), **f32)
         self.det_score = torch.empty((B, M), **f32)
-        self.iters = torch.empty((B,), dtype=torch.int32, device=self.device)
-        self.sim = torch.empty((B, M, N), **f32) if want_tables else None
+        self.iters = torch.empty((B,), **i32)
+        self.sim = torch.empty((B, M, N), **f32)
         self.R = torch.empty((B, M, self.Pp), **f32) if want_tables else None
-        self.Rb = torch.empty((B, M, self.Pp), **f32) if want_tables else None
+        self.Rb = torch.empty((B, M, self.Pp), **f32)
+        if not self.pipeline:
+            self.ws_bytes = int(L.dmm_workspace_bytes(B, N, M, D))
+            self.workspace = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=self.device)
+            return
+        self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
+        # inter | area_p | area_t of one half are contiguous -> one memset per cost launch
+        self.counts = [torch.empty(((e - b) * (M * N + N + M),), **i32) for (b, e) in self.halves]
+        self.pn = torch.empty((B, N, D), **f32)
+        self.tn = torch.empty((B, M, D), **f32)
+        self.cos = torch.empty((B, M, N), **f32)
+        with torch.cuda.device(self.device):
+            self.side = torch.cuda.Stream(device=self.device)
+            self.ev_start = torch.cuda.Event()
+            self.ev_cost = [torch.cuda.Event() for _ in self.halves]
+            self.ev_solved = [torch.cuda.Event() for _ in self.halves]
+        self.cost_events = None          # optional [(start, end)] timing events, set by bench.py
+
+    def _tables(self, h):
+        (b, e) = self.halves[h]
+        nb, M, N = e - b, self.M, self.N
+        c = self.counts[h]
+        return c[:nb * M * N], c[nb * M * N:nb * (M * N + N)], c[nb * (M * N + N):]
 
     def run(self, masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1,
             is_test=1, n_valid=None, m_valid=None):
         _need_gpu(masks_p, masks_t, feat_p, feat_t, score_p)
         masks_p, sp_b, sp_n = _planes(masks_p)
         masks_t, st_b, st_m = _planes(masks_t)
-        assert masks_p.shape == (self.B, self.N, self.H, self.W) and masks_t.shape == (self.B, self.M, self.H, self.W)
+        B, N, M, H, W, D, Pp = self.B, self.N, self.M, self.H, self.W, self.D, self.Pp
+        HW = H * W
+        assert masks_p.shape == (B, N, H, W) and masks_t.shape == (B, M, H, W)
         assert masks_p.dtype == self.mask_dtype and masks_t.dtype == self.mask_dtype
         assert feat_p.is_contiguous() and feat_t.is_contiguous() and score_p.is_contiguous()
         assert feat_p.dtype == torch.float32 and feat_t.dtype == torch.float32 and score_p.dtype == torch.float32
+        L = _lib.load()
+        dt = _DT[self.mask_dtype]
+        if not self.pipeline:
+            with torch.cuda.device(self.device):
+                rc = L.dmm_match_forward(
+                    _ptr(masks_p), _ptr(masks_t), dt, _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M, HW, D, sp_b,
+                    sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
+                    float(lr), int(is_test), _ptr(self.full_outmask), _ptr(self.match_score), _ptr(self.det_score),
+                    _ptr(self.sim), _ptr(self.R), _ptr(self.Rb), _ptr(self.iters), _ptr(self.workspace), self.ws_bytes,
+                    _stream(masks_p))
+            _lib.check(rc, "dmm_match_forward")
+            return self.full_outmask, self.match_score, self.det_score
+
+        es = masks_p.element_size()
+        nv = lambda t, b: None if t is None else t.data_ptr() + 4 * b
         with torch.cuda.device(self.device):
-            rc = _lib.load().dmm_match_forward(
-                _ptr(masks_p), _ptr(masks_t), _DT[self.mask_dtype], _ptr(feat_p), _ptr(feat_t), _ptr(score_p), self.B,
-                self.N, self.M, self.H * self.W, self.D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
-                float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(self.full_outmask),
-                _ptr(self.match_score), _ptr(self.det_score), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),
-                _ptr(self.iters), _ptr(self.workspace), self.ws_bytes, _stream(masks_p))
-        _lib.check(rc, "dmm_match_forward")
+            main = torch.cuda.current_stream(self.device)
+            side = self.side
+            ms, ss = main.cuda_stream, side.cuda_stream
+            self.ev_start.record(main)
+            # ---- latency lane: normalise + cosine for every frame --------------------------------------------
+            side.wait_event(self.ev_start)
+            rc = L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ss)
+            rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ss)
+            rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
+                                   _ptr(self.cos), ss)
+            # ---- streaming lane: cost(A), cost(B) ------------------------------------------------------------
+            for h, (b, e) in enumerate(self.halves):
+                inter, ap, at = self._tables(h)
+                if self.cost_events is not None:
+                    self.cost_events[h][0].record(main)
+                rc |= L.dmm_iou_counts(masks_p.data_ptr() + es * b * sp_b, masks_t.data_ptr() + es * b * st_b, dt,
+                                       e - b, N, M, HW, sp_b, sp_n, st_b, st_m, nv(n_valid, b), nv(m_valid, b),
+                                       _ptr(inter), _ptr(ap), _ptr(at), ms)
+                if self.cost_events is not None:
+                    self.cost_events[h][1].record(main)
+                self.ev_cost[h].record(main)
+            # ---- latency lane: solver(h) as soon as cost(h) is done ------------------------------------------
+            for h, (b, e) in enumerate(self.halves):
+                inter, ap, at = self._tables(h)
+                side.wait_event(self.ev_cost[h])
+                rc |= L.dmm_relax_match_f32(
+                    self.cos.data_ptr() + 4 * b * M * N, _ptr(inter), _ptr(ap), _ptr(at), score_p.data_ptr() + 4 * b * N,
+                    e - b, N, M, nv(n_valid, b), nv(m_valid, b), float(score_weight), int(max_iter), int(proj_iter),
+                    float(lr), int(is_test), self.sim.data_ptr() + 4 * b * M * N,
+                    None if self.R is None else self.R.data_ptr() + 4 * b * M * Pp, self.Rb.data_ptr() + 4 * b * M * Pp,
+                    self.match_score.data_ptr() + 4 * b * M, self.det_score.data_ptr() + 4 * b * M,
+                    self.iters.data_ptr() + 4 * b, None, ss)
+                self.ev_solved[h].record(side)
+            # ---- streaming lane: mix(A) after solver(A), mix(B) after solver(B) ------------------------------
+            for h, (b, e) in enumerate(self.halves):
+                main.wait_event(self.ev_solved[h])
+                rc |= L.dmm_mask_mix(self.Rb.data_ptr() + 4 * b * M * Pp, masks_p.data_ptr() + es * b * sp_b, dt, e - b,
+                                     N, M, Pp, HW, sp_b, sp_n, nv(n_valid, b), nv(m_valid, b),
+                                     self.full_outmask.data_ptr() + 4 * b * M * HW, M * HW, HW, ms)
+        _lib.check(rc, "ForwardPlan.run (pipelined)")
         return self.full_outmask, self.match_score, self.det_score

