@@ -62,7 +62,8 @@ class _MatchLayerFn(torch.autograd.Function):
             gt = _greedy_onehot(-gt_iou)
             diff = cos - gt
             cost_loss = (diff * diff).mean()
-        ctx.save_for_backward(pn, tn, pnorm, tnorm, r["sim"], r["R"], r["Rb"], sc, pm, gt if gt is not None else pn)
+        ctx.save_for_backward(pn, tn, pnorm, tnorm, pf, tf, cos, r["sim"], r["Rb"], sc, pm,
+                              gt if gt is not None else cos)
         ctx.has_targets = targets is not None
         ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
         ctx.mark_non_differentiable(r["iters"])
@@ -81,12 +82,12 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
     tm = mask_last_occurence.float()
     pf = proposed_feature.float()
     sc = proposal_score.float()
-    if len(template_feature) == 1:
-        tf = template_feature[0].float()
-    else:
-        # mean_t cos(t_t, p) == cos-like dot with the MEAN of the normalised template vectors; feed that
-        # mean (its own norm is re-applied by the kernel, so rescale to keep the dot unchanged)
-        raise NotImplementedError("template_feature lists longer than 1 are not used by DMM-Net (dmm_model.py:44)")
+    if len(template_feature) != 1:
+        # feature_sim is the mean of the per-entry cosines (match_model.py:71-76); DMM-Net always passes one
+        # entry (dmm_model.py:44, templates are fixed from frame 0), longer lists are rejected loudly.
+        raise NotImplementedError("template_feature lists longer than 1 are never produced by DMM-Net "
+                                  "(dmm_model.py:44); pass a single [O,D] tensor")
+    tf = template_feature[0].float()
     if algo == "hun":
         return _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test)
     full, ms, ds, loss, _ = _MatchLayerFn.apply(pf, tf, pm, tm, sc, targets, score_weight, max_iter, proj_iter, lr,

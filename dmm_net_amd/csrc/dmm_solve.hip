@@ -133,10 +133,19 @@ __device__ __forceinline__ float norm_torch_order(const float *xbuf, int cnt, fl
 // EXACT: n == MT at compile time (all row guards fold away).
 // xbuf: LDS [MT * 64 * NG] floats, rsbuf: LDS [MT + 1] floats.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NG, bool EXACT>
+// Tape (backward only): per executed sweep and thread one uint2 {relu bits (bit i <=> row i passed the relu),
+// column-over flag}; per outer iteration the number of executed sweeps.
+struct RelaxTape {
+    uint2 *bits;        // global [max_iter * proj_iter][64 * NG]
+    int *sweeps;        // LDS [max_iter]
+};
+
+template <int MT, int NG, bool EXACT, bool TAPE = false>
 __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                           BlockRed<MT, NG> &red, float *xbuf, float *rsbuf, float (&X)[MT],
-                                          float (&acc)[MT], float *cost_out /* global [max_iter+1] or null */) {
+                                          float (&acc)[MT], float *cost_out /* global [max_iter+1] or null */,
+                                          RelaxTape tape = RelaxTape{nullptr, nullptr}) {
+    int tape_pos = 0;
     const int n = EXACT ? MT : n_rt;
 #define DMM_ROW(i) (EXACT || (i) < n)
     const bool live = col < m;
@@ -203,8 +212,10 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
         if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
         ++len;
 
+        int sweeps_done = 0;
         for (int j = 0; j < prm.proj_iter; ++j) {
             float Xs[MT];
+            unsigned relu_bits = 0;
             // {X >= 0} (:74-76) then X = Y + P1 (:78)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -212,6 +223,7 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 if (DMM_ROW(i)) {
                     float x = X[i] + P0[i];
                     const float y = x > 0.0f ? x : 0.0f;
+                    if (TAPE && x > 0.0f) relu_bits |= 1u << i;
                     P0[i] = x - y;
                     X[i] = y + P1[i];
                 }
@@ -244,6 +256,11 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
             }
             // {column sums <= 1}: project_col (:21-34, :79-80); then X = Y + P2 (:82)
             const bool over = cs > 1.0f;                       // mask = (X_col_sum <= 1)
+            if (TAPE) {
+                tape.bits[(size_t)tape_pos * (64 * NG) + threadIdx.x] = make_uint2(relu_bits, over ? 1u : 0u);
+                ++tape_pos;
+            }
+            ++sweeps_done;
             const float tc = div_by_const(cs - 1.0f, fn, rcp_n);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -277,6 +294,7 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
             red.sum(dd);
             if (dd[0] == 0.0f) break;
         }
+        if (TAPE && threadIdx.x == 0) tape.sweeps[it] = sweeps_done;
         if (cost_prev == cost) break;                           // :96-98
         cost_prev = cost;
     }
@@ -435,6 +453,162 @@ __global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__res
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the layer kernel with respect to sim (reference: torch autograd through relax_matching,
+// relax_match.py:68-98, and match_model.py:121-147).  One workgroup per frame:
+//   1. re-run the forward solver from the saved sim (bit-identical: same code), taping per sweep the relu
+//      pass bits and the column-over flag, per outer iteration the executed sweep count;
+//   2. epilogue adjoints: Rb = R*logic, match_score = max clamp(R,0,1)*sim_pad, det_score = sum score*Rb
+//      -> dR and the direct d sim term;
+//   3. walk the tape backwards: every sweep is a linear map given its bits, the gradient step contributes
+//      dC -= lr * g; the greedy init, the masks and the exits carry no gradient;
+//   4. dsim = -dC on the live [M, N] block.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTapeOuter = 1024;
+
+template <int MT, int NG, bool EXACT>
+__global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
+    const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
+    const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
+    __shared__ float red_buf[2 * NG * (MT + 1)];
+    __shared__ float xbuf[MT * 64 * NG];
+    __shared__ float rsbuf[MT + 1];
+    __shared__ int sweeps_s[kMaxTapeOuter];
+    const int b = blockIdx.x;
+    const int col = threadIdx.x;
+    BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
+    const int Nb = n_valid ? n_valid[b] : N;
+    const int Mb = EXACT ? MT : (m_valid ? m_valid[b] : M);
+    const int PpS = N > M ? N : M + 1;
+    float *dsim_b = dsim_out + (int64_t)b * M * N;
+    if (Mb <= 0 || Nb <= 0) {
+        for (int i = threadIdx.x; i < M * N; i += 64 * NG) dsim_b[i] = 0.0f;
+        return;
+    }
+#define DMM_ROW(i) (EXACT || (i) < Mb)
+    const int Pp = Nb > Mb ? Nb : Mb + 1;
+    const bool has_prop = col < Nb;
+    const bool livec = col < Pp;
+    float C[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const float sv = (DMM_ROW(i) && has_prop) ? sim_in[(int64_t)b * M * N + (int64_t)i * N + col] : 0.0f;
+        C[i] = (DMM_ROW(i) && livec) ? -sv : 0.0f;
+    }
+    float X[MT], acc[MT];
+    RelaxTape tape{tape_ws + (size_t)b * prm.max_iter * prm.proj_iter * (64 * NG), sweeps_s};
+    const int iters = relax_core<MT, NG, EXACT, true>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape);
+    __syncthreads();                                                   // sweeps_s + tape visible to the block
+
+    // ---- epilogue adjoints -> dR (per X_list entry: g = dR / len) and the direct d(sim_pad) term ----
+    const float flen = (float)(iters + 1);
+    const float sc = has_prop ? score_p[(int64_t)b * N + col] : 0.0f;
+    float r[MT], rmax[MT], v[MT], vmax[MT], gdirect[MT], gl[MT];
+    int cand[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        r[i] = acc[i] / flen;
+        rmax[i] = (livec && DMM_ROW(i)) ? r[i] : -__builtin_inff();
+        const float rc = r[i] < 0.0f ? 0.0f : (r[i] > 1.0f ? 1.0f : r[i]);
+        v[i] = (livec && DMM_ROW(i)) ? rc * (-C[i]) : -__builtin_inff();
+        vmax[i] = v[i];
+    }
+    wave_max_rows<MT>(rmax);
+    red.fold(rmax, fmax_op());
+    wave_max_rows<MT>(vmax);
+    red.fold(vmax, fmax_op());
+#pragma unroll
+    for (int i = 0; i < MT; ++i) cand[i] = (livec && DMM_ROW(i) && v[i] == vmax[i]) ? col : 0x7fffffff;
+    wave_min_rows_i32<MT>(cand);
+    red.min_i32(cand);                                                 // torch.max(dim) backward: first maximal index
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        gl[i] = 0.0f;
+        gdirect[i] = 0.0f;
+        if (DMM_ROW(i) && livec) {
+            const float lg = is_test ? (r[i] == rmax[i] ? 1.0f : 0.0f) : (r[i] > 0.01f ? 1.0f : 0.0f);
+            const float dms = dms_in ? dms_in[(int64_t)b * M + i] : 0.0f;
+            const float dds = dds_in ? dds_in[(int64_t)b * M + i] : 0.0f;
+            float dR = ((dRb_in ? dRb_in[(int64_t)b * M * PpS + (int64_t)i * PpS + col] : 0.0f) + dds * sc) * lg;
+            if (col == cand[i]) {
+                const float rc = r[i] < 0.0f ? 0.0f : (r[i] > 1.0f ? 1.0f : r[i]);
+                if (r[i] >= 0.0f && r[i] <= 1.0f) dR += dms * (-C[i]);  // clamp passes its gradient on [0, 1]
+                gdirect[i] = dms * rc;                                 // d/d(sim_pad) of clamp(R) * sim_pad
+            }
+            gl[i] = dR / flen;                                          // R = sum(X_list) / len
+        }
+    }
+
+    // ---- reverse sweep through the taped iterations ----
+    float gX[MT], gP0[MT], gP1[MT], gP2[MT], gC[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { gX[i] = 0.0f; gP0[i] = 0.0f; gP1[i] = 0.0f; gP2[i] = 0.0f; gC[i] = 0.0f; }
+    const float inv_m = 1.0f / (float)Pp, inv_n = 1.0f / (float)Mb;
+    int pos = 0;
+    for (int it = 0; it < iters; ++it) pos += sweeps_s[it];
+    for (int it = iters - 1; it >= 0; --it) {
+        const int ns = sweeps_s[it];
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            --pos;
+            const uint2 bits = tape.bits[(size_t)pos * (64 * NG) + threadIdx.x];
+            // row projection: y2 = c - (rowsum(c) - 1)/m ; P2' = c - y2 ; X' = y2
+            float gy2[MT], rs[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                gy2[i] = (DMM_ROW(i) && livec) ? gX[i] - gP2[i] : 0.0f;
+                rs[i] = gy2[i];
+            }
+            wave_sum_rows<MT>(rs);
+            red.sum(rs);
+            float cg = 0.0f;
+            float gy1[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                gy1[i] = 0.0f;
+                if (DMM_ROW(i) && livec) {
+                    const float gc = gP2[i] + gy2[i] - rs[i] * inv_m;
+                    gP2[i] = gc;                                       // c = y1 + P2
+                    gy1[i] = gc - gP1[i];                              // P1' = b - y1
+                    cg += gy1[i];
+                }
+            }
+            // column projection: y1 = b - over * (colsum(b) - 1)/n
+            const float corr = bits.y ? cg * inv_n : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (DMM_ROW(i) && livec) {
+                    const float gb = gP1[i] + gy1[i] - corr;
+                    gP1[i] = gb;                                       // b = y0 + P1
+                    const float gy0 = gb - gP0[i];                     // P0' = a - y0
+                    const float ga = gP0[i] + (((bits.x >> i) & 1u) ? gy0 : 0.0f);   // y0 = relu(a)
+                    gX[i] = ga;                                        // a = X + P0
+                    gP0[i] = ga;
+                }
+            }
+        }
+        // gradient step: X_pre = X_prev - lr*C, and X_pre is the X_list entry of this iteration
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (DMM_ROW(i) && livec) {
+                const float g = gX[i] + gl[i];
+                gC[i] = gC[i] - prm.lr * g;
+                gX[i] = g;
+            }
+        }
+    }
+    // C = -sim_pad  ->  dsim = -dC (+ the direct match_score term); padded columns are dropped
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        if (DMM_ROW(i) && has_prop) dsim_b[(int64_t)i * N + col] = gdirect[i] - gC[i];
+#undef DMM_ROW
+    for (int i = Mb; i < M; ++i)
+        if (col < N) dsim_b[(int64_t)i * N + col] = 0.0f;
+    if (!has_prop && col < N)
+        for (int i = 0; i < Mb; ++i) dsim_b[(int64_t)i * N + col] = 0.0f;
+}
+
 }  // namespace dmm
 
 // Kernel selection: exact-row-count instantiations for the common small problems (one wave per
@@ -502,6 +676,37 @@ extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_
     hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream, C, \
                        n, m, prm, X_final, R_out, cost_out, iters_out)
     DMM_DISPATCH_SOLVER(n, m, true, DMM_CALL);
+#undef DMM_CALL
+    return dmm::check_launch();
+}
+
+extern "C" size_t dmm_relax_bwd_workspace_bytes(int B, int N, int M, int max_iter, int proj_iter) {
+    if (B <= 0 || N <= 0 || M <= 0 || max_iter < 0 || proj_iter < 0) return 0;
+    const int Pp = N > M ? N : M + 1;
+    const size_t threads = 64 * (size_t)((Pp + 63) / 64 == 3 ? 4 : (Pp + 63) / 64);
+    return sizeof(uint2) * (size_t)B * (size_t)max_iter * (size_t)proj_iter * threads + 256;
+}
+
+extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, int B, int N, int M,
+                                       const int32_t *n_valid, const int32_t *m_valid, int max_iter, int proj_iter,
+                                       float lr, int is_test, const float *dRb, const float *d_match_score,
+                                       const float *d_det_score, float *dsim_out, void *workspace,
+                                       size_t workspace_bytes, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0 || !sim || !score_p || !dsim_out) return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || max_iter > dmm::kMaxTapeOuter) return DMM_ERR_UNSUPPORTED;
+    if (workspace_bytes < dmm_relax_bwd_workspace_bytes(B, N, M, max_iter, proj_iter)) return DMM_ERR_WORKSPACE;
+    if (!workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
+    const dmm::RelaxParams prm{max_iter, proj_iter, lr};
+    const bool exact_ok = (m_valid == nullptr);
+    uint2 *tape = (uint2 *)workspace;
+#define DMM_CALL(MT_, NG_, EX_)                                                                                       \
+    hipLaunchKernelGGL((dmm::relax_match_bwd_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
+                       sim, score_p, N, M, n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out,  \
+                       tape)
+    DMM_DISPATCH_SOLVER(M, Pp, exact_ok, DMM_CALL);
 #undef DMM_CALL
     return dmm::check_launch();
 }

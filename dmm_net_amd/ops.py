@@ -116,6 +116,27 @@ def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, 
     return out
 
 
+def relax_match_bwd(sim, score_p, dRb, d_match_score, d_det_score, *, max_iter, proj_iter, lr, is_test,
+                    n_valid=None, m_valid=None) -> torch.Tensor:
+    """d loss / d sim [B,M,N] of ``relax_match`` (reverse sweep through the taped solver iterations)."""
+    _need_gpu(sim)
+    sim = sim.contiguous().float()
+    B, M, N = sim.shape
+    dev = sim.device
+    cf = lambda t: None if t is None else t.contiguous().float()
+    dRb, d_match_score, d_det_score, score_p = cf(dRb), cf(d_match_score), cf(d_det_score), cf(score_p)
+    L = _lib.load()
+    nbytes = int(L.dmm_relax_bwd_workspace_bytes(B, N, M, int(max_iter), int(proj_iter)))
+    ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dmm_relax_match_bwd_f32(_ptr(sim), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid), int(max_iter),
+                                       int(proj_iter), float(lr), int(is_test), _ptr(dRb), _ptr(d_match_score),
+                                       _ptr(d_det_score), _ptr(out), _ptr(ws), ws.numel(), _stream(sim))
+    _lib.check(rc, "dmm_relax_match_bwd_f32")
+    return out
+
+
 def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float):
     """relax_matching on cost matrices C [B,n,m] -> dict(X, R, cost [B,max_iter+1], iters [B])."""
     _need_gpu(C)

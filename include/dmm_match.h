@@ -124,6 +124,26 @@ DMM_API int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_ite
                         dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3b) Backward of (3) with respect to sim (the reference gets it from torch autograd through
+ * relax_match.py:68-98 and match_model.py:121-147; the greedy init, the masks and the early exits
+ * carry no gradient).  The kernel re-runs the forward solver from the saved `sim` (same code, hence
+ * the same iterates and exits), tapes 1 relu bit per element + 1 column bit per sweep into
+ * `workspace`, and walks the tape backwards.
+ *   dRb [B,M,Pp]        upstream gradient of Rb (= dOut @ masks_p^T; logic is applied inside); may be NULL
+ *   d_match_score, d_det_score [B,M]   upstream gradients of the two score vectors; may be NULL
+ *   dsim_out [B,M,N]    gradient of the loss w.r.t. sim (feature_sim gets (1-w) * dsim)
+ * workspace >= dmm_relax_bwd_workspace_bytes(...).  max_iter <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API size_t dmm_relax_bwd_workspace_bytes(int B, int N, int M, int max_iter, int proj_iter);
+
+DMM_API int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, int B, int N, int M,
+                                    const int32_t *n_valid, const int32_t *m_valid,
+                                    int max_iter, int proj_iter, float lr, int is_test,
+                                    const float *dRb, const float *d_match_score, const float *d_det_score,
+                                    float *dsim_out, void *workspace, size_t workspace_bytes,
+                                    dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) Assignment-weighted mask mix: full_outmask[b,m,:] = sum_n Rb[b,m,n] * masks_p[b,n,:]
  * (torch.mm at match_model.py:144; padded columns n >= N carry zero planes, :134-142).
  * Only planes with a non-zero weight are read (in test mode <= M planes per frame).

@@ -343,3 +343,43 @@ def test_pipelined_plan_matches_single_stream():
                              sc[3].cpu().numpy(), max_iter=10, proj_iter=5, is_test=0)
     assert np.array_equal(outs[1][3][3].cpu().numpy(), o["R"])
     close(outs[1][0][3], o["full_outmask"])
+
+
+# ------------------------------------------------------------------------------------ backward (G6)
+@pytest.mark.parametrize("name", ["c1_train", "c1_test", "pad", "mid"])
+def test_g6_backward_matches_reference_autograd(name):
+    g = golden("g6_backward")
+    P, O, H, W, D, mi, pi, is_test = [int(v) for v in g[f"{name}/shape"]]
+    fr = synth.make_frame(P, O, H, W, D, seed=synth.BASE_SEED + 600 + P + O, kind="structured", with_targets=True)
+    assert fr.checksum() == str(g[f"{name}/checksum"])
+    c = g.group(name)
+    model = MatchModel(cfg(mi, pi), is_test)
+    pf = dev(fr.proposed_feature).requires_grad_(True)
+    tf = dev(fr.template_feature).requires_grad_(True)
+    fo, ms, ds, _, loss = model(pf, dev(fr.proposed_mask), [tf], dev(fr.mask_last_occurence), dev(fr.proposal_score),
+                                dev(fr.targets))
+    close(fo, c["full_outmask"])
+    total = (fo * dev(c["wmask"])).sum() + (ms * dev(c["wms"])).sum() + (ds * dev(c["wds"])).sum() \
+        + 3.0 * loss["cost_loss"]
+    assert abs(float(total) - float(c["total"])) < 1e-3 * max(1.0, abs(float(c["total"])))
+    total.backward()
+    gp, gt_ = pf.grad.cpu().numpy(), tf.grad.cpu().numpy()
+    for mine, ref in ((gp, c["grad_pf"]), (gt_, c["grad_tf"])):
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(mine - ref).max())
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+
+
+def test_backward_mask_gradient_and_no_grad_paths():
+    fr = synth.make_config_frame(1, kind="structured", with_targets=True)
+    model = MatchModel(cfg(10, 5), 0)
+    pm = dev(fr.proposed_mask).requires_grad_(True)
+    pf = dev(fr.proposed_feature)
+    fo, ms, ds, _, loss = model(pf, pm, [dev(fr.template_feature)], dev(fr.mask_last_occurence),
+                                dev(fr.proposal_score), dev(fr.targets))
+    w = torch.rand_like(fo)
+    (fo * w).sum().backward()
+    o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                             fr.proposal_score, max_iter=10, proj_iter=5, is_test=0, want_outmask=False)
+    exp = np.einsum("op,ohw->phw", o["Rb"][:, :fr.proposed_mask.shape[0]], w.cpu().numpy())
+    close(pm.grad, exp, 1e-5)
