@@ -69,7 +69,7 @@ def load():
     L.dmm_cosine_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,
                                       c_int, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.dmm_relax_solve_f32.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_float, vp, vp, vp, vp, vp]
+    L.dmm_relax_solve_f32.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, vp]
     L.dmm_relax_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
     L.dmm_relax_bwd_workspace_bytes.restype = sz
     L.dmm_relax_match_bwd_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, c_int, c_int, c_float, c_int, vp, vp, vp,

@@ -1,15 +1,11 @@
-"""Autograd glue of the matching layer (one frame = a batch of 1 for the HIP kernels).
+"""Autograd glue of the matching layer: B frames per call (B = 1 reproduces one reference call).
 
-Forward: ops.iou_counts -> ops.feature_normalize -> ops.relax_match -> ops.mask_mix, all on the
-gfx950 library.  Gradients flow to ``proposed_feature`` and ``template_feature`` only, exactly as in
-the reference (the IoU part of the cost is computed under ``no_grad``/detached, match_helper.py:20-28;
-the greedy init carries no grad, relax_match.py:45-55).
+Forward: ops.iou_counts -> ops.feature_normalize -> ops.cosine -> ops.relax_match -> ops.mask_mix, all on
+the gfx950 library.  Gradients flow to ``proposed_feature`` and ``template_feature`` (and to
+``proposed_mask`` if it requires grad), exactly as in the reference: the IoU part of the cost is computed
+under ``no_grad``/detached (match_helper.py:20-28), the greedy init carries no grad (relax_match.py:45-55).
 
-Backward (reference: torch autograd through ~950 nodes at (10,5)):
-  dRb      = dOut @ mask_p^T                        (bandwidth bound, ops.mask_mix_bwd)
-  dsim     = reverse sweep through the relax iterations (ops.relax_match_bwd: the kernel re-runs the
-             forward, taping 1 relu bit per element and 1 column bit per sweep, then walks it back)
-  dfeat    = cosine / normalisation backward        (small dense algebra, torch on device)
+Backward: dmm_net_amd/backward.py.
 """
 from __future__ import annotations
 
@@ -18,12 +14,6 @@ from typing import List, Optional
 import torch
 
 from . import ops
-
-
-def _greedy_onehot(neg_cost: torch.Tensor) -> torch.Tensor:
-    """Greedy init of relax_matching on a [B,n,m] cost batch (relax_match.py:45-55) as a one-hot
-    matrix; device side via the solver kernel with max_iter = 0 (X_list == [X0])."""
-    return ops.relax_solve(neg_cost, 0, 0, 0.0)["X"]
 
 
 def hungarian_onehot(cost: torch.Tensor) -> torch.Tensor:
@@ -38,36 +28,55 @@ def hungarian_onehot(cost: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(X).float().to(cost.device)
 
 
+def matching_loss(pm_b, targets_b, cos, n_valid=None, m_valid=None):
+    """compute_matching_loss (match_helper.py:30-49) for B frames -> (loss [B], gt one-hot [B,O,P]).
+    IoU(proposal > 0.5, targets) -> greedy one-hot of -IoU (relax_matching(..., 0, 0, 0)) -> MSE with cos."""
+    B, O, P = cos.shape
+    gi, gap, gat = ops.iou_counts(pm_b, targets_b.to(pm_b.dtype), n_valid, m_valid)
+    union = (gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6
+    gt_iou = gi.float() / union
+    gt = ops.relax_solve(-gt_iou, 0, 0, 0.0, rows_valid=m_valid, cols_valid=n_valid)["X"]
+    diff = cos - gt
+    if n_valid is None and m_valid is None:
+        return (diff * diff).flatten(1).mean(1), gt, None
+    nv = n_valid if n_valid is not None else torch.full((B,), P, dtype=torch.int32, device=cos.device)
+    mv = m_valid if m_valid is not None else torch.full((B,), O, dtype=torch.int32, device=cos.device)
+    live = (torch.arange(O, device=cos.device)[None, :, None] < mv[:, None, None]) & \
+           (torch.arange(P, device=cos.device)[None, None, :] < nv[:, None, None])
+    cnt = (nv * mv).clamp_min(1).float()
+    sq = torch.where(live, diff * diff, torch.zeros_like(diff))
+    return sq.flatten(1).sum(1) / cnt, gt, (live, cnt)
+
+
 class _MatchLayerFn(torch.autograd.Function):
+    """pf [B,P,D], tf [B,O,D], pm [B,P,H,W], tm [B,O,H,W], sc [B,P], targets [B,O,H,W] | None."""
+
     @staticmethod
-    def forward(ctx, pf, tf, pm, tm, sc, targets, score_weight, max_iter, proj_iter, lr, is_test):
-        # pf [P,D], tf [O,D] (already averaged/normalised handling done by the caller), pm [P,H,W], tm [O,H,W]
-        P, O = pm.shape[0], tm.shape[0]
-        pm_b, tm_b = pm.unsqueeze(0), tm.unsqueeze(0)
-        inter, ap, at = ops.iou_counts(pm_b, tm_b)
-        pn, pnorm = ops.feature_normalize(pf.unsqueeze(0), want_norms=True)
-        tn, tnorm = ops.feature_normalize(tf.unsqueeze(0), want_norms=True)
-        cos = ops.cosine(tn, pn)
-        r = ops.relax_match(cos, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=max_iter,
-                            proj_iter=proj_iter, lr=lr, is_test=is_test)
-        full = ops.mask_mix(r["Rb"], pm_b)
-        cost_loss = pf.new_zeros(())
-        gt = None
+    def forward(ctx, pf, tf, pm, tm, sc, targets, n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test):
+        inter, ap, at = ops.iou_counts(pm, tm, n_valid, m_valid)
+        pn, pnorm = ops.feature_normalize(pf, want_norms=True)
+        tn, tnorm = ops.feature_normalize(tf, want_norms=True)
+        cos = ops.cosine(tn, pn, n_valid, m_valid)
+        r = ops.relax_match(cos, inter, ap, at, sc, score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter,
+                            lr=lr, is_test=is_test, n_valid=n_valid, m_valid=m_valid)
+        full = ops.mask_mix(r["Rb"], pm, n_valid, m_valid)
+        B = pf.shape[0]
+        cost_loss = pf.new_zeros((B,))
+        gt, live, cnt = None, None, None
         if targets is not None:
-            # compute_matching_loss (match_helper.py:30-49): IoU(proposal>0.5, targets) -> greedy one-hot -> MSE
-            tg = targets.unsqueeze(0).to(pm.dtype)
-            gi, gap, gat = ops.iou_counts(pm_b, tg)
-            union = (gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6
-            gt_iou = gi.float() / union
-            gt = _greedy_onehot(-gt_iou)
-            diff = cos - gt
-            cost_loss = (diff * diff).mean()
+            cost_loss, gt, lc = matching_loss(pm, targets, cos, n_valid, m_valid)
+            if lc is not None:
+                live, cnt = lc
+        empty = pf.new_zeros(())
         ctx.save_for_backward(pn, tn, pnorm, tnorm, pf, tf, cos, r["sim"], r["Rb"], sc, pm,
-                              gt if gt is not None else cos)
+                              gt if gt is not None else empty, live if live is not None else empty,
+                              cnt if cnt is not None else empty,
+                              n_valid if n_valid is not None else empty, m_valid if m_valid is not None else empty)
         ctx.has_targets = targets is not None
+        ctx.ragged = (n_valid is not None, m_valid is not None)
         ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
         ctx.mark_non_differentiable(r["iters"])
-        return full[0], r["match_score"][0], r["det_score"][0], cost_loss, r["iters"]
+        return full, r["match_score"], r["det_score"], cost_loss, r["iters"]
 
     @staticmethod
     def backward(ctx, d_full, d_ms, d_ds, d_loss, _d_iters):
@@ -75,24 +84,33 @@ class _MatchLayerFn(torch.autograd.Function):
         return match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss)
 
 
+def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
+                        proj_iter, lr, is_test):
+    """B frames through the layer with autograd.  Returns (full_outmask [B,O,H,W], match_score [B,O],
+    det_score [B,O], cost_loss [B], iters [B])."""
+    return _MatchLayerFn.apply(pf.float(), tf.float(), pm.float(), tm.float(), sc.float(),
+                               None if targets is None else targets.float(), n_valid, m_valid, float(score_weight),
+                               int(max_iter), int(proj_iter), float(lr), int(is_test))
+
+
 def match_layer_function(proposed_feature, proposed_mask, template_feature: List[torch.Tensor], mask_last_occurence,
                          proposal_score, targets: Optional[torch.Tensor], *, score_weight, max_iter, proj_iter, lr,
                          is_test, algo="relax"):
-    pm = proposed_mask.float()
-    tm = mask_last_occurence.float()
-    pf = proposed_feature.float()
-    sc = proposal_score.float()
+    """One frame (the reference's call): unsqueeze to B = 1."""
     if len(template_feature) != 1:
         # feature_sim is the mean of the per-entry cosines (match_model.py:71-76); DMM-Net always passes one
         # entry (dmm_model.py:44, templates are fixed from frame 0), longer lists are rejected loudly.
         raise NotImplementedError("template_feature lists longer than 1 are never produced by DMM-Net "
                                   "(dmm_model.py:44); pass a single [O,D] tensor")
-    tf = template_feature[0].float()
+    tf = template_feature[0]
     if algo == "hun":
-        return _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test)
-    full, ms, ds, loss, _ = _MatchLayerFn.apply(pf, tf, pm, tm, sc, targets, score_weight, max_iter, proj_iter, lr,
-                                                is_test)
-    return full, ms, ds, loss
+        return _hungarian_forward(proposed_feature.float(), tf.float(), proposed_mask.float(),
+                                  mask_last_occurence.float(), proposal_score.float(), targets, score_weight, is_test)
+    full, ms, ds, loss, _ = match_layer_batched(
+        proposed_feature.unsqueeze(0), proposed_mask.unsqueeze(0), tf.unsqueeze(0), mask_last_occurence.unsqueeze(0),
+        proposal_score.unsqueeze(0), None if targets is None else targets.unsqueeze(0), score_weight=score_weight,
+        max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+    return full[0], ms[0], ds[0], loss[0]
 
 
 def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
@@ -120,8 +138,5 @@ def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
     ds = (scp.view(1, -1) * Rb).sum(1)
     loss = pf.new_zeros(())
     if targets is not None:
-        gi, gap, gat = ops.iou_counts(pm_b, targets.unsqueeze(0).to(pm.dtype))
-        gt_iou = gi.float() / ((gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6)
-        gt = _greedy_onehot(-gt_iou)
-        loss = ((cos - gt) ** 2).mean()
+        loss = matching_loss(pm_b, targets.unsqueeze(0), cos)[0][0]
     return full, ms, ds, loss

@@ -1,12 +1,12 @@
 """Backward of the matching layer (counterpart of torch autograd through the reference's
 ``MatchModel.forward``; reference files: match_model.py:49-148, match_helper.py:30-64,
-relax_match.py:36-105).
+relax_match.py:36-105).  B frames per call.
 
-Chain (one frame, tensors on the MI355X):
+Chain (tensors on the MI355X):
 
-  d full_outmask [O,H,W]  --dOut @ mask_p^T-->  dRb [O,Pp]          (HBM bound, rocBLAS sgemm)
-  dRb, d match_score, d det_score  --dmm_relax_match_bwd_f32-->  dsim [O,P]   (HIP: taped reverse sweep)
-  dsim * (1-w) + d cost_loss * 2 (cos - gt) / (O P)  =  dcos [O,P]
+  d full_outmask [B,O,H,W]  --dOut @ mask_p^T-->  dRb [B,O,Pp]        (HBM bound, rocBLAS batched sgemm)
+  dRb, d match_score, d det_score  --dmm_relax_match_bwd_f32-->  dsim [B,O,P]   (HIP: taped reverse sweep)
+  dsim * (1-w) + d cost_loss * 2 (cos - gt) / (O P)  =  dcos [B,O,P]
   dcos  -->  d template_n = dcos @ pn,  d proposal_n = dcos^T @ tn          (tiny GEMMs, rocBLAS)
   normalisation backward  -->  d template_feature, d proposed_feature
 
@@ -20,9 +20,9 @@ import torch
 from . import ops
 
 
-def _normalize_backward(g_hat: torch.Tensor, x_hat: torch.Tensor, c: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """x_hat = x / c with c = max(||x||, eps) where torch clamps the VALUE in place under no_grad
-    (cosine_similarity): autograd differentiates c as ||x||.  g_hat, x_hat, x: [R, D]; c: [R]."""
+def _normalize_backward(g_hat: torch.Tensor, c: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """x_hat = x / c with c = max(||x||, eps), where torch clamps the VALUE in place under no_grad
+    (cosine_similarity): autograd differentiates c as ||x||.  g_hat, x: [..., D]; c: [...]."""
     c = c.unsqueeze(-1)
     n = x.norm(dim=-1, keepdim=True)
     dot = (g_hat * x).sum(-1, keepdim=True)
@@ -31,35 +31,42 @@ def _normalize_backward(g_hat: torch.Tensor, x_hat: torch.Tensor, c: torch.Tenso
 
 
 def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
-    pn, tn, pnorm, tnorm, pf, tf, cos, sim, Rb, sc, pm, gt = ctx.saved_tensors
+    (pn, tn, pnorm, tnorm, pf, tf, cos, sim, Rb, sc, pm, gt, live, cnt, n_valid, m_valid) = ctx.saved_tensors
+    n_valid = n_valid if ctx.ragged[0] else None
+    m_valid = m_valid if ctx.ragged[1] else None
     score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
-    P, O = pm.shape[0], sim.shape[1]
+    B, P = pm.shape[0], pm.shape[1]
+    O = sim.shape[1]
     H, W = pm.shape[-2], pm.shape[-1]
     Pp = Rb.shape[-1]
     need_pf, need_tf, need_pm = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
     g_pf = g_tf = g_pm = None
+    none = (None,) * 10
     if not (need_pf or need_tf or need_pm):
-        return (None,) * 11
-    pm2d = pm.reshape(P, H * W)
-    dOut = None if d_full is None else d_full.reshape(O, H * W).float()
+        return (None, None, None) + none
+    pm2d = pm.reshape(B, P, H * W)
+    dOut = None if d_full is None else d_full.reshape(B, O, H * W).float()
     if need_pm and dOut is not None:
-        g_pm = (Rb[0, :, :P].t() @ dOut).view(P, H, W)
+        g_pm = torch.bmm(Rb[:, :, :P].transpose(1, 2), dOut).view(B, P, H, W)
     if need_pf or need_tf:
         dRb = None
         if dOut is not None:
-            dRb = dOut.new_zeros((1, O, Pp))
-            dRb[0, :, :P] = dOut @ pm2d.t()                 # padded columns multiply zero planes
-        dsim = ops.relax_match_bwd(sim, sc.unsqueeze(0), dRb, None if d_ms is None else d_ms.unsqueeze(0),
-                                   None if d_ds is None else d_ds.unsqueeze(0), max_iter=max_iter,
-                                   proj_iter=proj_iter, lr=lr, is_test=is_test)[0]
+            dRb = dOut.new_zeros((B, O, Pp))
+            dRb[:, :, :P] = torch.bmm(dOut, pm2d.transpose(1, 2))     # padded columns multiply zero planes
+        dsim = ops.relax_match_bwd(sim, sc, dRb, d_ms, d_ds, max_iter=max_iter, proj_iter=proj_iter, lr=lr,
+                                   is_test=is_test, n_valid=n_valid, m_valid=m_valid)
         w_feat = torch.tensor(1.0 - score_weight, dtype=torch.float32).item()
         dcos = dsim * w_feat
         if ctx.has_targets and d_loss is not None:
-            dcos = dcos + d_loss * (2.0 / (O * P)) * (cos[0] - gt[0])
-        g_tn = dcos @ pn[0]                                  # [O,D]
-        g_pn = dcos.t() @ tn[0]                              # [P,D]
+            diff = cos - gt
+            if ctx.ragged[0] or ctx.ragged[1]:
+                dcos = dcos + torch.where(live, diff, torch.zeros_like(diff)) * (2.0 * d_loss / cnt)[:, None, None]
+            else:
+                dcos = dcos + diff * (2.0 / (O * P)) * d_loss[:, None, None]
+        g_tn = torch.bmm(dcos, pn)                               # [B,O,D]
+        g_pn = torch.bmm(dcos.transpose(1, 2), tn)               # [B,P,D]
         if need_pf:
-            g_pf = _normalize_backward(g_pn, pn[0], pnorm[0], pf)
+            g_pf = _normalize_backward(g_pn, pnorm, pf)
         if need_tf:
-            g_tf = _normalize_backward(g_tn, tn[0], tnorm[0], tf)
-    return g_pf, g_tf, g_pm, None, None, None, None, None, None, None, None
+            g_tf = _normalize_backward(g_tn, tnorm, tf)
+    return (g_pf, g_tf, g_pm) + none

@@ -428,7 +428,9 @@ __global__ __launch_bounds__(64 * NG) void relax_match_kernel(
 
 // Solver-only kernel on a caller-provided C [B, n, m].
 template <int MT, int NG, bool EXACT>
-__global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__restrict__ Cin, int n, int m,
+__global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__restrict__ Cin, int n_max, int m_max,
+                                                              const int32_t *__restrict__ rows_valid,
+                                                              const int32_t *__restrict__ cols_valid,
                                                               RelaxParams prm, float *__restrict__ X_final,
                                                               float *__restrict__ R_out, float *__restrict__ cost_out,
                                                               int32_t *__restrict__ iters_out) {
@@ -437,17 +439,31 @@ __global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__res
     __shared__ float rsbuf[MT + 1];
     const int b = blockIdx.x, col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
+    const int n = EXACT ? MT : (rows_valid ? rows_valid[b] : n_max);
+    const int m = cols_valid ? cols_valid[b] : m_max;
     float C[MT], X[MT], acc[MT];
+    if (n <= 0 || m <= 0) {                                     // dead frame
+        for (int i = threadIdx.x; i < n_max * m_max; i += 64 * NG) {
+            if (X_final) X_final[(int64_t)b * n_max * m_max + i] = 0.0f;
+            if (R_out) R_out[(int64_t)b * n_max * m_max + i] = 0.0f;
+        }
+        if (iters_out && threadIdx.x == 0) iters_out[b] = 0;
+        return;
+    }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) C[i] = (i < n && col < m) ? Cin[((int64_t)b * n + i) * m + col] : 0.0f;
+    for (int i = 0; i < MT; ++i) C[i] = (i < n && col < m) ? Cin[((int64_t)b * n_max + i) * m_max + col] : 0.0f;
     const int iters = relax_core<MT, NG, EXACT>(C, n, m, col, prm, red, xbuf, rsbuf, X, acc,
                                                 cost_out ? cost_out + (int64_t)b * (prm.max_iter + 1) : nullptr);
     const float flen = (float)(iters + 1);
+    for (int i = 0; i < n_max; ++i) {
+        if (col < m_max) {
+            const bool lv = i < n && col < m;
+            float xv = 0.0f, rv = 0.0f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if (i < n && col < m) {
-            if (X_final) X_final[((int64_t)b * n + i) * m + col] = X[i];
-            if (R_out) R_out[((int64_t)b * n + i) * m + col] = acc[i] / flen;
+            for (int k = 0; k < MT; ++k)
+                if (k == i) { xv = X[k]; rv = acc[k] / flen; }
+            if (X_final) X_final[((int64_t)b * n_max + i) * m_max + col] = lv ? xv : 0.0f;
+            if (R_out) R_out[((int64_t)b * n_max + i) * m_max + col] = lv ? rv : 0.0f;
         }
     }
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
@@ -664,7 +680,8 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
     return dmm::check_launch();
 }
 
-extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_iter, int proj_iter, float lr,
+extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const int32_t *rows_valid,
+                                   const int32_t *cols_valid, int max_iter, int proj_iter, float lr,
                                    float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
                                    dmm_stream_t stream) {
     if (B < 0 || n <= 0 || m <= 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
@@ -674,8 +691,8 @@ extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_
     const dmm::RelaxParams prm{max_iter, proj_iter, lr};
 #define DMM_CALL(MT_, NG_, EX_)                                                                                     \
     hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream, C, \
-                       n, m, prm, X_final, R_out, cost_out, iters_out)
-    DMM_DISPATCH_SOLVER(n, m, true, DMM_CALL);
+                       n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out)
+    DMM_DISPATCH_SOLVER(n, m, rows_valid == nullptr, DMM_CALL);
 #undef DMM_CALL
     return dmm::check_launch();
 }

@@ -1,0 +1,137 @@
+"""``DMM_Model`` -- counterpart of the reference's per-video driver ``dmm/modules/dmm_model.py``.
+
+The reference loops over the videos of a batch in Python (``for bid in range(B)``, dmm_model.py:62 / :115) and
+calls ``MatchModel`` once per video with the first-O rows selected by 0/1 ``OF_matrix`` matmuls
+(:144-158), scattering the O result rows back into F = maxseqlen slots (:78-80 / :133-135).
+
+Here all videos of the step go through ONE ragged batched launch sequence of the HIP layer
+(``n_valid`` = proposals per video, ``m_valid`` = live templates per video, valid templates are a prefix as in
+the reference, :124); the select / scatter matmuls become the kernels' zero-filled rows.  Semantics kept:
+
+  * O == 0 (or ``extra_frame`` at inference): output zeros, ``out_mask_last`` = the incoming
+    ``mask_last_occurence[b]`` unchanged, loss 0 (dmm_model.py:66-69, :118-122);
+  * otherwise ``output_mask[b]`` and ``out_mask_last[b]`` are BOTH the scattered ``full_outmask``
+    (MatchModel returns it twice, match_model.py:47);
+  * ``forward`` returns ``(output_mask, tplt_dict, match_loss list, out_mask_last)``; ``inference`` returns
+    ``match_loss = []`` (:85).
+
+Proposals are duck-typed like maskrcnn_benchmark ``BoxList``: ``len(p)``, ``p.get_field('mask')`` ([P,1,H,W]),
+``p.fields()``, ``p.get_field('objectness' | 'scores')``.  ROI feature extraction (reference
+``feature_extractor.py``, maskrcnn_benchmark Pooler) is injected as ``feature_extractor`` -- any callable
+``(backbone_feature, proposals) -> [sum P, D]``.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .autograd import match_layer_batched
+from .match_model import MatchModel
+
+
+def CHECK4D(t):
+    assert len(t.shape) == 4, "get {} {}".format(t.shape, len(t.shape))
+    return t.shape
+
+
+class DMM_Model(nn.Module):
+    def __init__(self, cfgs, is_test=0, feature_extractor: Optional[Callable] = None):
+        super().__init__()
+        self.match_layer = MatchModel(cfgs, is_test)
+        self.feature_extractor = feature_extractor
+        self.match_algo = cfgs["matching"]["algo"]
+        self.cfgs = cfgs
+        self.is_test = is_test
+
+    # ---- dmm_model.py:22-46 ------------------------------------------------------------------------
+    def fill_template_dict(self, args, proposals, features, y_mask, tplt_valid_batch):
+        backbone_feature = features["backbone_feature"]
+        refine_input_feat = features["refine_input_feat"]
+        boxes_per_image = [len(box) for box in proposals]
+        result_alllevel = self.feature_extractor(backbone_feature, proposals)
+        feats = result_alllevel.split(boxes_per_image, dim=0)
+        tplt_dict = {}
+        for b, feat in enumerate(feats):
+            tplt_dict[b] = {"feat": [feat],
+                            "refine_input_feat": [tuple([f[b] for f in refine_input_feat])]}
+        return tplt_dict
+
+    # ---- shared batched core -----------------------------------------------------------------------
+    def _match_batch(self, prop_feat: List[torch.Tensor], prop_m: List[torch.Tensor], prop_score: List[torch.Tensor],
+                     tplt_feat: List[torch.Tensor], mask_last_occurence, n_tplt: List[int], targets, skip: List[bool]):
+        """prop_feat[b] [P_b,D], prop_m[b] [P_b,H,W], tplt_feat[b] [F,D]; returns (full [B,F,H,W], loss [B])."""
+        B, F, H, W = CHECK4D(mask_last_occurence)
+        dev = mask_last_occurence.device
+        D = prop_feat[0].shape[1]
+        Pmax = max(int(p.shape[0]) for p in prop_m)
+        pf = prop_feat[0].new_zeros((B, Pmax, D))
+        pm = mask_last_occurence.new_zeros((B, Pmax, H, W))
+        sc = mask_last_occurence.new_zeros((B, Pmax))
+        for b in range(B):
+            P = prop_m[b].shape[0]
+            assert prop_m[b].shape[-2:] == mask_last_occurence[b].shape[-2:], \
+                "get {} {}".format(prop_m[b].shape[-2:], mask_last_occurence[b].shape[-2:])
+            assert prop_feat[b].shape[0] == P, "get {} {}".format(P, prop_feat[b].shape[0])
+            pf[b, :P] = prop_feat[b]
+            pm[b, :P] = prop_m[b]
+            sc[b, :P] = prop_score[b]
+        tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
+        n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
+        m_valid = torch.tensor([0 if skip[b] else n_tplt[b] for b in range(B)], dtype=torch.int32, device=dev)
+        cfg = self.match_layer
+        full, ms, ds, loss, _ = match_layer_batched(
+            pf, pm, tf, mask_last_occurence, sc, targets, n_valid, m_valid, score_weight=cfg.cfgs["score_weight"],
+            max_iter=cfg.max_iter, proj_iter=cfg.proj_iter, lr=cfg.relax_lr, is_test=int(bool(cfg.is_test)))
+        return full, loss
+
+    @staticmethod
+    def _proposal_fields(proposals):
+        prop_m = [p.get_field("mask").squeeze(1) for p in proposals]
+        prop_score = [p.get_field("objectness") if "objectness" in p.fields() else p.get_field("scores")
+                      for p in proposals]
+        return prop_m, prop_score
+
+    # ---- dmm_model.py:48-86 ------------------------------------------------------------------------
+    def inference(self, infos, proposals, backbone_feature, mask_last_occurence, tplt_dict, target=None):
+        extra_frame, tplt_valid_batch = infos["extra_frame"], infos["valid"]
+        B, F, H, W = CHECK4D(mask_last_occurence)
+        boxes_per_image = [len(box) for box in proposals]
+        prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
+        prop_m, prop_score = self._proposal_fields(proposals)
+        n_tplt = [int(tplt_valid_batch[b].sum().item()) for b in range(B)]
+        skip = [n_tplt[b] == 0 or bool(extra_frame[b]) for b in range(B)]
+        tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
+        tg = None
+        if target is not None:
+            tg = torch.stack([target[b] for b in range(B)], 0)
+        full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt, tg,
+                                    skip)
+        out_last = full.clone()
+        for b in range(B):
+            if skip[b]:
+                out_last[b] = mask_last_occurence[b]
+        return full, tplt_dict, [], out_last
+
+    # ---- dmm_model.py:88-142 -----------------------------------------------------------------------
+    def forward(self, args, proposals, backbone_feature, mask_last_occurence, tplt_dict, tplt_valid_batch, targets):
+        B, F, H, W = CHECK4D(mask_last_occurence)
+        assert targets is not None                                  # training mode must have targets (:128)
+        boxes_per_image = [len(box) for box in proposals]
+        prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
+        prop_m, prop_score = self._proposal_fields(proposals)
+        n_tplt = [int(tplt_valid_batch[b].sum().item()) for b in range(B)]
+        skip = [n_tplt[b] == 0 for b in range(B)]
+        tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
+        full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
+                                       targets, skip)
+        out_last = full.clone()
+        match_loss = []
+        for b in range(B):
+            if skip[b]:
+                out_last[b] = mask_last_occurence[b]
+                match_loss.append(prop_feat[b].sum() * 0)            # :121
+            else:
+                match_loss.append(loss[b])
+        return full, tplt_dict, match_loss, out_last

@@ -137,8 +137,9 @@ def relax_match_bwd(sim, score_p, dRb, d_match_score, d_det_score, *, max_iter, 
     return out
 
 
-def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float):
-    """relax_matching on cost matrices C [B,n,m] -> dict(X, R, cost [B,max_iter+1], iters [B])."""
+def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_valid=None, cols_valid=None):
+    """relax_matching on cost matrices C [B,n,m] -> dict(X, R, cost [B,max_iter+1], iters [B]).
+    rows_valid / cols_valid (int32 [B]) restrict each frame to its top-left live block."""
     _need_gpu(C)
     C = C.contiguous().float()
     B, n, m = C.shape
@@ -147,8 +148,9 @@ def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float):
     cost = torch.zeros((B, max_iter + 1), dtype=torch.float32, device=C.device)
     iters = torch.empty((B,), dtype=torch.int32, device=C.device)
     with torch.cuda.device(C.device):
-        rc = _lib.load().dmm_relax_solve_f32(_ptr(C), B, n, m, int(max_iter), int(proj_iter), float(lr), _ptr(X),
-                                             _ptr(R), _ptr(cost), _ptr(iters), _stream(C))
+        rc = _lib.load().dmm_relax_solve_f32(_ptr(C), B, n, m, _ptr(rows_valid), _ptr(cols_valid), int(max_iter),
+                                             int(proj_iter), float(lr), _ptr(X), _ptr(R), _ptr(cost), _ptr(iters),
+                                             _stream(C))
     _lib.check(rc, "dmm_relax_solve_f32")
     return dict(X=X, R=R, cost=cost, iters=iters)
 

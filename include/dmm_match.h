@@ -116,12 +116,16 @@ DMM_API int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const
                                 float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                                 dmm_stream_t stream);
 
-/* Solver only, on a caller-provided cost matrix C [B,n,m] (relax_matching itself,
- * relax_match.py:36-105): X_final, R = mean(X_list), cost list [B,max_iter+1] (may be NULL),
- * iters [B].  n <= DMM_MAX_TEMPLATES, m <= DMM_MAX_PROPOSALS. */
-DMM_API int dmm_relax_solve_f32(const float *C, int B, int n, int m, int max_iter, int proj_iter, float lr,
-                        float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
-                        dmm_stream_t stream);
+/* Solver only, on caller-provided cost matrices C [B,n,m] (relax_matching itself,
+ * relax_match.py:36-105; with max_iter = 0 it is the greedy initialisation used by
+ * compute_matching_loss, match_helper.py:44): X_final, R = mean(X_list), cost list [B,max_iter+1]
+ * (may be NULL), iters [B].  rows_valid / cols_valid [B] (may be NULL) restrict frame b to its top-left
+ * [rows_valid[b], cols_valid[b]] block (the rest of X_final / R is zero filled).
+ * n <= DMM_MAX_TEMPLATES, m <= DMM_MAX_PROPOSALS. */
+DMM_API int dmm_relax_solve_f32(const float *C, int B, int n, int m, const int32_t *rows_valid,
+                                const int32_t *cols_valid, int max_iter, int proj_iter, float lr,
+                                float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
+                                dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3b) Backward of (3) with respect to sim (the reference gets it from torch autograd through

@@ -46,8 +46,8 @@ def test_argument_validation_without_gpu():
     assert L.dmm_iou_counts(None, None, 0, 0, 4, 2, 16, 64, 16, 32, 16, None, None, None, None, None, None) == 0
     # M beyond the compiled solver envelope
     one = ctypes.c_void_p(8)
-    assert L.dmm_relax_solve_f32(one, 1, 33, 40, 1, 1, 0.1, one, one, None, one, None) == 2
-    assert L.dmm_relax_solve_f32(one, 1, 3, 257, 1, 1, 0.1, one, one, None, one, None) == 2
+    assert L.dmm_relax_solve_f32(one, 1, 33, 40, None, None, 1, 1, 0.1, one, one, None, one, None) == 2
+    assert L.dmm_relax_solve_f32(one, 1, 3, 257, None, None, 1, 1, 0.1, one, one, None, one, None) == 2
 
 
 def test_product_does_not_import_oracle():

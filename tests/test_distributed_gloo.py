@@ -1,0 +1,74 @@
+"""Multi-process path on CPU: gloo, world_size 2 (the GPU runs use the same code over RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dmm_net_amd.distributed import GradBucketer, init_from_env, reduce_loss_dict, shard_range
+
+
+def test_shard_range_partitions_frames():
+    for total in (0, 1, 7, 8, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    r, w = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    # a small "model": several tensors, a bucket limit that forces more than one bucket, one unused parameter
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (1000,), (64, 64), (3,))]
+    for i, p in enumerate(params[:-1]):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    params[-1].grad = None if rank == 0 else torch.ones(3)
+    gb = GradBucketer(params, bucket_mb=0.01)
+    assert 2 <= gb.num_collectives() < len(params) + 1
+    gb.all_reduce_mean()
+    ok = True
+    for i, p in enumerate(params[:-1]):
+        exp = (i + 1) * sum(range(1, world + 1)) / world
+        ok &= bool(torch.allclose(p.grad, torch.full_like(p, exp)))
+    ok &= bool(torch.allclose(params[-1].grad, torch.full((3,), (world - 1) / world)))
+    red = reduce_loss_dict({"loss": torch.tensor(float(rank + 1)), "match_loss": torch.tensor(2.0 * (rank + 1))})
+    if rank == 0:
+        ok &= abs(float(red["loss"]) - sum(range(1, world + 1)) / world) < 1e-6
+        ok &= abs(float(red["match_loss"]) - 2 * sum(range(1, world + 1)) / world) < 1e-6
+    # frame sharding + a max-over-ranks timing reduction as bench.py does
+    b, e = shard_range(11, rank, world)
+    t = torch.tensor([float(e - b)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok &= float(t) == 6.0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_gloo_world2_grad_bucketer_and_loss_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
