@@ -42,7 +42,7 @@ constexpr int kCosDC = 64;        // D-chunk staged per step: N x (64+1) floats 
 
 // block = 256 threads = `slots` template rows of TPM = 64*ceil(N/64) threads each; grid = (ceil(M/slots), B).
 // All slots of a block share the staged proposal tile.
-__global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ featn_t, const float *__restrict__ featn_p,
+__global__ __launch_bounds__(256, 4) void cosine_kernel(const float *__restrict__ featn_t, const float *__restrict__ featn_p,
                                                      int N, int M, int D, int tpm, const int32_t *__restrict__ n_valid,
                                                      const int32_t *__restrict__ m_valid, float *__restrict__ cos_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ f
         const float *qq = q_s + slot * kCosDC;
         if (dc == kCosDC && fast_ok) {
             if (class_a) {
-#pragma unroll
+#pragma unroll 1
                 for (int blk = 0; blk < 4; ++blk) {
                     float a = ca.a0;
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ f
                 }
             } else {                                          // 64 consecutive d = 16 per ILP chain (d0 % 64 == 0)
                 float a0 = c0.a0, a1 = c1.a0, a2 = c2.a0, a3 = c3.a0;
-#pragma unroll
+#pragma unroll 4
                 for (int t = 0; t < 16; ++t) {
                     a0 = a0 + qq[4 * t] * row[4 * t];
                     a1 = a1 + qq[4 * t + 1] * row[4 * t + 1];

@@ -19,6 +19,8 @@
 //   * epilogue: the 4 waves fold their integer partials with LDS atomics, then one global
 //     atomicAdd per table entry and workgroup (integers: result independent of order).
 // VALU work is ~8 % of the HBM time of a chunk; the kernel is a pure stream.
+#include <stdlib.h>
+
 #include "dmm_common.h"
 
 namespace dmm {
@@ -190,7 +192,8 @@ static int launch_tile(const T *masks_p, const T *masks_t, int B, int N, int M, 
                        int32_t *area_p, int32_t *area_t, int n0, int m0, int wap, int wat, hipStream_t stream) {
     const int nchunks = (HW + kChunk - 1) / kChunk;
     // >= ~2048 workgroups (8 per CU), at least 1 chunk per wave
-    int splits = (2048 + B - 1) / B;
+    static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 2048; }();
+    int splits = (target_wgs + B - 1) / B;
     const int max_splits = (nchunks + 3) / 4;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

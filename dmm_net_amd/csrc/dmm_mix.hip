@@ -7,6 +7,8 @@
 // fanned into the <= MT output rows held in registers.
 //
 // Roofline: HBM.  Bytes per frame = (#selected planes + M) * HW * 4  (test mode: <= 2*M*HW*4).
+#include <stdlib.h>
+
 #include "dmm_common.h"
 
 namespace dmm {
@@ -116,25 +118,155 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-major variant (default): one workgroup = one output row m of one frame over a pixel range.
+// In test mode a row has exactly one weighted plane, so the kernel degenerates to a scaled copy with
+// ONE read stream and ONE write stream per workgroup (many concurrent DRAM streams per workgroup cost
+// ~15 % of the bandwidth in the union kernel above).  Loads are issued kRowLoads at a time: G = 8 / cnt
+// consecutive 4 KiB steps of the row's cnt planes.  Planes shared by several rows (train mode) are
+// re-read per row; they are adjacent in time and mostly hit L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowLoads = 8;
+
+template <typename T, int CNT>   // CNT = entries of this row if 1 or 2, 0 = generic
+__device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const int *col_s, const float *w_s, int cnt,
+                                              float *orow, int HW, int s_begin, int s_end) {
+    constexpr int G = CNT == 1 ? 8 : (CNT == 2 ? 4 : 1);
+    for (int s0 = s_begin; s0 < s_end; s0 += G) {
+        float acc[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[g][k] = 0.0f;
+        if (CNT > 0) {
+            float v[G][CNT][4];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4;
+#pragma unroll
+                for (int e = 0; e < CNT; ++e) {
+                    const T *plane = Pb + (int64_t)col_s[e] * sp_n;
+                    if (s0 + g < s_end && x + 3 < HW) {
+                        MaskIO<T>::load4(plane + x, v[g][e]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[g][e][k] = (s0 + g < s_end && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < CNT; ++e) {
+                    const float w = w_s[e];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[g][k] = __builtin_fmaf(w, v[g][e][k], acc[g][k]);
+                }
+        } else {
+            const int x = (s0 * kMixThreads + threadIdx.x) * 4;
+            for (int e0 = 0; e0 < cnt; e0 += kRowLoads) {
+                float v[kRowLoads][4];
+#pragma unroll
+                for (int u = 0; u < kRowLoads; ++u) {
+                    const int e = e0 + u < cnt ? e0 + u : cnt - 1;
+                    const T *plane = Pb + (int64_t)col_s[e] * sp_n;
+                    if (x + 3 < HW) {
+                        MaskIO<T>::load4(plane + x, v[u]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[u][k] = x + k < HW ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kRowLoads; ++u)
+                    if (e0 + u < cnt) {
+                        const float w = w_s[e0 + u];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[0][k] = __builtin_fmaf(w, v[u][k], acc[0][k]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4;
+            if (s0 + g >= s_end || x >= HW) continue;
+            float *o = orow + x;
+            if (x + 3 < HW) {
+                float4u t;
+                t.x = acc[g][0]; t.y = acc[g][1]; t.z = acc[g][2]; t.w = acc[g][3];
+                *reinterpret_cast<float4u *>(o) = t;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < HW) o[k] = acc[g][k];
+            }
+        }
+    }
+}
+
+// grid = (pixel splits, M, B)
+template <typename T>
+__global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float *__restrict__ Rb,
+                                                                    const T *__restrict__ masks_p, int N, int M, int Pp,
+                                                                    int HW, int64_t sp_b, int64_t sp_n,
+                                                                    const int32_t *__restrict__ n_valid,
+                                                                    const int32_t *__restrict__ m_valid,
+                                                                    float *__restrict__ out, int64_t so_b, int64_t so_m,
+                                                                    int steps_per_wg) {
+    __shared__ float w_s[DMM_MAX_PROPOSALS];
+    __shared__ int col_s[DMM_MAX_PROPOSALS];
+    __shared__ int cnt_s;
+    const int b = blockIdx.z, m = blockIdx.y;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    if (threadIdx.x < 64) {
+        int base = 0;
+        if (m < Mb) {
+            const float *Rrow = Rb + ((int64_t)b * M + m) * Pp;
+            for (int n0 = 0; n0 < Nb; n0 += 64) {
+                const int n = n0 + threadIdx.x;
+                const float w = n < Nb ? Rrow[n] : 0.0f;
+                const unsigned long long bal = __ballot(w != 0.0f);
+                if (w != 0.0f) {
+                    const int pos = base + __builtin_popcountll(bal & ((1ull << threadIdx.x) - 1ull));
+                    col_s[pos] = n;
+                    w_s[pos] = w;
+                }
+                base += __builtin_popcountll(bal);
+            }
+        }
+        if (threadIdx.x == 0) cnt_s = base;
+    }
+    __syncthreads();
+    const int cnt = cnt_s;
+    const T *Pb = masks_p + (int64_t)b * sp_b;
+    float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
+    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_end = min(nsteps, s_begin + steps_per_wg);
+    if (cnt == 1) mix_row_range<T, 1>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);
+    else if (cnt == 2) mix_row_range<T, 2>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);
+    else mix_row_range<T, 0>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);   // cnt == 0 writes zeros
+}
+
 template <typename T>
 static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    int splits = (2048 + B - 1) / B;
-    if (splits > nsteps) splits = nsteps;
+    // many small workgroups (~40k, 16 steps = 64 KiB of the row each) balance the HBM channels best
+    // (measured 4.34 -> 4.98 TB/s going from 4k to 40k workgroups at B = 1024); DMM_MIX_WGS overrides
+    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 40000; }();
+    int splits = (target_wgs + B * M - 1) / (B * M);
+    const int max_splits = (nsteps + 7) / 8;
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    const int steps_per_wg = (nsteps + splits - 1) / splits;
+    const int steps_per_wg = ((nsteps + splits - 1) / splits + 7) / 8 * 8;
     splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
-    dim3 grid(splits, B);
-#define DMM_MIX_CASE(MT_)                                                                                            \
-    hipLaunchKernelGGL((mask_mix_kernel<T, MT_>), grid, dim3(kMixThreads), 0, stream, Rb, masks_p, N, M, Pp, HW, sp_b, \
-                       sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg)
-    if (M <= 4) DMM_MIX_CASE(4);
-    else if (M <= 8) DMM_MIX_CASE(8);
-    else if (M <= 16) DMM_MIX_CASE(16);
-    else DMM_MIX_CASE(32);
-#undef DMM_MIX_CASE
+    hipLaunchKernelGGL((mask_mix_rows_kernel<T>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, M, Pp,
+                       HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg);
     return check_launch();
 }
 
@@ -146,7 +278,7 @@ extern "C" int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int
     if (B < 0 || N < 0 || M < 0 || HW < 0 || Pp < N) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0 || HW == 0) return DMM_OK;
     if (!Rb || !masks_p || !out) return DMM_ERR_BAD_ARG;
-    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW || so_m < HW) return DMM_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
