@@ -1,0 +1,172 @@
+// dmm_roialign.hip -- fused 4-level ROIAlign + spatial mean on gfx950 (reference a9).
+//
+// Replaces the reference's ROI feature extractor (dmm/modules/feature_extractor.py:11-52): for each of
+// the 4 pyramid levels (scales 1/4 .. 1/32, :13) maskrcnn_benchmark's legacy (non-aligned) ROIAlign
+// (14x14 bins, sampling_ratio 2, :14-16) is run on EVERY roi (:50-51), the [R, 4, C, 14, 14] result is
+// materialised (:49) and then averaged over the 14x14 bins (:29) -> [R, 4*C].
+// Third-party arithmetic: maskrcnn_benchmark (github.com/ZENGXH/maskrcnn-benchmark, un-pinned HEAD,
+// INSTALL.md:24) is not vendored; its published ROIAlign definition is restated in oracle/dmm_oracle.c
+// (its roialign4_mean restatement) -- parity of this row is UN-PINNED (no reference fixtures exist for it).
+//
+// The 2x2 samples of the 14x14 bins form a uniform 28x28 grid over the roi and bilinear weights are
+// separable, so   out[r, l, c] = sum_h wy[h] * sum_w wx[w] * feat_l[b, c, h, w]   with two 1-D weight
+// vectors per (roi, level).  The 20 MB/frame intermediate of the reference is never formed; every feature
+// row inside the roi is read once per channel, coalesced along w.
+//
+// Roofline: L2 bandwidth (feature maps are a few MB per frame and are re-read by overlapping rois).
+#include "dmm_common.h"
+
+namespace dmm {
+
+constexpr int kRoiMaxDim = 1024;     // max H or W of a feature map
+constexpr int kRoiSamples = 28;      // 14 bins x sampling_ratio 2
+
+struct RoiLevels {
+    const void *feat[4];
+    float *dfeat[4];
+    int H[4], W[4];
+    float scale[4];
+};
+
+// 1-D weights of the 28 sample points of a roi along one axis (legacy ROIAlign bilinear rule).
+__device__ __forceinline__ void axis_weights(float start, float end, int size, float *w_s, int *lo_out, int *hi_out) {
+    float len = end - start;
+    len = len > 1.0f ? len : 1.0f;                       // roi size clamped to >= 1 (legacy, non-aligned)
+    const float bin = len / 14.0f;
+    int lo = size, hi = -1;
+    for (int k = 0; k < kRoiSamples; ++k) {
+        const int p = k >> 1, i = k & 1;
+        float y = start + (float)p * bin + ((float)i + 0.5f) * bin / 2.0f;
+        if (y < -1.0f || y > (float)size) continue;      // sample outside: contributes 0
+        if (y <= 0.0f) y = 0.0f;
+        int y_low = (int)y, y_high;
+        if (y_low >= size - 1) { y_high = y_low = size - 1; y = (float)y_low; }
+        else y_high = y_low + 1;
+        const float ly = y - (float)y_low, hy = 1.0f - ly;
+        w_s[y_low] += hy;
+        w_s[y_high] += ly;
+        lo = y_low < lo ? y_low : lo;
+        hi = y_high > hi ? y_high : hi;
+    }
+    *lo_out = lo;
+    *hi_out = hi;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v.v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_float(((uint32_t)v.v) << 16); }
+
+// grid = (R, 4); block = 256 (4 waves, each takes every 4th channel; lanes run along w).
+// BWD = false: out[r, l*C + c] = weighted sum.  BWD = true: dfeat[b,c,h,w] += wy*wx*dout[r, l*C + c] (fp32 atomics).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roialign4_mean_kernel(RoiLevels lv, int B, int C, const float *__restrict__ rois,
+                                                             int R, float *__restrict__ out_or_dout) {
+    __shared__ float wy_s[kRoiMaxDim], wx_s[kRoiMaxDim];
+    __shared__ int rng_s[4];
+    const int r = blockIdx.x, l = blockIdx.y;
+    const int H = lv.H[l], W = lv.W[l];
+    const float sc = lv.scale[l];
+    for (int i = threadIdx.x; i < H; i += 256) wy_s[i] = 0.0f;
+    for (int i = threadIdx.x; i < W; i += 256) wx_s[i] = 0.0f;
+    __syncthreads();
+    const float *roi = rois + (int64_t)r * 5;
+    const int b = (int)roi[0];
+    if (threadIdx.x == 0) axis_weights(roi[2] * sc, roi[4] * sc, H, wy_s, &rng_s[0], &rng_s[1]);
+    if (threadIdx.x == 64) axis_weights(roi[1] * sc, roi[3] * sc, W, wx_s, &rng_s[2], &rng_s[3]);
+    __syncthreads();
+    const int h0 = rng_s[0], h1 = rng_s[1], w0 = rng_s[2], w1 = rng_s[3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float norm = 1.0f / (float)(kRoiSamples * kRoiSamples);     // /4 per bin, /14, /14
+    const bool empty = h1 < h0 || w1 < w0 || b < 0 || b >= B;
+    if (!BWD) {
+        const T *f = (const T *)lv.feat[l] + (int64_t)(empty ? 0 : b) * C * H * W;
+        for (int c = wave; c < C; c += 4) {
+            float acc = 0.0f;
+            if (!empty) {
+                const T *fc = f + (int64_t)c * H * W;
+                for (int wq = w0 + lane; wq <= w1; wq += 64) {
+                    const float wxv = wx_s[wq];
+                    float col = 0.0f;
+                    for (int h = h0; h <= h1; ++h) col = __builtin_fmaf(wy_s[h], to_f32<T>(fc[(int64_t)h * W + wq]), col);
+                    acc = __builtin_fmaf(wxv, col, acc);
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) out_or_dout[(int64_t)r * 4 * C + (int64_t)l * C + c] = acc * norm;
+        }
+    } else {
+        if (empty) return;
+        float *df = lv.dfeat[l] + (int64_t)b * C * H * W;
+        for (int c = wave; c < C; c += 4) {
+            const float g = out_or_dout[(int64_t)r * 4 * C + (int64_t)l * C + c] * norm;
+            float *dc = df + (int64_t)c * H * W;
+            for (int wq = w0 + lane; wq <= w1; wq += 64) {
+                const float gx = g * wx_s[wq];
+                for (int h = h0; h <= h1; ++h) {
+                    const float v = gx * wy_s[h];
+                    if (v != 0.0f) atomicAdd(&dc[(int64_t)h * W + wq], v);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dmm
+
+static int roi_check(const void *const feat[4], const int H[4], const int W[4], const float scale[4], int B, int C,
+                     const float *rois, int R) {
+    if (B < 0 || C < 0 || R < 0) return DMM_ERR_BAD_ARG;
+    if (R == 0 || C == 0) return DMM_OK;
+    if (!feat || !H || !W || !scale || !rois) return DMM_ERR_BAD_ARG;
+    for (int l = 0; l < 4; ++l) {
+        if (!feat[l] || H[l] <= 0 || W[l] <= 0) return DMM_ERR_BAD_ARG;
+        if (H[l] > dmm::kRoiMaxDim || W[l] > dmm::kRoiMaxDim) return DMM_ERR_UNSUPPORTED;
+    }
+    return -1;
+}
+
+extern "C" int dmm_roialign4_mean_fwd(const void *const feat[4], int dtype, int B, int C, const int H[4], const int W[4],
+                                      const float scale[4], const float *rois, int R, float *out,
+                                      dmm_stream_t stream) {
+    const int rc = roi_check(feat, H, W, scale, B, C, rois, R);
+    if (rc >= 0) return rc;
+    if (!out) return DMM_ERR_BAD_ARG;
+    dmm::RoiLevels lv;
+    for (int l = 0; l < 4; ++l) {
+        lv.feat[l] = feat[l]; lv.dfeat[l] = nullptr; lv.H[l] = H[l]; lv.W[l] = W[l]; lv.scale[l] = scale[l];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case DMM_F32:
+            hipLaunchKernelGGL((dmm::roialign4_mean_kernel<float, false>), dim3(R, 4), dim3(256), 0, s, lv, B, C, rois, R,
+                               out);
+            break;
+        case DMM_F16:
+            hipLaunchKernelGGL((dmm::roialign4_mean_kernel<dmm::f16_t, false>), dim3(R, 4), dim3(256), 0, s, lv, B, C,
+                               rois, R, out);
+            break;
+        case DMM_BF16:
+            hipLaunchKernelGGL((dmm::roialign4_mean_kernel<dmm::bf16_t, false>), dim3(R, 4), dim3(256), 0, s, lv, B, C,
+                               rois, R, out);
+            break;
+        default:
+            return DMM_ERR_BAD_ARG;
+    }
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int H[4], const int W[4],
+                                      const float scale[4], const float *rois, int R, float *const dfeat[4],
+                                      dmm_stream_t stream) {
+    const int rc = roi_check((const void *const *)dfeat, H, W, scale, B, C, rois, R);
+    if (rc >= 0) return rc;
+    if (!dout) return DMM_ERR_BAD_ARG;
+    dmm::RoiLevels lv;
+    for (int l = 0; l < 4; ++l) {
+        lv.feat[l] = nullptr; lv.dfeat[l] = dfeat[l]; lv.H[l] = H[l]; lv.W[l] = W[l]; lv.scale[l] = scale[l];
+    }
+    hipLaunchKernelGGL((dmm::roialign4_mean_kernel<float, true>), dim3(R, 4), dim3(256), 0, (hipStream_t)stream, lv, B, C,
+                       rois, R, const_cast<float *>(dout));
+    return dmm::check_launch();
+}

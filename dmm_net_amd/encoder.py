@@ -1,0 +1,186 @@
+"""Encoder of the matching path: ResNet body + skip / proposal heads (reference a10).
+
+Counterpart of ``dmm/modules/vision.py:6-38`` (torchvision ``ResNet`` subclasses returning x5..x1),
+``dmm/modules/base.py:18-69`` (``FeatureExtractorBase``: ``sk2..5`` + ``bn2..5`` skip projections for the decoder,
+``prop2..5`` two-conv heads that feed the ROI feature extractor) and the feature part of
+``dmm/modules/model_encoder.py:86-162`` (``forward_base`` + the head calls :136-146).
+
+The convolutions are plain ``torch.nn`` modules: on ROCm they run on MIOpen (the only MFMA work on the whole path
+-- the matching kernels are bandwidth / latency bound and never touch the matrix cores).  ``channels_last`` +
+bf16 autocast are the MI355X-friendly settings (BASELINE config 3).  torchvision is not a dependency: the body is
+written out here with torchvision's parameter names (``conv1, bn1, layer1..4.N.convK/bnK/downsample.0/1, fc``)
+so reference checkpoints (``encoder`` keys, ``dmm/utils/utils.py:57-111``) load with ``load_state_dict``.
+
+Not here ("next"): offline-proposal lookup, mask paste, NMS + top-k
+(``model_encoder.py:115-134``) -- proposals are an input of this module's callers.
+
+Parity: un-pinned.  torchvision / pretrained weights are not available offline and the reference's encoder cannot
+be imported (needs maskrcnn_benchmark), so tests check structure (parameter counts of the published
+architectures, state-dict key names, output strides / channels) and gradient flow only.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+
+def get_skip_dims(model_name: str):
+    """dmm/utils/utils.py:249-256."""
+    if model_name in ("resnet50", "resnet101", "coco"):
+        return [2048, 1024, 512, 256, 64]
+    if model_name == "resnet34":
+        return [512, 256, 128, 64, 64]
+    raise Exception("The base model you chose is not supported ! {}".format(model_name))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    """torchvision's v1.5 bottleneck: the stride sits on the 3x3 convolution."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNetBody(nn.Module):
+    """ResNet returning (x5, x4, x3, x2, x1) like the reference's subclasses (vision.py:11-21)."""
+
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))      # unused by DMM-Net; kept for checkpoint key parity
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x1 = self.relu(self.bn1(self.conv1(x)))
+        x = self.maxpool(x1)
+        x2 = self.layer1(x)
+        x3 = self.layer2(x2)
+        x4 = self.layer3(x3)
+        x5 = self.layer4(x4)
+        return x5, x4, x3, x2, x1
+
+
+def ResNet34():
+    return ResNetBody(BasicBlock, [3, 4, 6, 3])
+
+
+def ResNet50():
+    return ResNetBody(Bottleneck, [3, 4, 6, 3])
+
+
+def ResNet101():
+    return ResNetBody(Bottleneck, [3, 4, 23, 3])
+
+
+def _prop_head(cin, cmid, cout, k, pad):
+    # base.py:43-54: conv -> BN -> ReLU -> conv -> BN
+    return nn.Sequential(nn.Conv2d(cin, cmid, k, padding=pad), nn.BatchNorm2d(cmid), nn.ReLU(),
+                         nn.Conv2d(cmid, cout, k, padding=pad), nn.BatchNorm2d(cout))
+
+
+class FeatureEncoder(nn.Module):
+    """Body + heads.  ``forward(img [B,3,H,W])`` returns the reference's feature dict (model_encoder.py:157-160):
+    ``backbone_feature`` = (p2, p3, p4, p5) (``hidden_size`` channels at strides 4/8/16/32),
+    ``refine_input_feat`` = (x5_skip, x4_skip, x3_skip, x2_skip), ``body_feature`` = (x2, x3, x4, x5)."""
+
+    def __init__(self, base_model: str = "resnet50", hidden_size: int = 128, kernel_size: int = 3):
+        super().__init__()
+        dims = get_skip_dims(base_model)
+        hid, ker = int(hidden_size), int(kernel_size)
+        pad = 0 if ker == 1 else 1
+        self.base = {"resnet34": ResNet34, "resnet50": ResNet50, "resnet101": ResNet101}[base_model]()
+        self.sk5 = nn.Conv2d(dims[0], hid, ker, padding=pad)
+        self.sk4 = nn.Conv2d(dims[1], hid, ker, padding=pad)
+        self.sk3 = nn.Conv2d(dims[2], hid // 2, ker, padding=pad)
+        self.sk2 = nn.Conv2d(dims[3], hid // 4, ker, padding=pad)
+        self.bn5, self.bn4 = nn.BatchNorm2d(hid), nn.BatchNorm2d(hid)
+        self.bn3, self.bn2 = nn.BatchNorm2d(hid // 2), nn.BatchNorm2d(hid // 4)
+        self.prop5 = _prop_head(dims[0], hid, hid, ker, pad)
+        self.prop4 = _prop_head(dims[1], hid, hid, ker, pad)
+        self.prop3 = _prop_head(dims[2], hid // 2, hid, ker, pad)
+        self.prop2 = _prop_head(dims[3], hid // 4, hid, ker, pad)
+
+    def get_skip_params(self):
+        """base.py:62-69."""
+        plist = []
+        for p in (self.sk2, self.sk3, self.sk4, self.sk5, self.bn2, self.bn3, self.bn4, self.bn5,
+                  self.prop5, self.prop4, self.prop3, self.prop2):
+            plist.extend(list(p.parameters()))
+        return plist
+
+    def get_backbone_para(self):
+        for _, p in self.base.named_parameters():
+            if p.requires_grad:
+                yield p
+
+    def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
+        assert img.dim() == 4 and img.shape[1] == 3, img.shape           # model_encoder.py:91-92
+        x5, x4, x3, x2, _ = self.base(img)
+        x5_skip = self.bn5(self.sk5(x5))
+        x4_skip = self.bn4(self.sk4(x4))
+        x3_skip = self.bn3(self.sk3(x3))
+        x2_skip = self.bn2(self.sk2(x2))
+        p5, p4, p3, p2 = self.prop5(x5), self.prop4(x4), self.prop3(x3), self.prop2(x2)
+        return {"backbone_feature": (p2, p3, p4, p5),
+                "refine_input_feat": (x5_skip, x4_skip, x3_skip, x2_skip),
+                "body_feature": (x2, x3, x4, x5)}

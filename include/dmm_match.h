@@ -177,6 +177,22 @@ DMM_API int dmm_match_forward(const void *masks_p, const void *masks_t, int mask
                       int32_t *iters_out /*[B] or NULL*/,
                       void *workspace, size_t workspace_bytes, dmm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (6) Fused 4-level ROIAlign + spatial mean: the reference's ROI feature extractor
+ * (dmm/modules/feature_extractor.py:20-52: maskrcnn_benchmark legacy ROIAlign, 14x14 bins,
+ * sampling_ratio 2, at the four scales on EVERY roi, then .mean(4).mean(3) -> [R, 4*C]).
+ * feat[l]: [B, C, H[l], W[l]] contiguous NCHW (dtype fp32 / fp16 / bf16), rois: [R,5] fp32
+ * (batch index, x1, y1, x2, y2) in image coordinates, scale[l] = 1/stride.  out: [R, 4*C] fp32,
+ * out[r, l*C + c].  The backward accumulates (fp32 atomics) into dfeat[l] (same shapes, fp32,
+ * zeroed by the caller); boxes receive no gradient (as in maskrcnn_benchmark).
+ * H[l], W[l] <= 1024.  Parity of this row is un-pinned upstream (third-party op, no fixtures).
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_roialign4_mean_fwd(const void *const feat[4], int dtype, int B, int C, const int H[4], const int W[4],
+                                   const float scale[4], const float *rois, int R, float *out, dmm_stream_t stream);
+DMM_API int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int H[4], const int W[4],
+                                   const float scale[4], const float *rois, int R, float *const dfeat[4],
+                                   dmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

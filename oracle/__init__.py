@@ -57,6 +57,9 @@ def lib():
         L.dmmo_match_forward.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, c_int, c_int, c_int, c_int,
                                          c_float, c_int, c_int, c_float, c_int] + [_vp] * 11
         L.dmmo_match_forward.restype = c_int
+        L.dmmo_roialign4_mean.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          _f32p, c_int, c_int, c_int, _f32p]
+        L.dmmo_roialign4_mean.restype = None
         L.dmmo_check_div_by_const.argtypes = [c_int, ctypes.c_long]
         L.dmmo_check_div_by_const.restype = ctypes.c_long
         _lib = L
@@ -173,3 +176,19 @@ def match_forward(prop_mask, tplt_mask, prop_feat, tplt_feat, prop_score, *, sco
 def check_div_by_const(bmax=256, samples=100000):
     """Mismatches of the device's reciprocal-refinement division against IEEE division (expect 0)."""
     return int(lib().dmmo_check_div_by_const(int(bmax), int(samples)))
+
+
+def roialign4_mean(feats, rois, scales=(0.25, 0.125, 0.0625, 0.03125), pooled=14, sampling=2):
+    """Reference ROI feature extractor (feature_extractor.py:20-52) on 4 NCHW fp32 maps -> [R, 4*C].
+    Literal legacy-ROIAlign restatement (third-party algorithm, parity un-pinned)."""
+    feats = [_c(f) for f in feats]
+    rois = _c(rois)
+    B, C = feats[0].shape[0], feats[0].shape[1]
+    R = rois.shape[0]
+    ptrs = (ctypes.c_void_p * 4)(*[f.ctypes.data for f in feats])
+    Hs = (ctypes.c_int * 4)(*[f.shape[2] for f in feats])
+    Ws = (ctypes.c_int * 4)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * 4)(*scales)
+    out = np.zeros((R, 4 * C), np.float32)
+    lib().dmmo_roialign4_mean(ptrs, B, C, Hs, Ws, sc, rois, R, int(pooled), int(sampling), out)
+    return out

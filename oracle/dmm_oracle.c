@@ -490,3 +490,64 @@ DMMO_API long dmmo_check_div_by_const(int bmax, long samples) {
     }
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------
+ * ROI feature extractor (dmm/modules/feature_extractor.py:11-52): maskrcnn_benchmark's legacy ROIAlign
+ * (third-party, github.com/ZENGXH/maskrcnn-benchmark un-pinned HEAD; algorithm restated from its published
+ * ROIAlign_cuda.cu / ROIAlign_cpu.cpp: roi size clamped to >= 1, sampling_ratio x sampling_ratio bilinear
+ * samples per bin averaged, samples outside [-1, size] contribute 0) on 4 levels for every roi, then the
+ * mean over the pooled H x W bins.  PARITY UN-PINNED: the package is absent and the reference holds no
+ * fixtures for it; this literal restatement is the checker for the fused HIP kernel.
+ * feat[l]: [B, C, H[l], W[l]] fp32; rois [R,5]; out [R, 4*C].
+ * ---------------------------------------------------------------------------------- */
+static float bilinear_legacy(const float *data, int height, int width, float y, float x) {
+    if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return 0.0f;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float v1 = data[y_low * width + x_low], v2 = data[y_low * width + x_high];
+    const float v3 = data[y_high * width + x_low], v4 = data[y_high * width + x_high];
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+DMMO_API void dmmo_roialign4_mean(const float *const feat[4], int B, int C, const int H[4], const int W[4],
+                                  const float scale[4], const float *rois, int R, int pooled, int sampling,
+                                  float *out) {
+    (void)B;
+    for (int r = 0; r < R; ++r) {
+        const float *roi = rois + 5 * r;
+        const int b = (int)roi[0];
+        for (int l = 0; l < 4; ++l) {
+            const float sw = roi[1] * scale[l], sh = roi[2] * scale[l], ew = roi[3] * scale[l], eh = roi[4] * scale[l];
+            const float rw = fmaxf(ew - sw, 1.0f), rh = fmaxf(eh - sh, 1.0f);
+            const float bh = rh / (float)pooled, bw = rw / (float)pooled;
+            const int gh = sampling > 0 ? sampling : (int)ceilf(rh / pooled);
+            const int gw = sampling > 0 ? sampling : (int)ceilf(rw / pooled);
+            const float count = (float)(gh * gw);
+            for (int c = 0; c < C; ++c) {
+                const float *data = feat[l] + ((size_t)b * C + c) * H[l] * W[l];
+                double mean_h = 0;                                  /* .mean(4) then .mean(3) */
+                for (int ph = 0; ph < pooled; ++ph) {
+                    double mean_w = 0;
+                    for (int pw = 0; pw < pooled; ++pw) {
+                        float v = 0.0f;
+                        for (int iy = 0; iy < gh; ++iy) {
+                            const float y = sh + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                            for (int ix = 0; ix < gw; ++ix) {
+                                const float x = sw + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                                v += bilinear_legacy(data, H[l], W[l], y, x);
+                            }
+                        }
+                        mean_w += (double)(v / count);
+                    }
+                    mean_h += mean_w / pooled;
+                }
+                out[(size_t)r * 4 * C + (size_t)l * C + c] = (float)(mean_h / pooled);
+            }
+        }
+    }
+}
