@@ -22,7 +22,7 @@ MAX_PROPOSALS = 256
 # every symbol include/dmm_match.h declares
 SYMBOLS = (
     "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
-    "dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
 )
@@ -65,6 +65,8 @@ def load():
     L.dmm_build_info.restype = ctypes.c_char_p
     L.dmm_iou_counts.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, vp, vp,
                                  vp, vp, vp, vp]
+    L.dmm_iou_counts_dual.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                      c_i64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dmm_feature_normalize_f32.argtypes = [vp, c_i64, c_int, vp, vp, vp]
     L.dmm_cosine_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,
@@ -83,7 +85,7 @@ def load():
     L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                     c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]
-    for f in ("dmm_iou_counts", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    for f in ("dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
               "dmm_roialign4_mean_bwd"):
         getattr(L, f).restype = c_int

@@ -28,11 +28,15 @@ def hungarian_onehot(cost: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(X).float().to(cost.device)
 
 
-def matching_loss(pm_b, targets_b, cos, n_valid=None, m_valid=None):
+def matching_loss(pm_b, targets_b, cos, n_valid=None, m_valid=None, counts=None):
     """compute_matching_loss (match_helper.py:30-49) for B frames -> (loss [B], gt one-hot [B,O,P]).
-    IoU(proposal > 0.5, targets) -> greedy one-hot of -IoU (relax_matching(..., 0, 0, 0)) -> MSE with cos."""
+    IoU(proposal > 0.5, targets) -> greedy one-hot of -IoU (relax_matching(..., 0, 0, 0)) -> MSE with cos.
+    ``counts`` = (inter2, area_p, area_t2) when the cost pass already intersected the targets (iou_counts_dual)."""
     B, O, P = cos.shape
-    gi, gap, gat = ops.iou_counts(pm_b, targets_b.to(pm_b.dtype), n_valid, m_valid)
+    if counts is not None:
+        gi, gap, gat = counts
+    else:
+        gi, gap, gat = ops.iou_counts(pm_b, targets_b.to(pm_b.dtype), n_valid, m_valid)
     union = (gap.unsqueeze(1) + gat.unsqueeze(2) - gi).float() + 1e-6
     gt_iou = gi.float() / union
     gt = ops.relax_solve(-gt_iou, 0, 0, 0.0, rows_valid=m_valid, cols_valid=n_valid)["X"]
@@ -53,7 +57,13 @@ class _MatchLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pf, tf, pm, tm, sc, targets, n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test):
-        inter, ap, at = ops.iou_counts(pm, tm, n_valid, m_valid)
+        tcounts = None
+        if targets is not None and tm.shape[1] <= 16:
+            # training: one pass over the proposal planes for both IoU tables (templates and targets)
+            (inter, ap, at), (gi, gat) = ops.iou_counts_dual(pm, tm, targets.to(pm.dtype), n_valid, m_valid)
+            tcounts = (gi, ap, gat)
+        else:
+            inter, ap, at = ops.iou_counts(pm, tm, n_valid, m_valid)
         pn, pnorm = ops.feature_normalize(pf, want_norms=True)
         tn, tnorm = ops.feature_normalize(tf, want_norms=True)
         cos = ops.cosine(tn, pn, n_valid, m_valid)
@@ -64,7 +74,7 @@ class _MatchLayerFn(torch.autograd.Function):
         cost_loss = pf.new_zeros((B,))
         gt, live, cnt = None, None, None
         if targets is not None:
-            cost_loss, gt, lc = matching_loss(pm, targets, cos, n_valid, m_valid)
+            cost_loss, gt, lc = matching_loss(pm, targets, cos, n_valid, m_valid, counts=tcounts)
             if lc is not None:
                 live, cnt = lc
         empty = pf.new_zeros(())

@@ -155,9 +155,14 @@ __device__ __forceinline__ float div_by_const(float a, float b, float rcp) {
     return __builtin_fmaf(r, rcp, q0);
 }
 
-// ---- mask element loads: 4 consecutive pixels as fp32 ---------------------------------------
+// ---- mask element loads: 4 consecutive pixels as fp32 (load4), or one full 16-byte lane load (loadv: 4 fp32 or
+// 8 half/bfloat16 pixels) for the streaming kernels -------------------------------------------------------
+typedef _Float16 half8u __attribute__((ext_vector_type(8), aligned(2)));
+typedef uint32_t uint4u __attribute__((ext_vector_type(4), aligned(2)));
 template <typename T> struct MaskIO;
 template <> struct MaskIO<float> {
+    static constexpr int kVec = 4;
+    static __device__ __forceinline__ void loadv(const float *p, float (&v)[4]) { load4(p, v); }
     static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
         float4u t = *reinterpret_cast<const float4u *>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -165,6 +170,12 @@ template <> struct MaskIO<float> {
     static __device__ __forceinline__ float load1(const float *p) { return *p; }
 };
 template <> struct MaskIO<f16_t> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ void loadv(const f16_t *p, float (&v)[8]) {
+        half8u t = *reinterpret_cast<const half8u *>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
     static __device__ __forceinline__ void load4(const f16_t *p, float (&v)[4]) {
         half4u t = *reinterpret_cast<const half4u *>(p);
         v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
@@ -172,6 +183,15 @@ template <> struct MaskIO<f16_t> {
     static __device__ __forceinline__ float load1(const f16_t *p) { return (float)p->v; }
 };
 template <> struct MaskIO<bf16_t> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ void loadv(const bf16_t *p, float (&v)[8]) {
+        uint4u t = *reinterpret_cast<const uint4u *>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(t[k] << 16);
+            v[2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
+        }
+    }
     static __device__ __forceinline__ void load4(const bf16_t *p, float (&v)[4]) {
         uint2u t = *reinterpret_cast<const uint2u *>(p);
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);

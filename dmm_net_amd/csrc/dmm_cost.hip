@@ -8,9 +8,9 @@
 // Roofline: HBM.  Algorithmic bytes per frame = (N+M)*HW*sizeof(elem) (+ 4*M*N table).
 //
 // Mapping (one workgroup = 4 independent waves, one frame, a contiguous range of 1024-pixel chunks):
-//   * a wave takes a 4 KiB run of a plane as 4 dwordx4 loads per lane (1 KiB / wave instruction,
-//     coalesced), thresholds `> 0.5` and bit-packs through v_cmp -> 64-bit lane masks (the
-//     hardware transposer): word 4j+k holds pixels 256j + 4*lane + k;
+//   * a wave takes a 1024-pixel run of a plane as 16-byte loads per lane (4 dwordx4 for fp32, 2 for
+//     half / bfloat16; 1 KiB per wave instruction, coalesced), thresholds `> 0.5` and bit-packs
+//     through v_cmp -> 64-bit lane masks (the hardware transposer);
 //   * the 64-bit words are parked in lane `plane` of 8 VGPRs with a lane-select (v_cndmask on
 //     lane == plane; proposal n -> lane n of group n/64, template m -> lane m of the template set),
 //     so the whole bit tile of a chunk lives in registers -- no LDS, no barriers in the streaming loop;
@@ -25,59 +25,65 @@
 
 namespace dmm {
 
-constexpr int kSub = 4;               // consecutive 256-pixel sub-chunks a wave takes from one plane per visit
-constexpr int kSubPix = 256;          // pixels per sub-chunk (64 lanes x 4)
-constexpr int kChunk = kSub * kSubPix;   // 1024 pixels = 4 KiB of one fp32 plane, contiguous: a plane row is only
-                                         // 4-byte aligned, so every 1 KiB wave load straddles one extra 128-B line;
-                                         // taking 4 KiB runs back to back shares those lines (HBM over-fetch 8.6% -> ~2%)
-constexpr int kUnroll = 2;            // planes in flight per wave: 2 x 4 x 1 KiB = 8 KiB of loads outstanding
-constexpr int kWords = 4 * kSub;      // 64-bit words per plane and chunk
+constexpr int kChunk = 1024;          // pixels a wave takes from one plane per visit: a contiguous run of
+                                      // 4 KiB (fp32) / 2 KiB (16-bit).  A plane row is only 4-byte (2-byte) aligned, so
+                                      // every wave load straddles one extra 128-B line; taking the run back to back
+                                      // shares those lines (measured HBM over-fetch 8.6 % -> 1.3 % for fp32)
+constexpr int kUnroll = 2;            // planes in flight per wave: 2 x (kChunk * sizeof(T)) bytes of loads outstanding
+constexpr int kWords = kChunk / 64;   // 64-bit words per plane and chunk (16)
 constexpr int kCostThreads = 256;
 
+// One 16-byte load per lane: E = 4 (fp32) or 8 (half / bfloat16) consecutive pixels; a chunk is kChunk / (64 E)
+// such loads (4 or 2).  Word index of pixel 64*E*j + E*lane + k is E*j + k.
 template <typename T, bool TAIL>
-__device__ __forceinline__ void load_pixels(const T *plane, int x, int HW, float (&v)[4]) {
-    if (!TAIL || x + 3 < HW) {
-        MaskIO<T>::load4(plane + x, v);
+__device__ __forceinline__ void load_pixels(const T *plane, int x, int HW, float (&v)[MaskIO<T>::kVec]) {
+    constexpr int E = MaskIO<T>::kVec;
+    if (!TAIL || x + E - 1 < HW) {
+        MaskIO<T>::loadv(plane + x, v);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+        for (int k = 0; k < E; ++k) v[k] = (x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
     }
 }
 
-// Bit tile of one group of <= 64 planes for one chunk: lane p holds the kWords words of plane p
-// (word 4*j + k = pixels 256*j + 4*lane + k of the chunk).
+// Bit tile of one group of <= 64 planes for one chunk: lane p holds the kWords words of plane p.
 struct BitTile {
     int lo[kWords], hi[kWords];
 };
 
 template <typename T, bool TAIL>
 __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t plane_stride, int nplanes,
-                                          int x, int HW) {
+                                          int x0, int HW, int lane0 = 0, bool clear = true) {
+    constexpr int E = MaskIO<T>::kVec;
+    constexpr int SUB = kChunk / (64 * E);
     const int lane = threadIdx.x & 63;
+    const int x = x0 + lane * E;
+    if (clear) {
 #pragma unroll
-    for (int k = 0; k < kWords; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
+        for (int k = 0; k < kWords; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
+    }
     for (int p0 = 0; p0 < nplanes; p0 += kUnroll) {
-        float v[kUnroll][kSub][4];
+        float v[kUnroll][SUB][E];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             // clamp: planes past the end re-read the last one; their words are never parked
             const int p = p0 + u < nplanes ? p0 + u : nplanes - 1;
 #pragma unroll
-            for (int j = 0; j < kSub; ++j)
-                load_pixels<T, TAIL>(base + (int64_t)p * plane_stride, x + j * kSubPix, HW, v[u][j]);
+            for (int j = 0; j < SUB; ++j)
+                load_pixels<T, TAIL>(base + (int64_t)p * plane_stride, x + j * 64 * E, HW, v[u][j]);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int p = p0 + u;
             if (p < nplanes) {
-                const bool mine = lane == p;   // park the words of plane p in lane p
+                const bool mine = lane == p + lane0;   // park the words of plane p in lane lane0 + p
 #pragma unroll
-                for (int j = 0; j < kSub; ++j)
+                for (int j = 0; j < SUB; ++j)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < E; ++k) {
                         const unsigned long long b = __ballot(v[u][j][k] > 0.5f);
-                        w.lo[4 * j + k] = mine ? (int)(unsigned)b : w.lo[4 * j + k];
-                        w.hi[4 * j + k] = mine ? (int)(unsigned)(b >> 32) : w.hi[4 * j + k];
+                        w.lo[E * j + k] = mine ? (int)(unsigned)b : w.lo[E * j + k];
+                        w.hi[E * j + k] = mine ? (int)(unsigned)(b >> 32) : w.hi[E * j + k];
                     }
             }
         }
@@ -85,11 +91,13 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
 }
 
 template <typename T, int MT, int NG, bool TAIL>
-__device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, int64_t sp_n, int64_t st_m, int Nb, int Mb,
-                                              int x, int HW, unsigned (&acc)[NG][MT], unsigned (&area_p)[NG],
-                                              unsigned &area_t) {
+__device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T *T2b, int64_t sp_n, int64_t st_m,
+                                              int64_t st2_m, int Nb, int Mb, int Mrows, int x0, int HW,
+                                              unsigned (&acc)[NG][MT], unsigned (&area_p)[NG], unsigned &area_t) {
+    // template tile: lanes [0, Mb) = planes of set 1, lanes [Mb, 2*Mb) = planes of set 2 (training: the targets)
     BitTile tw;
-    fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x, HW);
+    fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x0, HW);
+    if (T2b) fill_tile<T, TAIL>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
 #pragma unroll
     for (int k = 0; k < kWords; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
 #pragma unroll
@@ -98,12 +106,12 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, int64_t 
         if (nn <= 0) break;
         if (nn > kWave) nn = kWave;
         BitTile pw;
-        fill_tile<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x, HW);
+        fill_tile<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW);
 #pragma unroll
         for (int k = 0; k < kWords; ++k) area_p[g] += __builtin_popcount(pw.lo[k]) + __builtin_popcount(pw.hi[k]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (m < Mb) {
+            if (m < Mrows) {
                 unsigned a = acc[g][m];
 #pragma unroll
                 for (int k = 0; k < kWords; ++k) {
@@ -121,19 +129,22 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, int64_t 
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
 template <typename T, int MT, int NG>
 __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
-    const T *__restrict__ masks_p, const T *__restrict__ masks_t, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
-    int64_t st_b, int64_t st_m, const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid,
-    int32_t *__restrict__ inter, int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int n0, int m0,
-    int chunks_per_wg, int write_area_p, int write_area_t) {
+    const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
+    int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
+    int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
+    int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t) {
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
     Nb = min(Nb - n0, NG * kWave);
-    Mb = min(Mb - m0, MT);
+    Mb = min(Mb - m0, masks_t2 ? MT / 2 : MT);
     if (Nb <= 0 || Mb <= 0) return;
+    const int Mrows = masks_t2 ? 2 * Mb : Mb;                    // rows of the (template | target) tile
     const T *Pb = masks_p + (int64_t)b * sp_b + (int64_t)n0 * sp_n;
     const T *Tb = masks_t + (int64_t)b * st_b + (int64_t)m0 * st_m;
+    const T *T2b = masks_t2 ? masks_t2 + (int64_t)b * st2_b + (int64_t)m0 * st2_m : nullptr;
 
     unsigned acc[NG][MT];
     unsigned ap[NG];
@@ -150,11 +161,11 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     const int c_begin = blockIdx.x * chunks_per_wg;
     const int c_end = min(nchunks, c_begin + chunks_per_wg);
     for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
-        const int x = c * kChunk + lane * 4;      // sub-chunk j adds j * 256
+        const int x0 = c * kChunk;
         if (c < full_chunks)
-            process_chunk<T, MT, NG, false>(Pb, Tb, sp_n, st_m, Nb, Mb, x, HW, acc, ap, at);
+            process_chunk<T, MT, NG, false>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
         else
-            process_chunk<T, MT, NG, true>(Pb, Tb, sp_n, st_m, Nb, Mb, x, HW, acc, ap, at);
+            process_chunk<T, MT, NG, true>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
     }
 
     // fold the 4 waves (integer LDS atomics), then one global atomic per entry
@@ -168,28 +179,35 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
         if (col < Nb) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                if (m < Mb && acc[g][m]) atomicAdd(&red[m * NG * kWave + col], acc[g][m]);
+                if (m < Mrows && acc[g][m]) atomicAdd(&red[m * NG * kWave + col], acc[g][m]);
             if (ap[g]) atomicAdd(&red[MT * NG * kWave + col], ap[g]);
         }
     }
-    if (lane < Mb && at) atomicAdd(&red_at[lane], at);
+    if (lane < Mrows && at) atomicAdd(&red_at[lane], at);
     __syncthreads();
     int32_t *inter_b = inter + (int64_t)b * M * N;
+    int32_t *inter2_b = inter2 ? inter2 + (int64_t)b * M * N : nullptr;
     for (int i = threadIdx.x; i < MT * NG * kWave; i += kCostThreads) {
         const int m = i / (NG * kWave), col = i % (NG * kWave);
-        if (m < Mb && col < Nb && red[i]) atomicAdd(&inter_b[(int64_t)(m0 + m) * N + n0 + col], (int)red[i]);
+        if (col < Nb && red[i]) {
+            if (m < Mb) atomicAdd(&inter_b[(int64_t)(m0 + m) * N + n0 + col], (int)red[i]);
+            else if (m < Mrows) atomicAdd(&inter2_b[(int64_t)(m0 + m - Mb) * N + n0 + col], (int)red[i]);
+        }
     }
     if (write_area_p)
         for (int col = threadIdx.x; col < Nb; col += kCostThreads)
             if (red[MT * NG * kWave + col]) atomicAdd(&area_p[(int64_t)b * N + n0 + col], (int)red[MT * NG * kWave + col]);
-    if (write_area_t && threadIdx.x < Mb && red_at[threadIdx.x])
-        atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);
+    if (write_area_t && threadIdx.x < Mrows && red_at[threadIdx.x]) {
+        if (threadIdx.x < Mb) atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);
+        else atomicAdd(&area_t2[(int64_t)b * M + m0 + threadIdx.x - Mb], (int)red_at[threadIdx.x]);
+    }
 }
 
 template <typename T, int MT, int NG>
-static int launch_tile(const T *masks_p, const T *masks_t, int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
-                       int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, int32_t *inter,
-                       int32_t *area_p, int32_t *area_t, int n0, int m0, int wap, int wat, hipStream_t stream) {
+static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, int B, int N, int M, int HW, int64_t sp_b,
+                       int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
+                       const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
+                       int32_t *area_t2, int n0, int m0, int wap, int wat, hipStream_t stream) {
     const int nchunks = (HW + kChunk - 1) / kChunk;
     // >= ~2048 workgroups (8 per CU), at least 1 chunk per wave
     static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 2048; }();
@@ -200,16 +218,17 @@ static int launch_tile(const T *masks_p, const T *masks_t, int B, int N, int M, 
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
     dim3 grid(splits, B);
-    hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, N, M, HW,
-                       sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter, area_p, area_t, n0, m0, chunks_per_wg, wap,
-                       wat);
+    hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, masks_t2, N,
+                       M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,
+                       area_t2, n0, m0, chunks_per_wg, wap, wat);
     return check_launch();
 }
 
 template <typename T>
-static int iou_counts_typed(const T *masks_p, const T *masks_t, int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n,
-                            int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, int32_t *inter,
-                            int32_t *area_p, int32_t *area_t, hipStream_t stream) {
+static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t2, int B, int N, int M, int HW,
+                            int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+                            const int32_t *n_valid, const int32_t *m_valid, int32_t *inter, int32_t *area_p,
+                            int32_t *area_t, int32_t *inter2, int32_t *area_t2, hipStream_t stream) {
     if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
         // the three tables are one contiguous block (dmm_match_forward's workspace): one memset node
         DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
@@ -218,17 +237,23 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, int B, int N, in
         DMM_HIP_TRY(hipMemsetAsync(area_p, 0, sizeof(int32_t) * (size_t)B * N, stream));
         DMM_HIP_TRY(hipMemsetAsync(area_t, 0, sizeof(int32_t) * (size_t)B * M, stream));
     }
+    if (masks_t2) {
+        DMM_HIP_TRY(hipMemsetAsync(inter2, 0, sizeof(int32_t) * (size_t)B * M * N, stream));
+        DMM_HIP_TRY(hipMemsetAsync(area_t2, 0, sizeof(int32_t) * (size_t)B * M, stream));
+    }
     if (HW == 0) return DMM_OK;
-    // Tile the (N, M) table over the compiled envelopes; one launch covers N <= 256, M <= 32.
-    for (int m0 = 0; m0 < M; m0 += 32) {
-        const int mt = M - m0 < 32 ? M - m0 : 32;
+    // Tile the (N, M) table over the compiled envelopes; one launch covers N <= 256 and M <= 32 template rows
+    // (M <= 16 when a second template set rides along: both sets share the 32-row tile).
+    const int mstep = masks_t2 ? 16 : 32;
+    for (int m0 = 0; m0 < M; m0 += mstep) {
+        const int mt = (M - m0 < mstep ? M - m0 : mstep) * (masks_t2 ? 2 : 1);
         for (int n0 = 0; n0 < N; n0 += 256) {
             const int nt = N - n0 < 256 ? N - n0 : 256;
             const int wap = (m0 == 0), wat = (n0 == 0);
             int rc;
-#define DMM_COST_CASE(MT_, NG_)                                                                                   \
-    rc = launch_tile<T, MT_, NG_>(masks_p, masks_t, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter, \
-                                  area_p, area_t, n0, m0, wap, wat, stream)
+#define DMM_COST_CASE(MT_, NG_)                                                                                       \
+    rc = launch_tile<T, MT_, NG_>(masks_p, masks_t, masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, \
+                                  m_valid, inter, area_p, area_t, inter2, area_t2, n0, m0, wap, wat, stream)
             if (nt <= 64) {
                 if (mt <= 8) DMM_COST_CASE(8, 1);
                 else if (mt <= 16) DMM_COST_CASE(16, 1);
@@ -251,27 +276,51 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, int B, int N, in
 
 }  // namespace dmm
 
+static int iou_counts_dispatch(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, int B, int N,
+                               int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b,
+                               int64_t st2_m, const int32_t *n_valid, const int32_t *m_valid, int32_t *inter,
+                               int32_t *area_p, int32_t *area_t, int32_t *inter2, int32_t *area_t2,
+                               dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || N == 0 || M == 0) return DMM_OK;
+    if (!masks_p || !masks_t || !inter || !area_p || !area_t) return DMM_ERR_BAD_ARG;
+    if (masks_t2 && (!inter2 || !area_t2)) return DMM_ERR_BAD_ARG;
+    if (sp_n < HW || st_m < HW || (masks_t2 && st2_m < HW)) return DMM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case DMM_F32:
+            return dmm::iou_counts_typed<float>((const float *)masks_p, (const float *)masks_t, (const float *)masks_t2, B,
+                                                N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter,
+                                                area_p, area_t, inter2, area_t2, s);
+        case DMM_F16:
+            return dmm::iou_counts_typed<dmm::f16_t>((const dmm::f16_t *)masks_p, (const dmm::f16_t *)masks_t,
+                                                     (const dmm::f16_t *)masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m,
+                                                     st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,
+                                                     area_t2, s);
+        case DMM_BF16:
+            return dmm::iou_counts_typed<dmm::bf16_t>((const dmm::bf16_t *)masks_p, (const dmm::bf16_t *)masks_t,
+                                                      (const dmm::bf16_t *)masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m,
+                                                      st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,
+                                                      area_t2, s);
+        default:
+            return DMM_ERR_BAD_ARG;
+    }
+}
+
 extern "C" int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW,
                               int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
                               const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
                               dmm_stream_t stream) {
-    if (B < 0 || N < 0 || M < 0 || HW < 0) return DMM_ERR_BAD_ARG;
-    if (B == 0 || N == 0 || M == 0) return DMM_OK;
-    if (!masks_p || !masks_t || !inter || !area_p || !area_t) return DMM_ERR_BAD_ARG;
-    if (sp_n < HW || st_m < HW) return DMM_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    switch (dtype) {
-        case DMM_F32:
-            return dmm::iou_counts_typed<float>((const float *)masks_p, (const float *)masks_t, B, N, M, HW, sp_b, sp_n,
-                                                st_b, st_m, n_valid, m_valid, inter, area_p, area_t, s);
-        case DMM_F16:
-            return dmm::iou_counts_typed<dmm::f16_t>((const dmm::f16_t *)masks_p, (const dmm::f16_t *)masks_t, B, N, M, HW, sp_b,
-                                                 sp_n, st_b, st_m, n_valid, m_valid, inter, area_p, area_t, s);
-        case DMM_BF16:
-            return dmm::iou_counts_typed<dmm::bf16_t>((const dmm::bf16_t *)masks_p, (const dmm::bf16_t *)masks_t, B,
-                                                       N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter,
-                                                       area_p, area_t, s);
-        default:
-            return DMM_ERR_BAD_ARG;
-    }
+    return iou_counts_dispatch(masks_p, masks_t, nullptr, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, 0, 0, n_valid,
+                               m_valid, inter, area_p, area_t, nullptr, nullptr, stream);
+}
+
+extern "C" int dmm_iou_counts_dual(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, int B,
+                                   int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
+                                   int64_t st2_b, int64_t st2_m, const int32_t *n_valid, const int32_t *m_valid,
+                                   int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2, int32_t *area_t2,
+                                   dmm_stream_t stream) {
+    if (!masks_t2) return DMM_ERR_BAD_ARG;
+    return iou_counts_dispatch(masks_p, masks_t, masks_t2, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m,
+                               n_valid, m_valid, inter, area_p, area_t, inter2, area_t2, stream);
 }

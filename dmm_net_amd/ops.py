@@ -64,6 +64,29 @@ def iou_counts(masks_p: torch.Tensor, masks_t: torch.Tensor, n_valid=None, m_val
     return inter, ap, at
 
 
+def iou_counts_dual(masks_p: torch.Tensor, masks_t: torch.Tensor, masks_t2: torch.Tensor, n_valid=None, m_valid=None):
+    """One pass over the proposal planes against TWO template sets (templates + training targets).
+    -> (inter, area_p, area_t), (inter2, area_t2)."""
+    _need_gpu(masks_p, masks_t, masks_t2)
+    assert masks_p.dtype == masks_t.dtype == masks_t2.dtype and masks_p.dtype in _DT
+    assert masks_t.shape == masks_t2.shape
+    masks_p, sp_b, sp_n = _planes(masks_p)
+    masks_t, st_b, st_m = _planes(masks_t)
+    masks_t2, st2_b, st2_m = _planes(masks_t2)
+    B, N, H, W = masks_p.shape
+    M = masks_t.shape[1]
+    dev = masks_p.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    inter, inter2 = torch.empty((B, M, N), **i32), torch.empty((B, M, N), **i32)
+    ap, at, at2 = torch.empty((B, N), **i32), torch.empty((B, M), **i32), torch.empty((B, M), **i32)
+    with torch.cuda.device(dev):
+        rc = _lib.load().dmm_iou_counts_dual(_ptr(masks_p), _ptr(masks_t), _ptr(masks_t2), _DT[masks_p.dtype], B, N, M,
+                                             H * W, sp_b, sp_n, st_b, st_m, st2_b, st2_m, _ptr(n_valid), _ptr(m_valid),
+                                             _ptr(inter), _ptr(ap), _ptr(at), _ptr(inter2), _ptr(at2), _stream(masks_p))
+    _lib.check(rc, "dmm_iou_counts_dual")
+    return (inter, ap, at), (inter2, at2)
+
+
 def feature_normalize(x: torch.Tensor, want_norms: bool = False):
     """x [..., D] fp32 -> x / max(||x||, 1e-8) (and the clamped norms)."""
     _need_gpu(x)

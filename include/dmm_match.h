@@ -77,6 +77,15 @@ DMM_API int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtype, 
                    int32_t *inter /*[B,M,N]*/, int32_t *area_p /*[B,N]*/, int32_t *area_t /*[B,M]*/,
                    dmm_stream_t stream);
 
+/* (1b) Training: the same pass also intersects the proposals with a SECOND template set of M planes per
+ * frame -- the ground-truth targets of compute_matching_loss (match_helper.py:34-43) -- so the proposal
+ * planes (the bulk of the bytes) are streamed once instead of twice.  inter2 [B,M,N], area_t2 [B,M]. */
+DMM_API int dmm_iou_counts_dual(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, int B,
+                                int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
+                                int64_t st2_b, int64_t st2_m, const int32_t *n_valid, const int32_t *m_valid,
+                                int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2, int32_t *area_t2,
+                                dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (2) Row-normalise feature vectors: out[r,:] = in[r,:] / max(||in[r,:]||_2, 1e-8).
  * First half of F.cosine_similarity as get_cosine_score uses it (match_helper.py:51-64).

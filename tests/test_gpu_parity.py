@@ -433,3 +433,42 @@ def test_g8_dmm_model_driver(mode):
     close(last, g[f"{mode}/out_mask_last"])
     if mode == "test":
         assert np.array_equal(out.cpu().numpy(), g["test/output_mask"])   # gather: bit exact
+
+
+# ------------------------------------------------------------------------------------ config 5 (fp16 mask storage)
+def test_config5_fp16_masks_stress():
+    """BASELINE config 5: N=200, M=20, 255x255, masks stored in fp16 (the only bandwidth term), solver in fp32.
+    Bit exact against the oracle on the SAME fp16-rounded masks; argmax identical to the fp32 golden."""
+    c = synth.CONFIGS[5]
+    fr = synth.make_config_frame(5, kind="structured")
+    pm16 = torch.from_numpy(fr.proposed_mask).to(DEV).half()
+    tm16 = torch.from_numpy(fr.mask_last_occurence).to(DEV).half()
+    plan = ops.ForwardPlan(1, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, mask_dtype=torch.float16, want_tables=True,
+                           pipeline=False)
+    full, ms, ds = plan.run(pm16[None], tm16[None], dev(fr.proposed_feature)[None], dev(fr.template_feature)[None],
+                            dev(fr.proposal_score)[None], max_iter=20, proj_iter=5, is_test=1)
+    torch.cuda.synchronize()
+    o = oracle.match_forward(pm16.float().cpu().numpy(), tm16.float().cpu().numpy(), fr.proposed_feature,
+                             fr.template_feature, fr.proposal_score, max_iter=20, proj_iter=5, is_test=1)
+    assert np.array_equal(plan.R[0].cpu().numpy(), o["R"])
+    assert np.array_equal(plan.sim[0].cpu().numpy(), o["sim"])
+    assert int(plan.iters[0]) == o["iters"]
+    assert np.array_equal(full[0].cpu().numpy(), o["full_outmask"])
+    assert np.array_equal(ms[0].cpu().numpy(), o["match_score"])
+    g = golden("g4_big").group("c5/structured/t1")
+    assert np.array_equal(plan.R[0].cpu().numpy().argmax(1), g["argmax"])
+    close(plan.sim[0], g["sim"], 2e-3)           # fp16 rounding moves a few threshold pixels
+
+
+def test_iou_counts_dual_equals_two_passes():
+    rng = np.random.Generator(np.random.PCG64(21))
+    for (B, N, M, H, W) in [(3, 50, 10, 64, 67), (2, 130, 16, 33, 31), (2, 20, 17, 16, 16), (1, 8, 3, 255, 255)]:
+        pm = torch.from_numpy(rng.random((B, N, H, W), dtype=np.float32)).to(DEV)
+        tm = torch.from_numpy(rng.random((B, M, H, W), dtype=np.float32)).to(DEV)
+        tg = (torch.from_numpy(rng.random((B, M, H, W), dtype=np.float32)).to(DEV) > 0.5).float()
+        mv = torch.tensor([M, max(M - 2, 0), 1][:B], dtype=torch.int32, device=DEV)
+        (i1, ap, at), (i2, at2) = ops.iou_counts_dual(pm, tm, tg, None, mv)
+        a1, aap, aat = ops.iou_counts(pm, tm, None, mv)
+        a2, _, aat2 = ops.iou_counts(pm, tg, None, mv)
+        for x, y in ((i1, a1), (ap, aap), (at, aat), (i2, a2), (at2, aat2)):
+            assert torch.equal(x, y), (B, N, M)

@@ -8,8 +8,11 @@ import torch
 from dmm_net_amd import ops, synth
 
 dev = "cuda:0"
-c = synth.CONFIGS[2]
+CFG = int(os.environ.get("CFG", "2"))                  # CFG=5: N=200, M=20, fp16 masks
+c = synth.CONFIGS[CFG]
 N, M, H, W, D = c["P"], c["O"], c["H"], c["W"], c["D"]
+MDT = torch.float16 if CFG == 5 else torch.float32
+ES = 2 if CFG == 5 else 4
 
 
 def timeit(fn, iters=10, warm=2):
@@ -27,8 +30,8 @@ def timeit(fn, iters=10, warm=2):
 
 for B in [int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]:
     g = torch.Generator(device=dev).manual_seed(1)
-    pm = torch.rand((B, N, H, W), generator=g, device=dev)
-    tm = torch.rand((B, M, H, W), generator=g, device=dev)
+    pm = torch.rand((B, N, H, W), generator=g, device=dev).to(MDT)
+    tm = torch.rand((B, M, H, W), generator=g, device=dev).to(MDT)
     pf = torch.randn((B, N, D), generator=g, device=dev)
     tf = torch.randn((B, M, D), generator=g, device=dev)
     sc = torch.rand((B, N), generator=g, device=dev)
@@ -52,9 +55,9 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]:
     t_copy = timeit(lambda: dst.copy_(src))
     print(f"      torch copy of {src.numel() * 4 / 1e9:.2f} GB: {t_copy:8.1f}us ({2 * src.numel() * 4 / t_copy / 1e3:6.0f} GB/s r+w)")
     del src, dst
-    gb = B * (N + M) * H * W * 4 / 1e9
+    gb = B * (N + M) * H * W * ES / 1e9
     print(f"B={B:5d} cost {t_cost:8.1f}us ({gb / t_cost * 1e6:7.0f} GB/s)  norm {t_norm:6.1f} cos {t_cos:6.1f}  relax_match {t_relax:7.1f} "
           f"(iters=0: {t_relax0:6.1f})  solve-only {t_solve:7.1f} (init only {t_solve0:6.1f})  "
-          f"mix {t_mix:7.1f} ({B * 2 * M * H * W * 4 / t_mix / 1e3:6.0f} GB/s)", flush=True)
+          f"mix {t_mix:7.1f} ({B * M * H * W * (4 + ES) / t_mix / 1e3:6.0f} GB/s)", flush=True)
     del pm, tm
     torch.cuda.empty_cache()
