@@ -4,7 +4,7 @@ relax_match.py:36-105).  B frames per call.
 
 Chain (tensors on the MI355X):
 
-  d full_outmask [B,O,H,W]  --dOut @ mask_p^T-->  dRb [B,O,Pp]        (HBM bound, rocBLAS batched sgemm)
+  d full_outmask [B,O,H,W]  --dmm_mask_mix_bwd----->  dRb [B,O,Pp]    (HIP, HBM bound: selected planes only)
   dRb, d match_score, d det_score  --dmm_relax_match_bwd_f32-->  dsim [B,O,P]   (HIP: taped reverse sweep)
   dsim * (1-w) + d cost_loss * 2 (cos - gt) / (O P)  =  dcos [B,O,P]
   dcos  -->  d template_n = dcos @ pn,  d proposal_n = dcos^T @ tn          (tiny GEMMs, rocBLAS)
@@ -51,8 +51,8 @@ def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
     if need_pf or need_tf:
         dRb = None
         if dOut is not None:
-            dRb = dOut.new_zeros((B, O, Pp))
-            dRb[:, :, :P] = torch.bmm(dOut, pm2d.transpose(1, 2))     # padded columns multiply zero planes
+            # HIP: only the planes selected by Rb are streamed (padded columns multiply zero planes -> stay 0)
+            dRb = ops.mask_mix_bwd(Rb, pm, dOut, n_valid, m_valid)
         dsim = ops.relax_match_bwd(sim, sc, dRb, d_ms, d_ds, max_iter=max_iter, proj_iter=proj_iter, lr=lr,
                                    is_test=is_test, n_valid=n_valid, m_valid=m_valid)
         w_feat = torch.tensor(1.0 - score_weight, dtype=torch.float32).item()

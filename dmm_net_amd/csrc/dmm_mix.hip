@@ -251,6 +251,112 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     else mix_row_range<T, 0>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);   // cnt == 0 writes zeros
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the mix with respect to Rb:  dRb[b,m,n] = sum_x dOut[b,m,x] * masks_p[b,n,x], needed only where
+// the forward weight was non-zero (Rb = R * logic, match_model.py:130: logic is a constant 0/1 mask, so the
+// gradient of every masked-out entry is dropped anyway).  Same row-major decomposition as the forward:
+// one workgroup = one template row over a pixel range, it streams dOut[m] once per batch of 8 selected planes
+// and finishes with one fp32 atomic per (entry, workgroup) into dRb (zeroed by the launcher).
+// The reference gets this from torch.mm's autograd (a dense [O,HW] x [HW,P] product reading all P planes).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_kernel(const float *__restrict__ Rb,
+                                                                   const T *__restrict__ masks_p,
+                                                                   const float *__restrict__ dout, int N, int M, int Pp,
+                                                                   int HW, int64_t sp_b, int64_t sp_n,
+                                                                   const int32_t *__restrict__ n_valid,
+                                                                   const int32_t *__restrict__ m_valid,
+                                                                   float *__restrict__ dRb, int steps_per_wg) {
+    __shared__ int col_s[DMM_MAX_PROPOSALS];
+    __shared__ float part_s[4][kRowLoads];
+    __shared__ int cnt_s;
+    const int b = blockIdx.z, m = blockIdx.y;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    if (m >= Mb) return;
+    if (threadIdx.x < 64) {
+        int base = 0;
+        const float *Rrow = Rb + ((int64_t)b * M + m) * Pp;
+        for (int n0 = 0; n0 < Nb; n0 += 64) {
+            const int n = n0 + threadIdx.x;
+            const bool nz = n < Nb && Rrow[n] != 0.0f;
+            const unsigned long long bal = __ballot(nz);
+            if (nz) col_s[base + __builtin_popcountll(bal & ((1ull << threadIdx.x) - 1ull))] = n;
+            base += __builtin_popcountll(bal);
+        }
+        if (threadIdx.x == 0) cnt_s = base;
+    }
+    __syncthreads();
+    const int cnt = cnt_s;
+    if (cnt == 0) return;
+    const T *Pb = masks_p + (int64_t)b * sp_b;
+    const float *drow = dout + ((int64_t)b * M + m) * HW;
+    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_end = min(nsteps, s_begin + steps_per_wg);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int e0 = 0; e0 < cnt; e0 += kRowLoads) {
+        float acc[kRowLoads];
+#pragma unroll
+        for (int u = 0; u < kRowLoads; ++u) acc[u] = 0.0f;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int x = (s * kMixThreads + threadIdx.x) * 4;
+            float d[4];
+            if (x + 3 < HW) {
+                const float4u t = *reinterpret_cast<const float4u *>(drow + x);
+                d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = x + k < HW ? drow[x + k] : 0.0f;
+            }
+            float v[kRowLoads][4];
+#pragma unroll
+            for (int u = 0; u < kRowLoads; ++u) {
+                const int e = e0 + u < cnt ? e0 + u : cnt - 1;
+                const T *plane = Pb + (int64_t)col_s[e] * sp_n;
+                if (x + 3 < HW) {
+                    MaskIO<T>::load4(plane + x, v[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = x + k < HW ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRowLoads; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[u] = __builtin_fmaf(d[k], v[u][k], acc[u]);
+        }
+        wave_sum_rows<kRowLoads>(acc);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < kRowLoads; ++u) part_s[wave][u] = acc[u];
+        }
+        __syncthreads();
+        if (threadIdx.x < kRowLoads && e0 + threadIdx.x < cnt) {
+            const float t = ((part_s[0][threadIdx.x] + part_s[1][threadIdx.x]) + part_s[2][threadIdx.x]) + part_s[3][threadIdx.x];
+            atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e0 + threadIdx.x]], t);
+        }
+    }
+}
+
+template <typename T>
+static int mask_mix_bwd_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
+                              int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
+                              hipStream_t stream) {
+    DMM_HIP_TRY(hipMemsetAsync(dRb, 0, sizeof(float) * (size_t)B * M * Pp, stream));
+    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    int splits = (8192 + B * M - 1) / (B * M);
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    const int steps_per_wg = (nsteps + splits - 1) / splits;
+    splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
+    hipLaunchKernelGGL((mask_mix_bwd_kernel<T>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, dout, N, M,
+                       Pp, HW, sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg);
+    return check_launch();
+}
+
 template <typename T>
 static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
@@ -291,6 +397,30 @@ extern "C" int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int
         case DMM_BF16:
             return dmm::mask_mix_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
                                                      n_valid, m_valid, out, so_b, so_m, s);
+        default:
+            return DMM_ERR_BAD_ARG;
+    }
+}
+
+extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype, const float *dout, int B, int N, int M,
+                                int Pp, int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid,
+                                const int32_t *m_valid, float *dRb, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0 || Pp < N) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (!Rb || !masks_p || !dout || !dRb) return DMM_ERR_BAD_ARG;
+    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
+    if (sp_n < HW) return DMM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case DMM_F32:
+            return dmm::mask_mix_bwd_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n, n_valid,
+                                                  m_valid, dRb, s);
+        case DMM_F16:
+            return dmm::mask_mix_bwd_typed<dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n,
+                                                       n_valid, m_valid, dRb, s);
+        case DMM_BF16:
+            return dmm::mask_mix_bwd_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, dout, B, N, M, Pp, HW, sp_b,
+                                                        sp_n, n_valid, m_valid, dRb, s);
         default:
             return DMM_ERR_BAD_ARG;
     }

@@ -193,6 +193,22 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
     return out
 
 
+def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_valid=None, m_valid=None):
+    """dRb [B,M,Pp] = dout [B,M,H,W] . masks_p [B,N,H,W] on the support of Rb (zeros elsewhere)."""
+    _need_gpu(Rb, masks_p, dout)
+    masks_p, sp_b, sp_n = _planes(masks_p)
+    B, N, H, W = masks_p.shape
+    M, Pp = Rb.shape[1], Rb.shape[2]
+    Rb = Rb.contiguous().float()
+    dout = dout.contiguous().float().view(B, M, H * W)
+    dRb = torch.empty((B, M, Pp), dtype=torch.float32, device=Rb.device)
+    with torch.cuda.device(Rb.device):
+        rc = _lib.load().dmm_mask_mix_bwd(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], _ptr(dout), B, N, M, Pp, H * W,
+                                          sp_b, sp_n, _ptr(n_valid), _ptr(m_valid), _ptr(dRb), _stream(Rb))
+    _lib.check(rc, "dmm_mask_mix_bwd")
+    return dRb
+
+
 class ForwardPlan:
     """Pre-allocated forward of B same-shaped frames: nothing is allocated or synchronised per call.
 

@@ -167,6 +167,13 @@ DMM_API int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B,
                  int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
                  float *out, int64_t so_b, int64_t so_m, dmm_stream_t stream);
 
+/* (4b) Backward of (4) w.r.t. Rb: dRb[b,m,n] = <dout[b,m,:], masks_p[b,n,:]> on the support of Rb (entries with
+ * Rb == 0 were masked by the constant logic mask, match_model.py:124-130, and get 0).  dout: [B,M,HW] fp32
+ * contiguous; dRb: [B,M,Pp] fp32, overwritten.  Only the selected planes are read. */
+DMM_API int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype, const float *dout, int B, int N, int M,
+                             int Pp, int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid,
+                             const int32_t *m_valid, float *dRb, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (5) The whole forward of MatchModel for B frames (match_model.py:24-47, targets=None):
  * (1) -> (2) -> (3) -> (4) on `stream`, intermediates in `workspace`.
