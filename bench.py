@@ -149,6 +149,7 @@ def main():
     assert int(plan.iters.max()) == 20 and it_mean > 19.5, f"work was skipped inside the timed region ({it_mean})"
     assert bool(torch.isfinite(plan.full_outmask[-1]).all()) and float(plan.full_outmask[-1].abs().sum()) > 0
     # dominant kernel = dmm::iou_counts_kernel: HIP events around each of its launches, on its own stream
+    # (the pipelined plan launches it twice per step, once per half of the batch)
     cost_ms = float(np.mean([a.elapsed_time(b) for per_step in ev for (a, b) in per_step]))
     frames_per_launch = B / len(halves)
     alg_bytes = int(frames_per_launch * ((N + M) * HW * 4 + M * N * 4))   # B_cost x frames per launch
