@@ -209,6 +209,23 @@ DMM_API int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int H[
                                    const float scale[4], const float *rois, int R, float *const dfeat[4],
                                    dmm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (7) Proposal preprocessing (the step right before the path; host Python loops in the reference).
+ * dmm_paste_masks_f32: paste_mask_in_image + binmask_to_box (dmm/utils/masker.py:110-173) for P proposals:
+ *   prob [P,M,M] mask probabilities, boxes [P,4] xyxy -> planes [P, im_h*im_w] (plane_stride elements apart; the
+ *   soft masks the matching layer consumes) and new_boxes [P,4] = tight box of (plane > thresh), or
+ *   [0,0,im_h,im_w] when empty.  M + 2*padding <= 64.
+ * dmm_nms_f32: NMS + top-k of filter_results (dmm/utils/boxlist_ops.py:15-29, maskrcnn_benchmark nms semantics:
+ *   descending score, legacy +1 areas, IoU > thresh suppresses) per image: boxes [sum n,4], scores [sum n],
+ *   offsets [images+1] (device int32) -> keep[offsets[i] ...] = kept local indices in score order,
+ *   keep_count[i].  max_per_image (<= 1024) bounds n.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_paste_masks_f32(const float *prob, int P, int M, const float *boxes, int im_h, int im_w, float thresh,
+                                int padding, float *planes, int64_t plane_stride, float *new_boxes,
+                                dmm_stream_t stream);
+DMM_API int dmm_nms_f32(const float *boxes, const float *scores, const int32_t *offsets, int images, int max_per_image,
+                        float thresh, int max_keep, int32_t *keep, int32_t *keep_count, dmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

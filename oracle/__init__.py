@@ -60,6 +60,10 @@ def lib():
         L.dmmo_roialign4_mean.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           _f32p, c_int, c_int, c_int, _f32p]
         L.dmmo_roialign4_mean.restype = None
+        L.dmmo_paste_mask.argtypes = [_f32p, c_int, _f32p, c_int, c_int, c_float, c_int, _f32p, _f32p]
+        L.dmmo_paste_mask.restype = None
+        L.dmmo_nms.argtypes = [_f32p, _f32p, c_int, c_float, c_int, _i32p]
+        L.dmmo_nms.restype = c_int
         L.dmmo_check_div_by_const.argtypes = [c_int, ctypes.c_long]
         L.dmmo_check_div_by_const.restype = ctypes.c_long
         _lib = L
@@ -192,3 +196,24 @@ def roialign4_mean(feats, rois, scales=(0.25, 0.125, 0.0625, 0.03125), pooled=14
     out = np.zeros((R, 4 * C), np.float32)
     lib().dmmo_roialign4_mean(ptrs, B, C, Hs, Ws, sc, rois, R, int(pooled), int(sampling), out)
     return out
+
+
+def paste_masks(prob, boxes, im_h, im_w, thresh=0.4, padding=1):
+    """paste_mask_in_image + binmask_to_box (masker.py:110-173) for P proposals -> (masks [P,H,W], boxes [P,4])."""
+    prob, boxes = _c(prob), _c(boxes)
+    P, M = prob.shape[0], prob.shape[-1]
+    masks = np.zeros((P, im_h, im_w), np.float32)
+    nb = np.zeros((P, 4), np.float32)
+    for p in range(P):
+        lib().dmmo_paste_mask(prob[p].reshape(M, M), M, boxes[p], int(im_h), int(im_w), float(thresh), int(padding),
+                              masks[p], nb[p])
+    return masks, nb
+
+
+def nms(boxes, scores, thresh, max_keep=0):
+    """maskrcnn_benchmark-style greedy NMS (+1 areas) -> kept indices in descending score order."""
+    boxes, scores = _c(boxes), _c(scores)
+    n = boxes.shape[0]
+    keep = np.zeros(max(n, 1), np.int32)
+    cnt = lib().dmmo_nms(boxes.reshape(-1, 4), scores, n, float(thresh), int(max_keep), keep)
+    return keep[:cnt]

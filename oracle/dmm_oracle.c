@@ -551,3 +551,107 @@ DMMO_API void dmmo_roialign4_mean(const float *const feat[4], int B, int C, cons
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * Proposal preprocessing.
+ *
+ * paste_mask_in_image + binmask_to_box (dmm/utils/masker.py:110-173): the M x M mask probability of a
+ * proposal is zero-padded by `padding`, its box is expanded about the centre by (M+2p)/M (expand_boxes
+ * :93-107), truncated to int32, the padded mask is resized to the box with bilinear interpolation
+ * (torch F.interpolate, align_corners=False: src = fma(scale, dst+0.5, -0.5) clamped at 0, scale = in/out;
+ * value = fma(ly0, fma(lx0, v00, lx1*v01), ly1 * fma(lx0, v10, lx1*v11)) -- the contraction pattern of torch's
+ * vectorised CPU kernel; its scalar tail path differs in the last ulp, so goldens are matched to 2.4e-7) and
+ * pasted into an im_h x im_w plane; the tight box of (plane > thresh) is returned as
+ * [xmin, ymin, xmax, ymax] (inclusive), or [0, 0, im_h, im_w] if nothing passes (the reference's order).
+ * Pinned by tests/golden/g9_paste.npz (the same steps executed with torch in the build container).
+ * ---------------------------------------------------------------------------------- */
+DMMO_API void dmmo_paste_mask(const float *prob, int M, const float *box, int im_h, int im_w, float thresh,
+                              int padding, float *plane, float *new_box) {
+    const int Mp = M + 2 * padding;
+    float *pad = (float *)calloc((size_t)Mp * Mp, sizeof(float));
+    for (int y = 0; y < M; ++y)
+        for (int x = 0; x < M; ++x) pad[(y + padding) * Mp + x + padding] = prob[y * M + x];
+    const float scale = (float)((double)Mp / (double)M);      /* python float, then fp32 tensor multiply */
+    float w_half = (box[2] - box[0]) * 0.5f, h_half = (box[3] - box[1]) * 0.5f;
+    const float x_c = (box[2] + box[0]) * 0.5f, y_c = (box[3] + box[1]) * 0.5f;
+    w_half = w_half * scale;
+    h_half = h_half * scale;
+    const int bx0 = (int)(x_c - w_half), by0 = (int)(y_c - h_half);      /* .to(int32): truncation */
+    const int bx1 = (int)(x_c + w_half), by1 = (int)(y_c + h_half);
+    int w = bx1 - bx0 + 1, h = by1 - by0 + 1;
+    if (w < 1) w = 1;
+    if (h < 1) h = 1;
+    memset(plane, 0, sizeof(float) * (size_t)im_h * im_w);
+    const int x_0 = bx0 > 0 ? bx0 : 0, y_0 = by0 > 0 ? by0 : 0;
+    const int x_1 = bx1 + 1 < im_w ? bx1 + 1 : im_w, y_1 = by1 + 1 < im_h ? by1 + 1 : im_h;
+    const float sh = (float)Mp / (float)h, sw = (float)Mp / (float)w;
+    int xmin = im_w, ymin = im_h, xmax = -1, ymax = -1;
+    for (int y = y_0; y < y_1; ++y) {
+        float ry = fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
+        if (ry < 0.0f) ry = 0.0f;
+        const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
+        const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
+        for (int x = x_0; x < x_1; ++x) {
+            float rx = fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
+            if (rx < 0.0f) rx = 0.0f;
+            const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
+            const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
+            const float t1 = lx1 * pad[iy0 * Mp + ix1], b1 = lx1 * pad[iy1 * Mp + ix1];
+            const float top = fmaf(lx0, pad[iy0 * Mp + ix0], t1);
+            const float bot = fmaf(lx0, pad[iy1 * Mp + ix0], b1);
+            const float lb = ly1 * bot;
+            const float v = fmaf(ly0, top, lb);
+            plane[(size_t)y * im_w + x] = v;
+            if (v > thresh) {
+                if (x < xmin) xmin = x;
+                if (x > xmax) xmax = x;
+                if (y < ymin) ymin = y;
+                if (y > ymax) ymax = y;
+            }
+        }
+    }
+    if (xmax < 0) { new_box[0] = 0; new_box[1] = 0; new_box[2] = (float)im_h; new_box[3] = (float)im_w; }
+    else { new_box[0] = (float)xmin; new_box[1] = (float)ymin; new_box[2] = (float)xmax; new_box[3] = (float)ymax; }
+    free(pad);
+}
+
+/* ------------------------------------------------------------------------------------
+ * NMS as used by filter_results (dmm/utils/boxlist_ops.py:15-29): maskrcnn_benchmark.layers.nms
+ * (third-party, un-pinned: greedy suppression in descending score order with the legacy "+1" box area,
+ * IoU > thresh suppresses; restated from its published nms.cu).  Ties in score keep the lower index first.
+ * keep_out receives the kept indices in score order; returns their count (capped at max_keep if > 0).
+ * ---------------------------------------------------------------------------------- */
+DMMO_API int dmmo_nms(const float *boxes, const float *scores, int n, float thresh, int max_keep, int32_t *keep_out) {
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    uint8_t *dead = (uint8_t *)calloc(n > 0 ? n : 1, 1);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) {                                   /* stable insertion sort, descending */
+        const int32_t k = order[i];
+        int j = i - 1;
+        while (j >= 0 && scores[order[j]] < scores[k]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = k;
+    }
+    int cnt = 0;
+    for (int a = 0; a < n; ++a) {
+        const int i = order[a];
+        if (dead[i]) continue;
+        keep_out[cnt++] = i;
+        if (max_keep > 0 && cnt >= max_keep) break;
+        const float *bi = boxes + 4 * i;
+        const float ai = (bi[2] - bi[0] + 1.0f) * (bi[3] - bi[1] + 1.0f);
+        for (int c = a + 1; c < n; ++c) {
+            const int j = order[c];
+            if (dead[j]) continue;
+            const float *bj = boxes + 4 * j;
+            const float l = fmaxf(bi[0], bj[0]), r = fminf(bi[2], bj[2]);
+            const float t = fmaxf(bi[1], bj[1]), bb = fminf(bi[3], bj[3]);
+            const float iw = fmaxf(r - l + 1.0f, 0.0f), ih = fmaxf(bb - t + 1.0f, 0.0f);
+            const float inter = iw * ih;
+            const float aj = (bj[2] - bj[0] + 1.0f) * (bj[3] - bj[1] + 1.0f);
+            if (inter / (ai + aj - inter) > thresh) dead[j] = 1;
+        }
+    }
+    free(order);
+    free(dead);
+    return cnt;
+}

@@ -389,7 +389,70 @@ def g8():
     save("g8_harness", d)
 
 
+# ------------------------------------------------------------------------------------------ G9
+def g9():
+    """Proposal preprocessing: the steps of paste_mask_in_image / binmask_to_box (dmm/utils/masker.py:110-173)
+    re-executed with torch (masker.py itself needs maskrcnn_benchmark; its `interpolate` is torch's
+    F.interpolate for non-empty inputs).  Pins the bilinear paste + tight-box arithmetic."""
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(909))
+    d = {}
+    k = 0
+    for (im_h, im_w, P, M) in [(64, 96, 6, 28), (255, 255, 12, 28), (255, 448, 10, 28), (33, 47, 5, 14)]:
+        prob = rng.random((P, 1, M, M), dtype=np.float32)
+        x1 = rng.uniform(-10, im_w * 0.8, P)
+        y1 = rng.uniform(-10, im_h * 0.8, P)
+        bw = rng.uniform(0.3, im_w * 0.7, P)
+        bh = rng.uniform(0.3, im_h * 0.7, P)
+        boxes = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        boxes[0] = [3.2, 4.7, 3.9, 5.1]                     # sub-pixel box
+        boxes[1] = [im_w - 5.0, im_h - 6.0, im_w + 30.0, im_h + 12.0]   # sticks out bottom-right
+        prob[2] = 0.1                                       # nothing above the threshold -> fallback box
+        masks, nboxes = [], []
+        padding, thresh = 1, 0.4
+        for p in range(P):
+            mask = T(prob[p, 0])
+            box = T(boxes[p])
+            # expand_masks (masker.py:110-117)
+            pad2 = 2 * padding
+            scale = float(M + pad2) / M
+            padded = mask.new_zeros((1, 1, M + pad2, M + pad2))
+            padded[:, :, padding:-padding, padding:-padding] = mask
+            # expand_boxes (masker.py:93-107)
+            w_half = (box[2] - box[0]) * .5
+            h_half = (box[3] - box[1]) * .5
+            x_c = (box[2] + box[0]) * .5
+            y_c = (box[3] + box[1]) * .5
+            w_half = w_half * scale
+            h_half = h_half * scale
+            eb = torch.stack([x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half]).to(dtype=torch.int32)
+            w = max(int(eb[2] - eb[0] + 1), 1)
+            h = max(int(eb[3] - eb[1] + 1), 1)
+            m = F.interpolate(padded.to(torch.float32), size=(h, w), mode='bilinear', align_corners=False)[0][0]
+            im_mask = m.new_zeros((im_h, im_w))
+            x_0 = max(int(eb[0]), 0)
+            x_1 = min(int(eb[2]) + 1, im_w)
+            y_0 = max(int(eb[1]), 0)
+            y_1 = min(int(eb[3]) + 1, im_h)
+            if y_1 > y_0 and x_1 > x_0:
+                im_mask[y_0:y_1, x_0:x_1] = m[(y_0 - int(eb[1])):(y_1 - int(eb[1])), (x_0 - int(eb[0])):(x_1 - int(eb[0]))]
+            # binmask_to_box (masker.py:157-173)
+            inds = (im_mask > thresh).nonzero()
+            if inds.shape[0] < 1:
+                nb = [0, 0, im_h, im_w]
+            else:
+                nb = [int(inds[:, 1].min()), int(inds[:, 0].min()), int(inds[:, 1].max()), int(inds[:, 0].max())]
+            masks.append(im_mask.numpy())
+            nboxes.append(nb)
+        d.update(flat(f"c{k}", dict(prob=prob, boxes=boxes, size=np.array([im_h, im_w], np.int32),
+                                   masks=np.stack(masks), new_boxes=np.asarray(nboxes, np.float32),
+                                   thresh=np.float32(thresh), padding=np.int32(padding))))
+        k += 1
+    d["n"] = np.int32(k)
+    save("g9_paste", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

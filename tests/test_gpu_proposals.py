@@ -1,0 +1,46 @@
+"""Proposal preprocessing kernels against the goldens / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden
+from dmm_net_amd import proposals
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_g9_paste_masks_matches_reference_steps():
+    g = golden("g9_paste")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        h, w = [int(v) for v in c["size"]]
+        planes, nb = proposals.paste_masks(torch.from_numpy(c["prob"]).to(DEV), torch.from_numpy(c["boxes"]).to(DEV), h, w,
+                                           float(c["thresh"]), int(c["padding"]))
+        got = planes[:, 0].cpu().numpy()
+        assert float(np.abs(got - c["masks"]).max()) <= 2.4e-7          # torch's scalar-tail path differs by 1 ulp
+        assert np.array_equal(nb.cpu().numpy(), c["new_boxes"])
+        om, ob = oracle.paste_masks(c["prob"], c["boxes"], h, w, float(c["thresh"]), int(c["padding"]))
+        assert np.array_equal(got, om) and np.array_equal(nb.cpu().numpy(), ob)   # bit exact vs the oracle
+
+
+def test_nms_and_filter_results_match_oracle():
+    rng = np.random.default_rng(4)
+    lists, exp = [], []
+    for n in (0, 1, 37, 90, 300):
+        x1, y1 = rng.uniform(0, 200, n), rng.uniform(0, 200, n)
+        b = np.stack([x1, y1, x1 + rng.uniform(1, 90, n), y1 + rng.uniform(1, 90, n)], 1).astype(np.float32)
+        s = rng.random(n).astype(np.float32)
+        if n > 10:
+            s[5] = s[3]                                             # score tie: lower index first
+            b[7] = b[2]                                             # duplicate box
+        bl = proposals.SimpleBoxList(torch.from_numpy(b).to(DEV), (255, 255))
+        bl.add_field("scores", torch.from_numpy(s).to(DEV))
+        bl.add_field("mask", torch.arange(n, device=DEV).float())
+        lists.append(bl)
+        exp.append(oracle.nms(b, s, 0.4, 50))
+    out = proposals.filter_results(lists, nms_thresh=0.4, max_proposals=50)
+    for bl, e in zip(out, exp):
+        assert len(bl) == len(e) <= 50
+        assert np.array_equal(bl.get_field("mask").cpu().numpy().astype(np.int64), e.astype(np.int64))

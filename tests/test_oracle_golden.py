@@ -169,3 +169,25 @@ def test_g7_cosine_shapes_bit_exact():
         c = g.group(f"cos{j}")
         out = oracle.cosine(c["q"], c["k"])
         assert np.array_equal(out, c["cos"]), (j, c["q"].shape, c["k"].shape, np.abs(out - c["cos"]).max())
+
+
+# ------------------------------------------------------------------------------------------ G9
+def test_g9_paste_masks():
+    """paste_mask_in_image + binmask_to_box steps (masker.py:110-173) executed with torch in the build container."""
+    g = golden("g9_paste")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        h, w = [int(v) for v in c["size"]]
+        m, nb = oracle.paste_masks(c["prob"], c["boxes"], h, w, float(c["thresh"]), int(c["padding"]))
+        assert float(np.abs(m - c["masks"]).max()) <= 2.4e-7      # torch's scalar-tail path differs in the last ulp
+        assert np.array_equal(nb, c["new_boxes"])
+
+
+def test_nms_semantics():
+    b = np.array([[0, 0, 9, 9], [1, 1, 10, 10], [20, 20, 29, 29], [0, 0, 9, 9]], np.float32)
+    s = np.array([0.9, 0.8, 0.7, 0.9], np.float32)
+    # box 3 duplicates box 0 (same score: lower index first, the duplicate is suppressed); box 1 overlaps box 0 by
+    # 81/(100+100-81) = 0.68 > 0.4
+    assert list(oracle.nms(b, s, 0.4)) == [0, 2]
+    assert list(oracle.nms(b, s, 0.7)) == [0, 1, 2]
+    assert list(oracle.nms(b, s, 0.4, max_keep=1)) == [0]
