@@ -26,7 +26,15 @@ __global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__r
     nr = nr > 1e-8f ? nr : 1e-8f;                           // clamp_min(eps)
     nr = __shfl(nr, (threadIdx.x & 63) & ~7);               // group lane 0 -> its 8 lanes
     if (!valid) return;
-    for (int d = l; d < D; d += 8) out[r * D + d] = x[d] / nr;
+    if ((D & 3) == 0) {                                     // 8 lanes x float4, 128-B coalesced per step
+        for (int d = 4 * l; d < D; d += 32) {
+            float4u v = *reinterpret_cast<const float4u *>(x + d);
+            v.x = v.x / nr; v.y = v.y / nr; v.z = v.z / nr; v.w = v.w / nr;
+            *reinterpret_cast<float4u *>(out + r * D + d) = v;
+        }
+    } else {
+        for (int d = l; d < D; d += 8) out[r * D + d] = x[d] / nr;
+    }
     if (norms && l == 0) norms[r] = nr;
 }
 
@@ -38,7 +46,8 @@ __global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__r
 // contiguous (inner) reduction in torch; it is handled by an 8-lane group through LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int kCosMaxD1 = 4096;   // D limit of the N == 1 path (LDS staging)
-constexpr int kCosDC = 64;        // D-chunk staged per step: N x (64+1) floats <= 66.6 KB at N = 256
+constexpr int kCosDC = 64;        // D-chunk staged per step
+constexpr int kCosLD = kCosDC + 4; // LDS row stride: 16-B aligned rows (ds_read_b128), 68 floats: N x 68 x 4 B <= 69.6 KB
 
 // block = 256 threads = `slots` template rows of TPM = 64*ceil(N/64) threads each; grid = (ceil(M/slots), B).
 // All slots of a block share the staged proposal tile.
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 4) void cosine_kernel(const float *__restrict_
         return;
     }
     float *q_s = lds;                                        // [slots][kCosDC]
-    float *tp = lds + slots * kCosDC;                        // [Nb][kCosDC + 1]
+    float *tp = lds + slots * kCosDC;                        // [Nb][kCosLD]
     const bool live = row_live && n < Nb;
     const bool class_a = n < torder::outer_class_bound(Nb);
     torder::Cascade ca, c0, c1, c2, c3;
@@ -88,27 +97,37 @@ __global__ __launch_bounds__(256, 4) void cosine_kernel(const float *__restrict_
             for (int i = threadIdx.x; i < Nb * 16; i += 256) {
                 const int r = i >> 4, c4 = (i & 15) * 4;
                 const float4u v = *reinterpret_cast<const float4u *>(kbase + (int64_t)r * D + d0 + c4);
-                float *dst = tp + r * (kCosDC + 1) + c4;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                *reinterpret_cast<float4 *>(tp + r * kCosLD + c4) = make_float4(v.x, v.y, v.z, v.w);
             }
         } else {
             for (int i = threadIdx.x; i < Nb * dc; i += 256) {
                 const int r = i / dc, c = i - r * dc;
-                tp[r * (kCosDC + 1) + c] = kbase[(int64_t)r * D + d0 + c];
+                tp[r * kCosLD + c] = kbase[(int64_t)r * D + d0 + c];
             }
         }
         if (n < dc && m < M) q_s[slot * kCosDC + n] = q[d0 + n];   // tpm >= 64 >= dc
         __syncthreads();
         if (!live) continue;
-        const float *row = tp + n * (kCosDC + 1);
+        const float *row = tp + n * kCosLD;
         const float *qq = q_s + slot * kCosDC;
         if (dc == kCosDC && fast_ok) {
             if (class_a) {
 #pragma unroll 1
                 for (int blk = 0; blk < 4; ++blk) {
                     float a = ca.a0;
+                    float4 qv[4], rv[4];
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) a = a + qq[16 * blk + t] * row[16 * blk + t];
+                    for (int t = 0; t < 4; ++t) {
+                        qv[t] = *reinterpret_cast<const float4 *>(qq + 16 * blk + 4 * t);
+                        rv[t] = *reinterpret_cast<const float4 *>(row + 16 * blk + 4 * t);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a = a + qv[t].x * rv[t].x;
+                        a = a + qv[t].y * rv[t].y;
+                        a = a + qv[t].z * rv[t].z;
+                        a = a + qv[t].w * rv[t].w;
+                    }
                     ca.a0 = a;
                     ca.block16_done();
                 }
@@ -116,10 +135,12 @@ __global__ __launch_bounds__(256, 4) void cosine_kernel(const float *__restrict_
                 float a0 = c0.a0, a1 = c1.a0, a2 = c2.a0, a3 = c3.a0;
 #pragma unroll 4
                 for (int t = 0; t < 16; ++t) {
-                    a0 = a0 + qq[4 * t] * row[4 * t];
-                    a1 = a1 + qq[4 * t + 1] * row[4 * t + 1];
-                    a2 = a2 + qq[4 * t + 2] * row[4 * t + 2];
-                    a3 = a3 + qq[4 * t + 3] * row[4 * t + 3];
+                    const float4 qv = *reinterpret_cast<const float4 *>(qq + 4 * t);
+                    const float4 rv = *reinterpret_cast<const float4 *>(row + 4 * t);
+                    a0 = a0 + qv.x * rv.x;
+                    a1 = a1 + qv.y * rv.y;
+                    a2 = a2 + qv.z * rv.z;
+                    a3 = a3 + qv.w * rv.w;
                 }
                 c0.a0 = a0; c1.a0 = a1; c2.a0 = a2; c3.a0 = a3;
                 c0.block16_done(); c1.block16_done(); c2.block16_done(); c3.block16_done();
@@ -188,7 +209,7 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
     const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
     const int slots = 256 / tpm;
-    size_t lds = sizeof(float) * ((size_t)slots * dmm::kCosDC + (size_t)N * (dmm::kCosDC + 1));
+    size_t lds = sizeof(float) * ((size_t)slots * dmm::kCosDC + (size_t)N * dmm::kCosLD);
     if (N == 1 || n_valid) {
         const size_t l1 = sizeof(float) * (size_t)D * slots;
         lds = l1 > lds ? l1 : lds;

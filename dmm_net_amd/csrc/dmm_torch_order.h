@@ -172,12 +172,12 @@ __device__ __forceinline__ float norm2_group8(long n, int l, F x) {
     float a = 0.0f;
     const long nv = n - (n % TV);
     long d4 = 0;
-    for (; d4 + 4 * TV <= nv; d4 += 4 * TV) {           // 4 independent loads in flight, fmas stay in order
-        const float v0 = x(d4 + l), v1 = x(d4 + TV + l), v2 = x(d4 + 2 * TV + l), v3 = x(d4 + 3 * TV + l);
-        a = __builtin_fmaf(v0, v0, a);
-        a = __builtin_fmaf(v1, v1, a);
-        a = __builtin_fmaf(v2, v2, a);
-        a = __builtin_fmaf(v3, v3, a);
+    for (; d4 + 8 * TV <= nv; d4 += 8 * TV) {           // 8 independent loads in flight, fmas stay in order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x(d4 + q * TV + l);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a = __builtin_fmaf(v[q], v[q], a);
     }
     for (; d4 < nv; d4 += TV) {
         const float v = x(d4 + l);
