@@ -472,3 +472,46 @@ def test_iou_counts_dual_equals_two_passes():
         a2, _, aat2 = ops.iou_counts(pm, tg, None, mv)
         for x, y in ((i1, a1), (ap, aap), (at, aat), (i2, a2), (at2, aat2)):
             assert torch.equal(x, y), (B, N, M)
+
+
+def test_ragged_batched_backward_equals_per_video_calls():
+    """DMM_Model's single ragged launch sequence gives the same losses / outputs / gradients as one MatchModel call per
+    video (the reference's Python loop), for videos with different numbers of proposals and live templates."""
+    from dmm_net_amd.autograd import match_layer_batched
+    torch.manual_seed(1)
+    B, Pmax, F, H, W, D = 4, 9, 5, 24, 40, 48
+    nprop, ntplt = [9, 4, 6, 7], [5, 2, 0, 3]
+    frames = [synth.make_frame(Pmax, F, H, W, D, seed=4200 + b, kind="structured", with_targets=True) for b in range(B)]
+    pf = torch.stack([dev(f.proposed_feature) for f in frames]).requires_grad_(True)
+    tf = torch.stack([dev(f.template_feature) for f in frames]).requires_grad_(True)
+    pm = torch.stack([dev(f.proposed_mask) for f in frames])
+    tm = torch.stack([dev(f.mask_last_occurence) for f in frames])
+    sc = torch.stack([dev(f.proposal_score) for f in frames])
+    tg = torch.stack([dev(f.targets) for f in frames])
+    for b in range(B):                                     # junk beyond the live counts must not matter
+        pm[b, nprop[b]:] = 0.77
+        tm[b, ntplt[b]:] = 0.66
+    nv = torch.tensor(nprop, dtype=torch.int32, device=DEV)
+    mv = torch.tensor(ntplt, dtype=torch.int32, device=DEV)
+    wmask = torch.rand((B, F, H, W), device=DEV)
+    full, ms, ds, loss, _ = match_layer_batched(pf, pm, tf, tm, sc, tg, nv, mv, score_weight=0.3, max_iter=10,
+                                                proj_iter=5, lr=0.1, is_test=0)
+    ((full * wmask).sum() + loss.sum() * 2.0 + ms.sum() * 0.5).backward()
+    model = MatchModel(cfg(10, 5), 0)
+    for b in range(B):
+        P, O = nprop[b], ntplt[b]
+        if O == 0:
+            assert float(full[b].abs().max()) == 0.0 and float(loss[b]) == 0.0
+            assert float(pf.grad[b].abs().max()) == 0.0
+            continue
+        pfb = pf.detach()[b, :P].clone().requires_grad_(True)
+        tfb = tf.detach()[b, :O].clone().requires_grad_(True)
+        fo, msb, dsb, _, lo = model(pfb, pm[b, :P], [tfb], tm[b, :O], sc[b, :P], tg[b, :O])
+        ((fo * wmask[b, :O]).sum() + lo["cost_loss"] * 2.0 + msb.sum() * 0.5).backward()
+        assert torch.equal(full[b, :O], fo) and float(full[b, O:].abs().sum()) == 0.0
+        assert torch.equal(ms[b, :O], msb) and torch.equal(ds[b, :O], dsb)
+        assert abs(float(loss[b]) - float(lo["cost_loss"])) < 1e-7
+        for got, ref in ((pf.grad[b, :P], pfb.grad), (tf.grad[b, :O], tfb.grad)):
+            scale = float(ref.abs().max())
+            assert float((got - ref).abs().max()) <= 1e-5 * scale + 1e-9
+        assert float(pf.grad[b, P:].abs().sum()) == 0.0 and float(tf.grad[b, O:].abs().sum()) == 0.0
