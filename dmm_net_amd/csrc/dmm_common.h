@@ -162,6 +162,9 @@ typedef uint32_t uint4u __attribute__((ext_vector_type(4), aligned(2)));
 template <typename T> struct MaskIO;
 template <> struct MaskIO<float> {
     static constexpr int kVec = 4;
+    typedef float4u Raw;                                   // one 16-byte lane load, kept raw until it is consumed
+    static __device__ __forceinline__ Raw load_raw(const float *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ float elem(const Raw &r, int k) { return r[k]; }
     static __device__ __forceinline__ void loadv(const float *p, float (&v)[4]) { load4(p, v); }
     static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
         float4u t = *reinterpret_cast<const float4u *>(p);
@@ -171,6 +174,9 @@ template <> struct MaskIO<float> {
 };
 template <> struct MaskIO<f16_t> {
     static constexpr int kVec = 8;
+    typedef half8u Raw;
+    static __device__ __forceinline__ Raw load_raw(const f16_t *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ float elem(const Raw &r, int k) { return (float)r[k]; }
     static __device__ __forceinline__ void loadv(const f16_t *p, float (&v)[8]) {
         half8u t = *reinterpret_cast<const half8u *>(p);
 #pragma unroll
@@ -184,6 +190,11 @@ template <> struct MaskIO<f16_t> {
 };
 template <> struct MaskIO<bf16_t> {
     static constexpr int kVec = 8;
+    typedef uint4u Raw;
+    static __device__ __forceinline__ Raw load_raw(const bf16_t *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ float elem(const Raw &r, int k) {
+        return __uint_as_float((k & 1) ? (r[k >> 1] & 0xFFFF0000u) : (r[k >> 1] << 16));
+    }
     static __device__ __forceinline__ void loadv(const bf16_t *p, float (&v)[8]) {
         uint4u t = *reinterpret_cast<const uint4u *>(p);
 #pragma unroll

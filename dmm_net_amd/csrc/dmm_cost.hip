@@ -29,21 +29,30 @@ constexpr int kChunk = 1024;          // pixels a wave takes from one plane per 
                                       // 4 KiB (fp32) / 2 KiB (16-bit).  A plane row is only 4-byte (2-byte) aligned, so
                                       // every wave load straddles one extra 128-B line; taking the run back to back
                                       // shares those lines (measured HBM over-fetch 8.6 % -> 1.3 % for fp32)
-constexpr int kUnroll = 2;            // planes in flight per wave: 2 x (kChunk * sizeof(T)) bytes of loads outstanding
+constexpr int kLoadBytes = 8192;      // bytes of plane loads a wave keeps in flight: 2 fp32 planes or 4 16-bit planes
 constexpr int kWords = kChunk / 64;   // 64-bit words per plane and chunk (16)
 constexpr int kCostThreads = 256;
 
-// One 16-byte load per lane: E = 4 (fp32) or 8 (half / bfloat16) consecutive pixels; a chunk is kChunk / (64 E)
-// such loads (4 or 2).  Word index of pixel 64*E*j + E*lane + k is E*j + k.
+// One 16-byte load per lane: E = 4 (fp32) or 8 (half / bfloat16) consecutive pixels, kept RAW in 4 VGPRs until the
+// ballots consume it; a chunk is kChunk / (64 E) such loads (4 or 2).  Word index of pixel 64*E*j + E*lane + k is
+// E*j + k.
 template <typename T, bool TAIL>
-__device__ __forceinline__ void load_pixels(const T *plane, int x, int HW, float (&v)[MaskIO<T>::kVec]) {
+__device__ __forceinline__ typename MaskIO<T>::Raw load_pixels(const T *plane, int x, int HW) {
     constexpr int E = MaskIO<T>::kVec;
+    typename MaskIO<T>::Raw r;
     if (!TAIL || x + E - 1 < HW) {
-        MaskIO<T>::loadv(plane + x, v);
+        r = MaskIO<T>::load_raw(plane + x);
     } else {
+        // the chunk that straddles the end of the plane: element-wise, zero (never > 0.5) past the end
+        T tmp[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) v[k] = (x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+        for (int k = 0; k < E; ++k) {
+            if (x + k < HW) tmp[k] = plane[x + k];
+            else __builtin_memset(&tmp[k], 0, sizeof(T));
+        }
+        __builtin_memcpy(&r, tmp, sizeof(r));
     }
+    return r;
 }
 
 // Bit tile of one group of <= 64 planes for one chunk: lane p holds the kWords words of plane p.
@@ -56,6 +65,7 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
                                           int x0, int HW, int lane0 = 0, bool clear = true) {
     constexpr int E = MaskIO<T>::kVec;
     constexpr int SUB = kChunk / (64 * E);
+    constexpr int kUnroll = kLoadBytes / (kChunk * (int)sizeof(T));
     const int lane = threadIdx.x & 63;
     const int x = x0 + lane * E;
     if (clear) {
@@ -63,14 +73,14 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
         for (int k = 0; k < kWords; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
     }
     for (int p0 = 0; p0 < nplanes; p0 += kUnroll) {
-        float v[kUnroll][SUB][E];
+        typename MaskIO<T>::Raw v[kUnroll][SUB];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             // clamp: planes past the end re-read the last one; their words are never parked
             const int p = p0 + u < nplanes ? p0 + u : nplanes - 1;
 #pragma unroll
             for (int j = 0; j < SUB; ++j)
-                load_pixels<T, TAIL>(base + (int64_t)p * plane_stride, x + j * 64 * E, HW, v[u][j]);
+                v[u][j] = load_pixels<T, TAIL>(base + (int64_t)p * plane_stride, x + j * 64 * E, HW);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -81,7 +91,7 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
                 for (int j = 0; j < SUB; ++j)
 #pragma unroll
                     for (int k = 0; k < E; ++k) {
-                        const unsigned long long b = __ballot(v[u][j][k] > 0.5f);
+                        const unsigned long long b = __ballot(MaskIO<T>::elem(v[u][j], k) > 0.5f);
                         w.lo[E * j + k] = mine ? (int)(unsigned)b : w.lo[E * j + k];
                         w.hi[E * j + k] = mine ? (int)(unsigned)(b >> 32) : w.hi[E * j + k];
                     }
@@ -101,10 +111,10 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
 #pragma unroll
     for (int k = 0; k < kWords; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NG; ++g) {     // no `break` here: the loop must unroll fully or acc[g][m] lands in scratch
         int nn = Nb - g * kWave;
-        if (nn <= 0) break;
         if (nn > kWave) nn = kWave;
+        if (nn > 0) {
         BitTile pw;
         fill_tile<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW);
 #pragma unroll
@@ -122,11 +132,14 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
                 acc[g][m] = a;
             }
         }
+        }
     }
 }
 
 // grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
+// Large tiles (MT*NG >= 64 accumulators per lane) are compiled for 2 waves/SIMD so the accumulators stay in registers
+// (at the default 4 waves/SIMD target the 32x4 tile spilled 528 B/lane to scratch).
 template <typename T, int MT, int NG>
 __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
@@ -242,13 +255,17 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
         DMM_HIP_TRY(hipMemsetAsync(area_t2, 0, sizeof(int32_t) * (size_t)B * M, stream));
     }
     if (HW == 0) return DMM_OK;
-    // Tile the (N, M) table over the compiled envelopes; one launch covers N <= 256 and M <= 32 template rows
-    // (M <= 16 when a second template set rides along: both sets share the 32-row tile).
+    // Tile the (N, M) table over the compiled envelopes: <= 32 template rows per launch (<= 16 when a second
+    // template set rides along: both sets share the tile) x <= 256 proposals.  Register budget decides the
+    // proposal tile: accumulators are MT x NG per lane, and at MT > 16 a 4-group tile drops to 1 wave/SIMD
+    // (measured 2.6 TB/s on config 5), so those shapes run as 128-proposal tiles (templates re-read once
+    // per tile: +9 % bytes at N=200, M=20).
     const int mstep = masks_t2 ? 16 : 32;
     for (int m0 = 0; m0 < M; m0 += mstep) {
         const int mt = (M - m0 < mstep ? M - m0 : mstep) * (masks_t2 ? 2 : 1);
-        for (int n0 = 0; n0 < N; n0 += 256) {
-            const int nt = N - n0 < 256 ? N - n0 : 256;
+        const int nstep = mt > 16 ? 128 : 256;
+        for (int n0 = 0; n0 < N; n0 += nstep) {
+            const int nt = N - n0 < nstep ? N - n0 : nstep;
             const int wap = (m0 == 0), wat = (n0 == 0);
             int rc;
 #define DMM_COST_CASE(MT_, NG_)                                                                                       \
@@ -257,15 +274,16 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
             if (nt <= 64) {
                 if (mt <= 8) DMM_COST_CASE(8, 1);
                 else if (mt <= 16) DMM_COST_CASE(16, 1);
+                else if (mt <= 24) DMM_COST_CASE(24, 1);
                 else DMM_COST_CASE(32, 1);
             } else if (nt <= 128) {
                 if (mt <= 8) DMM_COST_CASE(8, 2);
                 else if (mt <= 16) DMM_COST_CASE(16, 2);
+                else if (mt <= 24) DMM_COST_CASE(24, 2);
                 else DMM_COST_CASE(32, 2);
             } else {
                 if (mt <= 8) DMM_COST_CASE(8, 4);
-                else if (mt <= 16) DMM_COST_CASE(16, 4);
-                else DMM_COST_CASE(32, 4);
+                else DMM_COST_CASE(16, 4);
             }
 #undef DMM_COST_CASE
             if (rc != DMM_OK) return rc;
