@@ -138,8 +138,8 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
 
 // grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
-// Large tiles (MT*NG >= 64 accumulators per lane) are compiled for 2 waves/SIMD so the accumulators stay in registers
-// (at the default 4 waves/SIMD target the 32x4 tile spilled 528 B/lane to scratch).
+
+
 template <typename T, int MT, int NG>
 __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
