@@ -515,3 +515,32 @@ def test_ragged_batched_backward_equals_per_video_calls():
             scale = float(ref.abs().max())
             assert float((got - ref).abs().max()) <= 1e-5 * scale + 1e-9
         assert float(pf.grad[b, P:].abs().sum()) == 0.0 and float(tf.grad[b, O:].abs().sum()) == 0.0
+
+
+def test_forward_is_hipgraph_capturable():
+    """include/dmm_match.h promises stream-ordered, allocation-free, sync-free entry points: capture the fused
+    forward in a HIP graph, replay it on new inputs and compare with eager execution."""
+    c = synth.CONFIGS[1]
+    B = 5
+    g = torch.Generator(device=DEV).manual_seed(11)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    pm, tm = mk(B, c["P"], c["H"], c["W"]), mk(B, c["O"], c["H"], c["W"])
+    pf, tf, sc = mk(B, c["P"], c["D"]) - 0.5, mk(B, c["O"], c["D"]) - 0.5, mk(B, c["P"])
+    plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+    plan.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)            # warm-up (module load)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)
+    # new inputs written in place, then replay
+    pm.copy_(mk(B, c["P"], c["H"], c["W"]))
+    tm.copy_(mk(B, c["O"], c["H"], c["W"]))
+    pf.copy_(mk(B, c["P"], c["D"]) - 0.5)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in (plan.full_outmask, plan.match_score, plan.det_score, plan.R, plan.iters)]
+    plan2 = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+    plan2.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)
+    torch.cuda.synchronize()
+    for a, b in zip(got, (plan2.full_outmask, plan2.match_score, plan2.det_score, plan2.R, plan2.iters)):
+        assert torch.equal(a, b)
