@@ -123,3 +123,58 @@ def test_config3_encoder_roi_match_end_to_end():
                 proj = (pm @ fo[o].flatten()) / (pm * pm).sum(1)
                 p = int(torch.argmax(proj * (pm * pm).sum(1).sqrt()))
                 assert float((fo[o].flatten() - proj[p] * pm[p]).abs().max()) < 1e-5, (tag, b, o)
+
+
+def test_training_step_end_to_end():
+    """BASELINE config 4 in miniature on one GPU: encoder -> ROI features -> DMM_Model (ragged batch) -> loss ->
+    backward through the HIP layer, the ROI kernel and the MIOpen encoder -> Adam step.  The matching loss on the
+    template/proposal features must go down (the reference trains exactly these parameters, base.py:62-69)."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd.proposals import SimpleBoxList
+    torch.manual_seed(0)
+    B, F, P, H, W = 2, 5, 12, 96, 128
+    enc = FeatureEncoder("resnet34", hidden_size=32).to(DEV).train()
+    fe = FeatureExtractor()
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    model = DMM_Model(cfgs, is_test=0, feature_extractor=fe)
+    opt = torch.optim.Adam(list(enc.get_skip_params()) + list(enc.get_backbone_para()), lr=1e-3)
+    frames = [synth.make_frame(P, F, H, W, 8, seed=7100 + b, kind="structured", with_targets=True) for b in range(B)]
+    n_tplt = [3, 5]
+
+    def boxes_of(masks):
+        out = []
+        for m in masks:
+            ys, xs = np.where(m > 0.5)
+            out.append([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1] if len(xs) else [0, 0, 8, 8])
+        return torch.from_numpy(np.asarray(out, np.float32)).to(DEV)
+
+    img = torch.randn(B, 3, H, W, device=DEV)
+    props, tboxes = [], []
+    for fr in frames:
+        bl = SimpleBoxList(boxes_of(fr.proposed_mask), (W, H))
+        bl.add_field("mask", torch.from_numpy(fr.proposed_mask).to(DEV).unsqueeze(1))
+        bl.add_field("scores", torch.from_numpy(fr.proposal_score).to(DEV))
+        props.append(bl)
+        tboxes.append(SimpleBoxList(boxes_of(fr.targets), (W, H)))
+    mask_last = torch.stack([torch.from_numpy(fr.mask_last_occurence).to(DEV) for fr in frames])
+    targets = torch.stack([torch.from_numpy(fr.targets).to(DEV) for fr in frames])
+    valid = torch.zeros(B, F, device=DEV)
+    for b in range(B):
+        valid[b, :n_tplt[b]] = 1
+    losses = []
+    for it in range(6):
+        feats = enc(img)
+        tplt_dict = model.fill_template_dict(None, tboxes, feats, None, valid)        # templates from the GT boxes
+        out, _, match_loss, last = model(None, props, feats["backbone_feature"], mask_last, tplt_dict, valid, targets)
+        assert out.shape == (B, F, H, W) and len(match_loss) == B
+        soft_iou = 1.0 - (out * targets).flatten(1).sum(1) / ((out + targets - out * targets).flatten(1).sum(1) + 1e-6)
+        loss = soft_iou.mean() + sum(match_loss) / B
+        opt.zero_grad()
+        loss.backward()
+        g_base, g_prop = enc.base.conv1.weight.grad, enc.prop2[0].weight.grad
+        assert g_base is not None and torch.isfinite(g_base).all() and float(g_base.abs().sum()) > 0
+        assert g_prop is not None and torch.isfinite(g_prop).all() and float(g_prop.abs().sum()) > 0
+        opt.step()
+        losses.append(float(sum(match_loss).detach()) / B)
+    assert losses[-1] < losses[0], losses
