@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdmm_match.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DMM_OK = 0
-DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_PACKED1 = 0, 1, 2, 3
 MAX_TEMPLATES = 32
 MAX_PROPOSALS = 256
 
@@ -25,7 +25,7 @@ SYMBOLS = (
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
-    "dmm_paste_masks_f32", "dmm_nms_f32",
+    "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks",
 )
 
 _lib = None
@@ -79,7 +79,10 @@ def load():
                                           vp, vp, sz, vp]
     L.dmm_roialign4_mean_fwd.argtypes = [vp, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, vp]
     L.dmm_roialign4_mean_bwd.argtypes = [vp, c_int, c_int, vp, vp, vp, vp, c_int, vp, vp]
-    L.dmm_paste_masks_f32.argtypes = [vp, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp, c_i64, vp, vp]
+    L.dmm_paste_masks_f32.argtypes = [vp, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp, c_i64, vp, vp, vp]
+    L.dmm_pack_words.argtypes = [c_int]
+    L.dmm_pack_words.restype = c_i64
+    L.dmm_pack_masks.argtypes = [vp, c_int, c_i64, c_int, c_i64, vp, c_i64, vp]
     L.dmm_nms_f32.argtypes = [vp, vp, vp, c_int, c_int, c_float, c_int, vp, vp, vp]
     L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
                                c_i64, vp]
@@ -91,7 +94,7 @@ def load():
                                     vp, vp, vp, vp, sz, vp]
     for f in ("dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
-              "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32"):
+              "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks"):
         getattr(L, f).restype = c_int
     if L.dmm_abi_version() != 1:
         raise DmmError("libdmm_match.so ABI version mismatch")

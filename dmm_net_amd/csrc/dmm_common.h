@@ -19,6 +19,10 @@ typedef _Float16 half4u __attribute__((ext_vector_type(4), aligned(2)));
 // 16-bit storage tags for mask planes (IEEE half / bfloat16); arithmetic is always fp32
 struct f16_t { _Float16 v; };
 struct bf16_t { uint16_t v; };
+// DMM_PACKED1 storage: 1 bit per pixel, already thresholded (x > 0.5).  Layout ("ballot layout"): pixels are taken
+// in blocks of 256; block q owns words 4q..4q+3; bit l of word 4q+k is pixel 256q + 4l + k (exactly what four wave
+// ballots over a 16-byte-per-lane load produce).  A plane of HW pixels has 4*ceil(HW/256) words, pad bits are 0.
+struct packed_t { unsigned long long v; };
 
 // ---- DPP cross-lane primitives -------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF>

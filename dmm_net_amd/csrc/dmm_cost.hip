@@ -21,6 +21,8 @@
 // VALU work is ~8 % of the HBM time of a chunk; the kernel is a pure stream.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dmm_common.h"
 
 namespace dmm {
@@ -59,6 +61,31 @@ __device__ __forceinline__ typename MaskIO<T>::Raw load_pixels(const T *plane, i
 struct BitTile {
     int lo[kWords], hi[kWords];
 };
+
+// DMM_PACKED1 planes: the words ARE the tile -- lane lane0+p loads the 16 words (128 B) of its plane's chunk.
+template <bool TAIL>
+__device__ __forceinline__ void fill_tile_packed(BitTile &w, const packed_t *base, int64_t plane_stride, int nplanes,
+                                                 int x0, int HW, int lane0, bool clear) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane - lane0;
+    const bool mine = p >= 0 && p < nplanes;
+    if (clear) {
+#pragma unroll
+        for (int k = 0; k < kWords; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
+    }
+    if (mine) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(base + (int64_t)p * plane_stride)
+                                        + (x0 >> 6);
+        const int nwords = 4 * ((HW + 255) / 256);
+#pragma unroll
+        for (int k = 0; k < kWords; ++k) {
+            unsigned long long v = 0;
+            if (!TAIL || (x0 >> 6) + k < nwords) v = src[k];
+            w.lo[k] = (int)(unsigned)v;
+            w.hi[k] = (int)(unsigned)(v >> 32);
+        }
+    }
+}
 
 template <typename T, bool TAIL>
 __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t plane_stride, int nplanes,
@@ -100,14 +127,21 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
     }
 }
 
+template <typename T, bool TAIL>
+__device__ __forceinline__ void fill_any(BitTile &w, const T *base, int64_t plane_stride, int nplanes, int x0, int HW,
+                                         int lane0, bool clear) {
+    if constexpr (std::is_same<T, packed_t>::value) fill_tile_packed<TAIL>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
+    else fill_tile<T, TAIL>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
+}
+
 template <typename T, int MT, int NG, bool TAIL>
 __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T *T2b, int64_t sp_n, int64_t st_m,
                                               int64_t st2_m, int Nb, int Mb, int Mrows, int x0, int HW,
                                               unsigned (&acc)[NG][MT], unsigned (&area_p)[NG], unsigned &area_t) {
     // template tile: lanes [0, Mb) = planes of set 1, lanes [Mb, 2*Mb) = planes of set 2 (training: the targets)
     BitTile tw;
-    fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x0, HW);
-    if (T2b) fill_tile<T, TAIL>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
+    fill_any<T, TAIL>(tw, Tb, st_m, Mb, x0, HW, 0, true);
+    if (T2b) fill_any<T, TAIL>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
 #pragma unroll
     for (int k = 0; k < kWords; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
 #pragma unroll
@@ -116,7 +150,7 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
         if (nn > kWave) nn = kWave;
         if (nn > 0) {
         BitTile pw;
-        fill_tile<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW);
+        fill_any<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW, 0, true);
 #pragma unroll
         for (int k = 0; k < kWords; ++k) area_p[g] += __builtin_popcount(pw.lo[k]) + __builtin_popcount(pw.hi[k]);
 #pragma unroll
@@ -303,9 +337,15 @@ static int iou_counts_dispatch(const void *masks_p, const void *masks_t, const v
     if (B == 0 || N == 0 || M == 0) return DMM_OK;
     if (!masks_p || !masks_t || !inter || !area_p || !area_t) return DMM_ERR_BAD_ARG;
     if (masks_t2 && (!inter2 || !area_t2)) return DMM_ERR_BAD_ARG;
-    if (sp_n < HW || st_m < HW || (masks_t2 && st2_m < HW)) return DMM_ERR_BAD_ARG;
+    const int64_t min_stride = dtype == DMM_PACKED1 ? 4 * ((int64_t)(HW + 255) / 256) : HW;
+    if (sp_n < min_stride || st_m < min_stride || (masks_t2 && st2_m < min_stride)) return DMM_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
+        case DMM_PACKED1:
+            return dmm::iou_counts_typed<dmm::packed_t>((const dmm::packed_t *)masks_p, (const dmm::packed_t *)masks_t,
+                                                        (const dmm::packed_t *)masks_t2, B, N, M, HW, sp_b, sp_n, st_b,
+                                                        st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t,
+                                                        inter2, area_t2, s);
         case DMM_F32:
             return dmm::iou_counts_typed<float>((const float *)masks_p, (const float *)masks_t, (const float *)masks_t2, B,
                                                 N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter,

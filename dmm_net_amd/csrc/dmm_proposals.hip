@@ -19,7 +19,8 @@ constexpr int kNmsMax = 1024;
 __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restrict__ prob, int M,
                                                           const float *__restrict__ boxes, int im_h, int im_w,
                                                           float thresh, int padding, float *__restrict__ planes,
-                                                          int64_t plane_stride, float *__restrict__ new_boxes) {
+                                                          int64_t plane_stride, float *__restrict__ new_boxes,
+                                                          unsigned long long *__restrict__ packed, int64_t packed_stride) {
     __shared__ float pad_s[64 * 64];
     __shared__ int box_s[4];
     const int p = blockIdx.x;
@@ -46,29 +47,47 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
     const float sh = (float)Mp / (float)h, sw = (float)Mp / (float)w;
     float *plane = planes + (int64_t)p * plane_stride;
     int xmin = im_w, ymin = im_h, xmax = -1, ymax = -1;
-    for (int i = threadIdx.x; i < im_h * im_w; i += 256) {
-        const int y = i / im_w, x = i - y * im_w;
-        float v = 0.0f;
-        if (y >= y_0 && y < y_1 && x >= x_0 && x < x_1) {
-            float ry = __builtin_fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
-            ry = ry < 0.0f ? 0.0f : ry;
-            const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
-            const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
-            float rx = __builtin_fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
-            rx = rx < 0.0f ? 0.0f : rx;
-            const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
-            const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
-            const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
-            const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
-            const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
-            const float lb = ly1 * bot;
-            v = __builtin_fmaf(ly0, top, lb);
-            if (v > thresh) {
-                xmin = min(xmin, x); xmax = max(xmax, x);
-                ymin = min(ymin, y); ymax = max(ymax, y);
+    // each thread produces 4 consecutive pixels per step, a wave 256: exactly one block of the packed ballot layout
+    const int HW = im_h * im_w;
+    const int lane = threadIdx.x & 63;
+    for (int i4 = 4 * threadIdx.x; i4 < ((HW + 255) / 256) * 256; i4 += 1024) {
+        float vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i4 + k;
+            float v = 0.0f;
+            if (i < HW) {
+                const int y = i / im_w, x = i - y * im_w;
+                if (y >= y_0 && y < y_1 && x >= x_0 && x < x_1) {
+                    float ry = __builtin_fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
+                    ry = ry < 0.0f ? 0.0f : ry;
+                    const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
+                    const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
+                    float rx = __builtin_fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
+                    rx = rx < 0.0f ? 0.0f : rx;
+                    const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
+                    const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
+                    const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
+                    const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
+                    const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
+                    const float lb = ly1 * bot;
+                    v = __builtin_fmaf(ly0, top, lb);
+                    if (v > thresh) {
+                        xmin = min(xmin, x); xmax = max(xmax, x);
+                        ymin = min(ymin, y); ymax = max(ymax, y);
+                    }
+                }
+                plane[i] = v;
             }
+            vv[k] = v;
         }
-        plane[i] = v;
+        if (packed) {
+            const unsigned long long b0 = __ballot(vv[0] > 0.5f), b1 = __ballot(vv[1] > 0.5f);
+            const unsigned long long b2 = __ballot(vv[2] > 0.5f), b3 = __ballot(vv[3] > 0.5f);
+            if (lane < 4)
+                packed[(int64_t)p * packed_stride + (i4 - 4 * lane) / 64 + lane] =
+                    lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+        }
     }
     atomicMin(&box_s[0], xmin);
     atomicMin(&box_s[1], ymin);
@@ -140,13 +159,14 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ boxe
 
 extern "C" int dmm_paste_masks_f32(const float *prob, int P, int M, const float *boxes, int im_h, int im_w, float thresh,
                                    int padding, float *planes, int64_t plane_stride, float *new_boxes,
-                                   dmm_stream_t stream) {
+                                   uint64_t *packed, dmm_stream_t stream) {
     if (P < 0 || M <= 0 || im_h < 0 || im_w < 0 || padding < 0) return DMM_ERR_BAD_ARG;
     if (P == 0) return DMM_OK;
     if (!prob || !boxes || !planes || !new_boxes || plane_stride < (int64_t)im_h * im_w) return DMM_ERR_BAD_ARG;
     if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dmm::paste_masks_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, prob, M, boxes, im_h, im_w,
-                       thresh, padding, planes, plane_stride, new_boxes);
+                       thresh, padding, planes, plane_stride, new_boxes, reinterpret_cast<unsigned long long *>(packed),
+                       dmm_pack_words(im_h * im_w));
     return dmm::check_launch();
 }
 

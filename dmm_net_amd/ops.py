@@ -64,6 +64,47 @@ def iou_counts(masks_p: torch.Tensor, masks_t: torch.Tensor, n_valid=None, m_val
     return inter, ap, at
 
 
+def pack_words(HW: int) -> int:
+    """uint64 words per packed plane of HW pixels (DMM_PACKED1 ballot layout)."""
+    return 4 * ((HW + 255) // 256)
+
+
+def pack_masks(masks: torch.Tensor) -> torch.Tensor:
+    """[B,K,H,W] soft masks -> [B,K,words] int64 bit planes of (x > 0.5) in the library's ballot layout."""
+    _need_gpu(masks)
+    masks, s_b, s_k = _planes(masks)
+    B, K, H, W = masks.shape
+    if s_b != K * s_k:
+        masks = masks.contiguous()
+        s_k = H * W
+    wd = pack_words(H * W)
+    out = torch.empty((B, K, wd), dtype=torch.int64, device=masks.device)
+    with torch.cuda.device(masks.device):
+        rc = _lib.load().dmm_pack_masks(_ptr(masks), _DT[masks.dtype], B * K, H * W, s_k, _ptr(out), wd, _stream(masks))
+    _lib.check(rc, "dmm_pack_masks")
+    return out
+
+
+def iou_counts_packed(packed_p: torch.Tensor, packed_t: torch.Tensor, HW: int, n_valid=None, m_valid=None):
+    """iou_counts on DMM_PACKED1 planes ([B,N,words], [B,M,words] int64): identical integer tables, 1/32 of the bytes."""
+    _need_gpu(packed_p, packed_t)
+    assert packed_p.dtype == torch.int64 and packed_t.dtype == torch.int64
+    packed_p, packed_t = packed_p.contiguous(), packed_t.contiguous()
+    B, N, wd = packed_p.shape
+    M = packed_t.shape[1]
+    assert wd == pack_words(HW) and packed_t.shape[2] == wd
+    dev = packed_p.device
+    inter = torch.empty((B, M, N), dtype=torch.int32, device=dev)
+    ap = torch.empty((B, N), dtype=torch.int32, device=dev)
+    at = torch.empty((B, M), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().dmm_iou_counts(_ptr(packed_p), _ptr(packed_t), _lib.DTYPE_PACKED1, B, N, M, HW, N * wd, wd,
+                                        M * wd, wd, _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at),
+                                        _stream(packed_p))
+    _lib.check(rc, "dmm_iou_counts (packed)")
+    return inter, ap, at
+
+
 def iou_counts_dual(masks_p: torch.Tensor, masks_t: torch.Tensor, masks_t2: torch.Tensor, n_valid=None, m_valid=None):
     """One pass over the proposal planes against TWO template sets (templates + training targets).
     -> (inter, area_p, area_t), (inter2, area_t2)."""

@@ -45,8 +45,9 @@ class SimpleBoxList:
 
 
 def paste_masks(mask_prob: torch.Tensor, boxes: torch.Tensor, im_h: int, im_w: int, thresh: float = 0.4,
-                padding: int = 1):
-    """mask_prob [P,1,M,M] (or [P,M,M]), boxes [P,4] xyxy -> (masks [P,1,im_h,im_w], tight boxes [P,4])."""
+                padding: int = 1, want_packed: bool = False):
+    """mask_prob [P,1,M,M] (or [P,M,M]), boxes [P,4] xyxy -> (masks [P,1,im_h,im_w], tight boxes [P,4]).
+    With ``want_packed`` also returns the 1-bit (mask > 0.5) planes [P, words] (int64, ``ops.iou_counts_packed``)."""
     if not mask_prob.is_cuda:
         raise _lib.DmmError("paste_masks needs tensors on an MI355X device (no CPU fallback)")
     prob = mask_prob.reshape(mask_prob.shape[0], mask_prob.shape[-2], mask_prob.shape[-1]).contiguous().float()
@@ -55,12 +56,16 @@ def paste_masks(mask_prob: torch.Tensor, boxes: torch.Tensor, im_h: int, im_w: i
     assert prob.shape[-2] == M and boxes.shape == (P, 4)
     planes = torch.empty((P, 1, im_h, im_w), dtype=torch.float32, device=prob.device)
     nb = torch.empty((P, 4), dtype=torch.float32, device=prob.device)
+    packed = None
+    if want_packed:
+        packed = torch.empty((P, 4 * ((im_h * im_w + 255) // 256)), dtype=torch.int64, device=prob.device)
     with torch.cuda.device(prob.device):
         rc = _lib.load().dmm_paste_masks_f32(prob.data_ptr(), P, M, boxes.data_ptr(), int(im_h), int(im_w), float(thresh),
                                              int(padding), planes.data_ptr(), im_h * im_w, nb.data_ptr(),
+                                             None if packed is None else packed.data_ptr(),
                                              torch.cuda.current_stream(prob.device).cuda_stream)
     _lib.check(rc, "dmm_paste_masks_f32")
-    return planes, nb
+    return (planes, nb, packed) if want_packed else (planes, nb)
 
 
 def nms_batched(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor], thresh: float, max_keep: int = 0):

@@ -45,7 +45,10 @@ typedef enum dmm_status {
     DMM_ERR_WORKSPACE = 4     /* workspace too small                                 */
 } dmm_status;
 
-typedef enum dmm_dtype { DMM_F32 = 0, DMM_F16 = 1, DMM_BF16 = 2 } dmm_dtype;
+typedef enum dmm_dtype {
+    DMM_F32 = 0, DMM_F16 = 1, DMM_BF16 = 2,
+    DMM_PACKED1 = 3   /* 1 bit per pixel, already thresholded; uint64 words in the library's ballot layout (see (1c)) */
+} dmm_dtype;
 
 typedef void *dmm_stream_t; /* hipStream_t */
 
@@ -76,6 +79,16 @@ DMM_API int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtype, 
                    const int32_t *n_valid, const int32_t *m_valid,
                    int32_t *inter /*[B,M,N]*/, int32_t *area_p /*[B,N]*/, int32_t *area_t /*[B,M]*/,
                    dmm_stream_t stream);
+
+/* (1c) Bit-packed planes.  dmm_pack_masks thresholds (x > 0.5) and packs `planes` mask planes of HW pixels into
+ * 4*ceil(HW/256) uint64 words each (ballot layout: bit l of word 4q+k = pixel 256q + 4l + k; pad bits 0);
+ * dmm_pack_words(HW) returns that word count.  dmm_iou_counts / dmm_iou_counts_dual accept dtype DMM_PACKED1:
+ * masks_* then point to such words and all strides are in WORDS.  Packing the proposal side once (or having
+ * dmm_paste_masks_f32 emit it) shrinks the bytes of the cost pass 32x for those planes; the integer tables are
+ * identical to the fp32 path by construction. */
+DMM_API int64_t dmm_pack_words(int HW);
+DMM_API int dmm_pack_masks(const void *masks, int dtype, int64_t planes, int HW, int64_t plane_stride,
+                           uint64_t *packed, int64_t packed_stride, dmm_stream_t stream);
 
 /* (1b) Training: the same pass also intersects the proposals with a SECOND template set of M planes per
  * frame -- the ground-truth targets of compute_matching_loss (match_helper.py:34-43) -- so the proposal
@@ -214,7 +227,7 @@ DMM_API int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int H[
  * dmm_paste_masks_f32: paste_mask_in_image + binmask_to_box (dmm/utils/masker.py:110-173) for P proposals:
  *   prob [P,M,M] mask probabilities, boxes [P,4] xyxy -> planes [P, im_h*im_w] (plane_stride elements apart; the
  *   soft masks the matching layer consumes) and new_boxes [P,4] = tight box of (plane > thresh), or
- *   [0,0,im_h,im_w] when empty.  M + 2*padding <= 64.
+ *   [0,0,im_h,im_w] when empty.  M + 2*padding <= 64.  Optionally also emits the DMM_PACKED1 form of the planes.
  * dmm_nms_f32: NMS + top-k of filter_results (dmm/utils/boxlist_ops.py:15-29, maskrcnn_benchmark nms semantics:
  *   descending score, legacy +1 areas, IoU > thresh suppresses) per image: boxes [sum n,4], scores [sum n],
  *   offsets [images+1] (device int32) -> keep[offsets[i] ...] = kept local indices in score order,
@@ -222,6 +235,7 @@ DMM_API int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int H[
  * ------------------------------------------------------------------------------------------- */
 DMM_API int dmm_paste_masks_f32(const float *prob, int P, int M, const float *boxes, int im_h, int im_w, float thresh,
                                 int padding, float *planes, int64_t plane_stride, float *new_boxes,
+                                uint64_t *packed /* NULL or [P, dmm_pack_words(im_h*im_w)]: (plane > 0.5) bits */,
                                 dmm_stream_t stream);
 DMM_API int dmm_nms_f32(const float *boxes, const float *scores, const int32_t *offsets, int images, int max_per_image,
                         float thresh, int max_keep, int32_t *keep, int32_t *keep_count, dmm_stream_t stream);

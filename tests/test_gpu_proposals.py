@@ -44,3 +44,37 @@ def test_nms_and_filter_results_match_oracle():
     for bl, e in zip(out, exp):
         assert len(bl) == len(e) <= 50
         assert np.array_equal(bl.get_field("mask").cpu().numpy().astype(np.int64), e.astype(np.int64))
+
+
+def test_packed_planes_give_identical_tables():
+    """DMM_PACKED1: pack once, count from 1/32 of the bytes -- same integer tables as the fp32 path."""
+    from dmm_net_amd import ops
+    rng = np.random.default_rng(8)
+    for (B, N, M, H, W) in [(2, 50, 10, 255, 255), (3, 7, 3, 5, 9), (1, 130, 20, 33, 40), (2, 20, 4, 16, 16)]:
+        pm = torch.from_numpy(rng.random((B, N, H, W), dtype=np.float32)).to(DEV)
+        tm = torch.from_numpy(rng.random((B, M, H, W), dtype=np.float32)).to(DEV)
+        pp, pt = ops.pack_masks(pm), ops.pack_masks(tm)
+        assert pp.shape == (B, N, ops.pack_words(H * W))
+        nv = torch.tensor([N, max(N - 3, 1), 1][:B], dtype=torch.int32, device=DEV)
+        a = ops.iou_counts(pm, tm, nv, None)
+        b = ops.iou_counts_packed(pp, pt, H * W, nv, None)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (B, N, M, H, W)
+        # pad bits are zero: total popcount of a packed plane == its area
+        bits = pp.view(torch.uint8)
+        pop = torch.tensor([bin(int(v)).count("1") for v in range(256)], device=DEV)[bits.long()].flatten(2).sum(2)
+        assert torch.equal(pop.int(), ops.iou_counts(pm, tm)[1])
+    # fp16 source
+    pm16 = pm.half()
+    assert torch.equal(ops.pack_masks(pm16), ops.pack_masks(pm16.float()))
+
+
+def test_paste_emits_the_packed_form():
+    from dmm_net_amd import ops
+    g = golden("g9_paste")
+    c = g.group("c1")
+    h, w = [int(v) for v in c["size"]]
+    planes, nb, packed = proposals.paste_masks(torch.from_numpy(c["prob"]).to(DEV), torch.from_numpy(c["boxes"]).to(DEV),
+                                               h, w, float(c["thresh"]), int(c["padding"]), want_packed=True)
+    assert torch.equal(packed, ops.pack_masks(planes.transpose(0, 1))[0])
+    assert np.array_equal(nb.cpu().numpy(), c["new_boxes"])

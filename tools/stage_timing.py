@@ -55,6 +55,14 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]:
     t_copy = timeit(lambda: dst.copy_(src))
     print(f"      torch copy of {src.numel() * 4 / 1e9:.2f} GB: {t_copy:8.1f}us ({2 * src.numel() * 4 / t_copy / 1e3:6.0f} GB/s r+w)")
     del src, dst
+    if os.environ.get("PACKED"):
+        pp, pt = ops.pack_masks(pm), ops.pack_masks(tm)
+        t_pack_t = timeit(lambda: ops.pack_masks(tm))
+        t_pack_p = timeit(lambda: ops.pack_masks(pm))
+        t_pc = timeit(lambda: ops.iou_counts_packed(pp, pt, H * W))
+        print(f"      packed: pack templates {t_pack_t:7.1f}us, pack proposals {t_pack_p:7.1f}us "
+              f"({B * N * H * W * ES / t_pack_p / 1e3:6.0f} GB/s), counts on packed planes {t_pc:7.1f}us")
+        del pp, pt
     gb = B * (N + M) * H * W * ES / 1e9
     print(f"B={B:5d} cost {t_cost:8.1f}us ({gb / t_cost * 1e6:7.0f} GB/s)  norm {t_norm:6.1f} cos {t_cos:6.1f}  relax_match {t_relax:7.1f} "
           f"(iters=0: {t_relax0:6.1f})  solve-only {t_solve:7.1f} (init only {t_solve0:6.1f})  "
