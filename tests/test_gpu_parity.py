@@ -544,3 +544,43 @@ def test_forward_is_hipgraph_capturable():
     torch.cuda.synchronize()
     for a, b in zip(got, (plan2.full_outmask, plan2.match_score, plan2.det_score, plan2.R, plan2.iters)):
         assert torch.equal(a, b)
+
+
+def test_solver_every_row_count_and_width_class_bit_exact():
+    """Sweep all row counts 1..32 (exact-row and guarded instantiations) against widths that hit every column/row-sum
+    class of the reference's reduction order (m < 8, multiples of 8 / 32, tails, 1 / 2 / 4 waves): bit exact vs the oracle."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    widths = [2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 255, 256]
+    for n in range(1, 33):
+        for m in widths:
+            if m < 2:
+                continue
+            C = (-rng.random((2, n, m), dtype=np.float32) * np.float32(0.7)).astype(np.float32)
+            r = ops.relax_solve(dev(C), 4, 3, 0.1)
+            X, R, it = r["X"].cpu().numpy(), r["R"].cpu().numpy(), r["iters"].cpu().numpy()
+            for b in range(2):
+                o = oracle.relax(C[b], 4, 3, 0.1)
+                assert int(it[b]) == o["iters"], (n, m, b)
+                assert np.array_equal(X[b], o["X"]), (n, m, b, float(np.abs(X[b] - o["X"]).max()))
+                assert np.array_equal(R[b], o["R"]), (n, m, b)
+
+
+def test_layer_many_shapes_bit_exact_vs_oracle():
+    """Whole layer (cosine + sim + solver + scores, test-mode mix) on odd shapes incl. the pad path and D not a multiple of 4/64."""
+    for k, (P, O, H, W, D) in enumerate([(1, 1, 5, 7, 16), (2, 3, 9, 9, 33), (9, 8, 17, 13, 100), (33, 5, 20, 20, 64),
+                                         (64, 16, 16, 16, 512), (65, 17, 12, 12, 40), (130, 20, 10, 11, 256),
+                                         (7, 32, 8, 8, 8), (255, 31, 6, 6, 48)]):
+        fr = synth.make_frame(P, O, H, W, D, seed=9100 + k, kind="uniform")
+        for is_test in (1, 0):
+            o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                                     fr.proposal_score, max_iter=6, proj_iter=3, is_test=is_test)
+            g = run_frame(fr, 6, 3, is_test)
+            assert np.array_equal(g["cos"], o["cos"]), (P, O, D, float(np.abs(g["cos"] - o["cos"]).max()))
+            assert np.array_equal(g["sim"], o["sim"]) and int(g["iters"]) == o["iters"], (P, O)
+            assert np.array_equal(g["R"], o["R"]) and np.array_equal(g["Rb"], o["Rb"]), (P, O)
+            assert np.array_equal(g["match_score"], o["match_score"]), (P, O)
+            assert np.array_equal(g["det_score"], o["det_score"]), (P, O)
+            if is_test:
+                assert np.array_equal(g["full_outmask"], o["full_outmask"]), (P, O)
+            else:
+                close(g["full_outmask"], o["full_outmask"])
