@@ -452,6 +452,35 @@ def g9():
     save("g9_paste", d)
 
 
+def verify_sweep():
+    """Not a fixture: cross-checks the ORACLE against the imported reference on the broad shape sweep that
+    tests/test_gpu_parity.py runs GPU-vs-oracle (all row counts 1..32 x 17 width classes, 12 cosine shapes).
+    Run in the build container: `python tests/golden/gen_golden.py verify_sweep` -> "0 mismatches"."""
+    import oracle
+    rng = np.random.Generator(np.random.PCG64(2024))
+    widths = [2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 128, 129, 200, 255, 256]
+    bad = tot = 0
+    for n in range(1, 33):
+        for m in widths:
+            C = (-rng.random((2, n, m), dtype=np.float32) * np.float32(0.7)).astype(np.float32)
+            for b in range(2):
+                X, cost, xl, _ = relax_matching(T(C[b]), max_iter=4, proj_iter=3, lr=0.1)
+                R = (sum(xl) / len(xl)).numpy()
+                o = oracle.relax(C[b], 4, 3, 0.1)
+                tot += 1
+                bad += not (np.array_equal(o["X"], X.numpy()) and np.array_equal(o["R"], R)
+                            and o["iters"] + 1 == len(xl))
+    for (O, P, D) in [(1, 1, 16), (2, 3, 33), (8, 9, 100), (5, 33, 64), (16, 64, 512), (17, 65, 40), (20, 130, 256),
+                      (32, 7, 8), (31, 255, 48), (3, 2, 9), (4, 8, 5), (2, 12, 1030)]:
+        q = rng.standard_normal((O, D), dtype=np.float32)
+        k = rng.standard_normal((P, D), dtype=np.float32)
+        ref = match_helper.get_cosine_score(T(q), T(k)).numpy()
+        tot += 1
+        bad += not np.array_equal(oracle.cosine(q, k), ref)
+    print(f"verify_sweep: {tot} cases, {bad} mismatches")
+    assert bad == 0
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
