@@ -295,6 +295,7 @@ class ForwardPlan:
         self.tn = torch.empty((B, M, D), **f32)
         self.cos = torch.empty((B, M, N), **f32)
         with torch.cuda.device(self.device):
+            # (stream priorities make no measurable difference here: 261.1 / 262.0 k frames/s at priority 0 / -1)
             self.side = torch.cuda.Stream(device=self.device)
             self.ev_start = torch.cuda.Event()
             self.ev_cost = [torch.cuda.Event() for _ in self.halves]

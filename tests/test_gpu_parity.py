@@ -584,3 +584,22 @@ def test_layer_many_shapes_bit_exact_vs_oracle():
                 assert np.array_equal(g["full_outmask"], o["full_outmask"]), (P, O)
             else:
                 close(g["full_outmask"], o["full_outmask"])
+
+
+def test_envelope_errors_are_loud():
+    """Shapes outside the compiled solver envelope raise (status 2), never fall back: M <= 32, Pp <= 256."""
+    from dmm_net_amd import _lib
+    rng = np.random.Generator(np.random.PCG64(3))
+    pm = torch.from_numpy(rng.random((1, 300, 8, 8), dtype=np.float32)).to(DEV)
+    tm = torch.from_numpy(rng.random((1, 4, 8, 8), dtype=np.float32)).to(DEV)
+    inter, ap, at = ops.iou_counts(pm, tm)                     # the count kernel tiles any N, M
+    ri, rp, rt = oracle.iou_counts(pm[0].cpu().numpy(), tm[0].cpu().numpy())
+    assert np.array_equal(inter[0].cpu().numpy(), ri) and np.array_equal(ap[0].cpu().numpy(), rp)
+    cos = torch.zeros((1, 4, 300), device=DEV)
+    with pytest.raises(_lib.DmmError, match="envelope"):
+        ops.relax_match(cos, inter, ap, at, torch.zeros((1, 300), device=DEV), score_weight=0.3, max_iter=2, proj_iter=2,
+                        lr=0.1, is_test=1)
+    with pytest.raises(_lib.DmmError):
+        ops.relax_solve(torch.zeros((1, 33, 40), device=DEV), 1, 1, 0.1)
+    with pytest.raises(_lib.DmmError, match="MI355X"):
+        ops.iou_counts(pm.cpu(), tm.cpu())                     # no CPU fallback
