@@ -60,3 +60,23 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), fn
                 assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", src), fn
                 assert "libdmm_oracle" not in src and "dmmo_" not in src.replace("dmmo_check_div_by_const", ""), fn
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No HIP library -> DmmError with build instructions; nothing falls back to a CPU path."""
+    import pytest
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdmm_match.so"))
+    with pytest.raises(_lib.DmmError, match="no CPU fallback"):
+        _lib.load()
+    # and the tensor-level ops refuse CPU tensors outright
+    import torch
+    from dmm_net_amd import ops
+    monkeypatch.undo()
+    with pytest.raises(_lib.DmmError, match="no CPU fallback"):
+        ops.iou_counts(torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4))
+    from dmm_net_amd.match_model import MatchModel
+    m = MatchModel({"matching": {"algo": "relax"}, "relax_max_iter": 2, "relax_proj_iter": 2,
+                    "relax_learning_rate": 0.1, "score_weight": 0.3}, 1)
+    with pytest.raises(_lib.DmmError):
+        m(torch.zeros(2, 8), torch.zeros(2, 4, 4), [torch.zeros(1, 8)], torch.zeros(1, 4, 4), torch.zeros(2))
