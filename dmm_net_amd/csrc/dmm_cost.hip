@@ -339,6 +339,20 @@ static int iou_counts_dispatch(const void *masks_p, const void *masks_t, const v
     if (masks_t2 && (!inter2 || !area_t2)) return DMM_ERR_BAD_ARG;
     const int64_t min_stride = dtype == DMM_PACKED1 ? 4 * ((int64_t)(HW + 255) / 256) : HW;
     if (sp_n < min_stride || st_m < min_stride || (masks_t2 && st2_m < min_stride)) return DMM_ERR_BAD_ARG;
+    if (B > 65535) {   // grid.y limit: run in batch slices
+        const size_t es = dtype == DMM_F32 ? 4 : (dtype == DMM_PACKED1 ? 8 : 2);
+        for (int b0 = 0; b0 < B; b0 += 65535) {
+            const int nb = B - b0 < 65535 ? B - b0 : 65535;
+            const int rc = iou_counts_dispatch(
+                (const char *)masks_p + es * (size_t)b0 * sp_b, (const char *)masks_t + es * (size_t)b0 * st_b,
+                masks_t2 ? (const char *)masks_t2 + es * (size_t)b0 * st2_b : nullptr, dtype, nb, N, M, HW, sp_b, sp_n,
+                st_b, st_m, st2_b, st2_m, n_valid ? n_valid + b0 : nullptr, m_valid ? m_valid + b0 : nullptr,
+                inter + (size_t)b0 * M * N, area_p + (size_t)b0 * N, area_t + (size_t)b0 * M,
+                inter2 ? inter2 + (size_t)b0 * M * N : nullptr, area_t2 ? area_t2 + (size_t)b0 * M : nullptr, stream);
+            if (rc != DMM_OK) return rc;
+        }
+        return DMM_OK;
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case DMM_PACKED1:

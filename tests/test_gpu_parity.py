@@ -603,3 +603,15 @@ def test_envelope_errors_are_loud():
         ops.relax_solve(torch.zeros((1, 33, 40), device=DEV), 1, 1, 0.1)
     with pytest.raises(_lib.DmmError, match="MI355X"):
         ops.iou_counts(pm.cpu(), tm.cpu())                     # no CPU fallback
+
+
+def test_iou_counts_batch_beyond_grid_limit():
+    """B > 65535 frames (grid.y limit) is sliced inside the launcher."""
+    B, N, M, H, W = 70001, 3, 2, 3, 5
+    g = torch.Generator(device=DEV).manual_seed(5)
+    pm = torch.rand((B, N, H, W), generator=g, device=DEV)
+    tm = torch.rand((B, M, H, W), generator=g, device=DEV)
+    inter, ap, at = ops.iou_counts(pm, tm)
+    a, b = (pm > 0.5).flatten(2), (tm > 0.5).flatten(2)
+    exp = (b[:, :, None, :] & a[:, None, :, :]).sum(-1).int()
+    assert torch.equal(inter, exp) and torch.equal(ap, a.sum(-1).int()) and torch.equal(at, b.sum(-1).int())
