@@ -11,14 +11,16 @@
 //   * a wave takes a 1024-pixel run of a plane as 16-byte loads per lane (4 dwordx4 for fp32, 2 for
 //     half / bfloat16; 1 KiB per wave instruction, coalesced), thresholds `> 0.5` and bit-packs
 //     through v_cmp -> 64-bit lane masks (the hardware transposer);
-//   * the 64-bit words are parked in lane `plane` of 8 VGPRs with a lane-select (v_cndmask on
+//   * the 16 64-bit words are parked in lane `plane` of 32 VGPRs with a lane-select (v_cndmask on
 //     lane == plane; proposal n -> lane n of group n/64, template m -> lane m of the template set),
 //     so the whole bit tile of a chunk lives in registers -- no LDS, no barriers in the streaming loop;
 //   * pair phase: lane = proposal, scalar loop over templates: v_readlane the template word
 //     into SGPRs, v_and + v_bcnt accumulate popc(P & T) into acc[m] (registers);
 //   * epilogue: the 4 waves fold their integer partials with LDS atomics, then one global
 //     atomicAdd per table entry and workgroup (integers: result independent of order).
-// VALU work is ~8 % of the HBM time of a chunk; the kernel is a pure stream.
+// VALU work is ~10 % of the HBM time of a chunk; the kernel is a pure stream.
+// DMM_PACKED1 input (1 bit per pixel, see dmm_pack.hip) skips the threshold/ballot step: lane p loads the 16 words
+// of its plane's chunk straight into the tile.
 #include <stdlib.h>
 
 #include <type_traits>
