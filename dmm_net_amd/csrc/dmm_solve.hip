@@ -116,6 +116,25 @@ __device__ __forceinline__ void row_sums_torch_order(const float *xbuf, int n, i
     }
     __syncthreads();                                   // rsbuf complete, xbuf free again
 }
+// Single-wave variant (NG == 1): the 8 group results of a pass are picked out of the wave with v_readlane, so the
+// second LDS round trip (store rs, barrier, reload) disappears; rs[] comes back wave-uniform in registers.
+template <int MT>
+__device__ __forceinline__ void row_sums_torch_order_wave(const float *xbuf, int n, int m, float (&rs)[MT]) {
+    __syncthreads();                                   // xbuf complete (one wave: just drains the LDS queue)
+    const int lane = threadIdx.x & 63, l = lane & 7, g = lane >> 3;
+#pragma unroll
+    for (int p = 0; p < (MT + 7) / 8; ++p) {
+        const int r = p * 8 + g;
+        float s = 0.0f;
+        if (r < n) {
+            const float *x = xbuf + r * m;
+            s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (p * 8 + k < MT) rs[p * 8 + k] = readlane_f32(s, 8 * k);
+    }
+}
 __device__ __forceinline__ float norm_torch_order(const float *xbuf, int cnt, float *slot) {
     __syncthreads();
     if (threadIdx.x < 8) {
@@ -274,25 +293,33 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 }
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
-            row_sums_torch_order<NG>(xbuf, n, m, rsbuf);
-            float dd[1] = {0.0f};
+            float rsv[MT];
+            if (NG == 1) {
+                row_sums_torch_order_wave<MT>(xbuf, n, m, rsv);
+            } else {
+                row_sums_torch_order<NG>(xbuf, n, m, rsbuf);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) rsv[i] = DMM_ROW(i) ? rsbuf[i] : 0.0f;
+            }
+            bool moved = false;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if (DMM_ROW(i) && live) {
-                    const float tr = div_by_const(rsbuf[i] - 1.0f, fm, rcp_m);
+                    const float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
                     const float x = X[i];
                     const float y = x - tr;
                     P2[i] = x - y;
                     X[i] = y;                                   // :86
                     const float d = y - Xs[i];
-                    dd[0] = __builtin_fmaf(d, d, dd[0]);
+                    const float sq = d * d;
+                    moved = moved || !(sq == 0.0f);             // NaN counts as "moved", like norm() == 0 being false
                 }
             }
-            // if ||X - X_start|| == 0: break (:88-89).  A sum of squares is zero iff every square rounds to
-            // zero, whatever the order: the tree reduction gives the reference's decision exactly.
-            dd[0] = wave_sum(dd[0]);
-            red.sum(dd);
-            if (dd[0] == 0.0f) break;
+            // if ||X - X_start|| == 0: break (:88-89).  A sum of squares is zero iff every square rounds to zero,
+            // whatever the order: "no lane saw a non-zero square" is exactly the reference's decision.
+            float mv[1] = {__ballot(moved) != 0ull ? 1.0f : 0.0f};
+            red.fold(mv, fmax_op());
+            if (mv[0] == 0.0f) break;
         }
         if (TAPE && threadIdx.x == 0) tape.sweeps[it] = sweeps_done;
         if (cost_prev == cost) break;                           // :96-98
