@@ -178,3 +178,55 @@ def test_training_step_end_to_end():
         opt.step()
         losses.append(float(sum(match_loss).detach()) / B)
     assert losses[-1] < losses[0], losses
+
+
+def test_inference_step_end_to_end():
+    """One inference step of the path with every stage from this package: encoder (MIOpen) -> proposal preprocessing
+    (paste + tight boxes, NMS + top-k) -> ROI features -> DMM_Model.inference (one ragged batched launch sequence)."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd import proposals as prop
+    torch.manual_seed(2)
+    rng = np.random.default_rng(2)
+    B, F, H, W, M28 = 3, 5, 96, 128, 28
+    enc = FeatureEncoder("resnet34", hidden_size=32).to(DEV).eval()
+    fe = FeatureExtractor()
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3, "encoder": {"nms_thresh": 0.4}, "sort_max_num": 50}
+    model = DMM_Model(cfgs, is_test=1, feature_extractor=fe)
+    img = torch.randn(B, 3, H, W, device=DEV)
+    # raw detector output per image: boxes, scores, 28x28 mask probabilities (what the offline proposal files hold)
+    raw = []
+    for b in range(B):
+        n = 60 + 7 * b
+        x1, y1 = rng.uniform(0, W - 20, n), rng.uniform(0, H - 20, n)
+        boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(8, 60, n), W - 1), np.minimum(y1 + rng.uniform(8, 50, n), H - 1)], 1)
+        bl = prop.SimpleBoxList(torch.from_numpy(boxes.astype(np.float32)).to(DEV), (W, H))
+        bl.add_field("scores", torch.from_numpy(rng.random(n).astype(np.float32)).to(DEV))
+        bl.add_field("mask", torch.from_numpy((rng.random((n, 1, M28, M28)) * 0.6 + 0.4).astype(np.float32)).to(DEV))
+        raw.append(bl)
+    with torch.no_grad():
+        feats = enc(img)
+        pasted = prop.forward_mask_prop([r.get_field("mask") for r in raw], raw, thresh=0.4, padding=1)
+        kept = prop.filter_results(pasted, nms_thresh=cfgs["encoder"]["nms_thresh"], max_proposals=cfgs["sort_max_num"])
+        for b, k in enumerate(kept):
+            assert 0 < len(k) <= 50 and k.get_field("mask").shape == (len(k), 1, H, W)
+        # templates: first-frame objects = the first n_obj kept proposals of each video
+        n_obj = [2, 0, 4]
+        tboxes = [prop.SimpleBoxList(kept[b].bbox[:max(n_obj[b], 1)].repeat(F, 1)[:F], (W, H)) for b in range(B)]
+        valid = torch.zeros(B, F, device=DEV)
+        mask_last = torch.zeros(B, F, H, W, device=DEV)
+        for b in range(B):
+            valid[b, :n_obj[b]] = 1
+            mask_last[b, :n_obj[b]] = kept[b].get_field("mask")[:n_obj[b], 0]
+        tplt_dict = model.fill_template_dict(None, tboxes, feats, None, valid)
+        out, _, loss, last = model.inference({"args": None, "shape": None, "extra_frame": [0, 0, 0], "valid": valid},
+                                             kept, feats["backbone_feature"], mask_last, tplt_dict)
+    assert out.shape == (B, F, H, W) and loss == []
+    assert float(out[1].abs().sum()) == 0.0 and torch.equal(last[1], mask_last[1])      # video without objects
+    for b in (0, 2):
+        assert float(out[b, n_obj[b]:].abs().sum()) == 0.0
+        for o in range(n_obj[b]):
+            # the template IS proposal o of this frame (identical mask and box): it must be matched to itself
+            pm_o = kept[b].get_field("mask")[o, 0]
+            w = (out[b, o] * pm_o).sum() / (pm_o * pm_o).sum()
+            assert float((out[b, o] - w * pm_o).abs().max()) < 1e-5 and 0.3 < float(w) <= 1.2, (b, o, float(w))
