@@ -53,10 +53,12 @@ def matching_loss(pm_b, targets_b, cos, n_valid=None, m_valid=None, counts=None)
 
 
 class _MatchLayerFn(torch.autograd.Function):
-    """pf [B,P,D], tf [B,O,D], pm [B,P,H,W], tm [B,O,H,W], sc [B,P], targets [B,O,H,W] | None."""
+    """pf [B,P,D], tf [T,B,O,D] (T template-feature entries, DMM-Net uses T = 1), pm [B,P,H,W], tm [B,O,H,W],
+    sc [B,P], targets [B,O,H,W] | None."""
 
     @staticmethod
     def forward(ctx, pf, tf, pm, tm, sc, targets, n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test):
+        T = tf.shape[0]
         tcounts = None
         if targets is not None and tm.shape[1] <= 16:
             # training: one pass over the proposal planes for both IoU tables (templates and targets)
@@ -65,8 +67,14 @@ class _MatchLayerFn(torch.autograd.Function):
         else:
             inter, ap, at = ops.iou_counts(pm, tm, n_valid, m_valid)
         pn, pnorm = ops.feature_normalize(pf, want_norms=True)
-        tn, tnorm = ops.feature_normalize(tf, want_norms=True)
-        cos = ops.cosine(tn, pn, n_valid, m_valid)
+        tn, tnorm = ops.feature_normalize(tf, want_norms=True)              # [T,B,O,D], [T,B,O]
+        # feature_sim = mean over the template-feature entries (match_model.py:71-76): zeros, += each, /= T
+        cos = ops.cosine(tn[0], pn, n_valid, m_valid)
+        if T > 1:
+            cos = torch.zeros_like(cos) + cos
+            for t in range(1, T):
+                cos = cos + ops.cosine(tn[t], pn, n_valid, m_valid)
+            cos = cos / T
         r = ops.relax_match(cos, inter, ap, at, sc, score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter,
                             lr=lr, is_test=is_test, n_valid=n_valid, m_valid=m_valid)
         full = ops.mask_mix(r["Rb"], pm, n_valid, m_valid)
@@ -96,8 +104,10 @@ class _MatchLayerFn(torch.autograd.Function):
 
 def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
                         proj_iter, lr, is_test):
-    """B frames through the layer with autograd.  Returns (full_outmask [B,O,H,W], match_score [B,O],
-    det_score [B,O], cost_loss [B], iters [B])."""
+    """B frames through the layer with autograd.  ``tf`` is [B,O,D] or, for several template-feature entries,
+    [T,B,O,D].  Returns (full_outmask [B,O,H,W], match_score [B,O], det_score [B,O], cost_loss [B], iters [B])."""
+    if tf.dim() == 3:
+        tf = tf.unsqueeze(0)
     return _MatchLayerFn.apply(pf.float(), tf.float(), pm.float(), tm.float(), sc.float(),
                                None if targets is None else targets.float(), n_valid, m_valid, float(score_weight),
                                int(max_iter), int(proj_iter), float(lr), int(is_test))
@@ -107,17 +117,16 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
                          proposal_score, targets: Optional[torch.Tensor], *, score_weight, max_iter, proj_iter, lr,
                          is_test, algo="relax"):
     """One frame (the reference's call): unsqueeze to B = 1."""
-    if len(template_feature) != 1:
-        # feature_sim is the mean of the per-entry cosines (match_model.py:71-76); DMM-Net always passes one
-        # entry (dmm_model.py:44, templates are fixed from frame 0), longer lists are rejected loudly.
-        raise NotImplementedError("template_feature lists longer than 1 are never produced by DMM-Net "
-                                  "(dmm_model.py:44); pass a single [O,D] tensor")
-    tf = template_feature[0]
+    # feature_sim is the mean of the per-entry cosines (match_model.py:71-76); DMM-Net itself always passes one
+    # entry (dmm_model.py:44, templates are fixed from frame 0)
+    tf = template_feature[0] if len(template_feature) == 1 else torch.stack(list(template_feature), 0)
     if algo == "hun":
+        assert len(template_feature) == 1, "algo 'hun' is wired for a single template-feature entry"
         return _hungarian_forward(proposed_feature.float(), tf.float(), proposed_mask.float(),
                                   mask_last_occurence.float(), proposal_score.float(), targets, score_weight, is_test)
     full, ms, ds, loss, _ = match_layer_batched(
-        proposed_feature.unsqueeze(0), proposed_mask.unsqueeze(0), tf.unsqueeze(0), mask_last_occurence.unsqueeze(0),
+        proposed_feature.unsqueeze(0), proposed_mask.unsqueeze(0),
+        tf.unsqueeze(0) if tf.dim() == 2 else tf.unsqueeze(1), mask_last_occurence.unsqueeze(0),
         proposal_score.unsqueeze(0), None if targets is None else targets.unsqueeze(0), score_weight=score_weight,
         max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
     return full[0], ms[0], ds[0], loss[0]

@@ -63,10 +63,14 @@ def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
                 dcos = dcos + torch.where(live, diff, torch.zeros_like(diff)) * (2.0 * d_loss / cnt)[:, None, None]
             else:
                 dcos = dcos + diff * (2.0 / (O * P)) * d_loss[:, None, None]
-        g_tn = torch.bmm(dcos, pn)                               # [B,O,D]
-        g_pn = torch.bmm(dcos.transpose(1, 2), tn)               # [B,P,D]
+        T = tn.shape[0]                                          # template-feature entries; cos = mean_t cos_t
+        dcos_t = dcos / T if T > 1 else dcos
+        g_pn = torch.bmm(dcos_t.transpose(1, 2), tn[0])          # [B,P,D]
+        for t in range(1, T):
+            g_pn = g_pn + torch.bmm(dcos_t.transpose(1, 2), tn[t])
         if need_pf:
             g_pf = _normalize_backward(g_pn, pnorm, pf)
         if need_tf:
+            g_tn = torch.stack([torch.bmm(dcos_t, pn) for _ in range(T)], 0)      # [T,B,O,D]
             g_tf = _normalize_backward(g_tn, tnorm, tf)
     return (g_pf, g_tf, g_pm) + none

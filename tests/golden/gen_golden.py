@@ -452,6 +452,35 @@ def g9():
     save("g9_paste", d)
 
 
+def g10():
+    """template_feature lists with more than one entry: feature_sim = mean of the per-entry cosines
+    (match_model.py:71-76).  DMM-Net itself always passes one entry; the layer's API allows more."""
+    d = {}
+    P, O, H, W, D = 9, 4, 32, 32, 96
+    fr = synth.make_frame(P, O, H, W, D, seed=synth.BASE_SEED + 1010, kind="structured", with_targets=True)
+    rng = np.random.Generator(np.random.PCG64(1010))
+    tf2 = (fr.template_feature + 0.5 * rng.standard_normal((O, D), dtype=np.float32)).astype(np.float32)
+    tf3 = rng.standard_normal((O, D), dtype=np.float32)
+    d["checksum"] = np.array(fr.checksum())
+    d["tf2"], d["tf3"] = tf2, tf3
+    for is_test in (0, 1):
+        model = MatchModel(cfg(10, 5), is_test)
+        pf = T(fr.proposed_feature).requires_grad_(True)
+        tfs = [T(fr.template_feature).requires_grad_(True), T(tf2).requires_grad_(True), T(tf3).requires_grad_(True)]
+        fo, ms, ds, _, loss = model(pf, T(fr.proposed_mask), tfs, T(fr.mask_last_occurence), T(fr.proposal_score),
+                                    T(fr.targets))
+        gen = torch.Generator().manual_seed(3)
+        wmask = torch.rand((O, H, W), generator=gen)
+        total = (fo * wmask).sum() + ms.sum() + 2.0 * loss["cost_loss"]
+        total.backward()
+        d.update(flat(f"t{is_test}", dict(full_outmask=fo.detach().numpy(), match_score=ms.detach().numpy(),
+                                          det_score=ds.detach().numpy(), cost_loss=np.float32(loss["cost_loss"].item()),
+                                          wmask=wmask.numpy(), grad_pf=pf.grad.numpy(),
+                                          grad_tf0=tfs[0].grad.numpy(), grad_tf1=tfs[1].grad.numpy(),
+                                          grad_tf2=tfs[2].grad.numpy())))
+    save("g10_multi_template", d)
+
+
 def verify_sweep():
     """Not a fixture: cross-checks the ORACLE against the imported reference on the broad shape sweep that
     tests/test_gpu_parity.py runs GPU-vs-oracle (all row counts 1..32 x 17 width classes, 12 cosine shapes).
@@ -482,6 +511,6 @@ def verify_sweep():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

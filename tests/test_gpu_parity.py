@@ -508,7 +508,7 @@ def test_ragged_batched_backward_equals_per_video_calls():
         tfb = tf.detach()[b, :O].clone().requires_grad_(True)
         fo, msb, dsb, _, lo = model(pfb, pm[b, :P], [tfb], tm[b, :O], sc[b, :P], tg[b, :O])
         ((fo * wmask[b, :O]).sum() + lo["cost_loss"] * 2.0 + msb.sum() * 0.5).backward()
-        assert torch.equal(full[b, :O], fo) and float(full[b, O:].abs().sum()) == 0.0
+            assert torch.equal(full[b, :O].detach(), fo.detach()) and float(full[b, O:].detach().abs().sum()) == 0.0
         assert torch.equal(ms[b, :O], msb) and torch.equal(ds[b, :O], dsb)
         assert abs(float(loss[b]) - float(lo["cost_loss"])) < 1e-7
         for got, ref in ((pf.grad[b, :P], pfb.grad), (tf.grad[b, :O], tfb.grad)):
@@ -615,3 +615,28 @@ def test_iou_counts_batch_beyond_grid_limit():
     a, b = (pm > 0.5).flatten(2), (tm > 0.5).flatten(2)
     exp = (b[:, :, None, :] & a[:, None, :, :]).sum(-1).int()
     assert torch.equal(inter, exp) and torch.equal(ap, a.sum(-1).int()) and torch.equal(at, b.sum(-1).int())
+
+
+@pytest.mark.parametrize("is_test", [0, 1])
+def test_g10_template_feature_list(is_test):
+    """feature_sim = mean over several template-feature entries (match_model.py:71-76), forward and backward."""
+    g = golden("g10_multi_template")
+    P, O, H, W, D = 9, 4, 32, 32, 96
+    fr = synth.make_frame(P, O, H, W, D, seed=synth.BASE_SEED + 1010, kind="structured", with_targets=True)
+    assert fr.checksum() == str(g["checksum"])
+    c = g.group(f"t{is_test}")
+    model = MatchModel(cfg(10, 5), is_test)
+    pf = dev(fr.proposed_feature).requires_grad_(True)
+    tfs = [dev(fr.template_feature).requires_grad_(True), dev(g["tf2"]).requires_grad_(True),
+           dev(g["tf3"]).requires_grad_(True)]
+    fo, ms, ds, _, loss = model(pf, dev(fr.proposed_mask), tfs, dev(fr.mask_last_occurence), dev(fr.proposal_score),
+                                dev(fr.targets))
+    close(fo, c["full_outmask"])
+    assert np.array_equal(ms.detach().cpu().numpy(), c["match_score"])
+    assert np.array_equal(ds.detach().cpu().numpy(), c["det_score"])
+    assert abs(float(loss["cost_loss"].detach()) - float(c["cost_loss"])) < 1e-6
+    ((fo * dev(c["wmask"])).sum() + ms.sum() + 2.0 * loss["cost_loss"]).backward()
+    for mine, ref in ((pf.grad, c["grad_pf"]), (tfs[0].grad, c["grad_tf0"]), (tfs[1].grad, c["grad_tf1"]),
+                      (tfs[2].grad, c["grad_tf2"])):
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        assert float(np.abs(mine.cpu().numpy() - ref).max()) <= 2e-4 * scale + 1e-7
