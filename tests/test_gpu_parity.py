@@ -508,7 +508,7 @@ def test_ragged_batched_backward_equals_per_video_calls():
         tfb = tf.detach()[b, :O].clone().requires_grad_(True)
         fo, msb, dsb, _, lo = model(pfb, pm[b, :P], [tfb], tm[b, :O], sc[b, :P], tg[b, :O])
         ((fo * wmask[b, :O]).sum() + lo["cost_loss"] * 2.0 + msb.sum() * 0.5).backward()
-            assert torch.equal(full[b, :O].detach(), fo.detach()) and float(full[b, O:].detach().abs().sum()) == 0.0
+        assert torch.equal(full[b, :O].detach(), fo.detach()) and float(full[b, O:].detach().abs().sum()) == 0.0
         assert torch.equal(ms[b, :O], msb) and torch.equal(ds[b, :O], dsb)
         assert abs(float(loss[b]) - float(lo["cost_loss"])) < 1e-7
         for got, ref in ((pf.grad[b, :P], pfb.grad), (tf.grad[b, :O], tfb.grad)):
