@@ -25,7 +25,7 @@ SYMBOLS = (
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
-    "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks",
+    "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32",
 )
 
 _lib = None
@@ -84,6 +84,8 @@ def load():
     L.dmm_pack_words.restype = c_i64
     L.dmm_pack_masks.argtypes = [vp, c_int, c_i64, c_int, c_i64, vp, c_i64, vp]
     L.dmm_nms_f32.argtypes = [vp, vp, vp, c_int, c_int, c_float, c_int, vp, vp, vp]
+    L.dmm_mask_boxes_f32.argtypes = [vp, c_int, c_int, c_int, c_i64, c_float, vp, vp, vp]
+    L.dmm_merge_labels_f32.argtypes = [vp, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp]
     L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
                                c_i64, vp]
     L.dmm_mask_mix_bwd.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, vp]
@@ -94,7 +96,8 @@ def load():
                                     vp, vp, vp, vp, sz, vp]
     for f in ("dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
-              "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks"):
+              "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks",
+              "dmm_mask_boxes_f32", "dmm_merge_labels_f32"):
         getattr(L, f).restype = c_int
     if L.dmm_abi_version() != 1:
         raise DmmError("libdmm_match.so ABI version mismatch")

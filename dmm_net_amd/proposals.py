@@ -43,6 +43,24 @@ class SimpleBoxList:
             out.add_field(k, v[idx])
         return out
 
+    def to(self, device):
+        out = SimpleBoxList(self.bbox.to(device), self.size, self.mode)
+        for k, v in self.extra_fields.items():
+            out.add_field(k, v.to(device) if hasattr(v, "to") else v)
+        return out
+
+    def resize(self, size):
+        """BoxList.resize of maskrcnn_benchmark for xyxy boxes: ``size`` = (width, height); tensor fields are kept."""
+        rw, rh = float(size[0]) / float(self.size[0]), float(size[1]) / float(self.size[1])
+        if rw == rh:
+            bbox = self.bbox * rw
+        else:
+            bbox = self.bbox * self.bbox.new_tensor([rw, rh, rw, rh])
+        out = SimpleBoxList(bbox, tuple(size), self.mode)
+        for k, v in self.extra_fields.items():
+            out.add_field(k, v if isinstance(v, torch.Tensor) else v.resize(size))
+        return out
+
 
 def paste_masks(mask_prob: torch.Tensor, boxes: torch.Tensor, im_h: int, im_w: int, thresh: float = 0.4,
                 padding: int = 1, want_packed: bool = False):

@@ -121,3 +121,36 @@ def make_config_frame(cfg_index: int, *, kind: str = "structured", with_targets:
     c = CONFIGS[cfg_index]
     return make_frame(c["P"], c["O"], c["H"], c["W"], c["D"], seed=BASE_SEED + cfg_index + seed_offset,
                       kind=kind, with_targets=with_targets)
+
+
+# ---- frame-loop reductions (tests/golden g11): inputs by seed ---------------------------------------------------
+def template_planes(seed: int, O: int, H: int, W: int) -> np.ndarray:
+    """[O,H,W] fp32 template planes for the box / valid reduction: plane o is empty, a binary rectangle, a soft
+    blob with zero holes, or a single pixel (kinds cycle with o + seed)."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    m = np.zeros((O, H, W), np.float32)
+    for o in range(O):
+        kind = (o + seed) % 4
+        if kind == 0:
+            continue
+        y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+        y1, x1 = int(rng.integers(y0, H)), int(rng.integers(x0, W))
+        if kind == 1:
+            m[o, y0:y1 + 1, x0:x1 + 1] = 1.0
+        elif kind == 2:
+            blk = rng.random((y1 - y0 + 1, x1 - x0 + 1)).astype(np.float32)
+            blk[blk < 0.3] = 0.0
+            m[o, y0:y1 + 1, x0:x1 + 1] = blk
+        else:
+            m[o, y0, x0] = 0.25
+    return m
+
+
+def refined_planes(seed: int, O: int, H: int, W: int) -> np.ndarray:
+    """[O,H,W] fp32 'refined masks' for the label merge: uniform values, the upper half quantised to quarters (so
+    background/foreground and foreground/foreground ties occur), the left third damped (background wins)."""
+    rng = np.random.Generator(np.random.PCG64(8000 + seed))
+    outs = rng.random((O, H, W)).astype(np.float32)
+    outs[:, : H // 2] = np.round(outs[:, : H // 2] * 4) / 4
+    outs[:, :, : W // 3] *= np.float32(0.4)
+    return outs

@@ -1,0 +1,248 @@
+"""Per-video frame loop around the matching layer + the data formats on either side of it.
+
+Counterparts in the reference:
+
+* ``mask_boxes`` / ``ohw_mask2boxlist``  -- ``dmm/utils/utils.py:179-210`` (+ ``binmask_to_bbox_xyxy_pt`` :114-143):
+  first-frame object masks -> template boxes + ``template_valid``.  One HIP workgroup per plane instead of a
+  ``nonzero()`` and four host syncs per object.
+* ``merge_labels``  -- the label map of ``dmm/modules/evaluator.py:134-139`` (background = 1 - max, arg-max over
+  [bg, objects]); one pass over the planes on the device, one byte per pixel out.
+* ``davis_palette`` / ``save_label_png``  -- ``plot_scores_map`` (``dmm/utils/eval_helper.py:22-38``): indexed PNG
+  with the DAVIS / PASCAL-VOC palette (the reference reads it from ``dmm/utils/bear/00000.png``; it is the standard
+  bit-interleaved colour map, generated here).
+* ``load_offline_proposals``  -- the offline proposal files (``predictions.pth`` / ``pred_DICT.pth`` /
+  ``videos/<vid>.pth``, written by ``tools/reduce_pth_size_by_videos.py:62-126``, read by
+  ``model_encoder.py:53-58``): pickled maskrcnn_benchmark ``BoxList`` objects, mapped onto ``SimpleBoxList``
+  without importing maskrcnn_benchmark.
+* ``FrameLoop``  -- the frame loop of ``Evaler.forward`` / ``inference_timestep`` (``evaluator.py:63-213``) with every
+  video of the batch in one ragged launch per frame and ``mask_hist`` resident on the device.  The decoder
+  (ConvLSTM refinement, out of scope for this package) is injected as ``refine``.
+
+Nothing here has a CPU implementation of the device work: CPU tensors raise ``DmmError``.
+"""
+from __future__ import annotations
+
+import io
+import os
+import pickle
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .proposals import SimpleBoxList, filter_results, forward_mask_prop
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# device reductions
+# ------------------------------------------------------------------------------------------------------------------
+def mask_boxes(masks: torch.Tensor, thresh: float = 0.0):
+    """masks [R,H,W] fp32 -> (boxes [R,4] fp32 xyxy of (mask > thresh), whole frame when empty; valid [R] int32)."""
+    if not masks.is_cuda:
+        raise _lib.DmmError("dmm_net_amd.video needs tensors on an MI355X device (no CPU fallback)")
+    assert masks.dim() == 3 and masks.dtype == torch.float32, (masks.shape, masks.dtype)
+    R, H, W = masks.shape
+    if R and not (masks.stride(2) == 1 and masks.stride(1) == W and masks.stride(0) >= H * W):
+        masks = masks.contiguous()
+    boxes = torch.empty((R, 4), dtype=torch.float32, device=masks.device)
+    valid = torch.empty((R,), dtype=torch.int32, device=masks.device)
+    with torch.cuda.device(masks.device):
+        rc = _lib.load().dmm_mask_boxes_f32(masks.data_ptr(), R, H, W, masks.stride(0) if R else H * W, float(thresh),
+                                            boxes.data_ptr(), valid.data_ptr(),
+                                            torch.cuda.current_stream(masks.device).cuda_stream)
+    _lib.check(rc, "dmm_mask_boxes_f32")
+    return boxes, valid
+
+
+def ohw_mask2boxlist(ohw_mask: torch.Tensor):
+    """utils.py:179-210: object masks [O,H,W] of one image -> (BoxList with 'mask' / 'scores', template_valid [O] long)."""
+    O, H, W = ohw_mask.shape
+    boxes, valid = mask_boxes(ohw_mask.float(), 0.0)
+    bl = SimpleBoxList(boxes, (W, H), "xyxy")
+    bl.add_field("mask", ohw_mask)
+    bl.add_field("scores", ohw_mask.new_zeros((O,)) + 1)
+    return bl, valid.long()
+
+
+def merge_labels(outs: torch.Tensor, tplt_valid_batch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """evaluator.py:134-139 for a batch: outs [B,O,HW] or [B,O,H,W] fp32, ``tplt_valid_batch`` [B,O] 0/1 (valid prefix)
+    or [B] counts -> uint8 labels [B,HW] / [B,H,W] (0 = background, o+1 = object o)."""
+    if not outs.is_cuda:
+        raise _lib.DmmError("dmm_net_amd.video needs tensors on an MI355X device (no CPU fallback)")
+    assert outs.dtype == torch.float32 and outs.dim() in (3, 4), (outs.shape, outs.dtype)
+    shape = outs.shape
+    hw = 1
+    for d in shape[2:]:
+        hw *= int(d)
+    m = outs.reshape(shape[0], shape[1], hw)
+    B, O, HW = m.shape
+    if B * O * HW and m.stride(2) != 1:
+        m = m.contiguous()
+    ov = None
+    if tplt_valid_batch is not None:
+        ov = tplt_valid_batch if tplt_valid_batch.dim() == 1 else tplt_valid_batch.sum(1)
+        ov = ov.to(device=m.device, dtype=torch.int32).contiguous()
+    labels = torch.empty((B, HW), dtype=torch.uint8, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = _lib.load().dmm_merge_labels_f32(m.data_ptr(), B, O, HW, m.stride(0), m.stride(1),
+                                              None if ov is None else ov.data_ptr(), labels.data_ptr(),
+                                              torch.cuda.current_stream(m.device).cuda_stream)
+    _lib.check(rc, "dmm_merge_labels_f32")
+    return labels.view(B, *shape[2:])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# output format: indexed PNG with the DAVIS palette
+# ------------------------------------------------------------------------------------------------------------------
+def davis_palette() -> List[int]:
+    """768 ints: colour of label i has bit k of i spread to bit 7 - k//3 of channel k % 3 (PASCAL-VOC colour map)."""
+    pal = []
+    for i in range(256):
+        r = g = b = 0
+        c = i
+        for j in range(8):
+            r |= ((c >> 0) & 1) << (7 - j)
+            g |= ((c >> 1) & 1) << (7 - j)
+            b |= ((c >> 2) & 1) << (7 - j)
+            c >>= 3
+        pal += [r, g, b]
+    return pal
+
+
+def save_label_png(labels, fname: str) -> None:
+    """plot_scores_map (eval_helper.py:22-38): label map [H,W] (or [1,H,W]) -> palette PNG; creates the directory."""
+    from PIL import Image                                    # stdlib-free PNG writing is not worth owning
+    import numpy as np
+    d = os.path.dirname(fname)
+    if d and not os.path.exists(d):
+        os.makedirs(d)
+    if isinstance(labels, torch.Tensor):
+        labels = labels.detach().cpu().numpy()
+    if labels.ndim == 3 and labels.shape[0] == 1:
+        labels = labels[0]
+    assert labels.ndim == 2, labels.shape
+    img = Image.fromarray(labels.astype(np.uint8), "P")
+    img.putpalette(davis_palette())
+    img.save(fname)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# input format: offline proposal files
+# ------------------------------------------------------------------------------------------------------------------
+class _BoxListUnpickler(pickle.Unpickler):
+    """Maps maskrcnn_benchmark's BoxList (attributes bbox / size / mode / extra_fields) onto SimpleBoxList."""
+
+    def find_class(self, module, name):
+        if name == "BoxList" and module.startswith("maskrcnn_benchmark"):
+            return SimpleBoxList
+        return super().find_class(module, name)
+
+
+class _BoxListPickle:
+    """``pickle_module`` for ``torch.load``."""
+    __name__ = "dmm_net_amd.video._BoxListPickle"
+    Unpickler = _BoxListUnpickler
+
+    @staticmethod
+    def load(f, **kw):
+        return _BoxListUnpickler(f, **kw).load()
+
+    @staticmethod
+    def loads(b, **kw):
+        return _BoxListUnpickler(io.BytesIO(b), **kw).load()
+
+
+def load_offline_proposals(path: str, map_location="cpu"):
+    """Read ``predictions.pth`` (list of BoxList), ``pred_DICT.pth`` ({vid: {frame: BoxList}}) or ``videos/<vid>.pth``
+    ({frame: BoxList}) without maskrcnn_benchmark: every BoxList becomes a ``SimpleBoxList`` with its fields
+    ('mask' [P,1,M,M] probabilities, 'scores' | 'objectness', ...)."""
+    return torch.load(path, map_location=map_location, pickle_module=_BoxListPickle, weights_only=False)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# frame loop
+# ------------------------------------------------------------------------------------------------------------------
+class FrameLoop:
+    """Frame loop of the evaluator for a batch of B videos (evaluator.py:63-213).
+
+    ``encoder(img [B,3,H,W]) -> features`` (dict with 'backbone_feature', 'refine_input_feat'),
+    ``dmm``: ``DMM_Model`` (is_test=1) with its ROI feature extractor,
+    ``refine(features, prev_mask [B,O,HW], y_mask [B,O,HW], init_pred [B,O,H,W], mask_hist_new [B,O,H,W], valid [B,O],
+    state) -> (outs [B,O,HW], mask_hist_new, state)``: the decoder step (:174-212); ``None`` = the matching layer's
+    masks are the prediction.  Proposals come per video and frame as BoxLists with the raw 'mask' probabilities
+    ([P,1,M,M], pasted + NMS-filtered here like model_encoder.py:115-134) or, with ``pasted=True``, already as
+    image-size planes.
+    """
+
+    def __init__(self, encoder: Callable, dmm, refine: Optional[Callable] = None, nms_thresh: float = 0.4,
+                 max_proposals: int = 50, mask_thresh: float = 0.4, padding: int = 1, pasted: bool = False):
+        self.encoder, self.dmm, self.refine = encoder, dmm, refine
+        self.nms_thresh, self.max_proposals = float(nms_thresh), int(max_proposals)
+        self.mask_thresh, self.padding, self.pasted = float(mask_thresh), int(padding), bool(pasted)
+
+    # model_encoder.py:115-134
+    def prepare_proposals(self, raw: Sequence, im_h: int, im_w: int, device):
+        props = []
+        for p in raw:
+            q = p.resize((im_w, im_h)) if tuple(p.size) != (im_w, im_h) else p
+            props.append(q.to(device))
+        if not self.pasted:
+            props = forward_mask_prop([p.get_field("mask") for p in props], props, self.mask_thresh, self.padding)
+        score_field = "scores" if "scores" in props[0].fields() else "objectness"
+        return filter_results(list(props), self.nms_thresh, self.max_proposals, score_field)
+
+    @torch.no_grad()
+    def run(self, frames: torch.Tensor, first_masks: torch.Tensor, proposals: Sequence[Sequence],
+            n_frames: Optional[Sequence[int]] = None, targets: Optional[torch.Tensor] = None,
+            on_labels: Optional[Callable] = None):
+        """frames [B,T,3,H,W]; first_masks [B,O,H*W] (frame-0 annotation); proposals[b][t] (the last entry is reused
+        for missing frames, evaluator.py:101-106); n_frames[b] = real length of video b (later frames are 'extra',
+        :86); targets [B,T,O,HW] optional per-frame annotation (zeros otherwise).  Calls ``on_labels(b, t, uint8 [H,W])``
+        for every real frame and returns the list over t of ``outs`` [B,O,HW]."""
+        B, T, C, H, W = frames.shape
+        O = first_masks.shape[1]
+        dev = frames.device
+        n_frames = list(n_frames) if n_frames is not None else [T] * B
+        history, state, mask_hist = [], None, None
+        tplt_dict = tplt_valid = prev_mask = None
+        for t in range(T):
+            extra = [n <= t for n in n_frames]
+            raw = [proposals[b][t] if len(proposals[b]) > t else proposals[b][-1] for b in range(B)]
+            x = frames[:, t]
+            if t == 0:
+                y_mask = first_masks.float().view(B, O, H * W)
+            elif targets is not None:
+                y_mask = targets[:, t].float().view(B, O, H * W)
+            else:
+                y_mask = first_masks.new_zeros((B, O, H * W), dtype=torch.float32)
+            features = self.encoder(x)
+            props = self.prepare_proposals(raw, H, W, dev)
+            if t == 0:                                                   # forward_timestep_init, :215-225
+                tpl, valid = [], []
+                for b in range(B):
+                    bl, v = ohw_mask2boxlist(y_mask[b].view(O, H, W))
+                    tpl.append(bl)
+                    valid.append(v)
+                tplt_valid = torch.stack(valid, 0)
+                tplt_dict = self.dmm.fill_template_dict(None, tpl, features, y_mask, tplt_valid)
+                prev_mask = y_mask
+            infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B}
+            hist_in = prev_mask.view(B, O, H, W) if mask_hist is None else mask_hist       # :168-169
+            init_pred, tplt_dict, _, hist_new = self.dmm.inference(infos, props, features["backbone_feature"], hist_in,
+                                                                   tplt_dict)
+            if self.refine is not None:
+                outs, hist_new, state = self.refine(features, prev_mask, y_mask, init_pred, hist_new, tplt_valid, state)
+            else:
+                outs = init_pred.reshape(B, O, H * W)
+            if t == 0:                                                   # frame 0 only warms the decoder state, :119-128
+                outs = y_mask
+            else:
+                mask_hist = hist_new
+            prev_mask = outs.view(B, O, H * W)
+            if on_labels is not None:
+                labels = merge_labels(outs.view(B, O, H, W), tplt_valid)
+                for b in range(B):
+                    if not extra[b]:
+                        on_labels(b, t, labels[b])
+            history.append(outs)
+        return history

@@ -240,6 +240,20 @@ DMM_API int dmm_paste_masks_f32(const float *prob, int P, int M, const float *bo
 DMM_API int dmm_nms_f32(const float *boxes, const float *scores, const int32_t *offsets, int images, int max_per_image,
                         float thresh, int max_keep, int32_t *keep, int32_t *keep_count, dmm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (8) Frame-loop reductions (the step right after the path).
+ * dmm_mask_boxes_f32: ohw_mask2boxlist (dmm/utils/utils.py:179-210, binmask_to_bbox_xyxy_pt :114-143) for R
+ *   planes [R, H*W] (plane_stride elements apart): boxes [R,4] = tight xyxy box of (plane > thresh), or
+ *   [0,0,W-1,H-1] when no pixel passes; valid [R] = 1 iff the plane has a pixel > 0 (reference: plane sum > 0).
+ * dmm_merge_labels_f32: the per-frame label map of the evaluator (dmm/modules/evaluator.py:134-139):
+ *   labels[b,x] = argmax([1 - max_o m[b,o,x], m[b,0,x], ..., m[b,O_b-1,x]]), first maximum wins (0 = background).
+ *   masks [B,O,HW] with element strides; o_valid [B] int32 (NULL = O) live-template prefix per video; O <= 255.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_mask_boxes_f32(const float *masks, int R, int H, int W, int64_t plane_stride, float thresh,
+                               float *boxes, int32_t *valid, dmm_stream_t stream);
+DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64_t stride_b, int64_t stride_o,
+                                 const int32_t *o_valid, uint8_t *labels, dmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,10 @@ def lib():
         L.dmmo_paste_mask.restype = None
         L.dmmo_nms.argtypes = [_f32p, _f32p, c_int, c_float, c_int, _i32p]
         L.dmmo_nms.restype = c_int
+        L.dmmo_mask_box.argtypes = [_f32p, c_int, c_int, c_float, _f32p]
+        L.dmmo_mask_box.restype = c_int
+        L.dmmo_merge_labels.argtypes = [_f32p, c_int, c_int, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+        L.dmmo_merge_labels.restype = None
         L.dmmo_check_div_by_const.argtypes = [c_int, ctypes.c_long]
         L.dmmo_check_div_by_const.restype = ctypes.c_long
         _lib = L
@@ -217,3 +221,25 @@ def nms(boxes, scores, thresh, max_keep=0):
     keep = np.zeros(max(n, 1), np.int32)
     cnt = lib().dmmo_nms(boxes.reshape(-1, 4), scores, n, float(thresh), int(max_keep), keep)
     return keep[:cnt]
+
+
+def mask_boxes(masks, thresh=0.0):
+    """ohw_mask2boxlist (utils.py:179-210) for planes [O,H,W] -> (boxes [O,4] f32, template_valid [O] i32)."""
+    masks = _c(masks)
+    O, H, W = masks.shape
+    boxes = np.zeros((O, 4), np.float32)
+    valid = np.zeros(O, np.int32)
+    for o in range(O):
+        valid[o] = lib().dmmo_mask_box(masks[o].reshape(-1), H, W, float(thresh), boxes[o])
+    return boxes, valid
+
+
+def merge_labels(masks, o_valid=None):
+    """Label maps of evaluator.py:134-139 for masks [B,O,HW] (o_valid[b] live templates) -> uint8 [B,HW]."""
+    masks = _c(masks)
+    B, O, HW = masks.shape
+    out = np.zeros((B, HW), np.uint8)
+    for b in range(B):
+        ob = O if o_valid is None else int(o_valid[b])
+        lib().dmmo_merge_labels(np.ascontiguousarray(masks[b, :ob]).reshape(-1), ob, HW, out[b])
+    return out

@@ -655,3 +655,50 @@ DMMO_API int dmmo_nms(const float *boxes, const float *scores, int n, float thre
     free(dead);
     return cnt;
 }
+
+/* ----------------------------------------------------------------------------------
+ * Frame-loop reductions.
+ * dmmo_mask_box: ohw_mask2boxlist for ONE plane (reference dmm/utils/utils.py:179-210 +
+ * binmask_to_bbox_xyxy_pt :114-143): box = [xmin, ymin, xmax, ymax] of (mask > thresh) (the reference uses
+ * thresh = 0: `mask > 0`, :120), the whole frame [0,0,W-1,H-1] when nothing passes (:195-196);
+ * returns template_valid = (sum of the plane > 0) (:191), summed in double here (masks are non-negative).
+ * ---------------------------------------------------------------------------------- */
+DMMO_API int dmmo_mask_box(const float *mask, int H, int W, float thresh, float *box) {
+    int xmin = W, ymin = H, xmax = -1, ymax = -1;
+    double s = 0.0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float v = mask[(size_t)y * W + x];
+            s += (double)v;
+            if (v > thresh) {
+                if (x < xmin) xmin = x;
+                if (x > xmax) xmax = x;
+                if (y < ymin) ymin = y;
+                if (y > ymax) ymax = y;
+            }
+        }
+    if (xmax < 0) { box[0] = 0.0f; box[1] = 0.0f; box[2] = (float)(W - 1); box[3] = (float)(H - 1); }
+    else { box[0] = (float)xmin; box[1] = (float)ymin; box[2] = (float)xmax; box[3] = (float)ymax; }
+    return s > 0.0;
+}
+
+/* dmmo_merge_labels: label map of one video frame (reference dmm/modules/evaluator.py:134-139):
+ * refine_bg = 1 - max_o mask[o]; labels = argmax over cat([bg, mask[0..O)]) along dim 0; torch CPU max(dim)
+ * returns the first maximal index.  O == 0 -> all background (the reference never reaches this case). */
+DMMO_API void dmmo_merge_labels(const float *masks, int O, int HW, uint8_t *labels) {
+    for (int x = 0; x < HW; ++x) {
+        if (O <= 0) { labels[x] = 0; continue; }
+        float mx = masks[x];
+        for (int o = 1; o < O; ++o) {
+            const float v = masks[(size_t)o * HW + x];
+            if (v > mx) mx = v;
+        }
+        float best = 1.0f - mx;
+        int arg = 0;
+        for (int o = 0; o < O; ++o) {
+            const float v = masks[(size_t)o * HW + x];
+            if (v > best) { best = v; arg = o + 1; }
+        }
+        labels[x] = (uint8_t)arg;
+    }
+}

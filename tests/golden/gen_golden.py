@@ -510,7 +510,52 @@ def verify_sweep():
     assert bad == 0
 
 
+def g11():
+    """Frame-loop reductions: the torch steps of ohw_mask2boxlist / binmask_to_bbox_xyxy_pt
+    (dmm/utils/utils.py:114-143, :179-210) and of the evaluator's label merge (dmm/modules/evaluator.py:134-139)
+    re-executed here (utils.py needs torchvision + maskrcnn_benchmark, evaluator.py the whole model stack)."""
+    d = {}
+
+    def ref_boxes(ohw):                                     # utils.py:188-199 + :120-143
+        O, H, W = ohw.shape
+        valid = (ohw.sum(2).sum(1) > 0).long()
+        boxes = []
+        for o in range(O):
+            inds = torch.nonzero((ohw[o] > 0).float())
+            if inds.shape[0] == 0:
+                boxes.append([0, 0, W - 1, H - 1])
+                continue
+            x_min = max(inds[:, 1].min() - 0, 0)
+            y_min = max(inds[:, 0].min() - 0, 0)
+            x_max = min(inds[:, 1].max() + 0, W - 1)
+            y_max = min(inds[:, 0].max() + 0, H - 1)
+            boxes.append([int(x_min), int(y_min), int(x_max), int(y_max)])
+        return np.asarray(boxes, np.float32), valid.numpy().astype(np.int32)
+
+    def ref_merge(outs, n_obj, H, W):                       # evaluator.py:134-139 for one video
+        refine_mask = outs[:n_obj].view(-1, H * W)
+        refine_bg = 1 - refine_mask.max(0)[0]
+        refine_fbg = torch.cat([refine_bg.view(1, H, W), refine_mask.view(-1, H, W)], dim=0)
+        _, max_i = refine_fbg.max(0)
+        return max_i.float().numpy().astype(np.uint8)       # plot_scores_map: astype(np.uint8) (eval_helper.py:36)
+
+    shapes = [(3, 17, 23), (5, 64, 64), (10, 255, 255), (1, 9, 1), (4, 33, 130), (8, 255, 448)]
+    for k, (O, H, W) in enumerate(shapes):                  # inputs by seed: synth.template_planes(k, O, H, W)
+        boxes, valid = ref_boxes(T(synth.template_planes(k, O, H, W)))
+        d[f"box{k}_shape"] = np.asarray([O, H, W], np.int64)
+        d[f"box{k}_boxes"] = boxes
+        d[f"box{k}_valid"] = valid
+    d["n_box"] = np.int64(len(shapes))
+    cases = [(5, 3, 20, 31), (5, 5, 64, 64), (3, 1, 7, 9), (10, 7, 255, 255), (6, 2, 40, 40), (5, 4, 255, 448)]
+    for k, (O, n_obj, H, W) in enumerate(cases):            # inputs by seed: synth.refined_planes(k, O, H, W)
+        outs = synth.refined_planes(k, O, H, W)
+        d[f"mrg{k}_shape"] = np.asarray([O, n_obj, H, W], np.int64)
+        d[f"mrg{k}_labels"] = ref_merge(T(outs.reshape(O, H * W)), n_obj, H, W)
+    d["n_mrg"] = np.int64(len(cases))
+    save("g11_frame_loop", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

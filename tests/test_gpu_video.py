@@ -1,0 +1,132 @@
+"""Frame-loop reductions and the frame loop itself on the GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import golden
+from dmm_net_amd import proposals as prop
+from dmm_net_amd import synth, video
+from dmm_net_amd.dmm_model import DMM_Model
+from dmm_net_amd.roi_features import FeatureExtractor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_g11_mask_boxes_match_reference_steps():
+    g = golden("g11_frame_loop")
+    for k in range(int(g["n_box"])):
+        O, H, W = [int(v) for v in g[f"box{k}_shape"]]
+        m = torch.from_numpy(synth.template_planes(k, O, H, W)).to(DEV)
+        boxes, valid = video.mask_boxes(m)
+        assert np.array_equal(boxes.cpu().numpy(), g[f"box{k}_boxes"]), k
+        assert np.array_equal(valid.cpu().numpy(), g[f"box{k}_valid"]), k
+        bl, tv = video.ohw_mask2boxlist(m)                               # utils.py:179-210 return values
+        assert bl.size == (W, H) and bl.mode == "xyxy" and tv.dtype == torch.long
+        assert torch.equal(bl.get_field("scores"), torch.ones(O, device=DEV)) and bl.get_field("mask") is m
+        assert torch.equal(tv, valid.long()) and torch.equal(bl.bbox, boxes)
+
+
+def test_g11_merge_labels_match_reference_steps():
+    g = golden("g11_frame_loop")
+    for k in range(int(g["n_mrg"])):
+        O, n_obj, H, W = [int(v) for v in g[f"mrg{k}_shape"]]
+        outs = torch.from_numpy(synth.refined_planes(k, O, H, W)).to(DEV)[None]
+        valid = torch.zeros(1, O, device=DEV)
+        valid[0, :n_obj] = 1
+        lab = video.merge_labels(outs, valid)
+        assert lab.shape == (1, H, W) and lab.dtype == torch.uint8
+        assert np.array_equal(lab[0].cpu().numpy(), g[f"mrg{k}_labels"]), k
+
+
+def test_reductions_vs_oracle_ragged_strided():
+    rng = np.random.default_rng(5)
+    for (B, O, H, W) in [(3, 5, 31, 17), (2, 1, 1, 1), (4, 7, 64, 65), (1, 12, 255, 255)]:
+        big = (rng.random((B, O + 2, H, W)) ** 2).astype(np.float32)
+        big[:, :, :, : W // 4] = 0.0
+        big[rng.random((B, O + 2)) < 0.3] = 0.0                          # some empty planes
+        t = torch.from_numpy(big).to(DEV)
+        view = t[:, 1:O + 1]                                             # strided batch / plane view
+        ov = rng.integers(0, O + 1, B).astype(np.int32)
+        lab = video.merge_labels(view, torch.from_numpy(ov).to(DEV))
+        exp = oracle.merge_labels(big[:, 1:O + 1].reshape(B, O, H * W), ov).reshape(B, H, W)
+        assert np.array_equal(lab.cpu().numpy(), exp)
+        for thresh in (0.0, 0.5):
+            boxes, valid = video.mask_boxes(view.reshape(B * O, H, W), thresh)
+            eb, ev = oracle.mask_boxes(big[:, 1:O + 1].reshape(B * O, H, W), thresh)
+            assert np.array_equal(boxes.cpu().numpy(), eb) and np.array_equal(valid.cpu().numpy(), ev)
+    # no live template -> all background; empty batch
+    z = video.merge_labels(torch.rand(2, 3, 50, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV))
+    assert int(z.sum()) == 0
+    assert video.merge_labels(torch.rand(0, 3, 50, device=DEV)).shape == (0, 50)
+    assert video.mask_boxes(torch.rand(0, 4, 4, device=DEV))[0].shape == (0, 4)
+
+
+class _PoolEncoder:
+    """Batch-independent toy encoder (pooling only): 4 levels, C channels, strides 4..32."""
+
+    def __init__(self, C=8):
+        self.mul = torch.linspace(0.5, 1.5, C, device=DEV).view(1, C, 1, 1)
+
+    def __call__(self, x):
+        g = x.mean(1, keepdim=True)
+        lv = tuple(F.avg_pool2d(g, s, ceil_mode=True) * self.mul for s in (4, 8, 16, 32))
+        return {"backbone_feature": lv, "refine_input_feat": lv}
+
+
+def _raw_proposals(rng, n, H, W):
+    x1, y1 = rng.uniform(0, W - 24, n), rng.uniform(0, H - 24, n)
+    boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(10, 60, n), W - 1), np.minimum(y1 + rng.uniform(10, 50, n), H - 1)], 1)
+    bl = prop.SimpleBoxList(torch.from_numpy(boxes.astype(np.float32)), (W, H))      # on the host, like a loaded file
+    bl.add_field("scores", torch.from_numpy(rng.random(n).astype(np.float32)))
+    bl.add_field("mask", torch.from_numpy((rng.random((n, 1, 28, 28)) * 0.6 + 0.4).astype(np.float32)))
+    return bl
+
+
+def test_frame_loop_batched_equals_per_video_and_writes_labels(tmp_path):
+    rng = np.random.default_rng(11)
+    B, T, O, H, W = 3, 4, 5, 96, 128
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    frames = torch.randn(B, T, 3, H, W, device=DEV)
+    n_frames = [4, 2, 3]                                                 # videos 1, 2 have 'extra' frames in the clip
+    n_obj = [2, 0, 4]
+    props = [[_raw_proposals(rng, 30 + 5 * b + t, H, W) for t in range(n_frames[b])] for b in range(B)]
+    first = torch.zeros(B, O, H, W, device=DEV)
+    for b in range(B):
+        for o in range(n_obj[b]):
+            y0, x0 = int(rng.integers(0, H - 30)), int(rng.integers(0, W - 30))
+            first[b, o, y0:y0 + 25, x0:x0 + 28] = 1.0
+    first = first.view(B, O, H * W)
+
+    def make_loop():
+        return video.FrameLoop(_PoolEncoder(), DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()),
+                               nms_thresh=0.4, max_proposals=20)
+
+    got = {}
+    hist = make_loop().run(frames, first, props, n_frames, on_labels=lambda b, t, lab: got.__setitem__((b, t), lab.clone()))
+    assert len(hist) == T and hist[0].shape == (B, O, H * W)
+    assert sorted(got) == sorted((b, t) for b in range(B) for t in range(n_frames[b]))      # extra frames are not written
+    assert torch.equal(hist[0], first)                                   # frame 0 reports the annotation (:119-121)
+    exp0 = oracle.merge_labels(first.cpu().numpy(), n_obj).reshape(B, H, W)
+    for b in range(B):
+        assert np.array_equal(got[(b, 0)].cpu().numpy(), exp0[b])
+    assert all(float(h[1].abs().sum()) == 0.0 for h in hist[1:])         # no template -> zeros (dmm_model.py:66-69)
+    assert float(hist[1][0, :2].sum()) > 0 and float(hist[1][0, 2:].abs().sum()) == 0.0
+    # video 1 runs out of frames after t = 1: its slots are skipped ('extra_frame') from t = 2 on
+    assert float(hist[3][2].abs().sum()) == 0.0 or n_frames[2] > 3
+    for b in range(B):                                                   # one launch per frame for all videos == per video
+        solo = {}
+        h1 = make_loop().run(frames[b:b + 1], first[b:b + 1], [props[b]], [n_frames[b]],
+                             on_labels=lambda _b, t, lab: solo.__setitem__(t, lab.clone()))
+        for t in range(T):
+            assert torch.equal(h1[t][0], hist[t][b]), (b, t)
+        for t in range(n_frames[b]):
+            assert torch.equal(solo[t], got[(b, t)])
+    # output format: one palette PNG per frame, read back identically
+    Image = pytest.importorskip("PIL.Image")
+    f = tmp_path / "merged" / "v0" / "00001.png"
+    video.save_label_png(got[(0, 1)], str(f))
+    assert np.array_equal(np.array(Image.open(str(f))), got[(0, 1)].cpu().numpy())

@@ -1,0 +1,92 @@
+"""Frame-loop side of the path on the CPU: oracle vs the G11 goldens, output / input file formats."""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden
+from dmm_net_amd import synth, video
+from dmm_net_amd.proposals import SimpleBoxList
+
+
+def test_g11_oracle_mask_boxes_and_valid():
+    g = golden("g11_frame_loop")
+    for k in range(int(g["n_box"])):
+        O, H, W = [int(v) for v in g[f"box{k}_shape"]]
+        boxes, valid = oracle.mask_boxes(synth.template_planes(k, O, H, W))
+        assert np.array_equal(boxes, g[f"box{k}_boxes"]), k
+        assert np.array_equal(valid, g[f"box{k}_valid"]), k
+
+
+def test_g11_oracle_merge_labels():
+    g = golden("g11_frame_loop")
+    for k in range(int(g["n_mrg"])):
+        O, n_obj, H, W = [int(v) for v in g[f"mrg{k}_shape"]]
+        outs = synth.refined_planes(k, O, H, W).reshape(1, O, H * W)
+        lab = oracle.merge_labels(outs, [n_obj])[0].reshape(H, W)
+        assert np.array_equal(lab, g[f"mrg{k}_labels"]), k
+        assert lab.max() <= n_obj
+
+
+def test_davis_palette_and_png_roundtrip(tmp_path):
+    pal = video.davis_palette()
+    assert len(pal) == 768 and pal[:12] == [0, 0, 0, 128, 0, 0, 0, 128, 0, 128, 128, 0]
+    assert pal[3 * 8:3 * 8 + 3] == [64, 0, 0] and pal[3 * 255:] == [224, 224, 192]
+    Image = pytest.importorskip("PIL.Image")
+    lab = (np.arange(40 * 30).reshape(40, 30) % 7).astype(np.uint8)
+    f = tmp_path / "merged" / "vid" / "00005.png"
+    video.save_label_png(torch.from_numpy(lab)[None], str(f))           # [1,H,W] accepted like plot_scores_map
+    im = Image.open(str(f))
+    assert im.mode == "P" and im.size == (30, 40)
+    assert np.array_equal(np.array(im), lab) and im.getpalette()[:768] == pal
+
+
+def test_load_offline_proposals_maps_boxlist_without_maskrcnn_benchmark(tmp_path):
+    """Pickle objects whose class path is maskrcnn_benchmark's BoxList (through a throw-away module), drop the
+    module, and read the file back through the package's unpickler."""
+    names = ["maskrcnn_benchmark", "maskrcnn_benchmark.structures", "maskrcnn_benchmark.structures.bounding_box"]
+    assert all(n not in sys.modules for n in names)
+
+    class BoxList:                                                      # attribute layout of the real class
+        def __init__(self, bbox, size, mode="xyxy"):
+            self.bbox, self.size, self.mode, self.extra_fields = bbox, size, mode, {}
+
+    BoxList.__module__, BoxList.__qualname__ = names[2], "BoxList"
+    mods = [types.ModuleType(n) for n in names]
+    mods[2].BoxList = BoxList
+    try:
+        for n, m in zip(names, mods):
+            sys.modules[n] = m
+        preds = {}
+        for fid, n in (("00000", 3), ("00005", 0)):
+            b = BoxList(torch.arange(4.0 * n).view(n, 4), (448, 255))
+            b.extra_fields["mask"] = torch.rand(n, 1, 28, 28)
+            b.extra_fields["scores"] = torch.rand(n)
+            preds[fid] = b
+        torch.save({"vidA": preds}, str(tmp_path / "pred_DICT.pth"))
+        torch.save([preds["00000"], preds["00005"]], str(tmp_path / "predictions.pth"))
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    d = video.load_offline_proposals(str(tmp_path / "pred_DICT.pth"))
+    p = d["vidA"]["00000"]
+    assert isinstance(p, SimpleBoxList) and len(p) == 3 and p.size == (448, 255) and p.mode == "xyxy"
+    assert sorted(p.fields()) == ["mask", "scores"] and p.get_field("mask").shape == (3, 1, 28, 28)
+    assert torch.equal(p.bbox, preds["00000"].bbox) and len(d["vidA"]["00005"]) == 0
+    lst = video.load_offline_proposals(str(tmp_path / "predictions.pth"))
+    assert [len(x) for x in lst] == [3, 0] and isinstance(lst[1], SimpleBoxList)
+    r = p.resize((224, 255))                                            # BoxList.resize: per-axis ratios
+    assert r.size == (224, 255) and torch.equal(r.bbox[:, 0], p.bbox[:, 0] * 0.5) and torch.equal(r.bbox[:, 1], p.bbox[:, 1])
+    top = p[p.get_field("scores").sort(0, descending=True)[1][:2]]      # reduce_pth_size_by_videos.py:80-84
+    assert len(top) == 2 and top.get_field("mask").shape[0] == 2
+
+
+def test_video_ops_refuse_cpu_tensors():
+    from dmm_net_amd._lib import DmmError
+    with pytest.raises(DmmError):
+        video.mask_boxes(torch.zeros(2, 4, 4))
+    with pytest.raises(DmmError):
+        video.merge_labels(torch.zeros(1, 2, 16))
