@@ -14,6 +14,7 @@ constexpr int kWave = 64;
 // so odd planes start 4/8/12 B off a 16-B boundary.  gfx950 global_load/store_dwordx4 only
 // need dword alignment; the aligned(4) typedef makes hipcc emit them instead of 4 dword ops.
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float4a __attribute__((ext_vector_type(4)));   // naturally (16-byte) aligned
 typedef uint32_t uint2u __attribute__((ext_vector_type(2), aligned(2)));  // 4 x 16-bit, 2-B aligned
 typedef _Float16 half4u __attribute__((ext_vector_type(4), aligned(2)));
 // 16-bit storage tags for mask planes (IEEE half / bfloat16); arithmetic is always fp32
@@ -159,6 +160,8 @@ __device__ __forceinline__ float div_by_const(float a, float b, float rcp) {
     return __builtin_fmaf(r, rcp, q0);
 }
 
+// Plane loads are NON-TEMPORAL: every mask plane is streamed once per kernel, and on gfx950 the `nt` load path
+// sustains 7.1-7.2 TB/s where cached loads stop at 6.3 TB/s (tools/hbm_probe.py).
 // ---- mask element loads: 4 consecutive pixels as fp32 (load4), or one full 16-byte lane load (loadv: 4 fp32 or
 // 8 half/bfloat16 pixels) for the streaming kernels -------------------------------------------------------
 typedef _Float16 half8u __attribute__((ext_vector_type(8), aligned(2)));
@@ -167,11 +170,14 @@ template <typename T> struct MaskIO;
 template <> struct MaskIO<float> {
     static constexpr int kVec = 4;
     typedef float4u Raw;                                   // one 16-byte lane load, kept raw until it is consumed
-    static __device__ __forceinline__ Raw load_raw(const float *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ Raw load_raw(const float *p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw *>(p)); }
     static __device__ __forceinline__ float elem(const Raw &r, int k) { return r[k]; }
     static __device__ __forceinline__ void loadv(const float *p, float (&v)[4]) { load4(p, v); }
-    static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
-        float4u t = *reinterpret_cast<const float4u *>(p);
+    template <bool NT = true> static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
+        const float4u *q = reinterpret_cast<const float4u *>(p);
+        float4u t;
+        if (NT) t = __builtin_nontemporal_load(q);
+        else t = *q;
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     static __device__ __forceinline__ float load1(const float *p) { return *p; }
@@ -179,15 +185,18 @@ template <> struct MaskIO<float> {
 template <> struct MaskIO<f16_t> {
     static constexpr int kVec = 8;
     typedef half8u Raw;
-    static __device__ __forceinline__ Raw load_raw(const f16_t *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ Raw load_raw(const f16_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw *>(p)); }
     static __device__ __forceinline__ float elem(const Raw &r, int k) { return (float)r[k]; }
     static __device__ __forceinline__ void loadv(const f16_t *p, float (&v)[8]) {
-        half8u t = *reinterpret_cast<const half8u *>(p);
+        half8u t = __builtin_nontemporal_load(reinterpret_cast<const half8u *>(p));
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
     }
-    static __device__ __forceinline__ void load4(const f16_t *p, float (&v)[4]) {
-        half4u t = *reinterpret_cast<const half4u *>(p);
+    template <bool NT = true> static __device__ __forceinline__ void load4(const f16_t *p, float (&v)[4]) {
+        const half4u *q = reinterpret_cast<const half4u *>(p);
+        half4u t;
+        if (NT) t = __builtin_nontemporal_load(q);
+        else t = *q;
         v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
     }
     static __device__ __forceinline__ float load1(const f16_t *p) { return (float)p->v; }
@@ -195,20 +204,23 @@ template <> struct MaskIO<f16_t> {
 template <> struct MaskIO<bf16_t> {
     static constexpr int kVec = 8;
     typedef uint4u Raw;
-    static __device__ __forceinline__ Raw load_raw(const bf16_t *p) { return *reinterpret_cast<const Raw *>(p); }
+    static __device__ __forceinline__ Raw load_raw(const bf16_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw *>(p)); }
     static __device__ __forceinline__ float elem(const Raw &r, int k) {
         return __uint_as_float((k & 1) ? (r[k >> 1] & 0xFFFF0000u) : (r[k >> 1] << 16));
     }
     static __device__ __forceinline__ void loadv(const bf16_t *p, float (&v)[8]) {
-        uint4u t = *reinterpret_cast<const uint4u *>(p);
+        uint4u t = __builtin_nontemporal_load(reinterpret_cast<const uint4u *>(p));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[2 * k] = __uint_as_float(t[k] << 16);
             v[2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
         }
     }
-    static __device__ __forceinline__ void load4(const bf16_t *p, float (&v)[4]) {
-        uint2u t = *reinterpret_cast<const uint2u *>(p);
+    template <bool NT = true> static __device__ __forceinline__ void load4(const bf16_t *p, float (&v)[4]) {
+        const uint2u *q = reinterpret_cast<const uint2u *>(p);
+        uint2u t;
+        if (NT) t = __builtin_nontemporal_load(q);
+        else t = *q;
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
         v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
     }

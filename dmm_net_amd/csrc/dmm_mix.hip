@@ -25,9 +25,14 @@ constexpr int kMixThreads = 256;
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowLoads = 8;
 
-template <typename T, int CNT>   // CNT = entries of this row if 1 or 2, 0 = generic
+template <typename T, int CNT, int NT>   // CNT = entries of this row if 1 or 2, 0 = generic; NT bit0 = nt loads, bit1 = nt stores
 __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const int *col_s, const float *w_s, int cnt,
-                                              float *orow, int HW, int s_begin, int s_end) {
+                                              float *orow, int HW, int pre, int s_begin, int s_end) {
+    // Pixel index of thread t at step s is x = (256 s + t) * 4 - pre with pre = elements the row start lies past a
+    // 16-byte boundary: every vector STORE is then 16-byte aligned (rows of 65025 floats start on 4-byte
+    // boundaries only; misaligned 16-byte stores straddle 64-byte lines and cost ~10 % of the write stream), the
+    // loads take the misalignment instead (free on gfx950, tools/hbm_probe.py).  The vectors that stick out of
+    // [0, HW) at either end go element-wise.
     constexpr int G = CNT == 1 ? 8 : (CNT == 2 ? 4 : 1);
     for (int s0 = s_begin; s0 < s_end; s0 += G) {
         float acc[G][4];
@@ -39,16 +44,16 @@ __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const i
             float v[G][CNT][4];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4;
+                const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4 - pre;
 #pragma unroll
                 for (int e = 0; e < CNT; ++e) {
                     const T *plane = Pb + (int64_t)col_s[e] * sp_n;
-                    if (s0 + g < s_end && x + 3 < HW) {
-                        MaskIO<T>::load4(plane + x, v[g][e]);
+                    if (s0 + g < s_end && x >= 0 && x + 3 < HW) {
+                        MaskIO<T>::template load4<(NT & 1) != 0>(plane + x, v[g][e]);
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            v[g][e][k] = (s0 + g < s_end && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                            v[g][e][k] = (s0 + g < s_end && x + k >= 0 && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
                     }
                 }
             }
@@ -61,18 +66,19 @@ __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const i
                     for (int k = 0; k < 4; ++k) acc[g][k] = __builtin_fmaf(w, v[g][e][k], acc[g][k]);
                 }
         } else {
-            const int x = (s0 * kMixThreads + threadIdx.x) * 4;
+            const int x = (s0 * kMixThreads + threadIdx.x) * 4 - pre;
             for (int e0 = 0; e0 < cnt; e0 += kRowLoads) {
                 float v[kRowLoads][4];
 #pragma unroll
                 for (int u = 0; u < kRowLoads; ++u) {
                     const int e = e0 + u < cnt ? e0 + u : cnt - 1;
                     const T *plane = Pb + (int64_t)col_s[e] * sp_n;
-                    if (x + 3 < HW) {
-                        MaskIO<T>::load4(plane + x, v[u]);
+                    if (x >= 0 && x + 3 < HW) {
+                        MaskIO<T>::template load4<(NT & 1) != 0>(plane + x, v[u]);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[u][k] = x + k < HW ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+                        for (int k = 0; k < 4; ++k)
+                            v[u][k] = (x + k >= 0 && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
                     }
                 }
 #pragma unroll
@@ -86,24 +92,25 @@ __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const i
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4;
+            const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4 - pre;
             if (s0 + g >= s_end || x >= HW) continue;
             float *o = orow + x;
-            if (x + 3 < HW) {
-                float4u t;
+            if (x >= 0 && x + 3 < HW) {
+                float4a t;
                 t.x = acc[g][0]; t.y = acc[g][1]; t.z = acc[g][2]; t.w = acc[g][3];
-                *reinterpret_cast<float4u *>(o) = t;
+                if (NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<float4a *>(o));
+                else *reinterpret_cast<float4a *>(o) = t;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (x + k < HW) o[k] = acc[g][k];
+                    if (x + k >= 0 && x + k < HW) o[k] = acc[g][k];
             }
         }
     }
 }
 
 // grid = (pixel splits, M, B)
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float *__restrict__ Rb,
                                                                     const T *__restrict__ masks_p, int N, int M, int Pp,
                                                                     int HW, int64_t sp_b, int64_t sp_n,
@@ -140,12 +147,13 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     const int cnt = cnt_s;
     const T *Pb = masks_p + (int64_t)b * sp_b;
     float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
-    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & 3);     // row start = 16-byte boundary + pre floats
+    const int nsteps = (HW + pre + kMixThreads * 4 - 1) / (kMixThreads * 4);
     const int s_begin = blockIdx.x * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
-    if (cnt == 1) mix_row_range<T, 1>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);
-    else if (cnt == 2) mix_row_range<T, 2>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);
-    else mix_row_range<T, 0>(Pb, sp_n, col_s, w_s, cnt, orow, HW, s_begin, s_end);   // cnt == 0 writes zeros
+    if (cnt == 1) mix_row_range<T, 1, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
+    else if (cnt == 2) mix_row_range<T, 2, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
+    else mix_row_range<T, 0, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);   // cnt == 0 writes zeros
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,18 +266,27 @@ template <typename T>
 static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
-    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    // many small workgroups (~40k, 16 steps = 64 KiB of the row each) balance the HBM channels best
-    // (measured 4.34 -> 4.98 TB/s going from 4k to 40k workgroups at B = 1024); DMM_MIX_WGS overrides
-    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 40000; }();
+    const int nsteps = (HW + 3 + kMixThreads * 4 - 1) / (kMixThreads * 4);    // + 3: worst-case row misalignment
+    // many small workgroups (~80k, 8 steps = 32 KiB of the row each) balance the HBM channels best
+    // (measured 4.2 / 4.5 / 4.9 / 5.1 / 5.1 TB/s at 10k / 20k / 40k / 80k / 160k workgroups, B = 1024); DMM_MIX_WGS overrides
+    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 80000; }();
     int splits = (target_wgs + B * M - 1) / (B * M);
     const int max_splits = (nsteps + 7) / 8;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int steps_per_wg = ((nsteps + splits - 1) / splits + 7) / 8 * 8;
     splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
-    hipLaunchKernelGGL((mask_mix_rows_kernel<T>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, M, Pp,
-                       HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg);
+    static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
+#define DMM_MIX_LAUNCH(NT)                                                                                              \
+    hipLaunchKernelGGL((mask_mix_rows_kernel<T, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, \
+                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg)
+    switch (nt_mode & 3) {
+        case 0: DMM_MIX_LAUNCH(0); break;
+        case 1: DMM_MIX_LAUNCH(1); break;
+        case 2: DMM_MIX_LAUNCH(2); break;
+        default: DMM_MIX_LAUNCH(3); break;
+    }
+#undef DMM_MIX_LAUNCH
     return check_launch();
 }
 

@@ -1,0 +1,160 @@
+// hbm_probe.hip -- read-only and copy streaming probes to calibrate the HBM ceiling the cost / mix kernels
+// are priced against (diagnostic tool; not part of libdmm_match.so).
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/hbm_probe.hip -o tools/libhbm_probe.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// every workgroup streams `per_wg` contiguous bytes (multiple of 256 * 16 * U)
+template <int U>
+__global__ __launch_bounds__(256) void read_kernel(const f4 *__restrict__ src, int64_t vec_per_wg, float *sink) {
+    const f4 *p = src + (int64_t)blockIdx.x * vec_per_wg + threadIdx.x;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = 0; i < vec_per_wg; i += 256 * U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// plain (cached) loads through a 4-byte-aligned vector type: what MaskIO<float>::load_raw issues
+template <int U>
+__global__ __launch_bounds__(256) void read_plain_kernel(const float *__restrict__ src, int64_t vec_per_wg, float *sink) {
+    const f4u *p = reinterpret_cast<const f4u *>(src) + (int64_t)blockIdx.x * vec_per_wg + threadIdx.x;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = 0; i < vec_per_wg; i += 256 * U) {
+        f4u v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void copy_kernel(const f4 *__restrict__ src, f4 *__restrict__ dst, int64_t vec_per_wg) {
+    const int64_t base = (int64_t)blockIdx.x * vec_per_wg + threadIdx.x;
+    for (int64_t i = 0; i < vec_per_wg; i += 256 * U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + base + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + base + i + u * 256);
+    }
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read(const void *src, int64_t bytes, int wgs, int unroll,
+                                                                 float *sink, void *stream) {
+    const int64_t vec_per_wg = bytes / 16 / wgs;
+    if (unroll == 4) hipLaunchKernelGGL(read_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, vec_per_wg, sink);
+    else if (unroll == 8) hipLaunchKernelGGL(read_kernel<8>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, vec_per_wg, sink);
+    else hipLaunchKernelGGL(read_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, vec_per_wg, sink);
+    return (int)hipGetLastError();
+}
+
+// the cost kernel's access pattern without its arithmetic: frame b = `planes` planes of HW floats (HW odd -> 4-byte
+// aligned plane bases); a wave takes 1024-pixel chunks, visiting every plane of the chunk with U planes in flight
+template <int U>
+__global__ __launch_bounds__(256) void read_planes_kernel(const float *__restrict__ src, int planes, int HW,
+                                                          int chunks_per_wg, float *sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *fb = src + (int64_t)blockIdx.y * planes * HW;
+    const int full = HW / 1024;
+    const int c_begin = blockIdx.x * chunks_per_wg, c_end = min(full, c_begin + chunks_per_wg);
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        const float *x = fb + c * 1024 + lane * 4;
+        for (int p0 = 0; p0 < planes; p0 += U) {
+            f4u v[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u < planes ? p0 + u : planes - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(x + (int64_t)p * HW + j * 256));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += v[u][j];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
+// same, but a wave visit takes RUN consecutive 4 KiB blocks of the plane (run length RUN * 4 KiB)
+template <int RUN>
+__global__ __launch_bounds__(256) void read_planes_run_kernel(const float *__restrict__ src, int planes, int HW,
+                                                              int chunks_per_wg, float *sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *fb = src + (int64_t)blockIdx.y * planes * HW;
+    const int full = HW / (1024 * RUN);
+    const int c_begin = blockIdx.x * chunks_per_wg, c_end = min(full, c_begin + chunks_per_wg);
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        const float *x = fb + (int64_t)c * 1024 * RUN + lane * 4;
+        for (int p = 0; p < planes; ++p) {
+            f4u v[RUN][4];
+#pragma unroll
+            for (int r = 0; r < RUN; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[r][j] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(x + (int64_t)p * HW + r * 1024 + j * 256));
+#pragma unroll
+            for (int r = 0; r < RUN; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += v[r][j];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read_planes_run(const void *src, int B, int planes, int HW,
+                                                                            int wgs, int run, float *sink, void *stream) {
+    const int nchunks = HW / (1024 * run);
+    int splits = (wgs + B - 1) / B;
+    if (splits > (nchunks + 3) / 4) splits = (nchunks + 3) / 4;
+    const int cpw = (nchunks + splits - 1) / splits;
+    splits = (nchunks + cpw - 1) / cpw;
+    dim3 grid(splits, B);
+    if (run == 1) hipLaunchKernelGGL(read_planes_run_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    else if (run == 2) hipLaunchKernelGGL(read_planes_run_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    else hipLaunchKernelGGL(read_planes_run_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read_planes(const void *src, int B, int planes, int HW,
+                                                                        int wgs, int unroll, float *sink, void *stream) {
+    const int nchunks = HW / 1024;
+    int splits = (wgs + B - 1) / B;
+    if (splits > (nchunks + 3) / 4) splits = (nchunks + 3) / 4;
+    const int cpw = (nchunks + splits - 1) / splits;
+    splits = (nchunks + cpw - 1) / cpw;
+    dim3 grid(splits, B);
+    if (unroll == 1) hipLaunchKernelGGL(read_planes_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    else if (unroll == 2) hipLaunchKernelGGL(read_planes_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    else hipLaunchKernelGGL(read_planes_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read_plain(const void *src, int64_t bytes, int wgs, int unroll,
+                                                                       float *sink, void *stream) {
+    const int64_t vec_per_wg = bytes / 16 / wgs;
+    if (unroll == 4) hipLaunchKernelGGL(read_plain_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const float *)src, vec_per_wg, sink);
+    else hipLaunchKernelGGL(read_plain_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const float *)src, vec_per_wg, sink);
+    return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_copy(const void *src, void *dst, int64_t bytes, int wgs,
+                                                                 int unroll, void *stream) {
+    const int64_t vec_per_wg = bytes / 16 / wgs;
+    if (unroll == 4) hipLaunchKernelGGL(copy_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, (f4 *)dst, vec_per_wg);
+    else hipLaunchKernelGGL(copy_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, (f4 *)dst, vec_per_wg);
+    return (int)hipGetLastError();
+}
