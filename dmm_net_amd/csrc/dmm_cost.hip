@@ -274,6 +274,134 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Template-lane variant (large tables: many proposals and / or > 16 template rows).
+// The kernel above parks BOTH bit tiles in registers (lane = proposal) and keeps MT x NG accumulators per lane; at
+// N = 200, M = 20 that is 2 waves / SIMD, 128-proposal tiles (templates re-read per tile) and a VALU share that no
+// longer hides under the loads.  Here only the TEMPLATE tile is parked (lane = template row, + one all-ones lane
+// whose count is the proposal's area) and proposal planes are never parked at all: the ballot of a proposal word
+// is a wave-uniform SGPR pair, v_and + v_bcnt against the parked template words give the counts of that proposal
+// against every template row at once (4 VALU ops per word), and one LDS atomic per (proposal, chunk) folds the
+// lane vector into the workgroup's [proposal][row] table.  No accumulator registers, no proposal tiling, no
+// per-tile template re-reads; ~80 VGPRs.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool TAIL>
+__device__ __forceinline__ void tl_chunk(const T *Pb, const T *Tb, const T *T2b, int64_t sp_n, int64_t st_m,
+                                         int64_t st2_m, int Nb, int Mb, int Mrows, int x0, int HW, unsigned *red, int RS,
+                                         unsigned &area_t) {
+    constexpr int E = MaskIO<T>::kVec;
+    constexpr int SUB = kChunk / (64 * E);
+    constexpr int kUnroll = kLoadBytes / (kChunk * (int)sizeof(T));
+    const int lane = threadIdx.x & 63;
+    BitTile tw;
+    fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x0, HW, 0, true);
+    if (T2b) fill_tile<T, TAIL>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
+    if (lane == Mrows) {                       // the all-ones row: popc(P & ~0) = area of the proposal
+#pragma unroll
+        for (int k = 0; k < kWords; ++k) { tw.lo[k] = -1; tw.hi[k] = -1; }
+    }
+    const int x = x0 + lane * E;
+    for (int p0 = 0; p0 < Nb; p0 += kUnroll) {
+        typename MaskIO<T>::Raw v[kUnroll][SUB];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int p = p0 + u < Nb ? p0 + u : Nb - 1;
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) v[u][j] = load_pixels<T, TAIL>(Pb + (int64_t)p * sp_n, x + j * 64 * E, HW);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (p0 + u < Nb) {
+                unsigned a = 0;
+#pragma unroll
+                for (int j = 0; j < SUB; ++j)
+#pragma unroll
+                    for (int k = 0; k < E; ++k) {
+                        const unsigned long long b = __ballot(MaskIO<T>::elem(v[u][j], k) > 0.5f);
+                        a += __builtin_popcount(tw.lo[E * j + k] & (int)(unsigned)b) +
+                             __builtin_popcount(tw.hi[E * j + k] & (int)(unsigned)(b >> 32));
+                    }
+                if (lane <= Mrows) atomicAdd(&red[(p0 + u) * RS + lane], a);
+            }
+        }
+    }
+}
+
+// grid = (splits, B); block = 256; dynamic LDS = (nt * RS + 64) * 4 bytes, RS = Mrows_max + 1.
+template <typename T>
+__global__ __launch_bounds__(kCostThreads) void iou_counts_tl_kernel(
+    const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
+    int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
+    int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
+    int32_t *__restrict__ area_t2, int n0, int m0, int nt, int mt, int chunks_per_wg, int write_area_p,
+    int write_area_t, int RS) {
+    extern __shared__ unsigned tl_red[];
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    Nb = min(Nb - n0, nt);
+    Mb = min(Mb - m0, mt);
+    if (Nb <= 0 || Mb <= 0) return;
+    const int Mrows = masks_t2 ? 2 * Mb : Mb;
+    const T *Pb = masks_p + (int64_t)b * sp_b + (int64_t)n0 * sp_n;
+    const T *Tb = masks_t + (int64_t)b * st_b + (int64_t)m0 * st_m;
+    const T *T2b = masks_t2 ? masks_t2 + (int64_t)b * st2_b + (int64_t)m0 * st2_m : nullptr;
+    unsigned *red_at = tl_red + nt * RS;
+    for (int i = threadIdx.x; i < nt * RS + kWave; i += kCostThreads) tl_red[i] = 0;
+    __syncthreads();
+    unsigned at = 0;
+    const int full_chunks = HW / kChunk;
+    const int nchunks = (HW + kChunk - 1) / kChunk;
+    const int c_begin = blockIdx.x * chunks_per_wg;
+    const int c_end = min(nchunks, c_begin + chunks_per_wg);
+    for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
+        const int x0 = c * kChunk;
+        if (c < full_chunks) tl_chunk<T, false>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, tl_red, RS, at);
+        else tl_chunk<T, true>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, tl_red, RS, at);
+    }
+    if (lane < Mrows && at) atomicAdd(&red_at[lane], at);
+    __syncthreads();
+    int32_t *inter_b = inter + (int64_t)b * M * N;
+    int32_t *inter2_b = inter2 ? inter2 + (int64_t)b * M * N : nullptr;
+    for (int i = threadIdx.x; i < Nb * RS; i += kCostThreads) {
+        const unsigned v = tl_red[i];
+        if (!v) continue;
+        const int p = i / RS, r = i - p * RS;
+        if (r < Mb) atomicAdd(&inter_b[(int64_t)(m0 + r) * N + n0 + p], (int)v);
+        else if (r < Mrows) atomicAdd(&inter2_b[(int64_t)(m0 + r - Mb) * N + n0 + p], (int)v);
+        else if (r == Mrows && write_area_p) atomicAdd(&area_p[(int64_t)b * N + n0 + p], (int)v);
+    }
+    if (write_area_t && threadIdx.x < Mrows && red_at[threadIdx.x]) {
+        if (threadIdx.x < Mb) atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);
+        else atomicAdd(&area_t2[(int64_t)b * M + m0 + threadIdx.x - Mb], (int)red_at[threadIdx.x]);
+    }
+}
+
+template <typename T>
+static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int B, int N, int M, int HW, int64_t sp_b,
+                     int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
+                     const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
+                     int32_t *area_t2, int n0, int m0, int nt, int mt, int wap, int wat, hipStream_t stream) {
+    const int nchunks = (HW + kChunk - 1) / kChunk;
+    static const int target_wgs = [] { const char *e = getenv("DMM_COST_TL_WGS"); return e ? atoi(e) : 2048; }();
+    int splits = (target_wgs + B - 1) / B;
+    const int max_splits = (nchunks + 3) / 4;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int chunks_per_wg = (nchunks + splits - 1) / splits;
+    splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
+    const int RS = (masks_t2 ? 2 * mt : mt) + 1;
+    const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave);
+    hipLaunchKernelGGL((iou_counts_tl_kernel<T>), dim3(splits, B), dim3(kCostThreads), lds, stream, masks_p, masks_t,
+                       masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t,
+                       inter2, area_t2, n0, m0, nt, mt, chunks_per_wg, wap, wat, RS);
+    return check_launch();
+}
+
 template <typename T>
 static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t2, int B, int N, int M, int HW,
                             int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
@@ -297,6 +425,27 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
     // proposal tile: accumulators are MT x NG per lane, and at MT > 16 a 4-group tile drops to 1 wave/SIMD
     // (measured 2.6 TB/s on config 5), so those shapes run as 128-proposal tiles (templates re-read once
     // per tile: +9 % bytes at N=200, M=20).
+    // kernel choice: DMM_COST_KERNEL = 0 (register tiles) / 1 (template lanes) / unset = by shape
+    const char *kernel_env = getenv("DMM_COST_KERNEL");          // read per call: tests flip it
+    const int kernel_mode = kernel_env ? atoi(kernel_env) : -1;
+    if constexpr (!std::is_same<T, packed_t>::value) {
+        const int rows = masks_t2 ? 2 * M : M;
+        const bool use_tl = kernel_mode == 1 || (kernel_mode < 0 && (rows > 16 || N > 128));
+        if (use_tl) {
+            const int mstep_tl = masks_t2 ? 16 : 32;
+            for (int m0 = 0; m0 < M; m0 += mstep_tl) {
+                const int mt = M - m0 < mstep_tl ? M - m0 : mstep_tl;
+                for (int n0 = 0; n0 < N; n0 += 256) {
+                    const int nt = N - n0 < 256 ? N - n0 : 256;
+                    const int rc = launch_tl<T>(masks_p, masks_t, masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b,
+                                                st2_m, n_valid, m_valid, inter, area_p, area_t, inter2, area_t2, n0, m0,
+                                                nt, mt, m0 == 0, n0 == 0, stream);
+                    if (rc != DMM_OK) return rc;
+                }
+            }
+            return DMM_OK;
+        }
+    }
     const int mstep = masks_t2 ? 16 : 32;
     for (int m0 = 0; m0 < M; m0 += mstep) {
         const int mt = (M - m0 < mstep ? M - m0 : mstep) * (masks_t2 ? 2 : 1);

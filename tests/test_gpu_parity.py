@@ -88,10 +88,20 @@ def check_against_golden(o, g, is_test, big=False):
 
 
 # ------------------------------------------------------------------------------------ cost kernel
+@pytest.fixture(params=["auto", "register-tiles", "template-lanes"])
+def cost_kernel(request, monkeypatch):
+    """The IoU-count entry point has two kernels (dmm_cost.hip); DMM_COST_KERNEL pins one (read per call)."""
+    if request.param != "auto":
+        monkeypatch.setenv("DMM_COST_KERNEL", "0" if request.param == "register-tiles" else "1")
+    else:
+        monkeypatch.delenv("DMM_COST_KERNEL", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("N,M,H,W", [(8, 3, 64, 64), (50, 10, 255, 255), (1, 1, 1, 7), (5, 2, 1, 7), (3, 5, 17, 31),
                                      (64, 8, 33, 40), (65, 9, 40, 33), (130, 17, 50, 41), (200, 20, 255, 255),
                                      (257, 33, 20, 23), (50, 10, 16, 16), (7, 4, 2, 2)])
-def test_iou_counts_bit_exact(N, M, H, W):
+def test_iou_counts_bit_exact(N, M, H, W, cost_kernel):
     fr = synth.make_frame(N, M, H, W, 8, seed=900 + N + M + H, kind="uniform")
     inter, ap, at = ops.iou_counts(dev(fr.proposed_mask)[None], dev(fr.mask_last_occurence)[None])
     ri, rp, rt = oracle.iou_counts(fr.proposed_mask, fr.mask_last_occurence)
@@ -101,7 +111,7 @@ def test_iou_counts_bit_exact(N, M, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_iou_counts_low_precision_storage(dtype):
+def test_iou_counts_low_precision_storage(dtype, cost_kernel):
     fr = synth.make_frame(20, 6, 37, 41, 8, seed=77, kind="uniform")
     pm, tm = dev(fr.proposed_mask, dtype)[None], dev(fr.mask_last_occurence, dtype)[None]
     inter, ap, at = ops.iou_counts(pm, tm)
@@ -111,7 +121,7 @@ def test_iou_counts_low_precision_storage(dtype):
     assert np.array_equal(ap[0].cpu().numpy(), rp) and np.array_equal(at[0].cpu().numpy(), rt)
 
 
-def test_iou_counts_batched_strided_ragged():
+def test_iou_counts_batched_strided_ragged(cost_kernel):
     B, N, M, H, W = 5, 12, 4, 19, 23
     rng = np.random.Generator(np.random.PCG64(5))
     big_p = torch.from_numpy(rng.random((B, N + 3, H, W), dtype=np.float32)).to(DEV)
@@ -460,9 +470,10 @@ def test_config5_fp16_masks_stress():
     close(plan.sim[0], g["sim"], 2e-3)           # fp16 rounding moves a few threshold pixels
 
 
-def test_iou_counts_dual_equals_two_passes():
+def test_iou_counts_dual_equals_two_passes(cost_kernel):
     rng = np.random.Generator(np.random.PCG64(21))
-    for (B, N, M, H, W) in [(3, 50, 10, 64, 67), (2, 130, 16, 33, 31), (2, 20, 17, 16, 16), (1, 8, 3, 255, 255)]:
+    for (B, N, M, H, W) in [(3, 50, 10, 64, 67), (2, 130, 16, 33, 31), (2, 20, 17, 16, 16), (1, 8, 3, 255, 255),
+                            (1, 200, 20, 40, 41), (1, 40, 32, 20, 21), (1, 260, 33, 9, 11)]:
         pm = torch.from_numpy(rng.random((B, N, H, W), dtype=np.float32)).to(DEV)
         tm = torch.from_numpy(rng.random((B, M, H, W), dtype=np.float32)).to(DEV)
         tg = (torch.from_numpy(rng.random((B, M, H, W), dtype=np.float32)).to(DEV) > 0.5).float()
