@@ -33,7 +33,7 @@ __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const i
     // boundaries only; misaligned 16-byte stores straddle 64-byte lines and cost ~10 % of the write stream), the
     // loads take the misalignment instead (free on gfx950, tools/hbm_probe.py).  The vectors that stick out of
     // [0, HW) at either end go element-wise.
-    constexpr int G = CNT == 1 ? 8 : (CNT == 2 ? 4 : 1);
+    constexpr int G = CNT == 0 ? 1 : 2;     // steps per iteration = the launcher's step quantum
     for (int s0 = s_begin; s0 < s_end; s0 += G) {
         float acc[G][4];
 #pragma unroll
@@ -267,14 +267,17 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
     const int nsteps = (HW + 3 + kMixThreads * 4 - 1) / (kMixThreads * 4);    // + 3: worst-case row misalignment
-    // many small workgroups (~80k, 8 steps = 32 KiB of the row each) balance the HBM channels best
-    // (measured 4.2 / 4.5 / 4.9 / 5.1 / 5.1 TB/s at 10k / 20k / 40k / 80k / 160k workgroups, B = 1024); DMM_MIX_WGS overrides
-    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 80000; }();
+    // MANY TINY workgroups: 2 steps = 8 KiB of the row each, up to ~320k of them.  Measured at B = 1024 (test mode,
+    // one plane per row): 4.2 / 4.9 / 5.1 / 5.2 / 5.75-6.1 TB/s at 10k / 40k / 80k / 160k / 320k workgroups; 1-step
+    // workgroups fall back to 5.5-5.8.  In dispatch order the resident workgroups then cover a compact, advancing
+    // window of the output instead of ~2000 independent 64 KiB streams.  DMM_MIX_WGS / DMM_MIX_STEPQ override.
+    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 320000; }();
     int splits = (target_wgs + B * M - 1) / (B * M);
-    const int max_splits = (nsteps + 7) / 8;
+    static const int step_q = [] { const char *e = getenv("DMM_MIX_STEPQ"); return e ? atoi(e) : 2; }();
+    const int max_splits = (nsteps + step_q - 1) / step_q;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    const int steps_per_wg = ((nsteps + splits - 1) / splits + 7) / 8 * 8;
+    const int steps_per_wg = ((nsteps + splits - 1) / splits + step_q - 1) / step_q * step_q;
     splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
     static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
 #define DMM_MIX_LAUNCH(NT)                                                                                              \

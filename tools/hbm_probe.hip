@@ -115,6 +115,39 @@ __global__ __launch_bounds__(256) void read_planes_run_kernel(const float *__res
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
 }
 
+// compact footprint: one workgroup = ONE 1024-pixel chunk of one frame, its 4 waves split the planes
+// (grid = (chunks, B)): the resident workgroups cover ~16 frames instead of ~64
+__global__ __launch_bounds__(256) void read_planes_split_kernel(const float *__restrict__ src, int planes, int HW,
+                                                                float *sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *x = src + (int64_t)blockIdx.y * planes * HW + blockIdx.x * 1024 + lane * 4;
+    const int per = (planes + 3) / 4;
+    const int p_begin = wave * per, p_end = min(planes, p_begin + per);
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = p_begin; p0 < p_end; p0 += 2) {
+        f4u v[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + u < p_end ? p0 + u : p_end - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(x + (int64_t)p * HW + j * 256));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += v[u][j];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read_planes_split(const void *src, int B, int planes, int HW,
+                                                                              float *sink, void *stream) {
+    hipLaunchKernelGGL(read_planes_split_kernel, dim3(HW / 1024, B), dim3(256), 0, (hipStream_t)stream, (const float *)src,
+                       planes, HW, sink);
+    return (int)hipGetLastError();
+}
+
 extern "C" __attribute__((visibility("default"))) int probe_read_planes_run(const void *src, int B, int planes, int HW,
                                                                             int wgs, int run, float *sink, void *stream) {
     const int nchunks = HW / (1024 * run);

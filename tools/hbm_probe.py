@@ -51,6 +51,12 @@ for unroll in (1, 2, 4):
         t = timed(lambda: L.probe_read_planes(src.data_ptr(), BF, PL, HW, wgs, unroll, sink.data_ptr(), st))
         print(f"read planes (cost-kernel pattern) unroll {unroll} wgs {wgs:6d}: {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
 L.probe_read_planes_run.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
+L.probe_read_planes_split.argtypes = [vp, ci, ci, ci, vp, vp]
+for rep in range(2):
+    t = timed(lambda: L.probe_read_planes_split(src.data_ptr(), BF, PL, HW, sink.data_ptr(), st))
+    print(f"read planes split (1 chunk / WG, waves split planes): {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
+    t = timed(lambda: L.probe_read_planes(src.data_ptr(), BF, PL, HW, 8192, 2, sink.data_ptr(), st))
+    print(f"read planes (cost-kernel pattern, 8192 wgs)        : {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
 for HWx in (65025, 65536):
     BFx = n // (4 * HWx * PL)
     for run in (1, 2, 4):
