@@ -35,7 +35,7 @@ constexpr int kChunk = 1024;          // pixels a wave takes from one plane per 
                                       // shares those lines (measured HBM over-fetch 8.6 % -> 1.3 % for fp32)
 constexpr int kLoadBytes = 8192;      // bytes of plane loads a wave keeps in flight: 2 fp32 planes or 4 16-bit planes
 constexpr int kWords = kChunk / 64;   // 64-bit words per plane and chunk (16)
-constexpr int kCostThreads = 256;
+constexpr int kCostThreads = 256;     // 4 waves; 1- and 2-wave workgroups measured 2-4 % slower
 
 // One 16-byte load per lane: E = 4 (fp32) or 8 (half / bfloat16) consecutive pixels, kept RAW in 4 VGPRs until the
 // ballots consume it; a chunk is kChunk / (64 E) such loads (4 or 2).  Word index of pixel 64*E*j + E*lane + k is
@@ -262,7 +262,7 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
     // best (B = 1024: 5.8 / 6.0 / 6.3 / 6.6 / 6.4 TB/s at 1k / 2k / 4k / 8k / 16k workgroups)
     static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
     int splits = (target_wgs + B - 1) / B;
-    const int max_splits = (nchunks + 3) / 4;
+    const int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
@@ -389,7 +389,7 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     const int nchunks = (HW + kChunk - 1) / kChunk;
     static const int target_wgs = [] { const char *e = getenv("DMM_COST_TL_WGS"); return e ? atoi(e) : 2048; }();
     int splits = (target_wgs + B - 1) / B;
-    const int max_splits = (nchunks + 3) / 4;
+    const int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
