@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Collect the per-round evidence under profiles/ on an MI355X box (run from the repo root):
+
+    python tools/collect_profiles.py r01 gpurun_out/profiles_new
+
+  <tag>_bench.json                  python bench.py
+  <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-cpu-baseline
+  <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-cpu-baseline
+  <tag>_kernel_stats_single_stream.csv   same with --no-pipeline
+  <tag>_pmc_traffic.json            two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), per-kernel averages;
+                                    bytes = KiB * 1024, FETCH x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section)
+  <tag>_agent_info.csv
+rocprofv3 runs from /tmp with TMPDIR=/tmp; --pmc is never combined with other trace domains than --kernel-trace.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+tag, out = sys.argv[1], os.path.abspath(sys.argv[2])
+only_pmc = len(sys.argv) > 3 and sys.argv[3] == "pmc"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(out, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+bench = [sys.executable, os.path.join(root, "bench.py")]
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, **kw)
+
+
+def last_json(stdout):
+    return [l for l in stdout.strip().splitlines() if l.startswith("{")][-1]
+
+
+if not only_pmc:
+    open(os.path.join(out, f"{tag}_bench.json"), "w").write(last_json(run(bench).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_single_stream.json"), "w").write(
+        last_json(run(bench + ["--no-pipeline", "--no-cpu-baseline"]).stdout) + "\n")
+
+for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]))):
+    d = f"/tmp/prof_stats{suffix}"
+    shutil.rmtree(d, ignore_errors=True)
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench +
+        ["--no-cpu-baseline"] + extra)
+    for f in glob.glob(d + "/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats{suffix}.csv"))
+    for f in glob.glob(d + "/**/*_agent_info.csv", recursive=True):
+        shutil.copy(f, os.path.join(out, f"{tag}_agent_info.csv"))
+
+kernels = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = f"/tmp/prof_{ctr}"
+    shutil.rmtree(d, ignore_errors=True)
+    run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + bench +
+        ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0]
+            name = name[5:] if name.startswith("void ") else name
+            if not name.startswith("dmm::") or row["Counter_Name"] != ctr:
+                continue
+            k = kernels.setdefault(name, {})
+            k.setdefault(ctr, []).append(float(row["Counter_Value"]))
+res = {"round": tag,
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python bench.py --steps 3 "
+                  "--warmup 1 --no-cpu-baseline (separate passes; default 2-lane schedule: 512 frames per cost launch)",
+       "units": "counter values are KiB (rocprofv3 FETCH_SIZE / WRITE_SIZE); bytes = value * 1024",
+       "gfx950_correction": "FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read on gfx950 "
+                            "(MI355X_MICROARCH.md, HBM section) -> read bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE used "
+                            "as is (uncalibrated)",
+       "kernels": {}}
+for name, k in kernels.items():
+    f, w = k.get("FETCH_SIZE", []), k.get("WRITE_SIZE", [])
+    fa, wa = (sum(f) / len(f) if f else 0.0), (sum(w) / len(w) if w else 0.0)
+    res["kernels"][name] = {"FETCH_SIZE_KiB_avg": fa, "FETCH_SIZE_samples": len(f), "WRITE_SIZE_KiB_avg": wa,
+                            "WRITE_SIZE_samples": len(w), "hbm_bytes_per_launch": int(fa * 1024 * 2 + wa * 1024)}
+cost = [v for n, v in res["kernels"].items() if n.startswith("dmm::iou_counts_kernel")]
+if cost:
+    res["hbm_bytes_per_launch_at_frames"] = {"512": cost[0]["hbm_bytes_per_launch"]}
+    res["algorithmic_bytes_per_launch_at_frames"] = {"512": 512 * (60 * 65025 * 4 + 2000)}
+json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({n: v["hbm_bytes_per_launch"] for n, v in res["kernels"].items()}, indent=1))
+if not only_pmc:
+    print(open(os.path.join(out, f"{tag}_bench.json")).read())
