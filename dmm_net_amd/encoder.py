@@ -6,8 +6,9 @@ Counterpart of ``dmm/modules/vision.py:6-38`` (torchvision ``ResNet`` subclasses
 ``dmm/modules/model_encoder.py:86-162`` (``forward_base`` + the head calls :136-146).
 
 The convolutions are plain ``torch.nn`` modules: on ROCm they run on MIOpen (the only MFMA work on the whole path
--- the matching kernels are bandwidth / latency bound and never touch the matrix cores).  ``channels_last`` +
-bf16 autocast are the MI355X-friendly settings (BASELINE config 3).  torchvision is not a dependency: the body is
+-- the matching kernels are bandwidth / latency bound and never touch the matrix cores).  For inference
+``fold_batchnorm`` + ``GraphedEncoder`` (bf16 autocast, NCHW) is the fast setting on MI355X with the MIOpen of this
+image (ResNet-50, 8 frames of 255x255: 3.6 ms eager channels_last bf16 -> 2.5 ms; ``tools/encoder_timing.py``).  torchvision is not a dependency: the body is
 written out here with torchvision's parameter names (``conv1, bn1, layer1..4.N.convK/bnK/downsample.0/1, fc``)
 so reference checkpoints (``encoder`` keys, ``dmm/utils/utils.py:57-111``) load with ``load_state_dict``.
 
@@ -184,3 +185,85 @@ class FeatureEncoder(nn.Module):
         return {"backbone_feature": (p2, p3, p4, p5),
                 "refine_input_feat": (x5_skip, x4_skip, x3_skip, x2_skip),
                 "body_feature": (x2, x3, x4, x5)}
+
+
+# ---- inference-time BatchNorm folding ---------------------------------------------------------------------------
+def _fold_pair(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
+    """conv -> BN(eval) == one conv with W' = W * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta."""
+    s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
+                    conv.groups, bias=True).to(device=conv.weight.device, dtype=conv.weight.dtype)
+    b = conv.bias.detach() if conv.bias is not None else torch.zeros_like(bn.running_mean)
+    with torch.no_grad():
+        out.weight.copy_(conv.weight.detach() * s.view(-1, 1, 1, 1))
+        out.bias.copy_((b - bn.running_mean.detach()) * s + bn.bias.detach())
+    return out
+
+
+def fold_batchnorm(encoder: "FeatureEncoder") -> "FeatureEncoder":
+    """Deep copy of an ``eval()`` encoder with every BatchNorm folded into the convolution before it (the body's
+    53 / 104 conv-BN pairs, the four ``sk``/``bn`` skips, both convolutions of the four ``prop`` heads).  Same
+    outputs up to fp32 rounding, about half the launches: BatchNorm inference + bias kernels were ~15 % of the
+    encoder's GPU time on MI355X.  Inference only (the copy has no BatchNorm state left to train)."""
+    import copy
+    assert not encoder.training, "fold_batchnorm needs eval() mode (running statistics)"
+    enc = copy.deepcopy(encoder)
+    body = enc.base
+    body.conv1, body.bn1 = _fold_pair(body.conv1, body.bn1), nn.Identity()
+    for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
+        for blk in layer:
+            for i in (1, 2, 3):
+                if hasattr(blk, f"conv{i}"):
+                    setattr(blk, f"conv{i}", _fold_pair(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}")))
+                    setattr(blk, f"bn{i}", nn.Identity())
+            if blk.downsample is not None:
+                blk.downsample = nn.Sequential(_fold_pair(blk.downsample[0], blk.downsample[1]), nn.Identity())
+    for k in (5, 4, 3, 2):
+        setattr(enc, f"sk{k}", _fold_pair(getattr(enc, f"sk{k}"), getattr(enc, f"bn{k}")))
+        setattr(enc, f"bn{k}", nn.Identity())
+        head = getattr(enc, f"prop{k}")
+        setattr(enc, f"prop{k}", nn.Sequential(_fold_pair(head[0], head[1]), nn.Identity(), head[2],
+                                                _fold_pair(head[3], head[4]), nn.Identity()))
+    return enc.eval()
+
+
+class GraphedEncoder:
+    """Inference-time replay of ``FeatureEncoder.forward`` from one captured HIP graph per input shape.
+
+    At the product's batch sizes the ResNet forward is launch bound on MI355X (ResNet-50, 8 frames of 255x255: ~160
+    MIOpen / elementwise launches, 3.9 ms eager against well under 1 ms of arithmetic); replaying a captured graph
+    removes the per-launch host cost.  The encoder must be in ``eval()`` mode (BatchNorm running statistics; nothing
+    in the graph may depend on host state).  Outputs are views of the graph's static buffers: consume (or clone) them
+    before the next call.  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
+    """
+
+    def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3):
+        assert not encoder.training, "capture needs eval() mode"
+        self.encoder, self.dtype, self.warmup = encoder, autocast_dtype, int(warmup)
+        self._graphs = {}
+
+    def _forward(self, x):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.dtype or torch.bfloat16, enabled=self.dtype is not None):
+            return self.encoder(x)
+
+    def __call__(self, img: torch.Tensor):
+        if not img.is_cuda:
+            raise RuntimeError("GraphedEncoder needs the images on the MI355X")
+        key = (tuple(img.shape), img.dtype, img.is_contiguous(memory_format=torch.channels_last), img.device.index)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = img.clone(memory_format=torch.preserve_format)
+            side = torch.cuda.Stream(device=img.device)
+            side.wait_stream(torch.cuda.current_stream(img.device))
+            with torch.cuda.stream(side):                         # warm-up off the capture: MIOpen picks its kernels
+                for _ in range(self.warmup):
+                    self._forward(static_in)
+            torch.cuda.current_stream(img.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._forward(static_in)
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(img)
+        graph.replay()
+        return static_out

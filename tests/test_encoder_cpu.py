@@ -28,3 +28,27 @@ def test_encoder_forward_shapes_and_grad_cpu():
     assert enc.base.conv1.weight.grad is not None and enc.prop2[0].weight.grad is not None
     assert enc.sk5.weight.grad is None                       # skip heads feed the decoder, not the matching path
     assert len(enc.get_skip_params()) == 4 * 2 + 4 * 2 + 4 * 8
+
+
+def test_fold_batchnorm_same_outputs_cpu():
+    from dmm_net_amd.encoder import fold_batchnorm
+    torch.manual_seed(0)
+    for name in ("resnet34", "resnet50"):
+        enc = FeatureEncoder(name, hidden_size=32)
+        for m in enc.modules():                              # non-trivial running statistics / affine parameters
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.2)
+        enc.eval()
+        folded = fold_batchnorm(enc)
+        assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
+        img = torch.randn(2, 3, 64, 96)
+        with torch.no_grad():
+            a, b = enc(img), folded(img)
+        for k in ("backbone_feature", "refine_input_feat", "body_feature"):
+            for x, y in zip(a[k], b[k]):
+                assert x.shape == y.shape
+                assert float((x - y).abs().max()) <= 2e-4 * max(1.0, float(x.abs().max())), (name, k)
+        assert any(isinstance(m, torch.nn.BatchNorm2d) for m in enc.modules())     # the original is untouched

@@ -230,3 +230,27 @@ def test_inference_step_end_to_end():
             pm_o = kept[b].get_field("mask")[o, 0]
             w = (out[b, o] * pm_o).sum() / (pm_o * pm_o).sum()
             assert float((out[b, o] - w * pm_o).abs().max()) < 1e-5 and 0.3 < float(w) <= 1.2, (b, o, float(w))
+
+
+def test_folded_graphed_encoder_matches_eager():
+    """Inference encoder: BatchNorm folded into the convolutions and replayed from a captured HIP graph == eager."""
+    from dmm_net_amd.encoder import GraphedEncoder, fold_batchnorm
+    torch.manual_seed(4)
+    enc = FeatureEncoder("resnet34", hidden_size=32).to(DEV)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    enc.eval()
+    genc = GraphedEncoder(fold_batchnorm(enc))
+    for seed in (0, 1, 2):                                   # replays with new inputs; second shape = second graph
+        shape = (2, 3, 64, 96) if seed < 2 else (1, 3, 96, 64)
+        img = torch.randn(*shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        with torch.no_grad():
+            ref = enc(img)
+        out = genc(img)
+        for k in ("backbone_feature", "refine_input_feat"):
+            for x, y in zip(ref[k], out[k]):
+                assert x.shape == y.shape
+                assert float((x - y).abs().max()) <= 5e-4 * max(1.0, float(x.abs().max())), (seed, k)
+    assert len(genc._graphs) == 2
