@@ -10,7 +10,8 @@ DDP's 25 MB buckets (train.py:178-184) and then repeats it with one un-awaited a
 PARAMETER TENSOR (``average_gradients``, train.py:62-68 -- ~230-390 tiny collectives whose handles are never
 waited on).  ``GradBucketer`` is the semantic equivalent done once: gradients are packed into a few large
 flat buckets (xGMI is point-to-point, a ring all-reduce is bound by one ~153 GB/s link, so fewer/larger
-messages win), each bucket is all-reduced asynchronously, then waited, scaled by 1/world and scattered back.
+messages win), each bucket is all-reduced asynchronously -- with ``overlap=True`` as soon as autograd has produced
+its last gradient, i.e. under the rest of the backward pass -- then waited, scaled by 1/world and scattered back.
 The matching layer itself owns no parameters (checkpoint neutral), so it contributes nothing to it.
 """
 from __future__ import annotations
@@ -44,14 +45,25 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
 
 
 class GradBucketer:
-    """Bucketed mean all-reduce of ``param.grad`` over the default process group."""
+    """Bucketed mean all-reduce of ``param.grad`` over the default process group.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0):
+    ``overlap=False``: call ``all_reduce_mean()`` after ``backward()``.
+    ``overlap=True``: buckets are laid out in REVERSE parameter order (gradients arrive last layer first) and
+    post-accumulate-grad hooks copy each gradient into its bucket as autograd produces it; the moment a bucket is
+    complete its all-reduce is issued asynchronously, so the collectives of the late layers run under the backward of
+    the early ones (what DDP does for the reference, train.py:178-184).  ``finish()`` after ``backward()`` issues the
+    buckets that never completed (parameters without a gradient this step count as zeros, like DDP with
+    ``find_unused_parameters=True``, train.py:181), waits, scales by 1/world and scatters back.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, overlap: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.overlap = bool(overlap)
+        order = list(reversed(self.params)) if self.overlap else self.params
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes, key = [], 0, None
-        for p in self.params:
+        for p in order:
             k = (p.dtype, p.device)
             nbytes = p.numel() * p.element_size()
             if cur and (k != key or cur_bytes + nbytes > self.bucket_bytes):
@@ -62,23 +74,92 @@ class GradBucketer:
             key = k
         if cur:
             self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._slot = {}
+        for bi, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._slot[id(p)] = (bi, off)
+                off += p.numel()
+        self._handles: List[Optional[object]] = [None] * len(self.buckets)
+        self._filled = [set() for _ in self.buckets]
+        self._hooks = []
+        if self.overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def num_collectives(self) -> int:
         return len(self.buckets)
 
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _flat_of(self, bi: int) -> torch.Tensor:
+        bucket = self.buckets[bi]
+        n = sum(p.numel() for p in bucket)
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != n:
+            flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            self._flat[bi] = flat
+        return flat
+
+    @torch.no_grad()
+    def _on_grad(self, p: torch.nn.Parameter):
+        bi, off = self._slot[id(p)]
+        if self._handles[bi] is not None:          # a second backward before finish(): fall back to finish()'s path
+            return
+        self._flat_of(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self._filled[bi].add(id(p))
+        if len(self._filled[bi]) == len(self.buckets[bi]):
+            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+
+    @torch.no_grad()
+    def _scatter_back(self, bi: int, world: int):
+        flat = self._flat[bi]
+        flat.div_(world)
+        off = 0
+        for p in self.buckets[bi]:
+            k = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + k].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[off:off + k].view_as(p))
+            off += k
+
+    @torch.no_grad()
+    def finish(self):
+        """After ``backward()`` with ``overlap=True``: complete, wait, average, scatter back."""
+        world = dist.get_world_size()
+        for bi, bucket in enumerate(self.buckets):
+            if self._handles[bi] is None:
+                flat = self._flat_of(bi)
+                off = 0
+                for p in bucket:                   # (re)fill: missing gradients are zeros
+                    k = p.numel()
+                    if p.grad is None:
+                        flat[off:off + k].zero_()
+                    elif id(p) not in self._filled[bi]:
+                        flat[off:off + k].copy_(p.grad.reshape(-1))
+                    off += k
+                self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        for bi in range(len(self.buckets)):
+            self._handles[bi].wait()
+            self._scatter_back(bi, world)
+            self._handles[bi] = None
+            self._filled[bi] = set()
+
     @torch.no_grad()
     def all_reduce_mean(self):
         """grad <- mean over ranks (params whose grad is None are treated as zeros, like DDP with
-        find_unused_parameters=True, train.py:181)."""
+        find_unused_parameters=True, train.py:181).  With ``overlap=True`` this is ``finish()``."""
+        if self.overlap:
+            return self.finish()
         world = dist.get_world_size()
         handles = []
         for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            flat = self._flat[i]
-            if flat is None or flat.numel() != n:
-                flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
-                self._flat[i] = flat
+            flat = self._flat_of(i)
             off = 0
             for p in bucket:
                 k = p.numel()
@@ -88,18 +169,9 @@ class GradBucketer:
                     flat[off:off + k].copy_(p.grad.reshape(-1))
                 off += k
             handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for i, bucket in enumerate(self.buckets):
+        for i in range(len(self.buckets)):
             handles[i].wait()
-            flat = self._flat[i]
-            flat.div_(world)
-            off = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + k].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + k].view_as(p))
-                off += k
+            self._scatter_back(i, world)
 
 
 @torch.no_grad()

@@ -72,3 +72,49 @@ def test_gloo_world2_grad_bucketer_and_loss_reduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _overlap_worker(rank, world, port, q):
+    """Real backward passes: overlapped bucketer (hooks fire during backward) == plain mean of per-rank gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    torch.manual_seed(0)                                      # identical initial weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 4))
+    unused = torch.nn.Parameter(torch.ones(5))                # never reaches the loss (find_unused_parameters case)
+    params = list(net.parameters()) + [unused]
+    gb = GradBucketer(params, bucket_mb=0.004, overlap=True)
+    ok = gb.num_collectives() >= 3
+    ok &= gb.buckets[0][0] is unused and gb.buckets[-1][-1] is params[0]      # reverse order: last layer first
+    for step in range(2):                                     # two steps: state resets between them
+        x = torch.randn(8, 16, generator=torch.Generator().manual_seed(100 * step + rank))
+        for p in params:
+            p.grad = None
+        net(x).pow(2).sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        launched = sum(h is not None for h in gb._handles)
+        ok &= launched >= 1                                   # some collectives were already in flight after backward
+        gb.finish()
+        for p, g in zip(params, local):
+            g = torch.zeros_like(p) if g is None else g
+            ref = g.clone()
+            dist.all_reduce(ref)
+            ok &= bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    gb.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world2_overlapped_grad_bucketer():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
