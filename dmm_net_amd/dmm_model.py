@@ -100,7 +100,8 @@ class DMM_Model(nn.Module):
         boxes_per_image = [len(box) for box in proposals]
         prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
         prop_m, prop_score = self._proposal_fields(proposals)
-        n_tplt = [int(tplt_valid_batch[b].sum().item()) for b in range(B)]
+        # live templates per video: one host sync unless the caller (video.FrameLoop) already knows them
+        n_tplt = infos.get("n_tplt") or [int(v) for v in tplt_valid_batch.sum(1).tolist()]
         skip = [n_tplt[b] == 0 or bool(extra_frame[b]) for b in range(B)]
         tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
         tg = None
@@ -121,7 +122,7 @@ class DMM_Model(nn.Module):
         boxes_per_image = [len(box) for box in proposals]
         prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
         prop_m, prop_score = self._proposal_fields(proposals)
-        n_tplt = [int(tplt_valid_batch[b].sum().item()) for b in range(B)]
+        n_tplt = [int(v) for v in tplt_valid_batch.sum(1).tolist()]         # one host sync for the whole batch
         skip = [n_tplt[b] == 0 for b in range(B)]
         tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
         full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,

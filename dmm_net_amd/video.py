@@ -204,7 +204,7 @@ class FrameLoop:
         dev = frames.device
         n_frames = list(n_frames) if n_frames is not None else [T] * B
         history, state, mask_hist = [], None, None
-        tplt_dict = tplt_valid = prev_mask = None
+        tplt_dict = tplt_valid = prev_mask = n_tplt = None
         for t in range(T):
             extra = [n <= t for n in n_frames]
             raw = [proposals[b][t] if len(proposals[b]) > t else proposals[b][-1] for b in range(B)]
@@ -215,8 +215,10 @@ class FrameLoop:
                 y_mask = targets[:, t].float().view(B, O, H * W)
             else:
                 y_mask = first_masks.new_zeros((B, O, H * W), dtype=torch.float32)
-            features = self.encoder(x)
+            # proposals first: their NMS ends in the step's only host sync (kept counts), which then waits for a few
+            # short kernels instead of the encoder; everything after it is enqueued without another sync
             props = self.prepare_proposals(raw, H, W, dev)
+            features = self.encoder(x)
             if t == 0:                                                   # forward_timestep_init, :215-225
                 tpl, valid = [], []
                 for b in range(B):
@@ -224,9 +226,10 @@ class FrameLoop:
                     tpl.append(bl)
                     valid.append(v)
                 tplt_valid = torch.stack(valid, 0)
+                n_tplt = [int(v) for v in tplt_valid.sum(1).tolist()]      # once per clip (the templates are fixed)
                 tplt_dict = self.dmm.fill_template_dict(None, tpl, features, y_mask, tplt_valid)
                 prev_mask = y_mask
-            infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B}
+            infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B, "n_tplt": n_tplt}
             hist_in = prev_mask.view(B, O, H, W) if mask_hist is None else mask_hist       # :168-169
             init_pred, tplt_dict, _, hist_new = self.dmm.inference(infos, props, features["backbone_feature"], hist_in,
                                                                    tplt_dict)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Inference frame loop (video.FrameLoop) wall time per frame on one MI355X: B videos, 255x448 frames, ResNet-50
+encoder (BatchNorm folded + HIP graph), raw 28x28 proposal masks pasted + NMS-filtered on the device, ROI features,
+DMM_Model.inference, label merge.  The refine decoder is not part of this package (refine=None)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from dmm_net_amd import video
+from dmm_net_amd.dmm_model import DMM_Model
+from dmm_net_amd.encoder import FeatureEncoder, GraphedEncoder, fold_batchnorm
+from dmm_net_amd.proposals import SimpleBoxList
+from dmm_net_amd.roi_features import FeatureExtractor
+
+dev = "cuda:0"
+B, T, O, H, W = int(os.environ.get("B", "4")), 12, 5, 255, 448
+rng = np.random.default_rng(0)
+cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+        "score_weight": 0.3}
+enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), autocast_dtype=torch.bfloat16)
+
+
+def raw(n):
+    x1, y1 = rng.uniform(0, W - 40, n), rng.uniform(0, H - 40, n)
+    boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(10, 150, n), W - 1), np.minimum(y1 + rng.uniform(10, 100, n), H - 1)], 1)
+    bl = SimpleBoxList(torch.from_numpy(boxes.astype(np.float32)), (W, H))
+    bl.add_field("scores", torch.from_numpy(rng.random(n).astype(np.float32)))
+    bl.add_field("mask", torch.from_numpy((rng.random((n, 1, 28, 28)) * 0.6 + 0.4).astype(np.float32)))
+    return bl
+
+
+frames = torch.randn(B, T, 3, H, W, device=dev)
+props = [[raw(50).to(dev) for _ in range(T)] for _ in range(B)]
+first = torch.zeros(B, O, H, W, device=dev)
+for b in range(B):
+    for o in range(3 + b % 3):
+        y0, x0 = int(rng.integers(0, H - 60)), int(rng.integers(0, W - 60))
+        first[b, o, y0:y0 + 50, x0:x0 + 55] = 1.0
+first = first.view(B, O, H * W)
+loop = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4, max_proposals=50)
+labels = []
+loop.run(frames[:, :3], first, props, on_labels=lambda b, t, lab: None)          # warm-up (graph capture, MIOpen)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+loop.run(frames, first, props, on_labels=lambda b, t, lab: labels.append(lab))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"FrameLoop B={B} videos x {T} frames: {dt / T * 1e3:.2f} ms per frame step = {B * T / dt:.0f} frames/s")
+if os.environ.get("PROFILE"):
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    loop.run(frames, first, props, on_labels=lambda b, t, lab: None)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
