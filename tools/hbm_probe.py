@@ -52,6 +52,11 @@ for unroll in (1, 2, 4):
         print(f"read planes (cost-kernel pattern) unroll {unroll} wgs {wgs:6d}: {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
 L.probe_read_planes_run.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
 L.probe_read_planes_split.argtypes = [vp, ci, ci, ci, vp, vp]
+L.probe_read_planes_aligned.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
+for rep in range(2):
+    for al in (16, 64, 128):
+        t = timed(lambda: L.probe_read_planes_aligned(src.data_ptr(), BF, PL, HW, 8192, al, sink.data_ptr(), st))
+        print(f"read planes, runs aligned down to {al:3d} B (8192 wgs)     : {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
 for rep in range(2):
     t = timed(lambda: L.probe_read_planes_split(src.data_ptr(), BF, PL, HW, sink.data_ptr(), st))
     print(f"read planes split (1 chunk / WG, waves split planes): {BF * PL * (HW // 1024) * 4096 / t / 1e9:7.1f} GB/s")
