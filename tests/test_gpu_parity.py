@@ -557,6 +557,78 @@ def test_forward_is_hipgraph_capturable():
         assert torch.equal(a, b)
 
 
+def test_pipelined_two_stream_schedule_is_hipgraph_capturable():
+    """The 2-lane schedule (streaming lane on the current stream, latency lane forked / joined with HIP events on a side
+    stream) captures into ONE HIP graph; the replay on new inputs equals the single-stream eager forward."""
+    c = synth.CONFIGS[1]
+    B = 6
+    g = torch.Generator(device=DEV).manual_seed(12)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    pm, tm = mk(B, c["P"], c["H"], c["W"]), mk(B, c["O"], c["H"], c["W"])
+    pf, tf, sc = mk(B, c["P"], c["D"]) - 0.5, mk(B, c["O"], c["D"]) - 0.5, mk(B, c["P"])
+    plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=True)
+    assert plan.pipeline and len(plan.halves) == 2
+    plan.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)
+    for t, shape in ((pm, (B, c["P"], c["H"], c["W"])), (tm, (B, c["O"], c["H"], c["W"]))):
+        t.copy_(mk(*shape))
+    pf.copy_(mk(B, c["P"], c["D"]) - 0.5)
+    sc.copy_(mk(B, c["P"]))
+    graph.replay()
+    graph.replay()                                           # replays are idempotent (tables are re-zeroed inside)
+    torch.cuda.synchronize()
+    ref = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+    ref.run(pm, tm, pf, tf, sc, max_iter=20, proj_iter=5, is_test=1)
+    torch.cuda.synchronize()
+    for a, b in zip((plan.full_outmask, plan.match_score, plan.det_score, plan.R, plan.iters, plan.sim),
+                    (ref.full_outmask, ref.match_score, ref.det_score, ref.R, ref.iters, ref.sim)):
+        assert torch.equal(a, b)
+
+
+def test_entry_points_are_reentrant_across_threads_and_streams():
+    """SURVEY 8b threading contract (nn.DataParallel-style callers): two host threads drive the fused forward on their
+    own streams and workspaces at the same time; each result equals the single-threaded one."""
+    import threading
+    c = synth.CONFIGS[1]
+    B, reps = 4, 6
+    data, expect = [], []
+    for k in range(2):
+        g = torch.Generator(device=DEV).manual_seed(50 + k)
+        mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+        d = (mk(B, c["P"], c["H"], c["W"]), mk(B, c["O"], c["H"], c["W"]), mk(B, c["P"], c["D"]) - 0.5,
+             mk(B, c["O"], c["D"]) - 0.5, mk(B, c["P"]))
+        data.append(d)
+        ref = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+        ref.run(*d, max_iter=20, proj_iter=5, is_test=1)
+        expect.append([t.clone() for t in (ref.full_outmask, ref.match_score, ref.det_score, ref.iters)])
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(device=DEV)
+            plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    plan.run(*data[k], max_iter=20, proj_iter=5, is_test=1)
+                stream.synchronize()
+                for a, b in zip((plan.full_outmask, plan.match_score, plan.det_score, plan.iters), expect[k]):
+                    if not torch.equal(a, b):
+                        errors.append((k, "mismatch"))
+        except Exception as e:                                # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_solver_every_row_count_and_width_class_bit_exact():
     """Sweep all row counts 1..32 (exact-row and guarded instantiations) against widths that hit every column/row-sum
     class of the reference's reduction order (m < 8, multiples of 8 / 32, tails, 1 / 2 / 4 waves): bit exact vs the oracle."""
