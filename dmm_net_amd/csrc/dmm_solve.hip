@@ -111,6 +111,8 @@ __device__ __forceinline__ void row_sums_torch_order(const float *xbuf, int n, i
     const int l = threadIdx.x & 7;
     for (int r = threadIdx.x >> 3; r < n; r += 8 * NG) {
         const float *x = xbuf + r * m;
+        // (a batched-read variant, torder::inner_sum_group8_batched, measured 25 % SLOWER per sweep here: at m = 200
+        // it fetches 42 words where 25 are needed and the clamping arithmetic outweighs the saved round trips)
         const float s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });   // m <= 256
         if (l == 0) rsbuf[r] = s;
     }
@@ -122,13 +124,47 @@ template <int MT>
 __device__ __forceinline__ void row_sums_torch_order_wave(const float *xbuf, int n, int m, float (&rs)[MT]) {
     __syncthreads();                                   // xbuf complete (one wave: just drains the LDS queue)
     const int lane = threadIdx.x & 63, l = lane & 7, g = lane >> 3;
+    // m <= 64 here (one wave).  Same order as torder::inner_sum_group8_small, but every LDS word a group can need --
+    // the 8 vector slots x[8 i + l] and up to 7 tail scalars -- is fetched up front in one batch (the loop form kept
+    // ONE ds_read in flight per step: ~5 serialized LDS round trips per pass); the adds then follow the ATen order
+    // under wave-uniform conditions on m.  Reads beyond the row stay inside xbuf and are never used.
+    const int vs = m >> 3, gq = vs >> 2, tail0 = vs << 3, ntail = m - tail0;
 #pragma unroll
     for (int p = 0; p < (MT + 7) / 8; ++p) {
         const int r = p * 8 + g;
-        float s = 0.0f;
-        if (r < n) {
-            const float *x = xbuf + r * m;
-            s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });
+        const int rr = r < n ? r : n - 1;
+        const float *x = xbuf + rr * m;
+        float v[8], t[7];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = x[8 * i + l];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int idx = rr * m + tail0 + k;
+            t[k] = xbuf[idx < MT * 64 ? idx : MT * 64 - 1];
+        }
+        float s;
+        if (m < torder::TV) {                          // scalar_inner_sum: ILP-4 over single elements (= the tail array)
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+            if (m >= 4) { p0 = p0 + t[0]; p1 = p1 + t[1]; p2 = p2 + t[2]; p3 = p3 + t[3]; }
+            const int b4 = m & ~3;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k >= b4 && k < m) p0 = p0 + t[k];
+            p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+            s = p0;
+        } else {
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+            if (gq >= 1) { p0 = p0 + v[0]; p1 = p1 + v[1]; p2 = p2 + v[2]; p3 = p3 + v[3]; }
+            if (gq >= 2) { p0 = p0 + v[4]; p1 = p1 + v[5]; p2 = p2 + v[6]; p3 = p3 + v[7]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i >= 4 * gq && i < vs) p0 = p0 + v[i];
+            p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;   // vec[l]
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < ntail) acc = acc + t[k];
+            s = torder::add_group8_seq(acc, p0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -224,8 +260,12 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 const float g = prm.lr * C[i];
                 X[i] = X[i] - g;
                 acc[i] = acc[i] + X[i];
-                if (live) xbuf[i * m + col] = X[i] * C[i];
             }
+        }
+        if (live) {                                              // one predicated block, not one exec dance per row
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (DMM_ROW(i)) xbuf[i * m + col] = X[i] * C[i];
         }
         const float cost = norm_torch_order(xbuf, n * m, rsbuf + MT);
         if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
@@ -289,8 +329,12 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                     P1[i] = x - y;
                     x = y + P2[i];
                     X[i] = x;
-                    if (live) xbuf[i * m + col] = x;
                 }
+            }
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (DMM_ROW(i)) xbuf[i * m + col] = X[i];
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
             float rsv[MT];
@@ -301,20 +345,22 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
 #pragma unroll
                 for (int i = 0; i < MT; ++i) rsv[i] = DMM_ROW(i) ? rsbuf[i] : 0.0f;
             }
-            bool moved = false;
-#pragma unroll
+            unsigned moved_bits = 0;                            // OR of the squares' bit patterns: non-zero <=> some square
+#pragma unroll                                                  // is non-zero (a NaN has non-zero bits: "moved")
             for (int i = 0; i < MT; ++i) {
-                if (DMM_ROW(i) && live) {
-                    const float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
+                if (DMM_ROW(i)) {
+                    float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
+                    tr = live ? tr : 0.0f;                      // dead columns keep their zeros (x - 0 = x, P2 = 0)
                     const float x = X[i];
                     const float y = x - tr;
                     P2[i] = x - y;
                     X[i] = y;                                   // :86
                     const float d = y - Xs[i];
                     const float sq = d * d;
-                    moved = moved || !(sq == 0.0f);             // NaN counts as "moved", like norm() == 0 being false
+                    moved_bits |= __float_as_uint(sq);
                 }
             }
+            const bool moved = moved_bits != 0u;
             // if ||X - X_start|| == 0: break (:88-89).  A sum of squares is zero iff every square rounds to zero,
             // whatever the order: "no lane saw a non-zero square" is exactly the reference's decision.
             float mv[1] = {__ballot(moved) != 0ull ? 1.0f : 0.0f};

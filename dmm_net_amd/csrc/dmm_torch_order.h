@@ -164,6 +164,54 @@ __device__ __forceinline__ float inner_sum_group8_small(int n, int l, F x) {
     return add_group8_seq(acc, p0);
 }
 
+// inner_sum_group8_small with the LDS / memory reads BATCHED: the remainder slots, the tail scalars and 16 vector
+// slots at a time are fetched before any add (the loop form keeps one read in flight per step, i.e. one full LDS
+// round trip per slot).  Same add order, same result.  x(i) must be readable for every 0 <= i < n; n < 512.
+template <typename F>
+__device__ __forceinline__ float inner_sum_group8_batched(int n, int l, F x) {
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    if (n < TV) {                                       // scalar_inner_sum: ILP-4 over single elements
+        float t[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t[k] = x(k < n ? k : n - 1);
+        if (n >= 4) { p0 = p0 + t[0]; p1 = p1 + t[1]; p2 = p2 + t[2]; p3 = p3 + t[3]; }
+        const int b4 = n & ~3;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k >= b4 && k < n) p0 = p0 + t[k];
+        p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+        return p0;
+    }
+    const int vs = n >> 3, g = vs >> 2, tail0 = vs * TV;
+    float rem[3], t[7];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rem[j] = x(TV * (4 * g + j < vs ? 4 * g + j : vs - 1) + l);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t[k] = x(tail0 + k < n ? tail0 + k : n - 1);
+    for (int q0 = 0; q0 < g; q0 += 4) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int slot = 4 * q0 + u;
+            v[u] = x(TV * (slot < vs ? slot : vs - 1) + l);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            if (q0 + qq < g) {
+                p0 = p0 + v[4 * qq]; p1 = p1 + v[4 * qq + 1]; p2 = p2 + v[4 * qq + 2]; p3 = p3 + v[4 * qq + 3];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (4 * g + j < vs) p0 = p0 + rem[j];
+    p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;           // vec[l]
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (tail0 + k < n) acc = acc + t[k];
+    return add_group8_seq(acc, p0);
+}
+
 // ||x[0..n)||_2 in the order of ATen's 2-norm fast path: 8 fma lanes, lanes added in order, tail in groups
 // of 4 (square rounded, then added), final < 4 remainder fused.  Computed by an aligned 8-lane group,
 // valid in its lane 0.
@@ -172,12 +220,19 @@ __device__ __forceinline__ float norm2_group8(long n, int l, F x) {
     float a = 0.0f;
     const long nv = n - (n % TV);
     long d4 = 0;
-    for (; d4 + 8 * TV <= nv; d4 += 8 * TV) {           // 8 independent loads in flight, fmas stay in order
-        float v[8];
+    for (; d4 + 16 * TV <= nv; d4 += 16 * TV) {         // 16 independent loads in flight, fmas stay in order
+        float v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x(d4 + q * TV + l);
+        for (int q = 0; q < 16; ++q) v[q] = x(d4 + q * TV + l);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a = __builtin_fmaf(v[q], v[q], a);
+        for (int q = 0; q < 16; ++q) a = __builtin_fmaf(v[q], v[q], a);
+    }
+    for (; d4 + 4 * TV <= nv; d4 += 4 * TV) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = x(d4 + q * TV + l);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a = __builtin_fmaf(v[q], v[q], a);
     }
     for (; d4 < nv; d4 += TV) {
         const float v = x(d4 + l);
