@@ -5,8 +5,9 @@
 //    pad the M x M mask probability, expand the box about its centre, truncate to int, bilinear-resize the padded
 //    mask into the box (torch F.interpolate, align_corners=False) and paste it into an H x W plane -- exactly the
 //    soft [P, H, W] masks the matching layer consumes -- and return the tight box of (plane > thresh).
-//    One workgroup per proposal; the (M+2)^2 padded mask sits in LDS, plane rows are written coalesced, the whole
-//    plane is produced (zeros outside the box) so no separate memset is needed.  HBM bound (plane writes).
+//    A proposal's plane is cut into bands of 4096 pixels, one workgroup each (a first one-workgroup-per-proposal version
+//    kept 50 CUs busy and wrote at 0.27 TB/s); the (M+2)^2 padded mask sits in LDS, 16-byte stores, the whole plane is
+//    produced (zeros outside the box) so no separate memset is needed.  HBM bound (plane writes).
 //  * nms_kernel: filter_results' NMS + top-k (dmm/utils/boxlist_ops.py:15-29; maskrcnn_benchmark nms semantics:
 //    descending score, legacy +1 areas, IoU > thresh suppresses).  One workgroup per image, <= 1024 boxes: rank by
 //    counting (stable), pairwise suppression bitmask in LDS, serial greedy scan by one lane.
@@ -16,6 +17,27 @@ namespace dmm {
 
 constexpr int kNmsMax = 1024;
 
+constexpr int kPasteIters = 4;       // 1024-pixel steps per workgroup (a band of the plane)
+
+// Tight boxes are reduced ACROSS the band workgroups of a proposal with integer atomics on the bit patterns of the
+// (non-negative, integer-valued) float coordinates in new_boxes itself: init = [W, H, -1, -1], atomicMin / atomicMax as
+// signed ints (order-preserving for floats >= 0; -1.0f is below all of them), then a finalize pass writes the
+// reference's empty-mask box.
+__global__ void paste_init_kernel(float *__restrict__ new_boxes, int P, int im_h, int im_w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float *nb = new_boxes + (int64_t)p * 4;
+    nb[0] = (float)im_w; nb[1] = (float)im_h; nb[2] = -1.0f; nb[3] = -1.0f;
+}
+__global__ void paste_finalize_kernel(float *__restrict__ new_boxes, int P, int im_h, int im_w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float *nb = new_boxes + (int64_t)p * 4;
+    if (nb[2] < 0.0f) { nb[0] = 0.0f; nb[1] = 0.0f; nb[2] = (float)im_h; nb[3] = (float)im_w; }   // masker.py:164
+}
+
+// grid = (bands, P); block = 256.  Every workgroup re-stages the (M + 2 pad)^2 probabilities in LDS (3.6 KB) and writes
+// kPasteIters * 1024 consecutive pixels of the plane, 16 bytes per thread and store.
 __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restrict__ prob, int M,
                                                           const float *__restrict__ boxes, int im_h, int im_w,
                                                           float thresh, int padding, float *__restrict__ planes,
@@ -23,7 +45,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
                                                           unsigned long long *__restrict__ packed, int64_t packed_stride) {
     __shared__ float pad_s[64 * 64];
     __shared__ int box_s[4];
-    const int p = blockIdx.x;
+    const int p = blockIdx.y;
     const int Mp = M + 2 * padding;
     for (int i = threadIdx.x; i < Mp * Mp; i += 256) {
         const int y = i / Mp - padding, x = i % Mp - padding;
@@ -50,36 +72,43 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
     // each thread produces 4 consecutive pixels per step, a wave 256: exactly one block of the packed ballot layout
     const int HW = im_h * im_w;
     const int lane = threadIdx.x & 63;
-    for (int i4 = 4 * threadIdx.x; i4 < ((HW + 255) / 256) * 256; i4 += 1024) {
+    const int i_end = min(((HW + 255) / 256) * 256, (int)(blockIdx.x + 1) * kPasteIters * 1024);
+    for (int i4 = blockIdx.x * kPasteIters * 1024 + 4 * threadIdx.x; i4 < i_end; i4 += 1024) {
         float vv[4];
+        int y = i4 / im_w, x = i4 - y * im_w;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int i = i4 + k;
             float v = 0.0f;
-            if (i < HW) {
-                const int y = i / im_w, x = i - y * im_w;
-                if (y >= y_0 && y < y_1 && x >= x_0 && x < x_1) {
-                    float ry = __builtin_fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
-                    ry = ry < 0.0f ? 0.0f : ry;
-                    const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
-                    const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
-                    float rx = __builtin_fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
-                    rx = rx < 0.0f ? 0.0f : rx;
-                    const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
-                    const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
-                    const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
-                    const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
-                    const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
-                    const float lb = ly1 * bot;
-                    v = __builtin_fmaf(ly0, top, lb);
-                    if (v > thresh) {
-                        xmin = min(xmin, x); xmax = max(xmax, x);
-                        ymin = min(ymin, y); ymax = max(ymax, y);
-                    }
+            if (i4 + k < HW && y >= y_0 && y < y_1 && x >= x_0 && x < x_1) {
+                float ry = __builtin_fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
+                ry = ry < 0.0f ? 0.0f : ry;
+                const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
+                const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
+                float rx = __builtin_fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
+                rx = rx < 0.0f ? 0.0f : rx;
+                const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
+                const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
+                const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
+                const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
+                const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
+                const float lb = ly1 * bot;
+                v = __builtin_fmaf(ly0, top, lb);
+                if (v > thresh) {
+                    xmin = min(xmin, x); xmax = max(xmax, x);
+                    ymin = min(ymin, y); ymax = max(ymax, y);
                 }
-                plane[i] = v;
             }
             vv[k] = v;
+            if (++x == im_w) { x = 0; ++y; }
+        }
+        if (i4 + 3 < HW) {
+            float4u t;
+            t.x = vv[0]; t.y = vv[1]; t.z = vv[2]; t.w = vv[3];
+            *reinterpret_cast<float4u *>(plane + i4) = t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i4 + k < HW) plane[i4 + k] = vv[k];
         }
         if (packed) {
             const unsigned long long b0 = __ballot(vv[0] > 0.5f), b1 = __ballot(vv[1] > 0.5f);
@@ -89,15 +118,19 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
                     lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
         }
     }
-    atomicMin(&box_s[0], xmin);
-    atomicMin(&box_s[1], ymin);
-    atomicMax(&box_s[2], xmax);
-    atomicMax(&box_s[3], ymax);
+    if (xmax >= 0) {
+        atomicMin(&box_s[0], xmin);
+        atomicMin(&box_s[1], ymin);
+        atomicMax(&box_s[2], xmax);
+        atomicMax(&box_s[3], ymax);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float *nb = new_boxes + (int64_t)p * 4;
-        if (box_s[2] < 0) { nb[0] = 0.0f; nb[1] = 0.0f; nb[2] = (float)im_h; nb[3] = (float)im_w; }   // masker.py:164
-        else { nb[0] = (float)box_s[0]; nb[1] = (float)box_s[1]; nb[2] = (float)box_s[2]; nb[3] = (float)box_s[3]; }
+    if (threadIdx.x == 0 && box_s[2] >= 0) {
+        int *nb = reinterpret_cast<int *>(new_boxes + (int64_t)p * 4);
+        atomicMin(&nb[0], __float_as_int((float)box_s[0]));
+        atomicMin(&nb[1], __float_as_int((float)box_s[1]));
+        atomicMax(&nb[2], __float_as_int((float)box_s[2]));
+        atomicMax(&nb[3], __float_as_int((float)box_s[3]));
     }
 }
 
@@ -164,9 +197,21 @@ extern "C" int dmm_paste_masks_f32(const float *prob, int P, int M, const float 
     if (P == 0) return DMM_OK;
     if (!prob || !boxes || !planes || !new_boxes || plane_stride < (int64_t)im_h * im_w) return DMM_ERR_BAD_ARG;
     if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(dmm::paste_masks_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, prob, M, boxes, im_h, im_w,
-                       thresh, padding, planes, plane_stride, new_boxes, reinterpret_cast<unsigned long long *>(packed),
-                       dmm_pack_words(im_h * im_w));
+    const int nsteps = (im_h * im_w + 1023) / 1024;
+    const int bands = (nsteps + dmm::kPasteIters - 1) / dmm::kPasteIters;
+    hipStream_t s = (hipStream_t)stream;
+    for (int p0 = 0; p0 < P; p0 += 65535) {                     // grid.y limit
+        const int np = P - p0 < 65535 ? P - p0 : 65535;
+        float *nb = new_boxes + (int64_t)p0 * 4;
+        hipLaunchKernelGGL(dmm::paste_init_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nb, np, im_h, im_w);
+        hipLaunchKernelGGL(dmm::paste_masks_kernel, dim3(bands, np), dim3(256), 0, s, prob + (int64_t)p0 * M * M, M,
+                           boxes + (int64_t)p0 * 4, im_h, im_w, thresh, padding, planes + (int64_t)p0 * plane_stride,
+                           plane_stride, nb,
+                           packed ? reinterpret_cast<unsigned long long *>(packed) + (int64_t)p0 * dmm_pack_words(im_h * im_w)
+                                  : nullptr,
+                           dmm_pack_words(im_h * im_w));
+        hipLaunchKernelGGL(dmm::paste_finalize_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nb, np, im_h, im_w);
+    }
     return dmm::check_launch();
 }
 

@@ -237,12 +237,23 @@ class GraphedEncoder:
     before the next call.  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
     """
 
-    def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3):
+    def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3, weights_dtype=None):
+        """``weights_dtype=torch.bfloat16`` converts the (BatchNorm-folded) encoder's parameters ONCE and runs the whole
+        forward in that dtype; ``autocast_dtype`` keeps fp32 parameters and lets autocast re-cast all of them on every
+        replay (131 cast kernels per ResNet-50 forward, ~15 % of the graph).  Use one or the other."""
         assert not encoder.training, "capture needs eval() mode"
-        self.encoder, self.dtype, self.warmup = encoder, autocast_dtype, int(warmup)
+        assert autocast_dtype is None or weights_dtype is None
+        if weights_dtype is not None:
+            assert not any(isinstance(m, nn.BatchNorm2d) for m in encoder.modules()), \
+                "fold_batchnorm() first: BatchNorm statistics should not be rounded to a 16-bit type"
+            encoder = encoder.to(weights_dtype)
+        self.encoder, self.dtype, self.warmup, self.wdtype = encoder, autocast_dtype, int(warmup), weights_dtype
         self._graphs = {}
 
     def _forward(self, x):
+        if self.wdtype is not None:
+            with torch.no_grad():
+                return self.encoder(x.to(self.wdtype))
         with torch.no_grad(), torch.autocast("cuda", dtype=self.dtype or torch.bfloat16, enabled=self.dtype is not None):
             return self.encoder(x)
 

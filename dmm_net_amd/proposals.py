@@ -118,11 +118,20 @@ def filter_results(boxlists: List, nms_thresh: float = 0.8, max_proposals: int =
 
 
 def forward_mask_prop(mask_prob: Sequence[torch.Tensor], boxlists: Sequence, thresh: float = 0.4, padding: int = 1):
-    """MaskPostProcessor.forward_mask_prop (masker.py:27-50): paste every image's masks, re-box tightly, carry the fields."""
+    """MaskPostProcessor.forward_mask_prop (masker.py:27-50): paste every image's masks, re-box tightly, carry the fields.
+    Images of one size (the usual case: one clip) go through ONE paste launch; the per-image planes are views of it."""
+    sizes = {tuple(bl.size) for bl in boxlists}
+    counts = [len(bl) for bl in boxlists]
+    if len(sizes) == 1 and len(boxlists) > 1 and sum(counts) > 0:
+        im_w, im_h = boxlists[0].size
+        planes, tight = paste_masks(torch.cat(list(mask_prob), 0), torch.cat([bl.bbox for bl in boxlists], 0), im_h, im_w,
+                                    thresh, padding)
+        per_image = list(zip(planes.split(counts, 0), tight.split(counts, 0)))
+    else:
+        per_image = [paste_masks(prob, bl.bbox, bl.size[1], bl.size[0], thresh, padding)
+                     for prob, bl in zip(mask_prob, boxlists)]
     out = []
-    for prob, bl in zip(mask_prob, boxlists):
-        im_w, im_h = bl.size
-        planes, tight = paste_masks(prob, bl.bbox, im_h, im_w, thresh, padding)
+    for (planes, tight), bl in zip(per_image, boxlists):
         nb = SimpleBoxList(tight, bl.size, "xyxy")
         for f in bl.fields():
             nb.add_field(f, bl.get_field(f))

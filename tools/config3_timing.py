@@ -67,7 +67,7 @@ for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
     enc_nchw.load_state_dict(fold_batchnorm(enc.to(memory_format=torch.contiguous_format)).state_dict())
     enc.to(memory_format=torch.channels_last)
     img_nchw = img.contiguous()
-    genc_ = GraphedEncoder(enc_nchw, autocast_dtype=None if dt == torch.float32 else dt)
+    genc_ = GraphedEncoder(enc_nchw, weights_dtype=None if dt == torch.float32 else dt)
     genc = lambda x: genc_(img_nchw)
     t_genc, gbf = timed(lambda: genc(img)["backbone_feature"])
     err = max(float((a.float() - b.float()).abs().max()) for a, b in zip(gbf, bf))

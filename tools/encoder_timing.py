@@ -42,4 +42,10 @@ for cl in (False, True):
         t_f = timed(lambda: run(folded))
         g = GraphedEncoder(folded, autocast_dtype=None if dt == torch.float32 else dt)
         t_g = timed(lambda: g(img))
-        print(f"channels_last={cl!s:5} {str(dt):15}: eager {t_e:.3f} ms | BN folded {t_f:.3f} ms | folded + HIP graph {t_g:.3f} ms")
+        msg = f"channels_last={cl!s:5} {str(dt):15}: eager {t_e:.3f} ms | BN folded {t_f:.3f} ms | folded + HIP graph {t_g:.3f} ms"
+        if dt != torch.float32:
+            import copy
+            g2 = GraphedEncoder(copy.deepcopy(folded), weights_dtype=dt)
+            t_w = timed(lambda: g2(img))
+            msg += f" | folded + {str(dt).split('.')[-1]} weights + HIP graph {t_w:.3f} ms"
+        print(msg)

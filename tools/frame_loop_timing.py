@@ -19,7 +19,7 @@ B, T, O, H, W = int(os.environ.get("B", "4")), 12, 5, 255, 448
 rng = np.random.default_rng(0)
 cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
         "score_weight": 0.3}
-enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), autocast_dtype=torch.bfloat16)
+enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), weights_dtype=torch.bfloat16)
 
 
 def raw(n):
@@ -57,3 +57,13 @@ if os.environ.get("PROFILE"):
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+if os.environ.get("KERNELS"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        loop.run(frames, first, props, on_labels=lambda b, t, lab: None)
+        torch.cuda.synchronize()
+    rows = [(e.key, e.self_device_time_total / T / 1e3, e.count / T) for e in prof.key_averages()]
+    tot = sum(r[1] for r in rows)
+    print(f"GPU kernel time per frame step: {tot:.3f} ms")
+    for k, t, c in sorted(rows, key=lambda r: -r[1])[:16]:
+        print(f"  {k[:100]:100s} {t:7.3f} ms/frame  x{c:.1f}")
