@@ -74,6 +74,8 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
         return DMM_ERR_BAD_ARG;
     const int Pp = N > M ? N : M + 1;
     if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    // the mix needs the pixel values: 1-bit planes are an input format of dmm_iou_counts only (reject before any launch)
+    if (mask_dtype != DMM_F32 && mask_dtype != DMM_F16 && mask_dtype != DMM_BF16) return DMM_ERR_BAD_ARG;
     dmm::Workspace w = dmm::carve(workspace, B, N, M, D);
     if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
     int rc = dmm_iou_counts(masks_p, masks_t, mask_dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid,

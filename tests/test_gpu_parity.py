@@ -686,6 +686,14 @@ def test_envelope_errors_are_loud():
         ops.relax_solve(torch.zeros((1, 33, 40), device=DEV), 1, 1, 0.1)
     with pytest.raises(_lib.DmmError, match="MI355X"):
         ops.iou_counts(pm.cpu(), tm.cpu())                     # no CPU fallback
+    # the fused forward needs pixel values for the mix: the 1-bit plane format is rejected before anything is launched
+    L = _lib.load()
+    ws = torch.empty(int(L.dmm_workspace_bytes(1, 8, 4, 16)), dtype=torch.uint8, device=DEV)
+    z = torch.zeros(4096, device=DEV)
+    rc = L.dmm_match_forward(z.data_ptr(), z.data_ptr(), _lib.DTYPE_PACKED1, z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                             1, 8, 4, 64, 16, 8 * 64, 64, 4 * 64, 64, None, None, 0.3, 2, 2, 0.1, 1, z.data_ptr(),
+                             z.data_ptr(), z.data_ptr(), None, None, None, None, ws.data_ptr(), ws.numel(), None)
+    assert rc == 1 and L.dmm_status_string(rc).decode() == "bad argument"
 
 
 def test_iou_counts_batch_beyond_grid_limit():
