@@ -4,7 +4,7 @@
 // `x > 0.5` (reference dmm/utils/match_helper.py:16-17).  Planes that are matched more than once (training: templates
 // AND targets; any re-use across calls) or that this library produces itself (dmm_paste_masks_f32) can be handed to
 // dmm_iou_counts already packed: 32x fewer bytes for fp32 sources, identical integer tables.
-// One wave packs 4 x 256 pixels per step: four lane loads in flight, 16 v_cmp ballots, lanes 0..15 store the words.
+// One wave packs 4 x 256 pixels per step: four lane loads in flight, 16 v_cmp ballots, the 16 words go to LDS.
 // Roofline: HBM (read side).
 #include <stdlib.h>
 
@@ -12,9 +12,7 @@
 
 namespace dmm {
 
-// grid = (gx, planes); block = 256.  A wave packs 4 consecutive blocks of 256 pixels per iteration (4 lane loads,
-// 16 ballots, lanes 0..15 store the 16 words = one 128-byte line) and walks the plane with the loads of the next
-// iteration already in flight.  Default = 1 iteration per wave (tiny workgroups measured best: 5.6 vs 5.4 TB/s at 16).
+// The 4 blocks (1024 pixels) a wave packs per iteration; the loads of the next iteration are issued before the ballots.
 template <typename T>
 __device__ __forceinline__ void pack_load(const T *src, int HW, int q0, int lane, float (&v)[4][4]) {
     if ((q0 + 4) * 256 <= HW) {                 // wave-uniform: the 4 loads issue back to back, no per-load branch
@@ -30,23 +28,30 @@ __device__ __forceinline__ void pack_load(const T *src, int HW, int q0, int lane
     }
 }
 
+constexpr int kPackSeg = 256;        // blocks of 256 pixels a workgroup packs per segment: 64 Ki pixels -> 8 KiB of words
+
+// grid = (segments, planes); block = 256.  The words of a segment are STAGED IN LDS and written out as one contiguous
+// 8 KiB burst at the end: a 128-byte store after every 4 KiB of reads (the first version) cost 20 % of the read
+// stream -- the same kernel with the stores removed reads at 6.75 TB/s, with them at 5.4 -- although the stores are
+// 3 % of the bytes.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_masks_kernel(const T *__restrict__ masks, int HW, int64_t plane_stride,
                                                          unsigned long long *__restrict__ packed,
                                                          int64_t packed_stride) {
+    __shared__ unsigned long long stage[kPackSeg * 4];
     const int64_t plane = blockIdx.y;
     const T *src = masks + plane * plane_stride;
     unsigned long long *dst = packed + plane * packed_stride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nblocks = (HW + 255) / 256;
-    const int stride = gridDim.x * 16;
-    int q0 = (blockIdx.x * 4 + wave) * 4;
-    if (q0 >= nblocks) return;
+    const int seg0 = blockIdx.x * kPackSeg;
+    const int seg_end = min(nblocks, seg0 + kPackSeg);
+    int q0 = seg0 + wave * 4;
     float cur[4][4], nxt[4][4];
-    pack_load<T>(src, HW, q0, lane, cur);
-    for (; q0 < nblocks; q0 += stride) {
-        const bool more = q0 + stride < nblocks;
-        if (more) pack_load<T>(src, HW, q0 + stride, lane, nxt);
+    if (q0 < seg_end) pack_load<T>(src, HW, q0, lane, cur);
+    for (; q0 < seg_end; q0 += 16) {
+        const bool more = q0 + 16 < seg_end;
+        if (more) pack_load<T>(src, HW, q0 + 16, lane, nxt);
         unsigned long long w = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void pack_masks_kernel(const T *__restrict__ m
                 const unsigned long long bal = __ballot(cur[u][k] > 0.5f);
                 w = lane == 4 * u + k ? bal : w;
             }
-        if (lane < 16 && q0 + (lane >> 2) < nblocks) dst[4 * q0 + lane] = w;
+        if (lane < 16) stage[4 * (q0 - seg0) + lane] = w;      // words of blocks past the plane are never copied out
         if (more) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -63,15 +68,16 @@ __global__ __launch_bounds__(256) void pack_masks_kernel(const T *__restrict__ m
                 for (int k = 0; k < 4; ++k) cur[u][k] = nxt[u][k];
         }
     }
+    __syncthreads();
+    const int nwords = 4 * (seg_end - seg0);
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[4 * seg0 + i] = stage[i];
 }
 
 template <typename T>
 static int pack_typed(const T *masks, int64_t planes, int HW, int64_t plane_stride, unsigned long long *packed,
                       int64_t packed_stride, hipStream_t stream) {
     const int nblocks = (HW + 255) / 256;
-    static const int iters = [] { const char *e = getenv("DMM_PACK_ITERS"); return e ? atoi(e) : 1; }();
-    int gx = (nblocks + 16 * iters - 1) / (16 * iters);
-    if (gx > 1024) gx = 1024;
+    const int gx = (nblocks + kPackSeg - 1) / kPackSeg;
     for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
         const int64_t np = planes - p0 < 65535 ? planes - p0 : 65535;
         hipLaunchKernelGGL((pack_masks_kernel<T>), dim3(gx, (unsigned)np), dim3(256), 0, stream, masks + p0 * plane_stride,
