@@ -255,17 +255,14 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
     for (int it = 0; it < prm.max_iter; ++it) {
         // gradient step X = X - lr*C  (:69); cost = ||X*C||_F (:70); X_list.append(X) (:71)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            if (DMM_ROW(i)) {
-                const float g = prm.lr * C[i];
-                X[i] = X[i] - g;
-                acc[i] = acc[i] + X[i];
-            }
+        for (int i = 0; i < MT; ++i) {                           // rows >= n hold zeros in C, X, P*: no guards needed
+            const float g = prm.lr * C[i];
+            X[i] = X[i] - g;
+            acc[i] = acc[i] + X[i];
         }
         if (live) {                                              // one predicated block, not one exec dance per row
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                if (DMM_ROW(i)) xbuf[i * m + col] = X[i] * C[i];
+            for (int i = 0; i < MT; ++i) xbuf[i * m + col] = X[i] * C[i];   // rows >= n land past the n x m matrix
         }
         const float cost = norm_torch_order(xbuf, n * m, rsbuf + MT);
         if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
@@ -279,13 +276,11 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 Xs[i] = X[i];
-                if (DMM_ROW(i)) {
-                    float x = X[i] + P0[i];
-                    const float y = x > 0.0f ? x : 0.0f;
-                    if (TAPE && x > 0.0f) relu_bits |= 1u << i;
-                    P0[i] = x - y;
-                    X[i] = y + P1[i];
-                }
+                float x = X[i] + P0[i];
+                const float y = x > 0.0f ? x : 0.0f;
+                if (TAPE && x > 0.0f) relu_bits |= 1u << i;
+                P0[i] = x - y;
+                X[i] = y + P1[i];
             }
             // X.sum(dim=0) in ATen's outer-sum order for this column's class (in-lane)
             float cs;
@@ -294,20 +289,21 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;   // class B: ILP-4 row_sum
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    if (DMM_ROW(i)) {
-                        a0 = a0 + X[i];
-                        if (((i + 1) & 15) == 0) { a1 = a1 + a0; a0 = 0.0f; }
-                        if (i < n4) {
-                            if ((i & 3) == 0) p0 = p0 + X[i];
-                            else if ((i & 3) == 1) p1 = p1 + X[i];
-                            else if ((i & 3) == 2) p2 = p2 + X[i];
-                            else p3 = p3 + X[i];
-                        }
-                    }
+                    // adding the zeros of rows >= n (and +0.0f for the rows a chain does not own) is exact, so the
+                    // row guards become selects on wave-uniform conditions instead of branches
+                    a0 = a0 + X[i];
+                    if (((i + 1) & 15) == 0) { a1 = a1 + a0; a0 = 0.0f; }
+                    const float xm = (EXACT ? i < 4 * (MT / 4) : i < n4) ? X[i] : 0.0f;
+                    if ((i & 3) == 0) p0 = p0 + xm;
+                    else if ((i & 3) == 1) p1 = p1 + xm;
+                    else if ((i & 3) == 2) p2 = p2 + xm;
+                    else p3 = p3 + xm;
                 }
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (DMM_ROW(i) && i >= n4) p0 = p0 + X[i];
+                for (int i = 0; i < MT; ++i) {
+                    if (EXACT) { if (i >= 4 * (MT / 4)) p0 = p0 + X[i]; }
+                    else p0 = p0 + (i >= n4 ? X[i] : 0.0f);
+                }
                 p0 = p0 + p1;
                 p0 = p0 + p2;
                 p0 = p0 + p3;
@@ -323,18 +319,16 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
             const float tc = div_by_const(cs - 1.0f, fn, rcp_n);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if (DMM_ROW(i)) {
-                    float x = X[i];
-                    const float y = over ? x - tc : x;
-                    P1[i] = x - y;
-                    x = y + P2[i];
-                    X[i] = x;
-                }
+                float x = X[i];
+                const float tci = DMM_ROW(i) ? tc : 0.0f;        // rows >= n stay zero
+                const float y = over ? x - tci : x;
+                P1[i] = x - y;
+                x = y + P2[i];
+                X[i] = x;
             }
             if (live) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (DMM_ROW(i)) xbuf[i * m + col] = X[i];
+                for (int i = 0; i < MT; ++i) xbuf[i * m + col] = X[i];
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
             float rsv[MT];
@@ -348,17 +342,15 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
             unsigned moved_bits = 0;                            // OR of the squares' bit patterns: non-zero <=> some square
 #pragma unroll                                                  // is non-zero (a NaN has non-zero bits: "moved")
             for (int i = 0; i < MT; ++i) {
-                if (DMM_ROW(i)) {
-                    float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
-                    tr = live ? tr : 0.0f;                      // dead columns keep their zeros (x - 0 = x, P2 = 0)
-                    const float x = X[i];
-                    const float y = x - tr;
-                    P2[i] = x - y;
-                    X[i] = y;                                   // :86
-                    const float d = y - Xs[i];
-                    const float sq = d * d;
-                    moved_bits |= __float_as_uint(sq);
-                }
+                float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
+                tr = (live && DMM_ROW(i)) ? tr : 0.0f;          // dead columns / rows keep their zeros (x - 0 = x, P2 = 0)
+                const float x = X[i];
+                const float y = x - tr;
+                P2[i] = x - y;
+                X[i] = y;                                       // :86
+                const float d = y - Xs[i];
+                const float sq = d * d;
+                moved_bits |= __float_as_uint(sq);
             }
             const bool moved = moved_bits != 0u;
             // if ||X - X_start|| == 0: break (:88-89).  A sum of squares is zero iff every square rounds to zero,
