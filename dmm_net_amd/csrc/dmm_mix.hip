@@ -29,9 +29,9 @@ template <typename T, int CNT, int NT>   // CNT = entries of this row if 1 or 2,
 __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const int *col_s, const float *w_s, int cnt,
                                               float *orow, int HW, int pre, int s_begin, int s_end) {
     // Pixel index of thread t at step s is x = (256 s + t) * 4 - pre with pre = elements the row start lies past a
-    // 16-byte boundary: every vector STORE is then 16-byte aligned (rows of 65025 floats start on 4-byte
-    // boundaries only; misaligned 16-byte stores straddle 64-byte lines and cost ~10 % of the write stream), the
-    // loads take the misalignment instead (free on gfx950, tools/hbm_probe.py).  The vectors that stick out of
+    // 128-byte line: every wave STORE then covers eight whole lines (rows of 65025 floats start on 4-byte boundaries
+    // only; measured 5.78 TB/s with 16-byte-aligned stores, 6.03 with line-aligned ones), the loads take the
+    // misalignment instead (free on gfx950, tools/hbm_probe.py).  The vectors that stick out of
     // [0, HW) at either end go element-wise.
     constexpr int G = CNT == 0 ? 1 : 2;     // steps per iteration = the launcher's step quantum
     for (int s0 = s_begin; s0 < s_end; s0 += G) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
                                                                     const int32_t *__restrict__ n_valid,
                                                                     const int32_t *__restrict__ m_valid,
                                                                     float *__restrict__ out, int64_t so_b, int64_t so_m,
-                                                                    int steps_per_wg) {
+                                                                    int steps_per_wg, int align_mask) {
     __shared__ float w_s[DMM_MAX_PROPOSALS];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ int cnt_s;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     const int cnt = cnt_s;
     const T *Pb = masks_p + (int64_t)b * sp_b;
     float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
-    const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & 3);     // row start = 16-byte boundary + pre floats
+    const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & align_mask);   // row start = boundary + pre floats
     const int nsteps = (HW + pre + kMixThreads * 4 - 1) / (kMixThreads * 4);
     const int s_begin = blockIdx.x * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
@@ -266,7 +266,8 @@ template <typename T>
 static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
-    const int nsteps = (HW + 3 + kMixThreads * 4 - 1) / (kMixThreads * 4);    // + 3: worst-case row misalignment
+    static const int align_mask = [] { const char *e = getenv("DMM_MIX_ALIGN"); return (e ? atoi(e) : 128) / 4 - 1; }();
+    const int nsteps = (HW + align_mask + kMixThreads * 4 - 1) / (kMixThreads * 4);    // worst-case row misalignment
     // MANY TINY workgroups: 2 steps = 8 KiB of the row each, up to ~320k of them.  Measured at B = 1024 (test mode,
     // one plane per row): 4.2 / 4.9 / 5.1 / 5.2 / 5.75-6.1 TB/s at 10k / 40k / 80k / 160k / 320k workgroups; 1-step
     // workgroups fall back to 5.5-5.8.  In dispatch order the resident workgroups then cover a compact, advancing
@@ -282,7 +283,7 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
     static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
 #define DMM_MIX_LAUNCH(NT)                                                                                              \
     hipLaunchKernelGGL((mask_mix_rows_kernel<T, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, \
-                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg)
+                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask)
     switch (nt_mode & 3) {
         case 0: DMM_MIX_LAUNCH(0); break;
         case 1: DMM_MIX_LAUNCH(1); break;
