@@ -22,7 +22,7 @@ Proposals are duck-typed like maskrcnn_benchmark ``BoxList``: ``len(p)``, ``p.ge
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional
+from typing import Callable, List, Optional
 
 import torch
 import torch.nn as nn

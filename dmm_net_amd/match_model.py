@@ -23,7 +23,6 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
 from .autograd import match_layer_function
 
 

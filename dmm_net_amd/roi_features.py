@@ -12,7 +12,7 @@ Parity: un-pinned upstream (third-party op without fixtures); checked against th
 from __future__ import annotations
 
 import ctypes
-from typing import List, Sequence
+from typing import Sequence
 
 import torch
 import torch.nn as nn

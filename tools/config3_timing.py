@@ -6,7 +6,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dmm_net_amd import ops, synth
+from dmm_net_amd import ops
 from dmm_net_amd.encoder import FeatureEncoder, GraphedEncoder, fold_batchnorm
 from dmm_net_amd.roi_features import FeatureExtractor
 from dmm_net_amd.proposals import SimpleBoxList

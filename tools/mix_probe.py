@@ -1,4 +1,4 @@
-import sys, os
+import sys
 sys.path.insert(0, "/root/repo")
 import torch
 from dmm_net_amd import ops
