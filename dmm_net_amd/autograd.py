@@ -108,7 +108,11 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
     [T,B,O,D].  Returns (full_outmask [B,O,H,W], match_score [B,O], det_score [B,O], cost_loss [B], iters [B])."""
     if tf.dim() == 3:
         tf = tf.unsqueeze(0)
-    return _MatchLayerFn.apply(pf.float(), tf.float(), pm.float(), tm.float(), sc.float(),
+    # 16-bit mask planes go to the kernels as they are (half the bytes of the cost pass; values are only thresholded and
+    # scaled); anything else is matched in fp32 like the reference
+    if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
+        pm, tm = pm.float(), tm.float()
+    return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(),
                                None if targets is None else targets.float(), n_valid, m_valid, float(score_weight),
                                int(max_iter), int(proj_iter), float(lr), int(is_test))
 

@@ -47,7 +47,7 @@ def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
     pm2d = pm.reshape(B, P, H * W)
     dOut = None if d_full is None else d_full.reshape(B, O, H * W).float()
     if need_pm and dOut is not None:
-        g_pm = torch.bmm(Rb[:, :, :P].transpose(1, 2), dOut).view(B, P, H, W)
+        g_pm = torch.bmm(Rb[:, :, :P].transpose(1, 2), dOut).view(B, P, H, W).to(pm.dtype)
     if need_pf or need_tf:
         dRb = None
         if dOut is not None:

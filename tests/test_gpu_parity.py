@@ -557,6 +557,28 @@ def test_forward_is_hipgraph_capturable():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_autograd_path_takes_16bit_mask_planes(dtype):
+    """fp16 / bf16 mask planes go through the autograd path without an fp32 copy: outputs, loss and feature gradients
+    equal the fp32 path on the rounded values (the kernels only threshold and scale mask values)."""
+    from dmm_net_amd.autograd import match_layer_batched
+    B, P, O, H, W, D = 3, 20, 6, 37, 41, 32
+    frs = [synth.make_frame(P, O, H, W, D, seed=880 + b, kind="structured", with_targets=True) for b in range(B)]
+    st = lambda name: torch.stack([dev(getattr(f, name)) for f in frs])
+    pm16, tm16 = st("proposed_mask").to(dtype), st("mask_last_occurence").to(dtype)
+    tg, sc = st("targets"), st("proposal_score")
+    kw = dict(score_weight=0.3, max_iter=10, proj_iter=5, lr=0.1, is_test=0)
+    res = []
+    for pm, tm in ((pm16, tm16), (pm16.float(), tm16.float())):
+        pf, tf = st("proposed_feature").requires_grad_(True), st("template_feature").requires_grad_(True)
+        full, ms, ds, loss, iters = match_layer_batched(pf, pm, tf, tm, sc, tg, **kw)
+        (full.sum() * 1e-3 + loss.sum()).backward()
+        res.append((full, ms, ds, loss, iters, pf.grad, tf.grad))
+    assert res[0][0].dtype == torch.float32
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 def test_pipelined_two_stream_schedule_is_hipgraph_capturable():
     """The 2-lane schedule (streaming lane on the current stream, latency lane forked / joined with HIP events on a side
     stream) captures into ONE HIP graph; the replay on new inputs equals the single-stream eager forward."""
