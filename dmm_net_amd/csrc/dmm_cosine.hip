@@ -187,6 +187,136 @@ __global__ __launch_bounds__(256, 4) void cosine_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide tables (N > 64, dense batch, D % 64 == 0): the kernel above stages all N proposal rows once per template
+// row (tpm = 128 / 256 leaves 2 / 1 template slots per block) -- 20 x per frame at N = 200, M = 20.  Here every thread
+// carries RPT template rows, so a staged tile is used RPT x as often, and the RPT independent add chains hide each
+// other's latency.  Same products, same ATen cascade order (level_step 16, D <= 2^19) as the fast path above.
+// ---------------------------------------------------------------------------------------------
+template <int RPT>
+__global__ __launch_bounds__(256, 2) void cosine_rows_kernel(const float *__restrict__ featn_t,
+                                                             const float *__restrict__ featn_p, int N, int M, int D,
+                                                             int tpm, float *__restrict__ cos_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int slots = 256 / tpm;
+    const int slot = threadIdx.x / tpm, n = threadIdx.x - slot * tpm;
+    const int m0 = (blockIdx.x * slots + slot) * RPT;
+    float *q_s = lds;                                        // [slots * RPT][kCosDC]
+    float *tp = lds + slots * RPT * kCosDC;                  // [N][kCosLD]
+    const float *kbase = featn_p + (int64_t)b * N * D;
+    const bool live = n < N && m0 < M;
+    const bool class_a = n < torder::outer_class_bound(N);
+    float A[RPT][4], Bc[RPT][4][4];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A[r][j] = 0.0f;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) Bc[r][j][l] = 0.0f;
+        }
+    int cnt_a = 0, cnt_b = 0;                                // completed 16-element blocks of the class-A / class-B chains
+    for (int d0 = 0; d0 < D; d0 += kCosDC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N * 16; i += 256) {
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            const float4u v = *reinterpret_cast<const float4u *>(kbase + (int64_t)r * D + d0 + c4);
+            *reinterpret_cast<float4 *>(tp + r * kCosLD + c4) = make_float4(v.x, v.y, v.z, v.w);
+        }
+        if (n < kCosDC) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                q_s[(slot * RPT + r) * kCosDC + n] =
+                    m0 + r < M ? featn_t[((int64_t)b * M + m0 + r) * D + d0 + n] : 0.0f;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const float *row = tp + n * kCosLD;
+        const float *qq = q_s + slot * RPT * kCosDC;
+        if (class_a) {
+#pragma unroll 1
+            for (int blk = 0; blk < 4; ++blk) {
+                float4 rv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rv[t] = *reinterpret_cast<const float4 *>(row + 16 * blk + 4 * t);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    float a = A[r][0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 qv = *reinterpret_cast<const float4 *>(qq + r * kCosDC + 16 * blk + 4 * t);
+                        a = a + qv.x * rv[t].x;
+                        a = a + qv.y * rv[t].y;
+                        a = a + qv.z * rv[t].z;
+                        a = a + qv.w * rv[t].w;
+                    }
+                    A[r][1] = A[r][1] + a;                   // Cascade::block16_done
+                    A[r][0] = 0.0f;
+                }
+                ++cnt_a;
+                if ((cnt_a & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) { A[r][2] = A[r][2] + A[r][1]; A[r][1] = 0.0f; }
+                    if ((cnt_a & 255) == 0) {
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) { A[r][3] = A[r][3] + A[r][2]; A[r][2] = 0.0f; }
+                    }
+                }
+            }
+        } else {                                             // ILP-4 row_sum: 16 products per chain and D-chunk
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const float4 rv = *reinterpret_cast<const float4 *>(row + 4 * t);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qq + r * kCosDC + 4 * t);
+                    Bc[r][0][0] = Bc[r][0][0] + qv.x * rv.x;
+                    Bc[r][1][0] = Bc[r][1][0] + qv.y * rv.y;
+                    Bc[r][2][0] = Bc[r][2][0] + qv.z * rv.z;
+                    Bc[r][3][0] = Bc[r][3][0] + qv.w * rv.w;
+                }
+            }
+            ++cnt_b;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Bc[r][j][1] = Bc[r][j][1] + Bc[r][j][0];
+                    Bc[r][j][0] = 0.0f;
+                    if ((cnt_b & 15) == 0) {
+                        Bc[r][j][2] = Bc[r][j][2] + Bc[r][j][1];
+                        Bc[r][j][1] = 0.0f;
+                        if ((cnt_b & 255) == 0) { Bc[r][j][3] = Bc[r][j][3] + Bc[r][j][2]; Bc[r][j][2] = 0.0f; }
+                    }
+                }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (m0 + r >= M) break;
+        float res;
+        if (class_a) {
+            res = A[r][0] + A[r][1];                         // Cascade::finish
+            res = res + A[r][2];
+            res = res + A[r][3];
+        } else {
+            float pj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pj[j] = Bc[r][j][0] + Bc[r][j][1];
+                pj[j] = pj[j] + Bc[r][j][2];
+                pj[j] = pj[j] + Bc[r][j][3];
+            }
+            res = pj[0] + pj[1];                             // row_sum_scalar: (((p0 + p1) + p2) + p3), no remainder
+            res = res + pj[2];
+            res = res + pj[3];
+        }
+        cos_out[((int64_t)b * M + m0 + r) * N + n] = res;
+    }
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, float *out, float *norms,
@@ -209,6 +339,18 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
     const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
     const int slots = 256 / tpm;
+    if (N > 64 && !n_valid && !m_valid && D % dmm::kCosDC == 0 && D <= (1 << 19)) {
+        constexpr int RPT = 4;                               // template rows per thread
+        const size_t lds4 = sizeof(float) * ((size_t)slots * RPT * dmm::kCosDC + (size_t)N * dmm::kCosLD);
+        if (lds4 > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_rows_kernel<RPT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
+        }
+        hipLaunchKernelGGL((dmm::cosine_rows_kernel<RPT>), dim3((M + slots * RPT - 1) / (slots * RPT), B), dim3(256), lds4,
+                           (hipStream_t)stream, featn_t, featn_p, N, M, D, tpm, cos_out);
+        return dmm::check_launch();
+    }
     size_t lds = sizeof(float) * ((size_t)slots * dmm::kCosDC + (size_t)N * dmm::kCosLD);
     if (N == 1 || n_valid) {
         const size_t l1 = sizeof(float) * (size_t)D * slots;

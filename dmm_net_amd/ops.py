@@ -270,7 +270,11 @@ class ForwardPlan:
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
         self.mask_dtype = mask_dtype
-        self.pipeline = (B >= 64) if pipeline is None else bool(pipeline)
+        # default: two lanes for large batches whose solver fits beside the streaming kernels (one wave per frame, exact
+        # row count: M <= 16, Pp <= 64); the multi-wave solvers of wide tables hold up to 256 VGPRs per wave and only
+        # serialise with them (config 5: 2.26 ms single stream vs 2.37 ms two lanes per 256 frames)
+        auto = B >= 64 and M <= 16 and self.Pp <= 64
+        self.pipeline = auto if pipeline is None else bool(pipeline)
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
