@@ -67,7 +67,8 @@ class DMM_Model(nn.Module):
         D = prop_feat[0].shape[1]
         Pmax = max(int(p.shape[0]) for p in prop_m)
         pf = prop_feat[0].new_zeros((B, Pmax, D))
-        pm = mask_last_occurence.new_zeros((B, Pmax, H, W))
+        # planes beyond n_valid[b] are never read by the ragged kernels: no need to clear 4 B * Pmax * H * W per video
+        pm = mask_last_occurence.new_empty((B, Pmax, H, W))
         sc = mask_last_occurence.new_zeros((B, Pmax))
         for b in range(B):
             P = prop_m[b].shape[0]

@@ -19,7 +19,15 @@ B, T, O, H, W = int(os.environ.get("B", "4")), 12, 5, 255, 448
 rng = np.random.default_rng(0)
 cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
         "score_weight": 0.3}
-enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), weights_dtype=torch.bfloat16)
+if os.environ.get("NOENC"):                                 # isolate this package's share: pooling-only stand-in encoder
+    import torch.nn.functional as F
+
+    def enc(x):
+        g = x.mean(1, keepdim=True)
+        lv = tuple(F.avg_pool2d(g, s, ceil_mode=True).expand(-1, 128, -1, -1).contiguous() for s in (4, 8, 16, 32))
+        return {"backbone_feature": lv, "refine_input_feat": lv}
+else:
+    enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), weights_dtype=torch.bfloat16)
 
 
 def raw(n):
