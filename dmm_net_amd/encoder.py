@@ -234,7 +234,8 @@ class GraphedEncoder:
     MIOpen / elementwise launches, 3.9 ms eager against well under 1 ms of arithmetic); replaying a captured graph
     removes the per-launch host cost.  The encoder must be in ``eval()`` mode (BatchNorm running statistics; nothing
     in the graph may depend on host state).  Outputs are views of the graph's static buffers: consume (or clone) them
-    before the next call.  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
+    before the next call.  ``torch.backends.cudnn.benchmark = True`` before the first call lets MIOpen search its
+    solvers during the warm-up (ResNet-50, 8 frames: 36 s once, 2.21 -> 2.08 ms per replay; tools/encoder_find_mode.py).  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
     """
 
     def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3, weights_dtype=None):
