@@ -172,6 +172,22 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
     }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs by linear id.  With the plain (range = blockIdx.x, frame =
+// blockIdx.y) mapping the chunk ranges of one frame land on different XCDs, so the 128-byte lines neighbouring ranges
+// share (plane rows are only 4-byte aligned) are fetched into several L2s.  Remapped, every complete group of 8 frames
+// gives each XCD ONE whole frame: measured +2 % on the cost launches (6.65 -> 6.79 TB/s at 512 frames).
+__device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &range) {
+    b = blockIdx.y;
+    range = blockIdx.x;
+    if (xcd_remap && (int)blockIdx.y < (int)(gridDim.y & ~7u)) {
+        const int splits = gridDim.x;
+        const int id = blockIdx.x + splits * blockIdx.y;
+        const int grp = id / (8 * splits), within = id - grp * 8 * splits;
+        b = grp * 8 + (within & 7);
+        range = within >> 3;
+    }
+}
+
 // grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
 
@@ -182,8 +198,10 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
     int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
-    int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t) {
-    const int b = blockIdx.y;
+    int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t,
+    int xcd_remap) {
+    int b, range;
+    xcd_frame_range(xcd_remap, b, range);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
 
     const int full_chunks = HW / kChunk;
     const int nchunks = (HW + kChunk - 1) / kChunk;
-    const int c_begin = blockIdx.x * chunks_per_wg;
+    const int c_begin = range * chunks_per_wg;
     const int c_end = min(nchunks, c_begin + chunks_per_wg);
     for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
         const int x0 = c * kChunk;
@@ -267,10 +285,11 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
+    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
     dim3 grid(splits, B);
     hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, masks_t2, N,
                        M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,
-                       area_t2, n0, m0, chunks_per_wg, wap, wat);
+                       area_t2, n0, m0, chunks_per_wg, wap, wat, xcd_remap);
     return check_launch();
 }
 
@@ -337,9 +356,10 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_tl_kernel(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
     int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
     int32_t *__restrict__ area_t2, int n0, int m0, int nt, int mt, int chunks_per_wg, int write_area_p,
-    int write_area_t, int RS) {
+    int write_area_t, int RS, int xcd_remap) {
     extern __shared__ unsigned tl_red[];
-    const int b = blockIdx.y;
+    int b, range;
+    xcd_frame_range(xcd_remap, b, range);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_tl_kernel(
     unsigned at = 0;
     const int full_chunks = HW / kChunk;
     const int nchunks = (HW + kChunk - 1) / kChunk;
-    const int c_begin = blockIdx.x * chunks_per_wg;
+    const int c_begin = range * chunks_per_wg;
     const int c_end = min(nchunks, c_begin + chunks_per_wg);
     for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
         const int x0 = c * kChunk;
@@ -394,11 +414,12 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
+    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
     const int RS = (masks_t2 ? 2 * mt : mt) + 1;
     const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave);
     hipLaunchKernelGGL((iou_counts_tl_kernel<T>), dim3(splits, B), dim3(kCostThreads), lds, stream, masks_p, masks_t,
                        masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t,
-                       inter2, area_t2, n0, m0, nt, mt, chunks_per_wg, wap, wat, RS);
+                       inter2, area_t2, n0, m0, nt, mt, chunks_per_wg, wap, wat, RS, xcd_remap);
     return check_launch();
 }
 
