@@ -117,11 +117,25 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
                                                                     const int32_t *__restrict__ n_valid,
                                                                     const int32_t *__restrict__ m_valid,
                                                                     float *__restrict__ out, int64_t so_b, int64_t so_m,
-                                                                    int steps_per_wg, int align_mask) {
+                                                                    int steps_per_wg, int align_mask, int xcd_remap) {
     __shared__ float w_s[DMM_MAX_PROPOSALS];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ int cnt_s;
-    const int b = blockIdx.z, m = blockIdx.y;
+    // XCD-aware mapping (workgroups go round-robin over the 8 XCDs by linear id): every complete group of 8 output rows
+    // gives each XCD one whole row, so the misaligned source lines neighbouring pixel ranges share stay in one L2
+    int b = blockIdx.z, m = blockIdx.y, range = blockIdx.x;
+    if (xcd_remap) {
+        const int splits = gridDim.x, rows = gridDim.y * gridDim.z;
+        const int row = blockIdx.y + gridDim.y * blockIdx.z;
+        if (row < (rows & ~7)) {
+            const int id = blockIdx.x + splits * row;
+            const int grp = id / (8 * splits), within = id - grp * 8 * splits;
+            const int r2 = grp * 8 + (within & 7);
+            range = within >> 3;
+            m = r2 % (int)gridDim.y;
+            b = r2 / (int)gridDim.y;
+        }
+    }
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
     if (Nb <= 0) Mb = 0;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
     const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & align_mask);   // row start = boundary + pre floats
     const int nsteps = (HW + pre + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_begin = range * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
     if (cnt == 1) mix_row_range<T, 1, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
     else if (cnt == 2) mix_row_range<T, 2, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
@@ -281,9 +295,10 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
     const int steps_per_wg = ((nsteps + splits - 1) / splits + step_q - 1) / step_q * step_q;
     splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
     static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
+    static const int xcd_remap = [] { const char *e = getenv("DMM_MIX_XCD"); return e ? atoi(e) : 1; }();
 #define DMM_MIX_LAUNCH(NT)                                                                                              \
     hipLaunchKernelGGL((mask_mix_rows_kernel<T, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, \
-                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask)
+                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask, xcd_remap)
     switch (nt_mode & 3) {
         case 0: DMM_MIX_LAUNCH(0); break;
         case 1: DMM_MIX_LAUNCH(1); break;
