@@ -339,7 +339,8 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
     const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
     const int slots = 256 / tpm;
-    if (N > 64 && !n_valid && !m_valid && D % dmm::kCosDC == 0 && D <= (1 << 19)) {
+    static const int rows_min_n = [] { const char *e = getenv("DMM_COS_ROWS_MIN_N"); return e ? atoi(e) : 65; }();
+    if (N >= rows_min_n && N > 1 && !n_valid && !m_valid && D % dmm::kCosDC == 0 && D <= (1 << 19)) {
         constexpr int RPT = 4;                               // template rows per thread
         const size_t lds4 = sizeof(float) * ((size_t)slots * RPT * dmm::kCosDC + (size_t)N * dmm::kCosLD);
         if (lds4 > 64 * 1024) {
