@@ -136,16 +136,36 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
     return full[0], ms[0], ds[0], loss[0]
 
 
+class _CosineFn(torch.autograd.Function):
+    """get_cosine_score (match_helper.py:51-64) for B frames with autograd: tf [B,O,D], pf [B,P,D] -> cos [B,O,P].
+    Used where the cosine table is needed OUTSIDE the fused layer function (algo 'hun': the assignment comes from
+    scipy and carries no gradient, but mse(cos, gt) still trains the features like in the reference)."""
+
+    @staticmethod
+    def forward(ctx, tf, pf):
+        pn, pnorm = ops.feature_normalize(pf, want_norms=True)
+        tn, tnorm = ops.feature_normalize(tf, want_norms=True)
+        ctx.save_for_backward(pn, tn, pnorm, tnorm, pf, tf)
+        return ops.cosine(tn, pn)
+
+    @staticmethod
+    def backward(ctx, dcos):
+        from .backward import _normalize_backward
+        pn, tn, pnorm, tnorm, pf, tf = ctx.saved_tensors
+        dcos = dcos.contiguous().float()
+        g_tf = _normalize_backward(torch.bmm(dcos, pn), tnorm, tf) if ctx.needs_input_grad[0] else None
+        g_pf = _normalize_backward(torch.bmm(dcos.transpose(1, 2), tn), pnorm, pf) if ctx.needs_input_grad[1] else None
+        return g_tf, g_pf
+
+
 def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
     """algo 'hun' slot (match_model.py:122-123): same cost matrix, assignment from scipy (host)."""
     P, O = pm.shape[0], tm.shape[0]
     pm_b, tm_b = pm.unsqueeze(0), tm.unsqueeze(0)
     inter, ap, at = ops.iou_counts(pm_b, tm_b)
-    pn = ops.feature_normalize(pf.unsqueeze(0))
-    tn = ops.feature_normalize(tf.unsqueeze(0))
-    cos = ops.cosine(tn, pn)
-    r = ops.relax_match(cos, inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=0, proj_iter=0,
-                        lr=0.0, is_test=is_test)
+    cos = _CosineFn.apply(tf.unsqueeze(0), pf.unsqueeze(0))          # differentiable: cost_loss reaches the features
+    r = ops.relax_match(cos.detach(), inter, ap, at, sc.unsqueeze(0), score_weight=score_weight, max_iter=0,
+                        proj_iter=0, lr=0.0, is_test=is_test)
     sim = r["sim"][0]
     Pp = ops.padded_width(P, O)
     simp = sim.new_zeros((O, Pp))
@@ -161,5 +181,7 @@ def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):
     ds = (scp.view(1, -1) * Rb).sum(1)
     loss = pf.new_zeros(())
     if targets is not None:
-        loss = matching_loss(pm_b, targets.unsqueeze(0), cos)[0][0]
+        with torch.no_grad():                                        # gt one-hot carries no grad (match_helper.py:34-44)
+            gt = matching_loss(pm_b, targets.unsqueeze(0).float(), cos.detach())[1]
+        loss = ((cos - gt) ** 2).mean()                              # F.mse_loss(feature_sim, gt_matched) (:48)
     return full, ms, ds, loss

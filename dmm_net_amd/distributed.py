@@ -51,12 +51,20 @@ class GradBucketer:
     ``overlap=True``: buckets are laid out in REVERSE parameter order (gradients arrive last layer first) and
     post-accumulate-grad hooks copy each gradient into its bucket as autograd produces it; the moment a bucket is
     complete its all-reduce is issued asynchronously, so the collectives of the late layers run under the backward of
-    the early ones (what DDP does for the reference, train.py:178-184).  ``finish()`` after ``backward()`` issues the
-    buckets that never completed (parameters without a gradient this step count as zeros, like DDP with
-    ``find_unused_parameters=True``, train.py:181), waits, scales by 1/world and scatters back.
+    the early ones (what DDP does for the reference, train.py:178-184).  Collectives are ALWAYS issued in bucket-index
+    order (a complete bucket waits for its predecessors), because RCCL pairs collectives across ranks by issue order
+    and per-rank autograd graphs may differ (unused parameters, videos without live templates).  ``finish()`` after
+    ``backward()`` issues the buckets that never completed (parameters without a gradient this step count as zeros,
+    like DDP with ``find_unused_parameters=True``, train.py:181), waits, scales by 1/world and scatters back;
+    parameters without a gradient on EVERY rank keep ``grad = None`` (``track_unused``: one [n_params] MAX all-reduce)
+    and, being known idle on every rank alike, no longer hold their bucket back in the next step.
+    A second ``backward()`` before ``finish()`` raises (the in-flight buckets would drop the accumulated part).
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, overlap: bool = False):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, overlap: bool = False,
+                 track_unused: bool = True):
+        self.track_unused = bool(track_unused)
+        self.launch_log: List[int] = []           # bucket indices in the order their collectives were issued
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.overlap = bool(overlap)
@@ -83,6 +91,13 @@ class GradBucketer:
                 off += p.numel()
         self._handles: List[Optional[object]] = [None] * len(self.buckets)
         self._filled = [set() for _ in self.buckets]
+        self._ready = [False] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._next = 0                            # lowest bucket index not launched yet (fixed issue order)
+        # parameters that received no gradient on ANY rank in the previous step (from the all-reduced used-mask, hence
+        # identical on every rank -- e.g. the ResNet's unused fc): a bucket does not wait for them, so one idle
+        # parameter in bucket 0 does not hold back every collective until finish()
+        self._idle = [set() for _ in self.buckets]
         self._hooks = []
         if self.overlap:
             for p in self.params:
@@ -108,47 +123,101 @@ class GradBucketer:
     @torch.no_grad()
     def _on_grad(self, p: torch.nn.Parameter):
         bi, off = self._slot[id(p)]
-        if self._handles[bi] is not None:          # a second backward before finish(): fall back to finish()'s path
-            return
+        if self._launched[bi] and id(p) in self._idle[bi] and id(p) not in self._filled[bi]:
+            raise RuntimeError("GradBucketer(overlap=True): a parameter that was idle on every rank in the previous "
+                               "step produced a gradient after its bucket had been issued; build the bucketer with "
+                               "track_unused=False (or overlap=False) for graphs that change from step to step")
+        if self._launched[bi]:
+            # a second backward() before finish() (gradient accumulation): the bucket already in flight holds only
+            # the first backward's gradient and finish() would overwrite p.grad with it -- refuse instead of
+            # silently dropping the accumulated part
+            raise RuntimeError("GradBucketer(overlap=True): backward() ran again before finish(); call finish() "
+                               "after every backward, or use overlap=False for gradient accumulation")
         self._flat_of(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._filled[bi].add(id(p))
-        if len(self._filled[bi]) == len(self.buckets[bi]):
-            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+        if len(self._filled[bi] | self._idle[bi]) == len(self.buckets[bi]):
+            for q in self.buckets[bi]:             # known-idle parameters of this bucket contribute zeros
+                if id(q) not in self._filled[bi]:
+                    _, qo = self._slot[id(q)]
+                    self._flat[bi][qo:qo + q.numel()].zero_()
+            self._ready[bi] = True
+            self._launch_ready_prefix()
 
     @torch.no_grad()
-    def _scatter_back(self, bi: int, world: int):
+    def _launch_ready_prefix(self):
+        """Collectives are matched across ranks by ISSUE ORDER (NCCL/RCCL), so buckets are always launched in index
+        order: a complete bucket waits until every bucket before it has been launched (DDP does the same).  Ranks
+        whose autograd graphs differ (unused parameters, skipped videos) then still pair bucket k with bucket k."""
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            bi = self._next
+            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+            self._launched[bi] = True
+            self.launch_log.append(bi)
+            self._next += 1
+
+    @torch.no_grad()
+    def _scatter_back(self, bi: int, world: int, used: Optional[torch.Tensor] = None, used_off: int = 0):
         flat = self._flat[bi]
         flat.div_(world)
         off = 0
-        for p in self.buckets[bi]:
+        for k_i, p in enumerate(self.buckets[bi]):
             k = p.numel()
             if p.grad is None:
-                p.grad = flat[off:off + k].view_as(p).clone()
+                # unused on THIS rank: materialise the mean only if some rank produced a gradient (a parameter
+                # unused everywhere keeps grad None, so optimisers with weight decay leave it alone like under DDP)
+                if used is None or bool(used[used_off + k_i]):
+                    p.grad = flat[off:off + k].view_as(p).clone()
             else:
                 p.grad.copy_(flat[off:off + k].view_as(p))
             off += k
 
     @torch.no_grad()
-    def finish(self):
-        """After ``backward()`` with ``overlap=True``: complete, wait, average, scatter back."""
-        world = dist.get_world_size()
+    def _used_mask(self) -> Optional[torch.Tensor]:
+        """One tiny MAX all-reduce telling which parameters received a gradient on ANY rank.  Only issued when
+        this rank has parameters without a gradient... which the other ranks cannot know, so it is issued whenever
+        ``track_unused`` is set (default) -- [n_params] uint8, issued FIRST in the fixed collective order."""
+        if not self.track_unused:
+            return None
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        m = torch.tensor([0 if p.grad is None else 1 for bucket in self.buckets for p in bucket], dtype=torch.int32,
+                         device=dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        m = m.cpu()
+        k = 0
         for bi, bucket in enumerate(self.buckets):
-            if self._handles[bi] is None:
-                flat = self._flat_of(bi)
-                off = 0
-                for p in bucket:                   # (re)fill: missing gradients are zeros
-                    k = p.numel()
-                    if p.grad is None:
-                        flat[off:off + k].zero_()
-                    elif id(p) not in self._filled[bi]:
-                        flat[off:off + k].copy_(p.grad.reshape(-1))
-                    off += k
-                self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            self._idle[bi] = {id(p) for j, p in enumerate(bucket) if not bool(m[k + j])}
+            k += len(bucket)
+        return m
+
+    @torch.no_grad()
+    def finish(self):
+        """After ``backward()`` with ``overlap=True``: complete (in bucket order), wait, average, scatter back."""
+        world = dist.get_world_size()
+        for bi in range(self._next, len(self.buckets)):
+            bucket = self.buckets[bi]
+            flat = self._flat_of(bi)
+            off = 0
+            for p in bucket:                       # (re)fill: missing gradients are zeros
+                k = p.numel()
+                if p.grad is None:
+                    flat[off:off + k].zero_()
+                elif id(p) not in self._filled[bi]:
+                    flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            self._ready[bi] = True
+        self._launch_ready_prefix()
+        assert self._next == len(self.buckets)
+        used = self._used_mask()                   # issued after all bucket collectives on every rank: same order
+        uo = 0
         for bi in range(len(self.buckets)):
             self._handles[bi].wait()
-            self._scatter_back(bi, world)
+            self._scatter_back(bi, world, used, uo)
+            uo += len(self.buckets[bi])
             self._handles[bi] = None
             self._filled[bi] = set()
+            self._ready[bi] = False
+            self._launched[bi] = False
+        self._next = 0
 
     @torch.no_grad()
     def all_reduce_mean(self):
@@ -169,9 +238,13 @@ class GradBucketer:
                     flat[off:off + k].copy_(p.grad.reshape(-1))
                 off += k
             handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            self.launch_log.append(i)
+        used = self._used_mask()
+        uo = 0
         for i in range(len(self.buckets)):
             handles[i].wait()
-            self._scatter_back(i, world)
+            self._scatter_back(i, world, used, uo)
+            uo += len(self.buckets[i])
 
 
 @torch.no_grad()

@@ -60,7 +60,8 @@ class DMM_Model(nn.Module):
 
     # ---- shared batched core -----------------------------------------------------------------------
     def _match_batch(self, prop_feat: List[torch.Tensor], prop_m: List[torch.Tensor], prop_score: List[torch.Tensor],
-                     tplt_feat: List[torch.Tensor], mask_last_occurence, n_tplt: List[int], targets, skip: List[bool]):
+                     tplt_feat: List[torch.Tensor], mask_last_occurence, n_tplt: List[int], targets, skip: List[bool],
+                     row_scale=None):
         """prop_feat[b] [P_b,D], prop_m[b] [P_b,H,W], tplt_feat[b] [F,D]; returns (full [B,F,H,W], loss [B])."""
         B, F, H, W = CHECK4D(mask_last_occurence)
         dev = mask_last_occurence.device
@@ -79,13 +80,54 @@ class DMM_Model(nn.Module):
             pm[b, :P] = prop_m[b]
             sc[b, :P] = prop_score[b]
         tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
+        if row_scale is not None:
+            # valid templates that are NOT a prefix: the reference's OF_matrix = diag(valid)[:O] (dmm_model.py:151-156)
+            # zeroes the feature rows -- and, transposed, the scattered output rows (:78-80) -- of slots i < O with
+            # valid[i] == 0
+            tf = tf * row_scale[:, :, None]
         n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
         m_valid = torch.tensor([0 if skip[b] else n_tplt[b] for b in range(B)], dtype=torch.int32, device=dev)
         cfg = self.match_layer
         full, ms, ds, loss, _ = match_layer_batched(
             pf, pm, tf, mask_last_occurence, sc, targets, n_valid, m_valid, score_weight=cfg.cfgs["score_weight"],
             max_iter=cfg.max_iter, proj_iter=cfg.proj_iter, lr=cfg.relax_lr, is_test=int(bool(cfg.is_test)))
+        if row_scale is not None:
+            full = full * row_scale[:, :, None, None]
         return full, loss
+
+    @staticmethod
+    def _valid_layout(tplt_valid_batch, n_tplt_hint=None):
+        """-> (live templates per video, row_scale [B,F] or None).  ONE host sync for the whole batch.  The reference
+        selects ``mask_last_occurence[bid, :O]`` with O = valid.sum() (dmm_model.py:117,124) and builds
+        ``OF_matrix = diag(valid)[:O]``: when the valid slots are a prefix (what ``ohw_mask2boxlist`` normally
+        produces) that is a plain row selection and row_scale is None; otherwise slots i < O with valid[i] == 0 get
+        zero template features and zero output rows, reproduced by ``row_scale``."""
+        rows = [[int(round(float(v))) for v in r] for r in tplt_valid_batch.tolist()]
+        n_tplt = [sum(r) for r in rows]
+        if all(all(v == 1 for v in r[:o]) for r, o in zip(rows, n_tplt)):
+            return n_tplt, None
+        scale = [[float(v) if i < o else 0.0 for i, v in enumerate(r)] for r, o in zip(rows, n_tplt)]
+        return n_tplt, torch.tensor(scale, dtype=torch.float32, device=tplt_valid_batch.device)
+
+    def _per_video(self, prop_feat, prop_m, prop_score, tplt_feat, mask_last_occurence, tplt_valid_batch, n_tplt,
+                   targets, skip):
+        """algo 'hun' (and any future non-batched solver): the reference's loop, one ``MatchModel`` call per video
+        (dmm_model.py:62-82 / :115-139) with the OF/FO selection matmuls of ``prepare_tplt_feature`` (:144-158)."""
+        B, F, H, W = CHECK4D(mask_last_occurence)
+        outs, losses = [], []
+        for b in range(B):
+            O = n_tplt[b]
+            if skip[b]:
+                outs.append(mask_last_occurence.new_zeros(F, H, W))
+                losses.append(prop_feat[b].sum() * 0)
+                continue
+            OF = torch.diag(tplt_valid_batch[b].float())[:O, :]
+            tfv = torch.mm(OF, tplt_feat[b].view(F, -1))
+            full, _, _, _, loss = self.match_layer(prop_feat[b], prop_m[b], [tfv], mask_last_occurence[b, :O],
+                                                   prop_score[b], None if targets is None else targets[b][:O])
+            outs.append(torch.mm(OF.t(), full.reshape(O, -1)).view(F, H, W))
+            losses.append(loss["cost_loss"] if len(loss) > 0 else prop_feat[b].sum() * 0)
+        return torch.stack(outs, 0), losses
 
     @staticmethod
     def _proposal_fields(proposals):
@@ -102,14 +144,21 @@ class DMM_Model(nn.Module):
         prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
         prop_m, prop_score = self._proposal_fields(proposals)
         # live templates per video: one host sync unless the caller (video.FrameLoop) already knows them
-        n_tplt = infos.get("n_tplt") or [int(v) for v in tplt_valid_batch.sum(1).tolist()]
+        if infos.get("n_tplt"):
+            n_tplt, row_scale = list(infos["n_tplt"]), infos.get("row_scale")
+        else:
+            n_tplt, row_scale = self._valid_layout(tplt_valid_batch)
         skip = [n_tplt[b] == 0 or bool(extra_frame[b]) for b in range(B)]
         tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
         tg = None
         if target is not None:
             tg = torch.stack([target[b] for b in range(B)], 0)
-        full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt, tg,
-                                    skip)
+        if self.match_algo != "relax":
+            full, _ = self._per_video(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
+                                      tplt_valid_batch, n_tplt, tg, skip)
+        else:
+            full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
+                                        tg, skip, row_scale)
         out_last = full.clone()
         for b in range(B):
             if skip[b]:
@@ -123,11 +172,15 @@ class DMM_Model(nn.Module):
         boxes_per_image = [len(box) for box in proposals]
         prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
         prop_m, prop_score = self._proposal_fields(proposals)
-        n_tplt = [int(v) for v in tplt_valid_batch.sum(1).tolist()]         # one host sync for the whole batch
+        n_tplt, row_scale = self._valid_layout(tplt_valid_batch)            # one host sync for the whole batch
         skip = [n_tplt[b] == 0 for b in range(B)]
         tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
-        full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
-                                       targets, skip)
+        if self.match_algo != "relax":
+            full, loss = self._per_video(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
+                                         tplt_valid_batch, n_tplt, targets, skip)
+        else:
+            full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
+                                           n_tplt, targets, skip, row_scale)
         out_last = full.clone()
         match_loss = []
         for b in range(B):

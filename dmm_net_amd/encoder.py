@@ -238,6 +238,8 @@ class GraphedEncoder:
     solvers during the warm-up (ResNet-50, 8 frames: 36 s once, 2.21 -> 2.08 ms per replay; tools/encoder_find_mode.py).  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
     """
 
+    static_outputs = True      # outputs alias the graph's buffers (video.FrameLoop clones what it keeps across frames)
+
     def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3, weights_dtype=None):
         """``weights_dtype=torch.bfloat16`` converts the (BatchNorm-folded) encoder's parameters ONCE and runs the whole
         forward in that dtype; ``autocast_dtype`` keeps fp32 parameters and lets autocast re-cast all of them on every

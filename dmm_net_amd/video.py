@@ -172,6 +172,11 @@ class FrameLoop:
     masks are the prediction.  Proposals come per video and frame as BoxLists with the raw 'mask' probabilities
     ([P,1,M,M], pasted + NMS-filtered here like model_encoder.py:115-134) or, with ``pasted=True``, already as
     image-size planes.
+
+    Lifetime of encoder outputs: with ``encoder.GraphedEncoder`` the feature maps are views of the graph's static
+    buffers and are overwritten by the next frame's replay.  Everything this loop keeps ACROSS frames is copied out
+    (template vectors are fresh tensors from the ROI kernel; ``refine_input_feat`` of frame 0 is cloned); a ``refine``
+    callable that keeps feature maps in its ``state`` must clone them likewise.
     """
 
     def __init__(self, encoder: Callable, dmm, refine: Optional[Callable] = None, nms_thresh: float = 0.4,
@@ -204,7 +209,7 @@ class FrameLoop:
         dev = frames.device
         n_frames = list(n_frames) if n_frames is not None else [T] * B
         history, state, mask_hist = [], None, None
-        tplt_dict = tplt_valid = prev_mask = n_tplt = None
+        tplt_dict = tplt_valid = prev_mask = n_tplt = row_scale = None
         for t in range(T):
             extra = [n <= t for n in n_frames]
             raw = [proposals[b][t] if len(proposals[b]) > t else proposals[b][-1] for b in range(B)]
@@ -226,10 +231,19 @@ class FrameLoop:
                     tpl.append(bl)
                     valid.append(v)
                 tplt_valid = torch.stack(valid, 0)
-                n_tplt = [int(v) for v in tplt_valid.sum(1).tolist()]      # once per clip (the templates are fixed)
+                # once per clip (the templates are fixed): live counts + the non-prefix row scale of the reference's
+                # OF_matrix (an object that is empty in frame 0 leaves a hole in the valid slots)
+                n_tplt, row_scale = self.dmm._valid_layout(tplt_valid)
                 tplt_dict = self.dmm.fill_template_dict(None, tpl, features, y_mask, tplt_valid)
+                if getattr(self.encoder, "static_outputs", False):
+                    # a GraphedEncoder returns views of its graph's static buffers; every later replay overwrites
+                    # them, so what the template dictionary keeps across frames must own its memory
+                    for b in tplt_dict:
+                        tplt_dict[b]["refine_input_feat"] = [tuple(f.clone() for f in tup)
+                                                             for tup in tplt_dict[b]["refine_input_feat"]]
                 prev_mask = y_mask
-            infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B, "n_tplt": n_tplt}
+            infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B, "n_tplt": n_tplt,
+                     "row_scale": row_scale}
             hist_in = prev_mask.view(B, O, H, W) if mask_hist is None else mask_hist       # :168-169
             init_pred, tplt_dict, _, hist_new = self.dmm.inference(infos, props, features["backbone_feature"], hist_in,
                                                                    tplt_dict)

@@ -21,6 +21,20 @@ are data only -- no reference source text is stored.  Groups follow SURVEY.md se
   G7 solver-only and cosine-only known answers on many [n, m] / (O, P, D) shapes (pins the reduction order)
   G8 the DMM_Model per-video harness steps (dmm_model.py:115-141) re-executed around the imported
      MatchModel (DMM_Model itself needs maskrcnn_benchmark and cannot be imported)
+  G9 / G11 FIRST HAND since round 2: ``dmm.utils.masker`` and ``dmm.utils.utils`` are imported behind a stub of the
+     absent third-party packages (``maskrcnn_benchmark``: ``interpolate`` = torch's F.interpolate -- what the real one
+     calls for non-empty inputs --, a minimal ``BoxList``; ``torchvision.transforms``: unused by the functions called)
+     and ``paste_mask_in_image`` / ``Masker`` / ``ohw_mask2boxlist`` / ``binmask_to_bbox_xyxy_pt`` themselves produce
+     the expected values; the round-1 step-by-step re-execution is kept as a cross-check (must agree bit for bit).
+  G12 legacy ROIAlign(14x14, sampling_ratio 2) on 4 levels + spatial mean as DIFFERENTIABLE CPU torch written from
+     the published per-bin definition (one gather per sample point; independent of the oracle's C loop nest and of
+     the kernel's separable 28x28 form): forward values and d feat_l / d loss for boxes incl. sub-pixel, clipped and
+     fully-outside ones.  Pins the ROI path's forward AND backward (feature_extractor.py:11-52).
+  G13 NMS + top-k through the REFERENCE's ``filter_results`` (dmm/utils/boxlist_ops.py:15-29, imported) with the
+     third-party ``nms`` symbol bound to a plain-Python greedy NMS from the published definition (+1 box extents,
+     IoU > thresh suppresses as in nms.cu, stable order for ties): duplicates, exact-threshold pairs, score ties.
+  G14 algo 'hun' through the imported MatchModel (hungarian_matching with its hard-coded .cuda() patched to a
+     no-op on this CPU-only box): outputs + gradients of cost_loss (the only differentiable term under 'hun').
 """
 import os
 import sys
@@ -34,6 +48,86 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+
+
+def _install_third_party_stubs():
+    """Two-symbol stand-ins for the packages the reference imports but this box lacks, so that the reference's OWN
+    functions (masker.py, utils.py, boxlist_ops.py) can be imported and called.  Nothing of the arithmetic under
+    test lives in the stubs except ``nms`` (documented at G13)."""
+    import types
+    import torch.nn.functional as F
+
+    class BoxList(object):
+        """Data holder with the published BoxList surface the called functions touch."""
+
+        def __init__(self, bbox, image_size, mode="xyxy"):
+            device = bbox.device if isinstance(bbox, torch.Tensor) else torch.device("cpu")
+            self.bbox = torch.as_tensor(bbox, dtype=torch.float32, device=device).reshape(-1, 4)
+            self.size, self.mode, self.extra_fields = image_size, mode, {}
+
+        def add_field(self, k, v):
+            self.extra_fields[k] = v
+
+        def get_field(self, k):
+            return self.extra_fields[k]
+
+        def fields(self):
+            return list(self.extra_fields.keys())
+
+        def convert(self, mode):
+            assert mode == self.mode
+            return self
+
+        def to(self, device):
+            return self
+
+        def __len__(self):
+            return self.bbox.shape[0]
+
+        def __getitem__(self, item):
+            b = BoxList(self.bbox[item], self.size, self.mode)
+            for k, v in self.extra_fields.items():
+                b.add_field(k, v[item])
+            return b
+
+    def nms(boxes, scores, thresh):
+        """Published maskrcnn_benchmark nms (layers/nms -> csrc/cuda/nms.cu): visit by descending score (stable),
+        extents with +1, a box is dropped when IoU with an already-kept box is > thresh; returns kept indices in
+        score order."""
+        order = sorted(range(len(scores)), key=lambda i: (-float(scores[i]), i))
+        keep = []
+        b = boxes.to(torch.float32)
+        for i in order:
+            ok = True
+            for j in keep:
+                left, right = torch.max(b[i, 0], b[j, 0]), torch.min(b[i, 2], b[j, 2])
+                top, bottom = torch.max(b[i, 1], b[j, 1]), torch.min(b[i, 3], b[j, 3])
+                w = torch.clamp(right - left + 1, min=0.0)
+                h = torch.clamp(bottom - top + 1, min=0.0)
+                inter = w * h
+                sa = (b[i, 2] - b[i, 0] + 1) * (b[i, 3] - b[i, 1] + 1)
+                sb = (b[j, 2] - b[j, 0] + 1) * (b[j, 3] - b[j, 1] + 1)
+                if float(inter / (sa + sb - inter)) > thresh:
+                    ok = False
+                    break
+            if ok:
+                keep.append(i)
+        return torch.tensor(keep, dtype=torch.int64)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    mod("maskrcnn_benchmark")
+    mod("maskrcnn_benchmark.layers", nms=nms)
+    mod("maskrcnn_benchmark.layers.misc", interpolate=F.interpolate)
+    mod("maskrcnn_benchmark.structures")
+    mod("maskrcnn_benchmark.structures.bounding_box", BoxList=BoxList)
+    mod("torchvision", transforms=types.SimpleNamespace())
+    return BoxList
+
 
 from dmm.modules.match_model import MatchModel  # noqa: E402  (reference)
 from dmm.modules.submodules.relax_match import relax_matching  # noqa: E402  (reference)
@@ -444,6 +538,20 @@ def g9():
                 nb = [int(inds[:, 1].min()), int(inds[:, 0].min()), int(inds[:, 1].max()), int(inds[:, 0].max())]
             masks.append(im_mask.numpy())
             nboxes.append(nb)
+        # FIRST HAND: the reference's own paste_mask_in_image / Masker (masker.py:120-230) on the same inputs; the
+        # re-execution above is only a cross-check of this
+        BoxList = _install_third_party_stubs()
+        from dmm.utils import masker as ref_masker            # noqa: E402  (reference)
+        fh_masks, fh_boxes = [], []
+        for p in range(P):
+            im_mask, new_box = ref_masker.paste_mask_in_image(T(prob[p, 0]), T(boxes[p]), im_h, im_w, thresh, padding)
+            fh_masks.append(im_mask.numpy())
+            fh_boxes.append([int(v) for v in new_box])
+        res, resb = ref_masker.Masker(threshold=thresh, padding=padding)([T(prob)], [BoxList(T(boxes), (im_w, im_h))])
+        assert np.array_equal(res[0][:, 0].numpy(), np.stack(fh_masks)) and resb[0].tolist() == fh_boxes
+        assert np.array_equal(np.stack(fh_masks), np.stack(masks)), "re-execution disagrees with masker.py"
+        assert fh_boxes == nboxes, (fh_boxes, nboxes)
+        masks, nboxes = fh_masks, fh_boxes
         d.update(flat(f"c{k}", dict(prob=prob, boxes=boxes, size=np.array([im_h, im_w], np.int32),
                                    masks=np.stack(masks), new_boxes=np.asarray(nboxes, np.float32),
                                    thresh=np.float32(thresh), padding=np.int32(padding))))
@@ -539,9 +647,17 @@ def g11():
         _, max_i = refine_fbg.max(0)
         return max_i.float().numpy().astype(np.uint8)       # plot_scores_map: astype(np.uint8) (eval_helper.py:36)
 
+    # FIRST HAND: the reference's own ohw_mask2boxlist / binmask_to_bbox_xyxy_pt (utils.py:114-143, :179-210)
+    _install_third_party_stubs()
+    from dmm.utils import utils as ref_utils                # noqa: E402  (reference)
     shapes = [(3, 17, 23), (5, 64, 64), (10, 255, 255), (1, 9, 1), (4, 33, 130), (8, 255, 448)]
     for k, (O, H, W) in enumerate(shapes):                  # inputs by seed: synth.template_planes(k, O, H, W)
-        boxes, valid = ref_boxes(T(synth.template_planes(k, O, H, W)))
+        planes = T(synth.template_planes(k, O, H, W))
+        boxes, valid = ref_boxes(planes)
+        bl, tv = ref_utils.ohw_mask2boxlist(planes)
+        assert np.array_equal(bl.bbox.numpy(), boxes) and np.array_equal(tv.numpy().astype(np.int32), valid), k
+        assert torch.equal(bl.get_field("scores"), torch.ones(O)) and bl.get_field("mask") is planes
+        boxes, valid = bl.bbox.numpy().astype(np.float32), tv.numpy().astype(np.int32)
         d[f"box{k}_shape"] = np.asarray([O, H, W], np.int64)
         d[f"box{k}_boxes"] = boxes
         d[f"box{k}_valid"] = valid
@@ -555,7 +671,205 @@ def g11():
     save("g11_frame_loop", d)
 
 
+# ------------------------------------------------------------------------------------------ G12
+def _roialign_legacy(feat, rois, scale, pooled=14, sampling=2):
+    """maskrcnn_benchmark's legacy (non-aligned) ROIAlign, forward of ROIAlign_cpu.cpp / ROIAlign_cuda.cu, as
+    differentiable torch: feat [B,C,H,W], rois [R,5] -> [R,C,pooled,pooled].  One gather of 4 corners per sample
+    point (ph, pw, iy, ix), all rois at once; nothing is separated into 1-D weight vectors."""
+    B, C, H, W = feat.shape
+    R = rois.shape[0]
+    bi = rois[:, 0].long()
+    x1, y1, x2, y2 = [rois[:, k] * scale for k in (1, 2, 3, 4)]
+    rw = torch.clamp(x2 - x1, min=1.0)
+    rh = torch.clamp(y2 - y1, min=1.0)
+    bw, bh = rw / pooled, rh / pooled
+    flat = feat.reshape(B, C, H * W)
+    out = feat.new_zeros((R, C, pooled, pooled))
+    cnt = float(sampling * sampling)
+    rows = []
+    for ph in range(pooled):
+        cols = []
+        for pw in range(pooled):
+            acc = feat.new_zeros((R, C))
+            for iy in range(sampling):
+                y = y1 + ph * bh + (iy + 0.5) * bh / sampling
+                for ix in range(sampling):
+                    x = x1 + pw * bw + (ix + 0.5) * bw / sampling
+                    empty = (y < -1.0) | (y > H) | (x < -1.0) | (x > W)
+                    yy, xx = torch.clamp(y, min=0.0), torch.clamp(x, min=0.0)
+                    yl, xl = yy.floor().long(), xx.floor().long()
+                    ytop, xtop = yl >= H - 1, xl >= W - 1
+                    yl = torch.where(ytop, torch.full_like(yl, H - 1), yl)
+                    xl = torch.where(xtop, torch.full_like(xl, W - 1), xl)
+                    yh = torch.where(ytop, yl, yl + 1)
+                    xh = torch.where(xtop, xl, xl + 1)
+                    yy = torch.where(ytop, yl.to(yy.dtype), yy)
+                    xx = torch.where(xtop, xl.to(xx.dtype), xx)
+                    ly, lx = yy - yl.to(yy.dtype), xx - xl.to(xx.dtype)
+                    hy, hx = 1.0 - ly, 1.0 - lx
+                    fb = flat[bi]                                        # [R,C,HW]
+
+                    def at(yi, xi):
+                        idx = (yi * W + xi).view(R, 1, 1).expand(R, C, 1)
+                        return fb.gather(2, idx).squeeze(2)
+                    val = (hy * hx).unsqueeze(1) * at(yl, xl) + (hy * lx).unsqueeze(1) * at(yl, xh) + \
+                          (ly * hx).unsqueeze(1) * at(yh, xl) + (ly * lx).unsqueeze(1) * at(yh, xh)
+                    acc = acc + torch.where(empty.unsqueeze(1), torch.zeros_like(val), val)
+            cols.append(acc / cnt)
+        rows.append(torch.stack(cols, -1))
+    return torch.stack(rows, -2)
+
+
+def _roi_feature_extractor(feats, rois):
+    """feature_extractor.py:20-52 on top of the above: every roi on ALL four levels (scales :13, output 14x14,
+    sampling_ratio 2 :14-16), [R,4,C,14,14] (:49) -> .mean(4).mean(3).view(R,-1) (:29)."""
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    per = [_roialign_legacy(f, rois, s) for f, s in zip(feats, scales)]
+    x = torch.stack(per, 1)
+    return x.mean(4).mean(3).reshape(rois.shape[0], -1)
+
+
+def g12():
+    d = {}
+    cases = [dict(B=2, C=8, H=64, W=96, R=9), dict(B=1, C=16, H=255, W=255, R=6), dict(B=3, C=4, H=33, W=47, R=12)]
+    for k, c in enumerate(cases):
+        B, C, H, W, R = c["B"], c["C"], c["H"], c["W"], c["R"]
+        rng = np.random.Generator(np.random.PCG64(1200 + k))
+        feats = [rng.standard_normal((B, C, -(-H // s), -(-W // s)), dtype=np.float32) for s in (4, 8, 16, 32)]
+        x1 = rng.uniform(0, W * 0.7, R)
+        y1 = rng.uniform(0, H * 0.7, R)
+        boxes = np.stack([x1, y1, x1 + rng.uniform(2, W * 0.6, R), y1 + rng.uniform(2, H * 0.6, R)], 1)
+        boxes[0] = [3.3, 4.6, 3.9, 5.2]                                  # sub-pixel box (size clamped to 1 per level)
+        boxes[1] = [W - 9.5, H - 7.25, W + 40.0, H + 25.0]               # clipped bottom-right (samples past the map)
+        boxes[2] = [-30.0, -12.0, 14.5, 9.75]                            # clipped top-left (negative samples -> 0 clamp)
+        boxes[3] = [W + 50.0, H + 50.0, W + 90.0, H + 80.0]              # fully outside: every sample is "empty"
+        boxes[4] = [0.0, 0.0, W - 1.0, H - 1.0]                          # whole frame
+        rois = np.concatenate([rng.integers(0, B, (R, 1)).astype(np.float32), boxes.astype(np.float32)], 1)
+        ft = [T(f).requires_grad_(True) for f in feats]
+        out = _roi_feature_extractor(ft, T(rois))
+        wgt = T(rng.standard_normal(out.shape, dtype=np.float32))
+        (out * wgt).sum().backward()
+        dd = dict(rois=rois, wgt=wgt.numpy(), out=out.detach().numpy(), shape=np.array([B, C, H, W, R], np.int32))
+        for l in range(4):
+            dd[f"feat{l}"] = feats[l]
+            dd[f"grad{l}"] = ft[l].grad.numpy()
+        d.update(flat(f"c{k}", dd))
+    d["n"] = np.int32(len(cases))
+    save("g12_roialign", d)
+
+
+# ------------------------------------------------------------------------------------------ G13
+def g13():
+    BoxList = _install_third_party_stubs()
+    from dmm.utils import boxlist_ops as ref_ops            # noqa: E402  (reference)
+    d = {}
+    rng = np.random.Generator(np.random.PCG64(1313))
+    cases = []
+    for n, thr, mx in [(40, 0.4, 50), (90, 0.4, 50), (120, 0.4, 50), (30, 0.7, 10), (64, 0.4, 5), (1, 0.4, 50)]:
+        cx, cy = rng.uniform(20, 200, n), rng.uniform(20, 200, n)
+        w, h = rng.uniform(5, 80, n), rng.uniform(5, 80, n)
+        boxes = np.round(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)).astype(np.float32)
+        scores = rng.random(n).astype(np.float32)
+        if n >= 30:
+            boxes[5] = boxes[3]                              # exact duplicates
+            boxes[9] = boxes[3]
+            scores[7] = scores[2]                            # score ties (stable order decides)
+            scores[11] = scores[2]
+            scores[5] = scores[3]                            # duplicate box AND tied score
+            boxes[20] = [10, 10, 19, 19]                     # 10x10 and a 10x10 shifted by 5: inter 50, union 150
+            boxes[21] = [15, 10, 24, 19]                     # -> IoU = 1/3 exactly; thr 0.4 keeps both
+            boxes[22] = [100, 100, 109, 109]
+            boxes[23] = [100, 100, 109, 105]                 # 6/10 of the other -> IoU 0.6 > 0.4 suppressed
+        cases.append((boxes, scores, thr, mx))
+    # an exact-threshold pair: IoU == thresh must NOT suppress (nms.cu compares with '>')
+    cases.append((np.array([[0, 0, 9, 9], [0, 0, 9, 4], [50, 50, 60, 60]], np.float32),
+                  np.array([0.9, 0.8, 0.7], np.float32), 0.5, 50))
+    for k, (boxes, scores, thr, mx) in enumerate(cases):
+        bl = BoxList(T(boxes), (256, 256))
+        bl.add_field("scores", T(scores))
+        out = ref_ops.filter_results([bl], nms_thresh=thr, max_proposals=mx, score_field="scores")[0]
+        keep = []
+        for b, sc in zip(out.bbox.numpy(), out.get_field("scores").numpy()):   # map kept rows back to indices
+            cand = [i for i in range(len(boxes)) if np.array_equal(boxes[i], b) and scores[i] == sc and i not in keep]
+            keep.append(cand[0])
+        d.update(flat(f"c{k}", dict(boxes=boxes, scores=scores, thresh=np.float32(thr), max_keep=np.int32(mx),
+                                   keep=np.asarray(keep, np.int32), kept_boxes=out.bbox.numpy(),
+                                   kept_scores=out.get_field("scores").numpy())))
+    d["n"] = np.int32(len(cases))
+    save("g13_nms", d)
+
+
+# ------------------------------------------------------------------------------------------ G14
+def g14():
+    """algo 'hun' (match_model.py:122-123, relax_match.py:120-126).  hungarian_matching hard-codes ``.cuda()`` on its
+    result (:125); on this CPU-only box torch.Tensor.cuda is patched to the identity for the duration of the call."""
+    d = {}
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for name, (P, O, is_test) in {"train": (8, 3, 0), "test": (8, 3, 1), "pad": (3, 5, 0)}.items():
+            fr = synth.make_frame(P, O, 48, 48, 128, seed=synth.BASE_SEED + 1400 + P + O, kind="structured",
+                                  with_targets=True)
+            model = MatchModel(cfg(10, 5, algo="hun"), is_test)
+            pf = T(fr.proposed_feature).requires_grad_(True)
+            tf = T(fr.template_feature).requires_grad_(True)
+            pm, tm, sc, tg = T(fr.proposed_mask), T(fr.mask_last_occurence), T(fr.proposal_score), T(fr.targets)
+            # the reference's 'hun' forward only runs without autograd: hungarian_matching calls .numpy() on the cost
+            # matrix (relax_match.py:121), which raises for a tensor that requires grad
+            with torch.no_grad():
+                fo, ms, ds, _, loss = model(pf, pm, [tf], tm, sc, tg)
+            # the one differentiable term under 'hun' is cost_loss = mse(feature_sim, gt_matched): its gradient comes
+            # first hand from the reference's compute_cost_matrix (match_model.py:49-91), which never reaches scipy
+            _, _, _, mloss = model.compute_cost_matrix({"proposed": pf, "template": [tf]},
+                                                       {"proposed": pm, "template": tm}, {"proposal_score": sc}, tg)
+            assert abs(float(mloss["cost_loss"]) - float(loss["cost_loss"])) < 1e-7
+            mloss["cost_loss"].backward()
+            d[f"{name}/checksum"] = np.array(fr.checksum())
+            d[f"{name}/shape"] = np.array([P, O, 48, 48, 128, is_test], np.int32)
+            d.update(flat(name, dict(full_outmask=fo.detach().numpy(), match_score=ms.detach().numpy(),
+                                     det_score=ds.detach().numpy(), cost_loss=np.float32(loss["cost_loss"].item()),
+                                     grad_pf=pf.grad.numpy(), grad_tf=tf.grad.numpy())))
+    finally:
+        torch.Tensor.cuda = orig
+    save("g14_hungarian", d)
+
+
+# ------------------------------------------------------------------------------------------ G15
+def g15():
+    """Non-prefix ``tplt_valid`` through the DMM_Model steps (dmm_model.py:115-158): OF_matrix = diag(valid)[:O]
+    zeroes the template features AND the scattered output rows of slots i < O with valid[i] == 0."""
+    d = {}
+    B, F, P, H, W, D = 3, 5, 8, 32, 32, 64
+    valid = np.array([[0, 1, 1, 0, 0], [1, 0, 1, 0, 1], [1, 1, 0, 0, 0]], np.float32)
+    frames = [synth.make_frame(P, F, H, W, D, seed=9900 + b, kind="structured", with_targets=True) for b in range(B)]
+    mask_last = np.stack([fr.mask_last_occurence for fr in frames])
+    tplt_feat = np.stack([fr.template_feature for fr in frames])
+    targets = np.stack([fr.targets for fr in frames])
+    for mode in ("train", "test"):
+        is_test = int(mode == "test")
+        layer = MatchModel(cfg(10, 5), is_test)
+        outs, losses = [], []
+        with torch.no_grad():
+            for b in range(B):
+                tv = T(valid[b])
+                O = int(tv.sum().item())
+                OF = torch.diag(tv).float()[:O, :]
+                tfv = [torch.mm(OF, T(tplt_feat[b]).view(F, -1)).view(O, D)]
+                fo, _, _, newm, loss = layer(T(frames[b].proposed_feature), T(frames[b].proposed_mask), tfv,
+                                             T(mask_last[b])[:O].view(O, H, W), T(frames[b].proposal_score),
+                                             targets=None if is_test else T(targets[b, :O]))
+                outs.append(torch.mm(OF.t(), fo.view(O, -1)).view(F, H, W))
+                losses.append(float(loss["cost_loss"]) if len(loss) > 0 else 0.0)
+        d[f"{mode}/output_mask"] = torch.stack(outs).numpy()
+        d[f"{mode}/losses"] = np.asarray(losses, np.float32)
+    d.update(valid=valid, shape=np.array([B, F, P, H, W, D], np.int32))
+    for b, fr in enumerate(frames):
+        d[f"frame{b}/checksum"] = np.array(fr.checksum())
+    save("g15_nonprefix_valid", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
+                             "g15"]
     for w in which:
         globals()[w]()

@@ -93,13 +93,31 @@ def _overlap_worker(rank, world, port, q):
         net(x).pow(2).sum().backward()
         local = [None if p.grad is None else p.grad.clone() for p in params]
         launched = sum(h is not None for h in gb._handles)
-        ok &= launched >= 1                                   # some collectives were already in flight after backward
+        # step 0: the idle parameter sits in bucket 0 and nothing may overtake it (fixed issue order); from step 1 on
+        # it is known idle on every rank and the collectives are in flight when backward() returns
+        ok &= launched == 0 if step == 0 else launched >= 1
         gb.finish()
         for p, g in zip(params, local):
+            if p is unused:                                   # unused on every rank: stays None (no zero grads for Adam)
+                ok &= p.grad is None
+                continue
             g = torch.zeros_like(p) if g is None else g
             ref = g.clone()
             dist.all_reduce(ref)
             ok &= bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+        ok &= gb.launch_log == sorted(gb.launch_log)          # fixed issue order
+        gb.launch_log.clear()
+    # gradient accumulation under overlap is refused, not silently dropped
+    for p in params:
+        p.grad = None
+    x = torch.randn(8, 16)
+    net(x).pow(2).sum().backward()
+    try:
+        net(x).pow(2).sum().backward()
+        ok = False
+    except RuntimeError as e:
+        ok &= "finish()" in str(e)
+    gb.finish()
     gb.remove_hooks()
     dist.barrier()
     dist.destroy_process_group()
@@ -111,6 +129,49 @@ def test_gloo_world2_overlapped_grad_bucketer():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _diverging_worker(rank, world, port, q):
+    """Per-rank autograd graphs DIFFER: rank 1 never uses a parameter that sits in a MIDDLE bucket, so its
+    buckets complete in another order than rank 0's.  Collectives must still be issued in bucket-index order on
+    both ranks (RCCL pairs by issue order) and the result must be the plain mean with zeros for the missing grad."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Linear(8, 300), torch.nn.Linear(8, 500), torch.nn.Linear(8, 700))   # different bucket sizes
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    gb = GradBucketer(params, bucket_mb=0.003, overlap=True)
+    ok = gb.num_collectives() >= 3
+    x = torch.randn(4, 8, generator=torch.Generator().manual_seed(7 + rank))
+    loss = a(x).sum() + c(x).pow(2).sum()
+    if rank == 0:
+        loss = loss + b(x).sum()                              # the middle layer only exists in rank 0's graph
+    loss.backward()
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    gb.finish()
+    ok &= gb.launch_log == list(range(gb.num_collectives()))
+    for p, g in zip(params, local):
+        ref = torch.zeros_like(p) if g is None else g.clone()
+        dist.all_reduce(ref)
+        ok &= p.grad is not None and bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    gb.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world2_bucket_order_is_fixed_when_graphs_differ():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diverging_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -49,6 +49,31 @@ def test_roialign4_mean_matches_oracle(B, C, H, W, n):
     assert torch.equal(convert_to_roi_format([Boxes(torch.from_numpy(bb)) for bb in boxes]), torch.from_numpy(rois))
 
 
+def test_roialign4_mean_forward_and_backward_match_g12_fixture():
+    """G12: forward values AND d feat_l of the fused HIP kernels against an independent differentiable torch
+    formulation of legacy ROIAlign(14x14, sr 2, 4 levels) + mean (per-bin definition, gen_golden.py:_roialign_legacy);
+    boxes include sub-pixel, clipped (both corners), fully-outside and whole-frame ones.  <= 1e-5 relative."""
+    from conftest import golden
+    g = golden("g12_roialign")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        B = int(c["shape"][0])
+        feats = [torch.from_numpy(c[f"feat{l}"]).to(DEV).requires_grad_(True) for l in range(4)]
+        rois = c["rois"]
+        # the extractor takes per-image box lists in image order: G12's rois are regrouped by batch index
+        order = np.argsort(rois[:, 0], kind="stable")
+        boxes = [Boxes(torch.from_numpy(rois[rois[:, 0] == b][:, 1:]).to(DEV)) for b in range(B)]
+        out = FeatureExtractor()(tuple(feats), boxes)
+        exp = c["out"][order]
+        err = float(np.abs(out.detach().cpu().numpy() - exp).max())
+        assert err <= 1e-5 * max(1.0, float(np.abs(exp).max())), (k, err)
+        out.backward(torch.from_numpy(c["wgt"][order]).to(DEV))
+        for l in range(4):
+            ge = c[f"grad{l}"]
+            gerr = float(np.abs(feats[l].grad.cpu().numpy() - ge).max())
+            assert gerr <= 1e-5 * max(1.0, float(np.abs(ge).max())), (k, l, gerr)
+
+
 def test_roialign4_mean_backward_is_the_adjoint():
     rng = np.random.default_rng(5)
     B, C, H, W = 2, 16, 96, 80

@@ -753,3 +753,95 @@ def test_g10_template_feature_list(is_test):
                       (tfs[2].grad, c["grad_tf2"])):
         scale = max(float(np.abs(ref).max()), 1e-12)
         assert float(np.abs(mine.cpu().numpy() - ref).max()) <= 2e-4 * scale + 1e-7
+
+
+# ------------------------------------------------------------------------------------ round 2: 'hun', non-prefix valid
+@pytest.mark.parametrize("name", ["train", "test", "pad"])
+def test_g14_hungarian_matches_reference(name):
+    """algo 'hun' against the imported reference MatchModel (G14): outputs (the assignment is scipy's, bit-identical
+    selection) and the gradient of cost_loss, the one differentiable term under 'hun' (it must have a
+    grad_fn; the reference's own 'hun' forward cannot even run with autograd on, relax_match.py:121)."""
+    g = golden("g14_hungarian")
+    P, O, H, W, D, is_test = [int(v) for v in g[f"{name}/shape"]]
+    fr = synth.make_frame(P, O, H, W, D, seed=synth.BASE_SEED + 1400 + P + O, kind="structured", with_targets=True)
+    assert fr.checksum() == str(g[f"{name}/checksum"])
+    model = MatchModel(cfg(10, 5, algo="hun"), is_test)
+    pf = dev(fr.proposed_feature).requires_grad_(True)
+    tf = dev(fr.template_feature).requires_grad_(True)
+    fo, ms, ds, fo2, loss = model(pf, dev(fr.proposed_mask), [tf], dev(fr.mask_last_occurence), dev(fr.proposal_score),
+                                  dev(fr.targets))
+    assert fo2 is fo
+    close(fo, g[f"{name}/full_outmask"])
+    close(ms, g[f"{name}/match_score"], 1e-6)
+    close(ds, g[f"{name}/det_score"], 1e-6)
+    assert abs(float(loss["cost_loss"]) - float(g[f"{name}/cost_loss"])) < 1e-6
+    assert loss["cost_loss"].grad_fn is not None
+    loss["cost_loss"].backward()
+    for got, exp in ((pf.grad, g[f"{name}/grad_pf"]), (tf.grad, g[f"{name}/grad_tf"])):
+        err = float(np.abs(got.cpu().numpy() - exp).max())
+        assert err <= 1e-4 * float(np.abs(exp).max()) + 1e-8, err
+
+
+@pytest.mark.parametrize("mode", ["train", "test"])
+def test_g15_dmm_model_nonprefix_valid(mode):
+    """tplt_valid with holes (an object empty in frame 0): the reference's OF_matrix = diag(valid)[:O] zeroes the
+    template features and the scattered rows of slots i < O with valid[i] == 0 (dmm_model.py:151-158, :133-135)."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    g = golden("g15_nonprefix_valid")
+    B, F, P, H, W, D = [int(v) for v in g["shape"]]
+    frames = [synth.make_frame(P, F, H, W, D, seed=9900 + b, kind="structured", with_targets=True) for b in range(B)]
+    for b, fr in enumerate(frames):
+        assert fr.checksum() == str(g[f"frame{b}/checksum"])
+    feats = torch.cat([dev(fr.proposed_feature) for fr in frames], 0)
+    model = DMM_Model(cfg(10, 5), is_test=int(mode == "test"), feature_extractor=lambda bf, props: feats)
+    props = [_Props(dev(fr.proposed_mask).unsqueeze(1), dev(fr.proposal_score)) for fr in frames]
+    tplt_dict = {b: {"feat": [dev(frames[b].template_feature)]} for b in range(B)}
+    valid = dev(g["valid"])
+    ml = torch.stack([dev(fr.mask_last_occurence) for fr in frames], 0)
+    if mode == "train":
+        tg = torch.stack([dev(fr.targets) for fr in frames], 0)
+        out, _, losses, _ = model(None, props, None, ml, tplt_dict, valid, tg)
+        for b in range(B):
+            assert abs(float(losses[b]) - float(g["train/losses"][b])) < 1e-6, b
+    else:
+        out, _, _, _ = model.inference({"args": None, "shape": None, "extra_frame": [0] * B, "valid": valid}, props,
+                                       None, ml, tplt_dict)
+    close(out, g[f"{mode}/output_mask"])
+    exp = g[f"{mode}/output_mask"]
+    v = g["valid"]
+    for b in range(B):
+        for i in range(F):
+            if not (v[b, i] == 1 and i < int(v[b].sum())):
+                assert float(np.abs(exp[b, i]).max()) == 0.0 and float(out[b, i].abs().max()) == 0.0
+
+
+def test_dmm_model_hungarian_runs_hungarian_not_relax():
+    """DMM_Model with algo 'hun' must go through MatchModel's Hungarian slot per video (the batched launch
+    sequence is the relax solver): compare with per-video MatchModel('hun') calls + the reference's scatter."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    B, F, P, H, W, D = 3, 5, 8, 32, 32, 64
+    n_valid = [0, 2, 5]
+    frames = [synth.make_frame(P, F, H, W, D, seed=4400 + b, kind="structured", with_targets=True) for b in range(B)]
+    feats = torch.cat([dev(fr.proposed_feature) for fr in frames], 0)
+    props = [_Props(dev(fr.proposed_mask).unsqueeze(1), dev(fr.proposal_score)) for fr in frames]
+    valid = torch.zeros((B, F), device=DEV)
+    for b, o in enumerate(n_valid):
+        valid[b, :o] = 1
+    ml = torch.stack([dev(fr.mask_last_occurence) for fr in frames], 0)
+    tplt_dict = {b: {"feat": [dev(frames[b].template_feature)]} for b in range(B)}
+    hun = DMM_Model(cfg(10, 5, algo="hun"), is_test=1, feature_extractor=lambda bf, props: feats)
+    rel = DMM_Model(cfg(10, 5, algo="relax"), is_test=1, feature_extractor=lambda bf, props: feats)
+    infos = {"args": None, "shape": None, "extra_frame": [0] * B, "valid": valid}
+    out_h, _, _, last_h = hun.inference(infos, props, None, ml, tplt_dict)
+    out_r, _, _, _ = rel.inference(infos, props, None, ml, tplt_dict)
+    layer = MatchModel(cfg(10, 5, algo="hun"), 1)
+    differs = False
+    for b, o in enumerate(n_valid):
+        if o == 0:
+            assert float(out_h[b].abs().max()) == 0.0 and torch.equal(last_h[b], ml[b])
+            continue
+        fo = layer(dev(frames[b].proposed_feature), dev(frames[b].proposed_mask), [dev(frames[b].template_feature)[:o]],
+                   ml[b, :o], dev(frames[b].proposal_score))[0]
+        assert torch.equal(out_h[b, :o], fo) and float(out_h[b, o:].abs().max()) == 0.0
+        differs |= not torch.equal(out_h[b], out_r[b])       # one-hot x mask vs mean-of-iterates weight x mask
+    assert differs

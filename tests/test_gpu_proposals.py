@@ -46,6 +46,22 @@ def test_nms_and_filter_results_match_oracle():
         assert np.array_equal(bl.get_field("mask").cpu().numpy().astype(np.int64), e.astype(np.int64))
 
 
+def test_g13_nms_topk_matches_reference_filter_results():
+    """G13: kept indices of the HIP NMS + top-k against the reference's own filter_results (imported,
+    boxlist_ops.py:15-29) over the published greedy NMS -- duplicates, score ties, exact-threshold pairs."""
+    g = golden("g13_nms")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        n = len(c["scores"])
+        bl = proposals.SimpleBoxList(torch.from_numpy(c["boxes"]).to(DEV), (256, 256))
+        bl.add_field("scores", torch.from_numpy(c["scores"]).to(DEV))
+        bl.add_field("mask", torch.arange(n, device=DEV).float())
+        out = proposals.filter_results([bl], nms_thresh=float(c["thresh"]), max_proposals=int(c["max_keep"]))[0]
+        assert np.array_equal(out.get_field("mask").cpu().numpy().astype(np.int32), c["keep"]), k
+        assert np.array_equal(out.bbox.cpu().numpy(), c["kept_boxes"])
+        assert np.array_equal(out.get_field("scores").cpu().numpy(), c["kept_scores"])
+
+
 def test_packed_planes_give_identical_tables():
     """DMM_PACKED1: pack once, count from 1/32 of the bytes -- same integer tables as the fp32 path."""
     from dmm_net_amd import ops

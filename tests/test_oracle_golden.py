@@ -191,3 +191,29 @@ def test_nms_semantics():
     assert list(oracle.nms(b, s, 0.4)) == [0, 2]
     assert list(oracle.nms(b, s, 0.7)) == [0, 1, 2]
     assert list(oracle.nms(b, s, 0.4, max_keep=1)) == [0]
+
+
+# ------------------------------------------------------------------------------------ G12 / G13 (round 2)
+def test_g12_roialign_oracle_matches_independent_torch_formulation():
+    """The C restatement of the 4-level legacy ROIAlign + mean against G12 (differentiable torch written from the
+    published per-bin definition, tests/golden/gen_golden.py:_roialign_legacy): <= 1e-5 relative."""
+    g = golden("g12_roialign")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        feats = [c[f"feat{l}"] for l in range(4)]
+        got = oracle.roialign4_mean(feats, c["rois"])
+        exp = c["out"]
+        assert got.shape == exp.shape
+        err = float(np.abs(got - exp).max())
+        assert err <= 1e-5 * max(1.0, float(np.abs(exp).max())), (k, err)
+        assert np.all(exp[3] == 0) and np.all(got[3] == 0)           # roi 3 lies outside the frame: every sample empty
+
+
+def test_g13_nms_oracle_matches_filter_results_fixture():
+    """oracle.nms against G13 = the reference's filter_results (boxlist_ops.py:15-29, imported) over the published
+    greedy NMS: duplicates, score ties, exact-threshold pairs, top-k truncation."""
+    g = golden("g13_nms")
+    for k in range(int(g["n"])):
+        c = g.group(f"c{k}")
+        keep = oracle.nms(c["boxes"], c["scores"], float(c["thresh"]), int(c["max_keep"]))
+        assert np.array_equal(keep.astype(np.int32), c["keep"]), k
