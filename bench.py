@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the DMM-Net cost+match layer on MI355X.
 
-Metric (BASELINE.json): frames/sec (cost+match layer) at N=50 proposals, M=10 templates, 255x255,
-20 outer x 5 inner solver iterations, fp32 (configs[1]).  One "step" = one pass of the whole layer
-(IoU cost tables -> cosine + relaxed assignment -> assignment-weighted mask mix; forward, is_test=1)
-over a batch of ``--frames`` synthetic frames already resident in HBM.
+Default workload = BASELINE.json configs[1] (the configuration the metric is quoted on): N=50 proposals,
+M=10 templates, 255x255 fp32 masks, 20 outer x 5 inner solver iterations.  One "step" = one pass of the whole layer
+(IoU cost tables -> cosine + relaxed assignment -> assignment-weighted mask mix; forward, is_test=1) over a batch of
+``--frames`` synthetic frames already resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--config 2|3|5]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank
-owns its own B frames (weak scaling; the forward has no exchange step), timing is bracketed by
-barrier + synchronize on both sides and the MAX over ranks is used.  Rank 0 prints ONE JSON line.
+``--config 5`` = configs[4] (N=200, M=20, fp16 mask planes, fp32 accumulation), ``--config 3`` = configs[2]
+(ResNet-50 + heads in bf16 -> fused 4-level ROIAlign+mean -> the layer, 8 frames); same JSON schema, ``config.workload``
+names the configuration.
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank owns its own B
+frames (weak scaling; the forward has no exchange step), timing is bracketed by barrier + synchronize on both sides and
+the MAX over ranks is used.  Rank 0 prints ONE JSON line.
+
+At N = 1 the line also carries (``--no-extras`` skips them): ``cpu_baseline`` (the C oracle on the host cores, bounded
+sample), ``batch_sweep`` / ``latency`` (frames per launch sequence in {1, 4, 8, 64, 512, 1024}), and ``roofline.traffic``
+measured by two child ``rocprofv3 --pmc`` passes of this same command (``traffic_source`` says where the number is from).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,35 +37,56 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md); never the 2:1-sparsity headline
+METRIC = "frames/sec (cost+match layer) at N=50 proposals, M=10 templates, 255x255"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (B)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE configs index + 1")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 256 for "
+                                                          "config 2 / 3 / 5)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream schedule")
+    ap.add_argument("--pipeline", action="store_true", help="force the 2-lane schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="no cpu_baseline / batch_sweep / in-run PMC traffic")
+    ap.add_argument("--no-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc child passes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank control flow on a single-GPU box)")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds):
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds, ci=2):
     """Oracle (plain-C port of the reference layer) timed on the host cores of this box on the same workload: one
     frame per call, one worker thread per core (ctypes releases the GIL; the C routine is re-entrant)."""
     import threading
     import oracle
     from dmm_net_amd import synth
-    c = synth.CONFIGS[2]
+    c = synth.CONFIGS[ci]
     fr = synth.make_frame(c["P"], c["O"], c["H"], c["W"], c["D"], seed=99, kind="uniform")
+    pm, tm = fr.proposed_mask, fr.mask_last_occurence
+    if ci == 5:                                      # fp16 storage: the port computes on the rounded values in fp32
+        pm, tm = pm.astype(np.float16).astype(np.float32), tm.astype(np.float16).astype(np.float32)
 
     def one():
-        oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
-                             fr.proposal_score, max_iter=20, proj_iter=5, is_test=1)
+        oracle.match_forward(pm, tm, fr.proposed_feature, fr.template_feature, fr.proposal_score, max_iter=20,
+                             proj_iter=5, is_test=1)
     one()                                                    # warm-up
     try:
         cores = len(os.sched_getaffinity(0))
@@ -73,137 +107,349 @@ def cpu_baseline(seconds):
         t.join()
     dt = time.perf_counter() - t0
     n = sum(counts)
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of the same workload (N=50, M=10, 255x255, 20x5 iters) in {dt:.1f} s, "
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{n} frames of the same workload (N={c['P']}, M={c['O']}, 255x255, 20x5 iters) in {dt:.1f} s, "
                       f"oracle/dmm_oracle.c, {cores} threads (one frame per call per thread)"}
+
+
+def pmc_traffic(extra_args, kernel_prefixes):
+    """HBM bytes per launch of the named kernels from two SEPARATE child passes ``rocprofv3 --kernel-trace --pmc
+    FETCH_SIZE`` / ``--pmc WRITE_SIZE`` of this same command (3 steps), as MI355X_MICROARCH.md's HBM section
+    prescribes: counter values are KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide streaming read (x2).
+    Returns {prefix: bytes per launch} or None when rocprofv3 is unavailable / fails."""
+    if shutil.which("rocprofv3") is None:
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    sums = {p: {"FETCH_SIZE": [], "WRITE_SIZE": []} for p in kernel_prefixes}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"dmm_pmc_{ctr}_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"]
+            r = subprocess.run(cmd + extra_args, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    name = row["Kernel_Name"]
+                    name = name[5:] if name.startswith("void ") else name
+                    for p in kernel_prefixes:
+                        if name.startswith(p):
+                            sums[p][ctr].append(float(row["Counter_Value"]))
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for p, v in sums.items():
+        if not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
+            return None
+        fa = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+        wa = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        out[p] = int(fa * 1024 * 2 + wa * 1024)
+    return out
+
+
+def profile_traffic(tag_file, key):
+    path = os.path.join(ROOT, "profiles", tag_file)
+    try:
+        return json.load(open(path)).get("hbm_bytes_per_launch_at_frames", {}).get(str(key)), "profiles/" + tag_file
+    except Exception:
+        return None, None
+
+
+class Runner:
+    """dist init, fences and the timed loop shared by the three workloads."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        local = local % max(torch.cuda.device_count(), 1)   # identity on a full node; lets 2 test ranks share 1 GPU
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)   # RCCL over xGMI
+            else:
+                dist.init_process_group(args.backend)
+
+    def fence(self):
+        torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+    def timed(self, step, steps, warmup):
+        """W untimed warm-up steps, then EXACTLY K steps between two fences; MAX over ranks."""
+        for _ in range(warmup):
+            step(None)
+        self.fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.args.backend == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def finish(self, out):
+        if self.rank == 0:
+            print(json.dumps(out), flush=True)
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def quick_ms(fn, n, warm=3, dev=None):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[1] (default) and configs[4]: the matching layer on resident mask batches
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_layer(R, ci):
+    from dmm_net_amd import _lib, ops, synth
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    _lib.load()                                              # loud failure if the HIP extension is missing
+    c = synth.CONFIGS[ci]
+    B = args.frames or (1024 if ci == 2 else 256)
+    N, M, H, W, D = c["P"], c["O"], c["H"], c["W"], c["D"]
+    HW = H * W
+    mdt = torch.float32 if ci == 2 else torch.float16
+    es = 4 if ci == 2 else 2
+    g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + ci + 1000 * rank)
+
+    def make_inputs(b):
+        pm = torch.rand((b, N, H, W), generator=g, device=dev)
+        tm = torch.rand((b, M, H, W), generator=g, device=dev)
+        if mdt != torch.float32:
+            pm, tm = pm.to(mdt), tm.to(mdt)
+        return (pm, tm, torch.randn((b, N, D), generator=g, device=dev), torch.randn((b, M, D), generator=g, device=dev),
+                torch.rand((b, N), generator=g, device=dev))
+    inputs = make_inputs(B)
+    # pre-allocated plan: nothing is allocated in the timed region.  pipeline = streaming lane (cost, mix) on the
+    # current stream + latency lane (normalise, cosine, solver) on a side stream (ops.ForwardPlan)
+    plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=mdt, pipeline=False if args.no_pipeline else (True if args.pipeline else None),
+                           time_kernels=True)
+    kw = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
+    ev = []
+
+    def step(k):
+        plan.kernel_events = None
+        if k is not None:
+            plan.kernel_events = {}
+            ev.append(plan.kernel_events)
+        plan.run(*inputs, **kw)
+
+    elapsed = R.timed(step, args.steps, args.warmup)
+    # every frame ran the solver; a frame may take the reference's data-dependent early exit (relax_match.py:96-98)
+    it_mean = float(plan.iters.float().mean())
+    assert int(plan.iters.max()) == 20 and it_mean > 19.5, f"work was skipped inside the timed region ({it_mean})"
+    assert bool(torch.isfinite(plan.full_outmask[-1].float()).all()) and float(plan.full_outmask[-1].float().abs().sum()) > 0
+
+    def avg_ms(name):
+        v = [a.elapsed_time(b) for per_step in ev for (a, b) in per_step.get(name, [])]
+        return float(np.mean(v)) if v else None
+    # dominant kernel = the IoU count kernel: HIP events around each of its launches, on the stream it runs on (the
+    # pipelined plan launches it once per half of the batch)
+    cost_ms, mix_ms = avg_ms("cost"), avg_ms("mix")
+    launches = len(plan.halves) if plan.pipeline else 1
+    fpl = B / launches
+    b_cost = (N + M) * HW * es + M * N * 4                                 # SURVEY 8d: B_cost per frame
+    b_mix = M * HW * es + M * HW * plan.full_outmask.element_size()       # test mode: M selected planes in, M planes out
+    alg_bytes = int(fpl * b_cost)
+    achieved = alg_bytes / (cost_ms * 1e-3) / 1e9
+    cost_kernel = "dmm::iou_counts_kernel<float,16,1>" if ci == 2 else "dmm::iou_counts_tl_kernel<__half,...>"
+    fps_rank = B * args.steps / elapsed
+    mix_gbs = fpl * b_mix / (mix_ms * 1e-3) / 1e9 if mix_ms else None
+    out = {
+        "metric": METRIC if ci == 2 else "frames/sec (cost+match layer) at N=200 proposals, M=20 templates, 255x255, "
+                                         "fp16 mask planes (BASELINE configs[4])",
+        "value": round(world * fps_rank, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ci == 2 else "f16 planes, f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[{ci - 1}]: {N} proposals x {M} templates, 255x255 "
+                                f"{'fp32' if ci == 2 else 'fp16'} masks, D=512, 20 outer x 5 inner relax iterations, "
+                                "forward is_test=1, uniform-random masks"),
+                   "frames_per_gpu_per_step": B, "mean_outer_iterations": round(it_mean, 3),
+                   "sharding": f"frames x{world} (no collective in the forward)", "schedule": plan.schedule_name()},
+        "roofline": {"bound": "hbm", "kernel": cost_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": int(fpl),
+                     "avg_launch_ms": round(cost_ms, 4)},
+        # whole layer on SURVEY 8d's two bases, per GPU: B_cost x frames/s, and cost + test-mode mix bytes x frames/s
+        "roofline_layer": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                           "b_cost_basis": {"bytes_per_frame": b_cost, "achieved": round(b_cost * fps_rank / 1e9, 1),
+                                            "frac": round(b_cost * fps_rank / 1e9 / HBM_PEAK_GBS, 4)},
+                           "b_layer_basis": {"bytes_per_frame": b_cost + b_mix,
+                                             "achieved": round((b_cost + b_mix) * fps_rank / 1e9, 1),
+                                             "frac": round((b_cost + b_mix) * fps_rank / 1e9 / HBM_PEAK_GBS, 4)}},
+    }
+    if mix_ms:
+        out["roofline_mix"] = {"bound": "hbm", "kernel": "dmm::mask_mix_rows_kernel", "achieved": round(mix_gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mix_gbs / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_per_launch": int(fpl * b_mix), "avg_launch_ms": round(mix_ms, 4)}
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras:
+        # frames per launch sequence: 1 and 4 are the product's sizes (one call per video / per training batch)
+        sweep = {}
+        for b in (1, 4, 8, 64, 512, 1024):
+            if b > B:
+                continue
+            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt)
+            inp = inputs if b == B else tuple(t[:b] for t in inputs)
+            ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
+            sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}
+        out["batch_sweep"] = sweep
+        out["latency"] = {"B1_ms": sweep["1"]["ms"], "B4_ms": sweep["4"]["ms"],
+                          "note": "one launch sequence (HIP-graph replay where the plan captured one), device-side "
+                                  "time per call averaged over back-to-back calls"}
+        del inputs, plan
+        torch.cuda.empty_cache()
+        if not args.no_traffic:
+            pref = "dmm::iou_counts_kernel" if ci == 2 else "dmm::iou_counts_tl_kernel"
+            extra = ["--config", str(ci), "--frames", str(B)] + (["--no-pipeline"] if args.no_pipeline else [])
+            t = pmc_traffic(extra, [pref, "dmm::mask_mix_rows_kernel"])
+            if t is not None:
+                out["roofline"]["traffic"] = t[pref]
+                out["roofline"]["traffic_source"] = ("measured in this run: child passes `rocprofv3 --kernel-trace "
+                                                     "--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` of this command (3 "
+                                                     "steps), KiB x 1024, FETCH x 2 (gfx950)")
+                if "roofline_mix" in out:
+                    out["roofline_mix"]["traffic"] = t["dmm::mask_mix_rows_kernel"]
+        if out["roofline"]["traffic"] is None and ci == 2:
+            tv, src = profile_traffic("r01_pmc_traffic.json", int(fpl))
+            out["roofline"]["traffic"] = tv
+            out["roofline"]["traffic_source"] = f"NOT measured in this run; from {src}" if src else None
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, ci)
+    R.finish(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[2]: ResNet-50 + heads (bf16, MIOpen) -> fused 4-level ROIAlign+mean -> the layer, batch of 8 frames
+# ---------------------------------------------------------------------------------------------------------------------
+def conv_flops(module, x):
+    """2 x MACs of every Conv2d in one forward (hooks); the encoder's matrix work."""
+    total = [0]
+    hooks = []
+
+    def hook(m, inp, out):
+        total[0] += 2 * out.numel() * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+    for m in module.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            hooks.append(m.register_forward_hook(hook))
+    with torch.no_grad():
+        module(x)
+    for h in hooks:
+        h.remove()
+    return total[0]
+
+
+def bench_config3(R):
+    from dmm_net_amd import _lib, ops, synth
+    from dmm_net_amd.encoder import FeatureEncoder, GraphedEncoder, fold_batchnorm
+    from dmm_net_amd.proposals import SimpleBoxList
+    from dmm_net_amd.roi_features import FeatureExtractor
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    _lib.load()
+    B, P, O, H, W, D = args.frames or 8, 50, 10, 255, 255, 512
+    torch.manual_seed(0)
+    g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + 3 + 1000 * rank)
+    enc_fp32 = fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval())
+    img = torch.randn(B, 3, H, W, device=dev)
+    flops = conv_flops(enc_fp32, img)
+    enc = GraphedEncoder(enc_fp32, weights_dtype=torch.bfloat16)
+    fe = FeatureExtractor()
+    pm = torch.rand((B, P, H, W), generator=g, device=dev)
+    tm = torch.rand((B, O, H, W), generator=g, device=dev)
+    sc = torch.rand((B, P), generator=g, device=dev)
+
+    def boxes(n):
+        x1 = torch.rand(n, generator=g, device=dev) * (W - 40)
+        y1 = torch.rand(n, generator=g, device=dev) * (H - 40)
+        w = 8 + torch.rand(n, generator=g, device=dev) * 100
+        h = 8 + torch.rand(n, generator=g, device=dev) * 100
+        return torch.stack([x1, y1, (x1 + w).clamp(max=W - 1), (y1 + h).clamp(max=H - 1)], 1)
+    pbox = [SimpleBoxList(boxes(P), (W, H)) for _ in range(B)]
+    tbox = [SimpleBoxList(boxes(O), (W, H)) for _ in range(B)]
+    plan = ops.ForwardPlan(B, P, O, H, W, D, dev)
+    kw = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
+    ev = []
+
+    def step(k):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if k is not None else None
+        if e:
+            e[0].record()
+        f = enc(img)["backbone_feature"]
+        if e:
+            e[1].record()
+        with torch.no_grad():
+            a, b = fe(f, pbox).view(B, P, D), fe(f, tbox).view(B, O, D)
+        if e:
+            e[2].record()
+        plan.run(pm, tm, a, b, sc, **kw)
+        if e:
+            e[3].record()
+            ev.append(e)
+    elapsed = R.timed(step, args.steps, args.warmup)
+    assert int(plan.iters.max()) >= 1 and bool(torch.isfinite(plan.full_outmask).all())
+    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    roi_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    lay_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    tflops = flops / (enc_ms * 1e-3) / 1e12
+    out = {
+        "metric": "frames/sec (ResNet-50 encoder + ROI features + cost+match layer), batch of 8 frames, bf16 encoder "
+                  "(BASELINE configs[2])",
+        "value": round(world * B * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16 encoder, f32 matching layer", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {B} frames of 255x255, ResNet-50 + sk/prop heads (BatchNorm "
+                               "folded, bf16 weights, one HIP graph, MIOpen), 60 rois/frame x 4 levels fused "
+                               "ROIAlign+mean, 50 proposals x 10 templates cost + 20x5 solver + mix; random-init weights",
+                   "frames_per_gpu_per_step": B, "sharding": f"frames x{world}",
+                   "stage_ms": {"encoder": round(enc_ms, 4), "roi_features": round(roi_ms, 4),
+                                "matching_layer": round(lay_ms, 4)}, "schedule": plan.schedule_name()},
+        "roofline": {"bound": "mfma", "kernel": "MIOpen convolutions of the encoder graph (all kernels of the replay)",
+                     "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                     "algorithmic_flops_per_launch": int(flops), "avg_launch_ms": round(enc_ms, 4),
+                     "note": "2 x MACs of every convolution of one 8-frame forward / HIP-event time of the graph "
+                             "replay; per-kernel table in profiles/r02_encoder_kernel_table.md"},
+    }
+    R.finish(out)
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = local % max(torch.cuda.device_count(), 1)       # identity on a full node; lets 2 test ranks share 1 GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group(args.backend)
-
-    from dmm_net_amd import _lib, ops, synth
-    _lib.load()                                              # loud failure if the HIP extension is missing
-    c = synth.CONFIGS[2]
-    B, N, M, H, W, D = args.frames, c["P"], c["O"], c["H"], c["W"], c["D"]
-    HW = H * W
-    g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + 2 + 1000 * rank)
-    pm = torch.rand((B, N, H, W), generator=g, device=dev)
-    tm = torch.rand((B, M, H, W), generator=g, device=dev)
-    pf = torch.randn((B, N, D), generator=g, device=dev)
-    tf = torch.randn((B, M, D), generator=g, device=dev)
-    sc = torch.rand((B, N), generator=g, device=dev)
-
-    # pre-allocated plan: nothing is allocated in the timed region.  pipeline=True = streaming lane (cost, mix)
-    # on the current stream + latency lane (normalise, cosine, solver) on a side stream (ops.ForwardPlan).
-    plan = ops.ForwardPlan(B, N, M, H, W, D, dev, pipeline=not args.no_pipeline)
-    halves = plan.halves if plan.pipeline else [(0, B)]
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in halves]
-          for _ in range(args.steps)]
-    if not plan.pipeline:
-        # unpipelined: time the cost kernel through the granular C-ABI calls on the current stream
-        L = _lib.load()
-        Pp = ops.padded_width(N, M)
-        i32, f32 = dict(dtype=torch.int32, device=dev), dict(dtype=torch.float32, device=dev)
-        counts = torch.empty((B * M * N + B * N + B * M,), **i32)
-        inter, ap, at = counts[:B * M * N], counts[B * M * N:B * M * N + B * N], counts[B * M * N + B * N:]
-        pn, tn, cosv = torch.empty_like(pf), torch.empty_like(tf), torch.empty((B, M, N), **f32)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        P = lambda t: t.data_ptr()
-
-    def step(k=None):
-        if plan.pipeline:
-            plan.cost_events = ev[k] if k is not None else None
-            plan.run(pm, tm, pf, tf, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
-            return
-        if k is not None:
-            ev[k][0][0].record()
-        rc = L.dmm_iou_counts(P(pm), P(tm), 0, B, N, M, HW, N * HW, HW, M * HW, HW, None, None, P(inter), P(ap), P(at),
-                              stream)
-        if k is not None:
-            ev[k][0][1].record()
-        rc |= L.dmm_feature_normalize_f32(P(pf), B * N, D, P(pn), None, stream)
-        rc |= L.dmm_feature_normalize_f32(P(tf), B * M, D, P(tn), None, stream)
-        rc |= L.dmm_cosine_f32(P(tn), P(pn), B, N, M, D, None, None, P(cosv), stream)
-        rc |= L.dmm_relax_match_f32(P(cosv), P(inter), P(ap), P(at), P(sc), B, N, M, None, None, 0.3, 20, 5, 0.1, 1,
-                                    P(plan.sim), None, P(plan.Rb), P(plan.match_score), P(plan.det_score),
-                                    P(plan.iters), None, stream)
-        rc |= L.dmm_mask_mix(P(plan.Rb), P(pm), 0, B, N, M, Pp, HW, N * HW, HW, None, None, P(plan.full_outmask),
-                             M * HW, HW, stream)
-        if rc:
-            raise RuntimeError(f"libdmm_match call failed: {rc}")
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # every frame ran the solver; a frame may take the reference's data-dependent early exit (relax_match.py:96-98)
-    it_mean = float(plan.iters.float().mean())
-    assert int(plan.iters.max()) == 20 and it_mean > 19.5, f"work was skipped inside the timed region ({it_mean})"
-    assert bool(torch.isfinite(plan.full_outmask[-1]).all()) and float(plan.full_outmask[-1].abs().sum()) > 0
-    # dominant kernel = dmm::iou_counts_kernel: HIP events around each of its launches, on its own stream
-    # (the pipelined plan launches it twice per step, once per half of the batch)
-    cost_ms = float(np.mean([a.elapsed_time(b) for per_step in ev for (a, b) in per_step]))
-    frames_per_launch = B / len(halves)
-    alg_bytes = int(frames_per_launch * ((N + M) * HW * 4 + M * N * 4))   # B_cost x frames per launch
-    achieved = alg_bytes / (cost_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_at_frames", {}).get(str(int(frames_per_launch)))
-        except Exception:
-            traffic = None
-    out = {
-        "metric": "frames/sec (cost+match layer) at N=50 proposals, M=10 templates, 255x255",
-        "value": round(world * B * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 50 proposals x 10 templates, 255x255 fp32 masks, D=512, "
-                               "20 outer x 5 inner relax iterations, forward is_test=1, uniform-random masks",
-                   "frames_per_gpu_per_step": B, "mean_outer_iterations": round(it_mean, 3), "sharding": f"frames x{world} (no collective in the forward)",
-                   "schedule": "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
-                               if plan.pipeline else "single stream"},
-        "roofline": {"bound": "hbm", "kernel": "dmm::iou_counts_kernel<float,16,1>", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                     "frames_per_launch": int(frames_per_launch), "avg_launch_ms": round(cost_ms, 4)},
-    }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R = Runner(args)
+    if args.config == 3:
+        bench_config3(R)
+    else:
+        bench_layer(R, args.config)
 
 
 if __name__ == "__main__":

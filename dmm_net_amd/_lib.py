@@ -25,6 +25,7 @@ SYMBOLS = (
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
+    "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
     "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32",
 )
 
@@ -68,6 +69,13 @@ def load():
                                  vp, vp, vp, vp]
     L.dmm_iou_counts_dual.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64,
                                       c_i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dmm_iou_counts_frames.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp,
+                                        vp]
+    L.dmm_iou_counts_dual_frames.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64,
+                                             c_i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dmm_mask_mix_frames.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, vp, vp, vp, c_i64, c_i64,
+                                      vp]
+    L.dmm_mask_mix_bwd_frames.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_i64, vp, vp, vp, vp]
     L.dmm_feature_normalize_f32.argtypes = [vp, c_i64, c_int, vp, vp, vp]
     L.dmm_cosine_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,
@@ -94,7 +102,8 @@ def load():
     L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                     c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]
-    for f in ("dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    for f in ("dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
+              "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
               "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks",
               "dmm_mask_boxes_f32", "dmm_merge_labels_f32"):

@@ -62,7 +62,7 @@ class _MatchLayerFn(torch.autograd.Function):
         tcounts = None
         if targets is not None and tm.shape[1] <= 16:
             # training: one pass over the proposal planes for both IoU tables (templates and targets)
-            (inter, ap, at), (gi, gat) = ops.iou_counts_dual(pm, tm, targets.to(pm.dtype), n_valid, m_valid)
+            (inter, ap, at), (gi, gat) = ops.iou_counts_dual(pm, tm, targets.to(tm.dtype), n_valid, m_valid)
             tcounts = (gi, ap, gat)
         else:
             inter, ap, at = ops.iou_counts(pm, tm, n_valid, m_valid)
@@ -86,7 +86,9 @@ class _MatchLayerFn(torch.autograd.Function):
             if lc is not None:
                 live, cnt = lc
         empty = pf.new_zeros(())
-        ctx.save_for_backward(pn, tn, pnorm, tnorm, pf, tf, cos, r["sim"], r["Rb"], sc, pm,
+        ctx.frame_planes = pm if isinstance(pm, ops.FramePlanes) else None     # per-frame tensors + pointer table
+        ctx.save_for_backward(pn, tn, pnorm, tnorm, pf, tf, cos, r["sim"], r["Rb"], sc,
+                              empty if ctx.frame_planes is not None else pm,
                               gt if gt is not None else empty, live if live is not None else empty,
                               cnt if cnt is not None else empty,
                               n_valid if n_valid is not None else empty, m_valid if m_valid is not None else empty)
@@ -108,6 +110,21 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
     [T,B,O,D].  Returns (full_outmask [B,O,H,W], match_score [B,O], det_score [B,O], cost_loss [B], iters [B])."""
     if tf.dim() == 3:
         tf = tf.unsqueeze(0)
+    if isinstance(pm, (list, tuple)):
+        # one tensor per frame (DMM_Model's per-video proposal planes): matched in place through the pointer-table
+        # entry points; only a mask gradient or mixed dtypes force the stacked copy
+        if any(t.requires_grad for t in pm) or len({t.dtype for t in pm}) > 1 or pm[0].dtype not in ops._DT:
+            pm = ops.FramePlanes([t.float() for t in pm]).stacked()
+        else:
+            pm = ops.FramePlanes(pm)
+            if n_valid is None:
+                n_valid = pm.n_valid()
+            if tm.dtype != pm.dtype:
+                tm = tm.to(pm.dtype)
+            if targets is not None:
+                targets = targets.to(pm.dtype)
+            return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
+                                       float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test))
     # 16-bit mask planes go to the kernels as they are (half the bytes of the cost pass; values are only thresholded and
     # scaled); anything else is matched in fp32 like the reference
     if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):

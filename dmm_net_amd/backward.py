@@ -35,18 +35,21 @@ def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
     n_valid = n_valid if ctx.ragged[0] else None
     m_valid = m_valid if ctx.ragged[1] else None
     score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
-    B, P = pm.shape[0], pm.shape[1]
+    if ctx.frame_planes is not None:                 # per-frame tensors: the HIP kernels take the pointer table
+        pm = ctx.frame_planes
+        B, P, H, W = pm.B, pm.N, pm.H, pm.W
+    else:
+        B, P = pm.shape[0], pm.shape[1]
+        H, W = pm.shape[-2], pm.shape[-1]
     O = sim.shape[1]
-    H, W = pm.shape[-2], pm.shape[-1]
     Pp = Rb.shape[-1]
     need_pf, need_tf, need_pm = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
     g_pf = g_tf = g_pm = None
     none = (None,) * 10
     if not (need_pf or need_tf or need_pm):
         return (None, None, None) + none
-    pm2d = pm.reshape(B, P, H * W)
     dOut = None if d_full is None else d_full.reshape(B, O, H * W).float()
-    if need_pm and dOut is not None:
+    if need_pm and dOut is not None:                 # (never with frame planes: they carry no gradient by construction)
         g_pm = torch.bmm(Rb[:, :, :P].transpose(1, 2), dOut).view(B, P, H, W).to(pm.dtype)
     if need_pf or need_tf:
         dRb = None

@@ -10,6 +10,16 @@ namespace dmm {
 
 constexpr int kWave = 64;
 
+// Frame addressing of the proposal planes.  Either the B frames are equally spaced (frame b at base + b * stride_b
+// elements), or -- the per-video tensors of DMM_Model, the *_frames entry points of the C ABI -- `base` is a DEVICE
+// ARRAY of B pointers to each frame's first plane; the launchers mark that with the stride sentinel kFrameTable.
+constexpr int64_t kFrameTable = INT64_MIN;
+template <typename T>
+__device__ __forceinline__ const T *frame_base(const T *base, int b, int64_t stride_b) {
+    if (stride_b == kFrameTable) return reinterpret_cast<const T *const *>(base)[b];
+    return base + (int64_t)b * stride_b;
+}
+
 // 16-byte vectors that are only guaranteed 4-byte aligned: a 255x255 fp32 plane is 260100 B,
 // so odd planes start 4/8/12 B off a 16-B boundary.  gfx950 global_load/store_dwordx4 only
 // need dword alignment; the aligned(4) typedef makes hipcc emit them instead of 4 dword ops.

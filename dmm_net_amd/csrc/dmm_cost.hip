@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     Mb = min(Mb - m0, masks_t2 ? MT / 2 : MT);
     if (Nb <= 0 || Mb <= 0) return;
     const int Mrows = masks_t2 ? 2 * Mb : Mb;                    // rows of the (template | target) tile
-    const T *Pb = masks_p + (int64_t)b * sp_b + (int64_t)n0 * sp_n;
+    const T *Pb = frame_base(masks_p, b, sp_b) + (int64_t)n0 * sp_n;
     const T *Tb = masks_t + (int64_t)b * st_b + (int64_t)m0 * st_m;
     const T *T2b = masks_t2 ? masks_t2 + (int64_t)b * st2_b + (int64_t)m0 * st2_m : nullptr;
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_tl_kernel(
     Mb = min(Mb - m0, mt);
     if (Nb <= 0 || Mb <= 0) return;
     const int Mrows = masks_t2 ? 2 * Mb : Mb;
-    const T *Pb = masks_p + (int64_t)b * sp_b + (int64_t)n0 * sp_n;
+    const T *Pb = frame_base(masks_p, b, sp_b) + (int64_t)n0 * sp_n;
     const T *Tb = masks_t + (int64_t)b * st_b + (int64_t)m0 * st_m;
     const T *T2b = masks_t2 ? masks_t2 + (int64_t)b * st2_b + (int64_t)m0 * st2_m : nullptr;
     unsigned *red_at = tl_red + nt * RS;
@@ -416,7 +416,10 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
     static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
     const int RS = (masks_t2 ? 2 * mt : mt) + 1;
-    const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave);
+    // DMM_COST_TL_LDS_PAD (bytes, experiment): extra dynamic LDS per workgroup = an occupancy throttle, so that the
+    // latency-lane kernels of a concurrent stream always find free VGPRs / wave slots next to this kernel
+    const char *pad_env = getenv("DMM_COST_TL_LDS_PAD");
+    const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave) + (pad_env ? (size_t)atoi(pad_env) : 0);
     hipLaunchKernelGGL((iou_counts_tl_kernel<T>), dim3(splits, B), dim3(kCostThreads), lds, stream, masks_p, masks_t,
                        masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t,
                        inter2, area_t2, n0, m0, nt, mt, chunks_per_wg, wap, wat, RS, xcd_remap);
@@ -517,7 +520,9 @@ static int iou_counts_dispatch(const void *masks_p, const void *masks_t, const v
         for (int b0 = 0; b0 < B; b0 += 65535) {
             const int nb = B - b0 < 65535 ? B - b0 : 65535;
             const int rc = iou_counts_dispatch(
-                (const char *)masks_p + es * (size_t)b0 * sp_b, (const char *)masks_t + es * (size_t)b0 * st_b,
+                sp_b == dmm::kFrameTable ? (const char *)masks_p + sizeof(void *) * (size_t)b0
+                                         : (const char *)masks_p + es * (size_t)b0 * sp_b,
+                (const char *)masks_t + es * (size_t)b0 * st_b,
                 masks_t2 ? (const char *)masks_t2 + es * (size_t)b0 * st2_b : nullptr, dtype, nb, N, M, HW, sp_b, sp_n,
                 st_b, st_m, st2_b, st2_m, n_valid ? n_valid + b0 : nullptr, m_valid ? m_valid + b0 : nullptr,
                 inter + (size_t)b0 * M * N, area_p + (size_t)b0 * N, area_t + (size_t)b0 * M,
@@ -568,4 +573,24 @@ extern "C" int dmm_iou_counts_dual(const void *masks_p, const void *masks_t, con
     if (!masks_t2) return DMM_ERR_BAD_ARG;
     return iou_counts_dispatch(masks_p, masks_t, masks_t2, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m,
                                n_valid, m_valid, inter, area_p, area_t, inter2, area_t2, stream);
+}
+
+// ---- per-frame pointer tables for the proposal planes (the per-video tensors of DMM_Model: no batch copy) ----
+extern "C" int dmm_iou_counts_frames(const void *const *masks_p_frames, const void *masks_t, int dtype, int B, int N,
+                                     int M, int HW, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                                     const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                                     dmm_stream_t stream) {
+    return iou_counts_dispatch((const void *)masks_p_frames, masks_t, nullptr, dtype, B, N, M, HW, dmm::kFrameTable, sp_n,
+                               st_b, st_m, 0, 0, n_valid, m_valid, inter, area_p, area_t, nullptr, nullptr, stream);
+}
+
+extern "C" int dmm_iou_counts_dual_frames(const void *const *masks_p_frames, const void *masks_t, const void *masks_t2,
+                                          int dtype, int B, int N, int M, int HW, int64_t sp_n, int64_t st_b,
+                                          int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
+                                          const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                                          int32_t *inter2, int32_t *area_t2, dmm_stream_t stream) {
+    if (!masks_t2) return DMM_ERR_BAD_ARG;
+    return iou_counts_dispatch((const void *)masks_p_frames, masks_t, masks_t2, dtype, B, N, M, HW, dmm::kFrameTable,
+                               sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2, area_t2,
+                               stream);
 }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     }
     __syncthreads();
     const int cnt = cnt_s;
-    const T *Pb = masks_p + (int64_t)b * sp_b;
+    const T *Pb = frame_base(masks_p, b, sp_b);
     float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
     const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & align_mask);   // row start = boundary + pre floats
     const int nsteps = (HW + pre + kMixThreads * 4 - 1) / (kMixThreads * 4);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_kernel(const float *
     __syncthreads();
     const int cnt = cnt_s;
     if (cnt == 0) return;
-    const T *Pb = masks_p + (int64_t)b * sp_b;
+    const T *Pb = frame_base(masks_p, b, sp_b);
     const float *drow = dout + ((int64_t)b * M + m) * HW;
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
     const int s_begin = blockIdx.x * steps_per_wg;
@@ -357,4 +357,19 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
         default:
             return DMM_ERR_BAD_ARG;
     }
+}
+
+// ---- per-frame pointer tables for the proposal planes (the per-video tensors of DMM_Model: no batch copy) ----
+extern "C" int dmm_mask_mix_frames(const float *Rb, const void *const *masks_p_frames, int dtype, int B, int N, int M,
+                                   int Pp, int HW, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                   float *out, int64_t so_b, int64_t so_m, dmm_stream_t stream) {
+    return dmm_mask_mix(Rb, (const void *)masks_p_frames, dtype, B, N, M, Pp, HW, dmm::kFrameTable, sp_n, n_valid,
+                        m_valid, out, so_b, so_m, stream);
+}
+
+extern "C" int dmm_mask_mix_bwd_frames(const float *Rb, const void *const *masks_p_frames, int dtype, const float *dout,
+                                       int B, int N, int M, int Pp, int HW, int64_t sp_n, const int32_t *n_valid,
+                                       const int32_t *m_valid, float *dRb, dmm_stream_t stream) {
+    return dmm_mask_mix_bwd(Rb, (const void *)masks_p_frames, dtype, dout, B, N, M, Pp, HW, dmm::kFrameTable, sp_n,
+                            n_valid, m_valid, dRb, stream);
 }

@@ -21,9 +21,18 @@
 //
 // Roofline: neither HBM nor MFMA -- a latency-bound dependent chain (~400 VALU ops per sweep);
 // throughput comes from running one frame per wave on all 1024 SIMDs.
-#include "dmm_torch_order.h"
+#include <stdlib.h>
+
+#include "dmm_solve.h"
 
 namespace dmm {
+
+bool use_row_split(int B, int M, int Pp) {
+    const char *e = getenv("DMM_SOLVER_KERNEL");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return Pp > 64 || M > 16 || B <= 128;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Cross-wave plumbing for NG > 1 (Pp > 64): per-wave partials go through LDS.
@@ -90,11 +99,6 @@ struct BlockRed {
         }
         phase ^= 1;
     }
-};
-
-struct RelaxParams {
-    int max_iter, proj_iter;
-    float lr;
 };
 
 struct fmax_op { __device__ __forceinline__ float operator()(float a, float b) const { return b > a ? b : a; } };
@@ -735,6 +739,10 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
     const dmm::RelaxParams prm{max_iter, proj_iter, lr};
     // python: sim*(1-w) + iou*w with w a python float -> both scalars rounded to fp32 once
     const float w_feat = (float)(1.0 - (double)score_weight), w_iou = score_weight;
+    if (dmm::use_row_split(B, M, Pp))
+        return dmm::launch_relax_match_rs(cos_in, inter, area_p, area_t, score_p, B, N, M, n_valid, m_valid, w_feat,
+                                          w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,
+                                          iters_out, X_final, (hipStream_t)stream);
     const bool exact_ok = (m_valid == nullptr);   // every frame has exactly M templates
 #define DMM_CALL(MT_, NG_, EX_)                                                                                    \
     hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
@@ -754,6 +762,9 @@ extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const in
     if (!C) return DMM_ERR_BAD_ARG;
     if (n > DMM_MAX_TEMPLATES || m > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
     const dmm::RelaxParams prm{max_iter, proj_iter, lr};
+    if (dmm::use_row_split(B, n, m))
+        return dmm::launch_relax_solve_rs(C, B, n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out,
+                                          (hipStream_t)stream);
 #define DMM_CALL(MT_, NG_, EX_)                                                                                     \
     hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream, C, \
                        n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out)

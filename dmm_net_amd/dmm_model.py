@@ -68,8 +68,6 @@ class DMM_Model(nn.Module):
         D = prop_feat[0].shape[1]
         Pmax = max(int(p.shape[0]) for p in prop_m)
         pf = prop_feat[0].new_zeros((B, Pmax, D))
-        # planes beyond n_valid[b] are never read by the ragged kernels: no need to clear 4 B * Pmax * H * W per video
-        pm = mask_last_occurence.new_empty((B, Pmax, H, W))
         sc = mask_last_occurence.new_zeros((B, Pmax))
         for b in range(B):
             P = prop_m[b].shape[0]
@@ -77,8 +75,10 @@ class DMM_Model(nn.Module):
                 "get {} {}".format(prop_m[b].shape[-2:], mask_last_occurence[b].shape[-2:])
             assert prop_feat[b].shape[0] == P, "get {} {}".format(P, prop_feat[b].shape[0])
             pf[b, :P] = prop_feat[b]
-            pm[b, :P] = prop_m[b]
             sc[b, :P] = prop_score[b]
+        # the mask planes stay where they are: one tensor per video, handed to the kernels as a pointer table (the
+        # round-1 driver copied them into a [B, Pmax, H, W] batch: 2 x 13 MB per video in front of a 15.6 MB cost pass)
+        pm = list(prop_m)
         tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
         if row_scale is not None:
             # valid templates that are NOT a prefix: the reference's OF_matrix = diag(valid)[:O] (dmm_model.py:151-156)

@@ -38,6 +38,53 @@ def _planes(t: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
     return t, t.stride(0), t.stride(1)
 
 
+class FramePlanes:
+    """Proposal planes of B frames held as ONE TENSOR PER FRAME (the reference's ``prop_m[bid]``, dmm_model.py:58 / :111)
+    plus the device pointer table the ``*_frames`` entry points of the C ABI take -- the frames go through one launch
+    without being copied into a [B, Nmax, H, W] batch first.  Frame b has ``planes[b].shape[0]`` planes (ragged: pass
+    ``n_valid``); all frames share H, W, dtype and the plane stride."""
+
+    def __init__(self, planes):
+        planes = list(planes)
+        assert len(planes) > 0
+        H, W = int(planes[0].shape[-2]), int(planes[0].shape[-1])
+        self.dtype, self.device = planes[0].dtype, planes[0].device
+        assert self.dtype in _DT, self.dtype
+        fixed = []
+        for t in planes:
+            _need_gpu(t)
+            assert t.dim() == 3 and tuple(t.shape[-2:]) == (H, W) and t.dtype == self.dtype and t.device == self.device
+            if t.shape[0] and not (t.stride(2) == 1 and t.stride(1) == W and t.stride(0) >= H * W):
+                t = t.contiguous()
+            fixed.append(t)
+        strides = {int(t.stride(0)) for t in fixed if t.shape[0] > 1}
+        if len(strides) > 1:                         # mixed plane strides: densify the odd ones
+            fixed = [t if (t.shape[0] <= 1 or t.stride(0) == H * W) else t.contiguous() for t in fixed]
+            strides = {int(t.stride(0)) for t in fixed if t.shape[0] > 1}
+            if len(strides) > 1:
+                fixed = [t.contiguous() for t in fixed]
+                strides = {H * W}
+        self.planes = fixed                          # keeps the storage alive
+        self.plane_stride = strides.pop() if strides else H * W
+        self.H, self.W, self.B = H, W, len(fixed)
+        self.N = max(int(t.shape[0]) for t in fixed)
+        self.counts = [int(t.shape[0]) for t in fixed]
+        # one small H2D copy; frames without planes get a valid dummy address (never dereferenced: n_valid = 0)
+        any_ptr = next((t.data_ptr() for t in fixed if t.shape[0]), 0)
+        self.table = torch.tensor([t.data_ptr() if t.shape[0] else any_ptr for t in fixed], dtype=torch.int64,
+                                  device=self.device)
+
+    def n_valid(self) -> torch.Tensor:
+        return torch.tensor(self.counts, dtype=torch.int32, device=self.device)
+
+    def stacked(self) -> torch.Tensor:
+        """[B, N, H, W] copy (zero planes beyond a frame's count) -- only for paths without a pointer-table kernel."""
+        out = self.planes[0].new_zeros((self.B, self.N, self.H, self.W))
+        for b, t in enumerate(self.planes):
+            out[b, :t.shape[0]] = t
+        return out
+
+
 def padded_width(N: int, M: int) -> int:
     """Pp = solver width after the reference's zero padding (match_model.py:109-113)."""
     return N if N > M else M + 1
@@ -45,6 +92,23 @@ def padded_width(N: int, M: int) -> int:
 
 def iou_counts(masks_p: torch.Tensor, masks_t: torch.Tensor, n_valid=None, m_valid=None):
     """-> inter [B,M,N] i32, area_p [B,N] i32, area_t [B,M] i32 (match_helper.py:9-28 on all pairs)."""
+    if isinstance(masks_p, FramePlanes):
+        fp = masks_p
+        _need_gpu(masks_t)
+        assert fp.dtype == masks_t.dtype and n_valid is not None
+        masks_t, st_b, st_m = _planes(masks_t)
+        B, N, H, W, M = fp.B, fp.N, fp.H, fp.W, masks_t.shape[1]
+        assert masks_t.shape[0] == B and tuple(masks_t.shape[2:]) == (H, W)
+        dev = fp.device
+        inter = torch.empty((B, M, N), dtype=torch.int32, device=dev)
+        ap = torch.empty((B, N), dtype=torch.int32, device=dev)
+        at = torch.empty((B, M), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().dmm_iou_counts_frames(_ptr(fp.table), _ptr(masks_t), _DT[fp.dtype], B, N, M, H * W,
+                                                   fp.plane_stride, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
+                                                   _ptr(inter), _ptr(ap), _ptr(at), _stream(masks_t))
+        _lib.check(rc, "dmm_iou_counts_frames")
+        return inter, ap, at
     _need_gpu(masks_p, masks_t)
     assert masks_p.dtype == masks_t.dtype and masks_p.dtype in _DT
     masks_p, sp_b, sp_n = _planes(masks_p)
@@ -108,6 +172,23 @@ def iou_counts_packed(packed_p: torch.Tensor, packed_t: torch.Tensor, HW: int, n
 def iou_counts_dual(masks_p: torch.Tensor, masks_t: torch.Tensor, masks_t2: torch.Tensor, n_valid=None, m_valid=None):
     """One pass over the proposal planes against TWO template sets (templates + training targets).
     -> (inter, area_p, area_t), (inter2, area_t2)."""
+    if isinstance(masks_p, FramePlanes):
+        fp = masks_p
+        _need_gpu(masks_t, masks_t2)
+        assert fp.dtype == masks_t.dtype == masks_t2.dtype and masks_t.shape == masks_t2.shape and n_valid is not None
+        masks_t, st_b, st_m = _planes(masks_t)
+        masks_t2, st2_b, st2_m = _planes(masks_t2)
+        B, N, H, W, M = fp.B, fp.N, fp.H, fp.W, masks_t.shape[1]
+        i32 = dict(dtype=torch.int32, device=fp.device)
+        inter, inter2 = torch.empty((B, M, N), **i32), torch.empty((B, M, N), **i32)
+        ap, at, at2 = torch.empty((B, N), **i32), torch.empty((B, M), **i32), torch.empty((B, M), **i32)
+        with torch.cuda.device(fp.device):
+            rc = _lib.load().dmm_iou_counts_dual_frames(_ptr(fp.table), _ptr(masks_t), _ptr(masks_t2), _DT[fp.dtype], B,
+                                                        N, M, H * W, fp.plane_stride, st_b, st_m, st2_b, st2_m,
+                                                        _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at),
+                                                        _ptr(inter2), _ptr(at2), _stream(masks_t))
+        _lib.check(rc, "dmm_iou_counts_dual_frames")
+        return (inter, ap, at), (inter2, at2)
     _need_gpu(masks_p, masks_t, masks_t2)
     assert masks_p.dtype == masks_t.dtype == masks_t2.dtype and masks_p.dtype in _DT
     assert masks_t.shape == masks_t2.shape
@@ -221,6 +302,19 @@ def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_
 
 def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None) -> torch.Tensor:
     """full_outmask [B,M,H,W] = Rb [B,M,Pp] @ masks_p [B,N,H*W] (zero planes for the padded columns)."""
+    if isinstance(masks_p, FramePlanes):
+        fp = masks_p
+        _need_gpu(Rb)
+        B, N, H, W = fp.B, fp.N, fp.H, fp.W
+        M, Pp = Rb.shape[1], Rb.shape[2]
+        Rb = Rb.contiguous().float()
+        out = torch.empty((B, M, H, W), dtype=torch.float32, device=Rb.device)
+        with torch.cuda.device(Rb.device):
+            rc = _lib.load().dmm_mask_mix_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], B, N, M, Pp, H * W,
+                                                 fp.plane_stride, _ptr(n_valid), _ptr(m_valid), _ptr(out), M * H * W,
+                                                 H * W, _stream(Rb))
+        _lib.check(rc, "dmm_mask_mix_frames")
+        return out
     _need_gpu(Rb, masks_p)
     masks_p, sp_b, sp_n = _planes(masks_p)
     B, N, H, W = masks_p.shape
@@ -236,6 +330,20 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
 
 def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_valid=None, m_valid=None):
     """dRb [B,M,Pp] = dout [B,M,H,W] . masks_p [B,N,H,W] on the support of Rb (zeros elsewhere)."""
+    if isinstance(masks_p, FramePlanes):
+        fp = masks_p
+        _need_gpu(Rb, dout)
+        B, N, H, W = fp.B, fp.N, fp.H, fp.W
+        M, Pp = Rb.shape[1], Rb.shape[2]
+        Rb = Rb.contiguous().float()
+        dout = dout.contiguous().float().view(B, M, H * W)
+        dRb = torch.empty((B, M, Pp), dtype=torch.float32, device=Rb.device)
+        with torch.cuda.device(Rb.device):
+            rc = _lib.load().dmm_mask_mix_bwd_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], _ptr(dout), B, N, M, Pp,
+                                                     H * W, fp.plane_stride, _ptr(n_valid), _ptr(m_valid), _ptr(dRb),
+                                                     _stream(Rb))
+        _lib.check(rc, "dmm_mask_mix_bwd_frames")
+        return dRb
     _need_gpu(Rb, masks_p, dout)
     masks_p, sp_b, sp_n = _planes(masks_p)
     B, N, H, W = masks_p.shape
@@ -265,7 +373,7 @@ class ForwardPlan:
     """
 
     def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None,
-                 split=0.5):
+                 split=0.5, time_kernels=False):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
@@ -275,6 +383,10 @@ class ForwardPlan:
         # serialise with them (config 5: 2.26 ms single stream vs 2.37 ms two lanes per 256 frames)
         auto = B >= 64 and M <= 16 and self.Pp <= 64
         self.pipeline = auto if pipeline is None else bool(pipeline)
+        # time_kernels: the single-stream form issues the granular C-ABI calls (same kernels as dmm_match_forward) so
+        # that HIP events can bracket the cost and mix launches; bench.py sets kernel_events = {} per timed step
+        self.time_kernels = bool(time_kernels)
+        self.kernel_events = None
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
@@ -288,6 +400,12 @@ class ForwardPlan:
         if not self.pipeline:
             self.ws_bytes = int(L.dmm_workspace_bytes(B, N, M, D))
             self.workspace = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=self.device)
+            if self.time_kernels:
+                self.counts = [torch.empty((B * (M * N + N + M),), **i32)]
+                self.halves = [(0, B)]
+                self.pn = torch.empty((B, N, D), **f32)
+                self.tn = torch.empty((B, M, D), **f32)
+                self.cos = torch.empty((B, M, N), **f32)
             return
         # A = first `split` of the frames, B = the rest.  Measured at B = 1024: 1:1 gives 255 k frames/s, 7:1 only 245 k
         # (the normalise/cosine kernels then overlap one long cost launch and slow it down by what they cost alone).
@@ -304,7 +422,22 @@ class ForwardPlan:
             self.ev_start = torch.cuda.Event()
             self.ev_cost = [torch.cuda.Event() for _ in self.halves]
             self.ev_solved = [torch.cuda.Event() for _ in self.halves]
-        self.cost_events = None          # optional [(start, end)] timing events, set by bench.py
+
+    def schedule_name(self) -> str:
+        if self.pipeline:
+            return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
+        return "single stream"
+
+    def _mark(self, name, stream, begin):
+        """HIP event on ``stream`` before / after a kernel launch when bench.py asked for kernel timing."""
+        if self.kernel_events is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        if begin:
+            self.kernel_events.setdefault(name, []).append([e, None])
+        else:
+            self.kernel_events[name][-1][1] = e
 
     def _tables(self, h):
         (b, e) = self.halves[h]
@@ -325,6 +458,32 @@ class ForwardPlan:
         assert feat_p.dtype == torch.float32 and feat_t.dtype == torch.float32 and score_p.dtype == torch.float32
         L = _lib.load()
         dt = _DT[self.mask_dtype]
+        if not self.pipeline and self.time_kernels:
+            with torch.cuda.device(self.device):
+                main = torch.cuda.current_stream(self.device)
+                ms = main.cuda_stream
+                inter, ap, at = self._tables(0)
+                self._mark("cost", main, True)
+                rc = L.dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), dt, B, N, M, HW, sp_b, sp_n, st_b, st_m,
+                                      _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
+                self._mark("cost", main, False)
+                rc |= L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ms)
+                rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ms)
+                rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
+                                       _ptr(self.cos), ms)
+                self._mark("solver", main, True)
+                rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
+                                            _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter),
+                                            int(proj_iter), float(lr), int(is_test), _ptr(self.sim), _ptr(self.R),
+                                            _ptr(self.Rb), _ptr(self.match_score), _ptr(self.det_score),
+                                            _ptr(self.iters), None, ms)
+                self._mark("solver", main, False)
+                self._mark("mix", main, True)
+                rc |= L.dmm_mask_mix(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
+                                     _ptr(m_valid), _ptr(self.full_outmask), M * HW, HW, ms)
+                self._mark("mix", main, False)
+            _lib.check(rc, "ForwardPlan.run (granular, timed)")
+            return self.full_outmask, self.match_score, self.det_score
         if not self.pipeline:
             with torch.cuda.device(self.device):
                 rc = L.dmm_match_forward(
@@ -352,13 +511,11 @@ class ForwardPlan:
             # ---- streaming lane: cost(A), cost(B) ------------------------------------------------------------
             for h, (b, e) in enumerate(self.halves):
                 inter, ap, at = self._tables(h)
-                if self.cost_events is not None:
-                    self.cost_events[h][0].record(main)
+                self._mark("cost", main, True)
                 rc |= L.dmm_iou_counts(masks_p.data_ptr() + es * b * sp_b, masks_t.data_ptr() + es * b * st_b, dt,
                                        e - b, N, M, HW, sp_b, sp_n, st_b, st_m, nv(n_valid, b), nv(m_valid, b),
                                        _ptr(inter), _ptr(ap), _ptr(at), ms)
-                if self.cost_events is not None:
-                    self.cost_events[h][1].record(main)
+                self._mark("cost", main, False)
                 self.ev_cost[h].record(main)
             # ---- latency lane: solver(h) as soon as cost(h) is done ------------------------------------------
             for h, (b, e) in enumerate(self.halves):
@@ -375,8 +532,10 @@ class ForwardPlan:
             # ---- streaming lane: mix(A) after solver(A), mix(B) after solver(B) ------------------------------
             for h, (b, e) in enumerate(self.halves):
                 main.wait_event(self.ev_solved[h])
+                self._mark("mix", main, True)
                 rc |= L.dmm_mask_mix(self.Rb.data_ptr() + 4 * b * M * Pp, masks_p.data_ptr() + es * b * sp_b, dt, e - b,
                                      N, M, Pp, HW, sp_b, sp_n, nv(n_valid, b), nv(m_valid, b),
                                      self.full_outmask.data_ptr() + 4 * b * M * HW, M * HW, HW, ms)
+                self._mark("mix", main, False)
         _lib.check(rc, "ForwardPlan.run (pipelined)")
         return self.full_outmask, self.match_score, self.det_score

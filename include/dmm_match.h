@@ -99,6 +99,28 @@ DMM_API int dmm_iou_counts_dual(const void *masks_p, const void *masks_t, const 
                                 int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2, int32_t *area_t2,
                                 dmm_stream_t stream);
 
+/* (1d) / (4c) PER-FRAME POINTER TABLES for the proposal planes.  The reference's driver holds the proposal masks
+ * of a step as one tensor PER VIDEO (`prop_m[bid] = proposals[bid].get_field('mask').squeeze(1)`,
+ * dmm/modules/dmm_model.py:58 / :111) and loops over them (:62 / :115).  The *_frames entry points take a DEVICE
+ * array of B pointers -- masks_p_frames[b] = first plane of frame b, N_b planes at stride sp_n -- instead of
+ * (masks_p, sp_b), so all videos go through one launch WITHOUT first being copied into a [B,Nmax,H,W] batch
+ * (that copy moved 2 x 13 MB per video in front of a 15.6 MB cost pass).  Everything else as in (1), (1b), (4), (4b). */
+DMM_API int dmm_iou_counts_frames(const void *const *masks_p_frames, const void *masks_t, int dtype, int B, int N,
+                                  int M, int HW, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                                  const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                                  dmm_stream_t stream);
+DMM_API int dmm_iou_counts_dual_frames(const void *const *masks_p_frames, const void *masks_t, const void *masks_t2,
+                                       int dtype, int B, int N, int M, int HW, int64_t sp_n, int64_t st_b,
+                                       int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
+                                       const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                                       int32_t *inter2, int32_t *area_t2, dmm_stream_t stream);
+DMM_API int dmm_mask_mix_frames(const float *Rb, const void *const *masks_p_frames, int dtype, int B, int N, int M,
+                                int Pp, int HW, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                float *out, int64_t so_b, int64_t so_m, dmm_stream_t stream);
+DMM_API int dmm_mask_mix_bwd_frames(const float *Rb, const void *const *masks_p_frames, int dtype, const float *dout,
+                                    int B, int N, int M, int Pp, int HW, int64_t sp_n, const int32_t *n_valid,
+                                    const int32_t *m_valid, float *dRb, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (2) Row-normalise feature vectors: out[r,:] = in[r,:] / max(||in[r,:]||_2, 1e-8).
  * First half of F.cosine_similarity as get_cosine_score uses it (match_helper.py:51-64).

@@ -17,7 +17,8 @@ tm = torch.rand((B, M, H, W), generator=g, device=dev).half()
 pf = torch.randn((B, N, D), generator=g, device=dev)
 tf = torch.randn((B, M, D), generator=g, device=dev)
 sc = torch.rand((B, N), generator=g, device=dev)
-for pipe in (False, True):
+for pipe, pad in ((False, 0), (True, 0), (True, 16384), (True, 24576), (True, 32768), (False, 24576)):
+    os.environ['DMM_COST_TL_LDS_PAD'] = str(pad)
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=torch.float16, pipeline=pipe)
     run = lambda: plan.run(pm, tm, pf, tf, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
     for _ in range(3):
@@ -31,5 +32,5 @@ for pipe in (False, True):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 10
     byt = B * ((N + M) * H * W * 2 + 2 * M * H * W * 3)          # planes read once (fp16) + selected read (fp16) + fp32 out
-    print(f"config 5 B={B} {'2-lane' if pipe else 'single stream'}: {ms:.3f} ms per step = {B / ms * 1e3:.0f} frames/s "
+    print(f"config 5 B={B} {'2-lane' if pipe else 'single stream'} tl LDS pad {pad}: {ms:.3f} ms per step = {B / ms * 1e3:.0f} frames/s "
           f"(mean iters {float(plan.iters.float().mean()):.2f}; ~{byt / ms / 1e9:.2f} TB/s of algorithmic layer bytes)")
