@@ -48,10 +48,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE configs index + 1")
-    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 256 for "
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 512 for "
                                                           "config 2 / 3 / 5)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream schedule")
     ap.add_argument("--pipeline", action="store_true", help="force the 2-lane schedule")
+    ap.add_argument("--parts", type=int, default=0, help="slices of the batch in the 2-lane schedule (default 2)")
+    ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="no cpu_baseline / batch_sweep / in-run PMC traffic")
     ap.add_argument("--no-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc child passes")
@@ -234,11 +236,12 @@ def bench_layer(R, ci):
     args, dev, rank, world = R.args, R.dev, R.rank, R.world
     _lib.load()                                              # loud failure if the HIP extension is missing
     c = synth.CONFIGS[ci]
-    B = args.frames or (1024 if ci == 2 else 256)
+    B = args.frames or (1024 if ci == 2 else 512)
     N, M, H, W, D = c["P"], c["O"], c["H"], c["W"], c["D"]
     HW = H * W
     mdt = torch.float32 if ci == 2 else torch.float16
     es = 4 if ci == 2 else 2
+    odt = mdt if (ci == 5 and not args.f32_out) else torch.float32   # config 5: matched masks stay in the storage type
     g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + ci + 1000 * rank)
 
     def make_inputs(b):
@@ -252,7 +255,7 @@ def bench_layer(R, ci):
     # pre-allocated plan: nothing is allocated in the timed region.  pipeline = streaming lane (cost, mix) on the
     # current stream + latency lane (normalise, cosine, solver) on a side stream (ops.ForwardPlan)
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=mdt, pipeline=False if args.no_pipeline else (True if args.pipeline else None),
-                           time_kernels=True)
+                           time_kernels=True, out_dtype=odt, parts=args.parts or 2)
     kw = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
     ev = []
 
@@ -289,7 +292,7 @@ def bench_layer(R, ci):
                                          "fp16 mask planes (BASELINE configs[4])",
         "value": round(world * fps_rank, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ci == 2 else "f16 planes, f32 accumulate",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ci == 2 else "f16 planes (in and out), f32 accumulate",
         "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[{ci - 1}]: {N} proposals x {M} templates, 255x255 "
                                 f"{'fp32' if ci == 2 else 'fp16'} masks, D=512, 20 outer x 5 inner relax iterations, "
@@ -319,7 +322,7 @@ def bench_layer(R, ci):
         for b in (1, 4, 8, 64, 512, 1024):
             if b > B:
                 continue
-            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt)
+            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt)
             inp = inputs if b == B else tuple(t[:b] for t in inputs)
             ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
             sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}

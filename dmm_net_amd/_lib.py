@@ -24,7 +24,7 @@ SYMBOLS = (
     "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
-    "dmm_mask_mix", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
+    "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
     "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32",
 )
@@ -96,6 +96,9 @@ def load():
     L.dmm_merge_labels_f32.argtypes = [vp, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp]
     L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
                                c_i64, vp]
+    L.dmm_mask_mix_to.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_int, c_i64,
+                                  c_i64, vp]
+    L.dmm_mask_mix_to.restype = c_int
     L.dmm_mask_mix_bwd.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, vp]
     L.dmm_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     L.dmm_workspace_bytes.restype = sz

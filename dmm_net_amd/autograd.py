@@ -145,6 +145,17 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
         assert len(template_feature) == 1, "algo 'hun' is wired for a single template-feature entry"
         return _hungarian_forward(proposed_feature.float(), tf.float(), proposed_mask.float(),
                                   mask_last_occurence.float(), proposal_score.float(), targets, score_weight, is_test)
+    needs_grad = torch.is_grad_enabled() and (proposed_feature.requires_grad or tf.requires_grad
+                                              or proposed_mask.requires_grad)
+    if targets is None and not needs_grad and tf.dim() == 2:
+        # inference (the evaluator's call, dmm_model.py:75-77): one fused C-ABI call, no autograd bookkeeping
+        pm, tm = proposed_mask, mask_last_occurence
+        if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
+            pm, tm = pm.float(), tm.float()
+        full, ms, ds, _ = ops.match_forward(pm.unsqueeze(0), tm.unsqueeze(0), proposed_feature.unsqueeze(0),
+                                            tf.unsqueeze(0), proposal_score.unsqueeze(0), score_weight=score_weight,
+                                            max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+        return full[0], ms[0], ds[0], proposed_feature.new_zeros(())
     full, ms, ds, loss, _ = match_layer_batched(
         proposed_feature.unsqueeze(0), proposed_mask.unsqueeze(0),
         tf.unsqueeze(0) if tf.dim() == 2 else tf.unsqueeze(1), mask_last_occurence.unsqueeze(0),

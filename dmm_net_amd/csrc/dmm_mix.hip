@@ -25,37 +25,99 @@ constexpr int kMixThreads = 256;
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowLoads = 8;
 
-template <typename T, int CNT, int NT>   // CNT = entries of this row if 1 or 2, 0 = generic; NT bit0 = nt loads, bit1 = nt stores
+// Output element types: fp32 (the nn.Module boundary) or the 16-bit storage type of the input planes (config 5: the
+// matched masks become the next frame's fp16 templates; one rounding of the fp32 result).
+template <typename TO> struct MixOut;
+template <> struct MixOut<float> {
+    template <int E, bool NT>
+    static __device__ __forceinline__ void store(float *o, const float (&a)[E]) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            float4a t;
+            t.x = a[4 * q]; t.y = a[4 * q + 1]; t.z = a[4 * q + 2]; t.w = a[4 * q + 3];
+            if (NT) __builtin_nontemporal_store(t, reinterpret_cast<float4a *>(o) + q);
+            else reinterpret_cast<float4a *>(o)[q] = t;
+        }
+    }
+    static __device__ __forceinline__ void store1(float *o, float v) { *o = v; }
+};
+template <> struct MixOut<f16_t> {
+    typedef _Float16 half8a __attribute__((ext_vector_type(8)));
+    template <int E, bool NT>
+    static __device__ __forceinline__ void store(f16_t *o, const float (&a)[E]) {
+        static_assert(E == 8, "16-bit outputs are written 8 pixels (16 bytes) per lane");
+        half8a t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (_Float16)a[k];
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<half8a *>(o));
+        else *reinterpret_cast<half8a *>(o) = t;
+    }
+    static __device__ __forceinline__ void store1(f16_t *o, float v) { o->v = (_Float16)v; }
+};
+template <> struct MixOut<bf16_t> {
+    typedef uint32_t uint4a __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ uint32_t rne(float v) {            // fp32 -> bfloat16 bits, round to nearest even
+        const uint32_t u = __float_as_uint(v);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    template <int E, bool NT>
+    static __device__ __forceinline__ void store(bf16_t *o, const float (&a)[E]) {
+        static_assert(E == 8, "16-bit outputs are written 8 pixels (16 bytes) per lane");
+        uint4a t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = rne(a[2 * k]) | (rne(a[2 * k + 1]) << 16);
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<uint4a *>(o));
+        else *reinterpret_cast<uint4a *>(o) = t;
+    }
+    static __device__ __forceinline__ void store1(bf16_t *o, float v) { o->v = (uint16_t)rne(v); }
+};
+
+// E pixels of one plane at x (may stick out of [0, HW) at either end: those go element-wise, zeros outside)
+template <typename T, int E, bool NT>
+__device__ __forceinline__ void mix_load(const T *plane, int x, int HW, bool on, float (&v)[E]) {
+    if (on && x >= 0 && x + E - 1 < HW) {
+        if (E == 4) {
+            float t[4];
+            MaskIO<T>::template load4<NT>(plane + x, t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = t[k];
+        } else {
+            typename MaskIO<T>::Raw r = MaskIO<T>::load_raw(plane + x);     // one 16-byte (8 x 16-bit) lane load
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = MaskIO<T>::elem(r, k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) v[k] = (on && x + k >= 0 && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
+    }
+}
+
+template <typename T, typename TO, int CNT, int NT>   // CNT = entries of this row if 1 or 2, 0 = generic; NT bit0 = nt loads, bit1 = nt stores
 __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const int *col_s, const float *w_s, int cnt,
-                                              float *orow, int HW, int pre, int s_begin, int s_end) {
-    // Pixel index of thread t at step s is x = (256 s + t) * 4 - pre with pre = elements the row start lies past a
-    // 128-byte line: every wave STORE then covers eight whole lines (rows of 65025 floats start on 4-byte boundaries
+                                              TO *orow, int HW, int pre, int s_begin, int s_end) {
+    // A lane takes E = 16 bytes / sizeof(T) consecutive pixels (4 fp32 or 8 16-bit: always one full-width lane load).
+    // Pixel index of thread t at step s is x = (256 s + t) * E - pre with pre = elements the row start lies past a
+    // 128-byte line: every wave STORE then covers whole lines (rows of 65025 elements start on element boundaries
     // only; measured 5.78 TB/s with 16-byte-aligned stores, 6.03 with line-aligned ones), the loads take the
     // misalignment instead (free on gfx950, tools/hbm_probe.py).  The vectors that stick out of
     // [0, HW) at either end go element-wise.
+    constexpr int E = 16 / (int)sizeof(T);
     constexpr int G = CNT == 0 ? 1 : 2;     // steps per iteration = the launcher's step quantum
     for (int s0 = s_begin; s0 < s_end; s0 += G) {
-        float acc[G][4];
+        float acc[G][E];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[g][k] = 0.0f;
+            for (int k = 0; k < E; ++k) acc[g][k] = 0.0f;
         if (CNT > 0) {
-            float v[G][CNT][4];
+            float v[G][CNT][E];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4 - pre;
+                const int x = ((s0 + g) * kMixThreads + threadIdx.x) * E - pre;
 #pragma unroll
-                for (int e = 0; e < CNT; ++e) {
-                    const T *plane = Pb + (int64_t)col_s[e] * sp_n;
-                    if (s0 + g < s_end && x >= 0 && x + 3 < HW) {
-                        MaskIO<T>::template load4<(NT & 1) != 0>(plane + x, v[g][e]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[g][e][k] = (s0 + g < s_end && x + k >= 0 && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
-                    }
-                }
+                for (int e = 0; e < CNT; ++e)
+                    mix_load<T, E, (NT & 1) != 0>(Pb + (int64_t)col_s[e] * sp_n, x, HW, s0 + g < s_end, v[g][e]);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -63,61 +125,53 @@ __device__ __forceinline__ void mix_row_range(const T *Pb, int64_t sp_n, const i
                 for (int e = 0; e < CNT; ++e) {
                     const float w = w_s[e];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[g][k] = __builtin_fmaf(w, v[g][e][k], acc[g][k]);
+                    for (int k = 0; k < E; ++k) acc[g][k] = __builtin_fmaf(w, v[g][e][k], acc[g][k]);
                 }
         } else {
-            const int x = (s0 * kMixThreads + threadIdx.x) * 4 - pre;
-            for (int e0 = 0; e0 < cnt; e0 += kRowLoads) {
-                float v[kRowLoads][4];
+            constexpr int UL = E == 4 ? kRowLoads : kRowLoads / 2;      // same bytes in flight per lane
+            const int x = (s0 * kMixThreads + threadIdx.x) * E - pre;
+            for (int e0 = 0; e0 < cnt; e0 += UL) {
+                float v[UL][E];
 #pragma unroll
-                for (int u = 0; u < kRowLoads; ++u) {
+                for (int u = 0; u < UL; ++u) {
                     const int e = e0 + u < cnt ? e0 + u : cnt - 1;
-                    const T *plane = Pb + (int64_t)col_s[e] * sp_n;
-                    if (x >= 0 && x + 3 < HW) {
-                        MaskIO<T>::template load4<(NT & 1) != 0>(plane + x, v[u]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[u][k] = (x + k >= 0 && x + k < HW) ? MaskIO<T>::load1(plane + x + k) : 0.0f;
-                    }
+                    mix_load<T, E, (NT & 1) != 0>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < kRowLoads; ++u)
+                for (int u = 0; u < UL; ++u)
                     if (e0 + u < cnt) {
                         const float w = w_s[e0 + u];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[0][k] = __builtin_fmaf(w, v[u][k], acc[0][k]);
+                        for (int k = 0; k < E; ++k) acc[0][k] = __builtin_fmaf(w, v[u][k], acc[0][k]);
                     }
             }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int x = ((s0 + g) * kMixThreads + threadIdx.x) * 4 - pre;
+            const int x = ((s0 + g) * kMixThreads + threadIdx.x) * E - pre;
             if (s0 + g >= s_end || x >= HW) continue;
-            float *o = orow + x;
-            if (x >= 0 && x + 3 < HW) {
-                float4a t;
-                t.x = acc[g][0]; t.y = acc[g][1]; t.z = acc[g][2]; t.w = acc[g][3];
-                if (NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<float4a *>(o));
-                else *reinterpret_cast<float4a *>(o) = t;
+            TO *o = orow + x;
+            if (x >= 0 && x + E - 1 < HW) {
+                MixOut<TO>::template store<E, (NT & 2) != 0>(o, acc[g]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (x + k >= 0 && x + k < HW) o[k] = acc[g][k];
+                for (int k = 0; k < E; ++k)
+                    if (x + k >= 0 && x + k < HW) MixOut<TO>::store1(o + k, acc[g][k]);
             }
         }
     }
 }
 
 // grid = (pixel splits, M, B)
-template <typename T, int NT>
+template <typename T, typename TO, int NT>
 __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float *__restrict__ Rb,
                                                                     const T *__restrict__ masks_p, int N, int M, int Pp,
                                                                     int HW, int64_t sp_b, int64_t sp_n,
                                                                     const int32_t *__restrict__ n_valid,
                                                                     const int32_t *__restrict__ m_valid,
-                                                                    float *__restrict__ out, int64_t so_b, int64_t so_m,
+                                                                    TO *__restrict__ out, int64_t so_b, int64_t so_m,
                                                                     int steps_per_wg, int align_mask, int xcd_remap) {
+    constexpr int E = 16 / (int)sizeof(T);
     __shared__ float w_s[DMM_MAX_PROPOSALS];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ int cnt_s;
@@ -160,14 +214,15 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     __syncthreads();
     const int cnt = cnt_s;
     const T *Pb = frame_base(masks_p, b, sp_b);
-    float *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
-    const int pre = (int)((reinterpret_cast<uintptr_t>(orow) >> 2) & align_mask);   // row start = boundary + pre floats
-    const int nsteps = (HW + pre + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    TO *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
+    // row start = 128-byte boundary + pre elements (align_mask = elements per aligned unit - 1)
+    const int pre = (int)((reinterpret_cast<uintptr_t>(orow) / sizeof(TO)) & align_mask);
+    const int nsteps = (HW + pre + kMixThreads * E - 1) / (kMixThreads * E);
     const int s_begin = range * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
-    if (cnt == 1) mix_row_range<T, 1, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
-    else if (cnt == 2) mix_row_range<T, 2, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
-    else mix_row_range<T, 0, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);   // cnt == 0 writes zeros
+    if (cnt == 1) mix_row_range<T, TO, 1, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
+    else if (cnt == 2) mix_row_range<T, TO, 2, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);
+    else mix_row_range<T, TO, 0, NT>(Pb, sp_n, col_s, w_s, cnt, orow, HW, pre, s_begin, s_end);   // cnt == 0 writes zeros
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,12 +331,14 @@ static int mask_mix_bwd_typed(const float *Rb, const T *masks_p, const float *do
     return check_launch();
 }
 
-template <typename T>
+template <typename T, typename TO>
 static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
-                          int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out, int64_t so_b,
+                          int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
-    static const int align_mask = [] { const char *e = getenv("DMM_MIX_ALIGN"); return (e ? atoi(e) : 128) / 4 - 1; }();
-    const int nsteps = (HW + align_mask + kMixThreads * 4 - 1) / (kMixThreads * 4);    // worst-case row misalignment
+    constexpr int E = 16 / (int)sizeof(T);
+    static const int align_bytes = [] { const char *e = getenv("DMM_MIX_ALIGN"); return e ? atoi(e) : 128; }();
+    const int align_mask = align_bytes / (int)sizeof(TO) - 1;
+    const int nsteps = (HW + align_mask + kMixThreads * E - 1) / (kMixThreads * E);    // worst-case row misalignment
     // MANY TINY workgroups: 2 steps = 8 KiB of the row each, up to ~320k of them.  Measured at B = 1024 (test mode,
     // one plane per row): 4.2 / 4.9 / 5.1 / 5.2 / 5.75-6.1 TB/s at 10k / 40k / 80k / 160k / 320k workgroups; 1-step
     // workgroups fall back to 5.5-5.8.  In dispatch order the resident workgroups then cover a compact, advancing
@@ -297,8 +354,8 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
     static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
     static const int xcd_remap = [] { const char *e = getenv("DMM_MIX_XCD"); return e ? atoi(e) : 1; }();
 #define DMM_MIX_LAUNCH(NT)                                                                                              \
-    hipLaunchKernelGGL((mask_mix_rows_kernel<T, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, N, \
-                       M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask, xcd_remap)
+    hipLaunchKernelGGL((mask_mix_rows_kernel<T, TO, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, \
+                       N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask, xcd_remap)
     switch (nt_mode & 3) {
         case 0: DMM_MIX_LAUNCH(0); break;
         case 1: DMM_MIX_LAUNCH(1); break;
@@ -311,28 +368,43 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
 
 }  // namespace dmm
 
-extern "C" int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
-                            int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out,
-                            int64_t so_b, int64_t so_m, dmm_stream_t stream) {
+extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                               int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, void *out,
+                               int out_dtype, int64_t so_b, int64_t so_m, dmm_stream_t stream) {
     if (B < 0 || N < 0 || M < 0 || HW < 0 || Pp < N) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0 || HW == 0) return DMM_OK;
     if (!Rb || !masks_p || !out) return DMM_ERR_BAD_ARG;
     if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW || so_m < HW) return DMM_ERR_BAD_ARG;
+    if (out_dtype != DMM_F32 && out_dtype != dtype) return DMM_ERR_BAD_ARG;      // fp32, or the planes' own 16-bit type
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case DMM_F32:
-            return dmm::mask_mix_typed<float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid,
-                                              out, so_b, so_m, s);
+            return dmm::mask_mix_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n, n_valid,
+                                                     m_valid, (float *)out, so_b, so_m, s);
         case DMM_F16:
-            return dmm::mask_mix_typed<dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp, HW, sp_b, sp_n, n_valid,
-                                               m_valid, out, so_b, so_m, s);
+            if (out_dtype == DMM_F16)
+                return dmm::mask_mix_typed<dmm::f16_t, dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp, HW, sp_b,
+                                                                   sp_n, n_valid, m_valid, (dmm::f16_t *)out, so_b, so_m, s);
+            return dmm::mask_mix_typed<dmm::f16_t, float>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
+                                                          n_valid, m_valid, (float *)out, so_b, so_m, s);
         case DMM_BF16:
-            return dmm::mask_mix_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
-                                                     n_valid, m_valid, out, so_b, so_m, s);
+            if (out_dtype == DMM_BF16)
+                return dmm::mask_mix_typed<dmm::bf16_t, dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW,
+                                                                     sp_b, sp_n, n_valid, m_valid, (dmm::bf16_t *)out,
+                                                                     so_b, so_m, s);
+            return dmm::mask_mix_typed<dmm::bf16_t, float>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
+                                                           n_valid, m_valid, (float *)out, so_b, so_m, s);
         default:
             return DMM_ERR_BAD_ARG;
     }
+}
+
+extern "C" int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                            int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out,
+                            int64_t so_b, int64_t so_m, dmm_stream_t stream) {
+    return dmm_mask_mix_to(Rb, masks_p, dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, DMM_F32, so_b, so_m,
+                           stream);
 }
 
 extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype, const float *dout, int B, int N, int M,

@@ -29,9 +29,13 @@ namespace dmm {
 
 bool use_row_split(int B, int M, int Pp) {
     const char *e = getenv("DMM_SOLVER_KERNEL");
+    if (Pp > 64) return false;                  // the row-split form is compiled for one column group (Pp <= 64)
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return Pp > 64 || M > 16 || B <= 128;
+    // measured (tools/solver_timing.py, 20 x 5 iterations, us per solve of one frame, thread-per-column vs row-split):
+    // 5 x 50: 61 vs 82, 10 x 50: 102 vs 99, 16 x 64: 124 vs 112; beyond ~256 frames in flight the 4x waves of the
+    // row-split form cost throughput (10 x 50, B = 1024: 109 vs 162 us per launch)
+    return M >= 12 && B <= 256;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,7 +379,9 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
 // Layer kernel: iou + mix with the cosine table + pad + solver + scores.  grid = B, block = 64*NG.
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NG, bool EXACT>
-__global__ __launch_bounds__(64 * NG) void relax_match_kernel(
+// (4-wave instantiations up to 20 rows are capped at 256 registers -- 4 spilled -- so that two frames share a CU:
+// 20 x 200 needed 256 VGPRs + 12 AGPRs = one wave per SIMD, i.e. 256 frames filled the chip and 512 took twice as long)
+__global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_match_kernel(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,

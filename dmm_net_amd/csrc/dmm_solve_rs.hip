@@ -5,17 +5,24 @@
 //
 // dmm_solve.hip gives one thread a whole COLUMN (all M rows in registers): ideal when thousands of frames are in
 // flight (one wave per frame on every SIMD), but a single frame is then one wave issuing ~370 dependent-ish VALU
-// instructions per sweep (1.1 us / sweep at 10 x 50), and a wide table (20 x 200) needs 256 VGPRs per wave, which
-// cannot share a SIMD with the streaming kernels.  Here a frame is solved by a WORKGROUP OF RG x CG WAVES:
+// instructions per sweep (1.0 us / sweep at 10 x 50).  Here a frame is solved by a WORKGROUP OF RG x CG WAVES
+// ("rows across waves, column sums via LDS"):
 //
 //     wave (rg, cg): rows [rg*RW, rg*RW + RW) x columns [cg*64, cg*64 + 64);  lane = column, RW <= 8 rows in registers.
 //
-// State per thread: RW x (C, X, P0, P1, P2, acc) -- 30-50 VGPRs at 20 x 200.  The reductions go through LDS:
+// State per thread: RW x (C, X, P0, P1, P2, acc).  The reductions go through LDS:
 //   * column sums: every wave reads its lanes' columns (all n rows) from the ping-pong buffer the relu step wrote;
 //   * row sums:    the waves of a row group read their own rows (aligned 8-lane groups = ATen's AVX2 lanes).
 // One barrier per sweep (two when CG > 1).  The "did anything move" flags of sweep j are read at the barrier of sweep
 // j+1 (the relu step done in between is undone when the reference would have left the loop), so the exit test costs
 // no barrier of its own.
+//
+// RESULT (tools/solver_timing.py, MI355X, us per solve at 20 x 5 iterations, thread-per-column vs this): 5 x 50: 61 vs
+// 82; 10 x 50: 102 vs 99; 16 x 64: 124 vs 112; 20 x 200 (CG = 4): 216 vs 343.  The sweep is bound by instruction issue,
+// not by the row count: the column-sum and row-sum code is replicated in every wave and the per-row work is the small
+// part (~300 instructions per sweep and wave at RW = 3 against ~370 for all 10 rows in one wave), and each sweep adds
+// a barrier and three LDS round trips.  So this mapping is used only where it wins (>= 12 rows, <= 64 columns, few
+// frames in flight; dmm_solve.hip use_row_split), and only the CG = 1 form is instantiated.
 //
 // BIT EXACTNESS: every fp32 operation and every summation order is the one of dmm_solve.hip / dmm_torch_order.h
 // (ATen outer-sum order for the column sums, vectorized inner-sum order for the row sums, the 2-norm fast path for
@@ -533,30 +540,14 @@ __global__ __launch_bounds__(256 * CG) void relax_solve_rs_kernel(const float *_
 }  // namespace rs
 
 // ---- launchers --------------------------------------------------------------------------------------------------
+// Only the one-column-group form (Pp <= 64) is instantiated: with CG = 2 / 4 (two barriers per sweep, 8-16 waves) the
+// row-split mapping measured 1.5x SLOWER than thread-per-column (20 x 200: 343 vs 216 us, 32 x 256: 662 vs 448 us).
 #define DMM_RS_DISPATCH(RW_, CG_, CALL)                                                                            \
     do {                                                                                                           \
-        switch ((CG_)) {                                                                                           \
-            case 1:                                                                                                \
-                switch ((RW_)) {                                                                                   \
-                    case 1: CALL(1, 1); break; case 2: CALL(2, 1); break; case 3: CALL(3, 1); break;               \
-                    case 4: CALL(4, 1); break; case 5: CALL(5, 1); break; case 6: CALL(6, 1); break;               \
-                    case 7: CALL(7, 1); break; default: CALL(8, 1); break;                                         \
-                }                                                                                                  \
-                break;                                                                                             \
-            case 2:                                                                                                \
-                switch ((RW_)) {                                                                                   \
-                    case 1: CALL(1, 2); break; case 2: CALL(2, 2); break; case 3: CALL(3, 2); break;               \
-                    case 4: CALL(4, 2); break; case 5: CALL(5, 2); break; case 6: CALL(6, 2); break;               \
-                    case 7: CALL(7, 2); break; default: CALL(8, 2); break;                                         \
-                }                                                                                                  \
-                break;                                                                                             \
-            default:                                                                                               \
-                switch ((RW_)) {                                                                                   \
-                    case 1: CALL(1, 4); break; case 2: CALL(2, 4); break; case 3: CALL(3, 4); break;               \
-                    case 4: CALL(4, 4); break; case 5: CALL(5, 4); break; case 6: CALL(6, 4); break;               \
-                    case 7: CALL(7, 4); break; default: CALL(8, 4); break;                                         \
-                }                                                                                                  \
-                break;                                                                                             \
+        switch ((RW_)) {                                                                                           \
+            case 1: CALL(1, 1); break; case 2: CALL(2, 1); break; case 3: CALL(3, 1); break;                       \
+            case 4: CALL(4, 1); break; case 5: CALL(5, 1); break; case 6: CALL(6, 1); break;                       \
+            case 7: CALL(7, 1); break; default: CALL(8, 1); break;                                                 \
         }                                                                                                          \
     } while (0)
 
@@ -565,8 +556,7 @@ struct RsShape {
 };
 static RsShape rs_shape(int rows, int width) {
     RsShape s;
-    const int ng = (width + 63) / 64;
-    s.CG = ng <= 1 ? 1 : (ng == 2 ? 2 : 4);
+    s.CG = 1;                                                   // width <= 64 (use_row_split)
     s.RW = (rows + 3) / 4;                                      // at most 4 row groups: n <= 4 RW inside the core
     s.RG = (rows + s.RW - 1) / s.RW;
     return s;

@@ -6,6 +6,7 @@ batch ragged.  No function here has a CPU implementation: CPU tensors raise.
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -300,7 +301,7 @@ def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_
     return dict(X=X, R=R, cost=cost, iters=iters)
 
 
-def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None) -> torch.Tensor:
+def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None, out_dtype=None) -> torch.Tensor:
     """full_outmask [B,M,H,W] = Rb [B,M,Pp] @ masks_p [B,N,H*W] (zero planes for the padded columns)."""
     if isinstance(masks_p, FramePlanes):
         fp = masks_p
@@ -320,11 +321,13 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
     B, N, H, W = masks_p.shape
     M, Pp = Rb.shape[1], Rb.shape[2]
     Rb = Rb.contiguous().float()
-    out = torch.empty((B, M, H, W), dtype=torch.float32, device=Rb.device)
+    out_dtype = out_dtype or torch.float32
+    out = torch.empty((B, M, H, W), dtype=out_dtype, device=Rb.device)
     with torch.cuda.device(Rb.device):
-        rc = _lib.load().dmm_mask_mix(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], B, N, M, Pp, H * W, sp_b, sp_n,
-                                      _ptr(n_valid), _ptr(m_valid), _ptr(out), M * H * W, H * W, _stream(Rb))
-    _lib.check(rc, "dmm_mask_mix")
+        rc = _lib.load().dmm_mask_mix_to(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], B, N, M, Pp, H * W, sp_b, sp_n,
+                                         _ptr(n_valid), _ptr(m_valid), _ptr(out), _DT[out_dtype], M * H * W, H * W,
+                                         _stream(Rb))
+    _lib.check(rc, "dmm_mask_mix_to")
     return out
 
 
@@ -358,12 +361,57 @@ def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_
     return dRb
 
 
+_WORKSPACES = {}
+# HIP stream capture is process-global by default: a second host thread that touches the runtime while one captures
+# aborts the process.  Captures are serialised and run in thread-local capture mode (nn.DataParallel-style callers).
+_CAPTURE_LOCK = threading.Lock()
+
+
+def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test,
+                  n_valid=None, m_valid=None):
+    """The whole forward of B frames as ONE C-ABI call (``dmm_match_forward``: counts -> normalise -> cosine -> solver
+    -> mix on the current stream): fresh output tensors, intermediates in a workspace cached per (device, stream).
+    The inference path of ``MatchModel`` (no autograd bookkeeping, 1 ctypes call instead of 7, no per-call
+    intermediate allocations).  Returns (full_outmask [B,M,H,W], match_score [B,M], det_score [B,M], iters [B])."""
+    _need_gpu(masks_p, masks_t, feat_p, feat_t, score_p)
+    assert masks_p.dtype == masks_t.dtype and masks_p.dtype in _DT
+    masks_p, sp_b, sp_n = _planes(masks_p)
+    masks_t, st_b, st_m = _planes(masks_t)
+    B, N, H, W = masks_p.shape
+    M, D = masks_t.shape[1], feat_p.shape[-1]
+    feat_p, feat_t, score_p = feat_p.contiguous().float(), feat_t.contiguous().float(), score_p.contiguous().float()
+    dev = masks_p.device
+    L = _lib.load()
+    stream = _stream(masks_p)
+    need = int(L.dmm_workspace_bytes(B, N, M, D))
+    key = (dev.index, stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WORKSPACES[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    full = torch.empty((B, M, H, W), **f32)
+    ms, ds = torch.empty((B, M), **f32), torch.empty((B, M), **f32)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dmm_match_forward(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p), _ptr(feat_t),
+                                 _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
+                                 float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(full),
+                                 _ptr(ms), _ptr(ds), None, None, None, _ptr(iters), _ptr(ws), ws.numel(), stream)
+    _lib.check(rc, "dmm_match_forward")
+    return full, ms, ds, iters
+
+
 class ForwardPlan:
     """Pre-allocated forward of B same-shaped frames: nothing is allocated or synchronised per call.
 
     Two execution shapes:
 
     * ``pipeline=False`` -- one ``dmm_match_forward`` C call, all kernels back to back on the current stream;
+      With ``graph`` (default for B <= 32: the product's sizes, where a frame step is launch / latency bound) the
+      sequence is captured ONCE into a HIP graph the second time ``run`` sees the same tensors (same addresses and
+      strides) and replayed from then on: one graph launch instead of 7 kernel launches, and the two independent
+      branches of the layer -- IoU counts (masks) | normalise + cosine (features) -- run side by side before the
+      solver joins them.  Callers that hand in fresh tensors every step simply never trigger the capture.
     * ``pipeline=True``  -- "streaming lane + latency lane".  The batch is split in two halves A, B.  The
       current stream runs only the HBM-bound kernels, serialised at full bandwidth:
       cost(A) -> cost(B) -> mix(A) -> mix(B)  (A, B = the two halves of the batch).  A side stream runs the latency-bound ones:
@@ -373,7 +421,7 @@ class ForwardPlan:
     """
 
     def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None,
-                 split=0.5, time_kernels=False):
+                 split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
@@ -385,12 +433,19 @@ class ForwardPlan:
         self.pipeline = auto if pipeline is None else bool(pipeline)
         # time_kernels: the single-stream form issues the granular C-ABI calls (same kernels as dmm_match_forward) so
         # that HIP events can bracket the cost and mix launches; bench.py sets kernel_events = {} per timed step
-        self.time_kernels = bool(time_kernels)
+        # out_dtype: fp32 (default, the nn.Module boundary) or the planes' own 16-bit type (config 5: the matched masks
+        # are the next frame's fp16 templates); the fused single C call writes fp32 only -> granular launches otherwise
+        self.out_dtype = out_dtype or torch.float32
+        assert self.out_dtype in (torch.float32, mask_dtype)
+        self.time_kernels = bool(time_kernels) or self.out_dtype != torch.float32
         self.kernel_events = None
+        self.graph_mode = (B <= 32 and not self.pipeline and not self.time_kernels) if graph is None else \
+            (bool(graph) and not self.pipeline and not self.time_kernels)
+        self._graph = self._graph_key = self._last_key = None
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
-        self.full_outmask = torch.empty((B, M, H, W), **f32)
+        self.full_outmask = torch.empty((B, M, H, W), dtype=self.out_dtype, device=self.device)
         self.match_score = torch.empty((B, M), **f32)
         self.det_score = torch.empty((B, M), **f32)
         self.iters = torch.empty((B,), **i32)
@@ -400,17 +455,26 @@ class ForwardPlan:
         if not self.pipeline:
             self.ws_bytes = int(L.dmm_workspace_bytes(B, N, M, D))
             self.workspace = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=self.device)
-            if self.time_kernels:
+            if self.time_kernels or self.graph_mode:
+                if self.graph_mode:
+                    with torch.cuda.device(self.device):
+                        self.side = torch.cuda.Stream(device=self.device)
                 self.counts = [torch.empty((B * (M * N + N + M),), **i32)]
                 self.halves = [(0, B)]
                 self.pn = torch.empty((B, N, D), **f32)
                 self.tn = torch.empty((B, M, D), **f32)
                 self.cos = torch.empty((B, M, N), **f32)
             return
-        # A = first `split` of the frames, B = the rest.  Measured at B = 1024: 1:1 gives 255 k frames/s, 7:1 only 245 k
-        # (the normalise/cosine kernels then overlap one long cost launch and slow it down by what they cost alone).
-        cut = min(B - 1, max(1, int(round(B * split)))) if B > 1 else B
-        self.halves = [(0, cut), (cut, B)] if B > 1 else [(0, B)]
+        # ``parts`` equal slices of the batch (2 = halves A, B; with split != 0.5 the first slice takes that fraction).
+        # Measured at B = 1024, config 2: 1:1 gives 255 k frames/s, 7:1 only 245 k (the normalise / cosine kernels then
+        # overlap one long cost launch and slow it down by what they cost alone).
+        parts = max(1, min(int(parts), B))
+        if parts == 2 and B > 1:
+            cut = min(B - 1, max(1, int(round(B * split))))
+            self.halves = [(0, cut), (cut, B)]
+        else:
+            edges = [round(B * k / parts) for k in range(parts + 1)]
+            self.halves = [(edges[k], edges[k + 1]) for k in range(parts) if edges[k + 1] > edges[k]]
         # inter | area_p | area_t of one half are contiguous -> one memset per cost launch
         self.counts = [torch.empty(((e - b) * (M * N + N + M),), **i32) for (b, e) in self.halves]
         self.pn = torch.empty((B, N, D), **f32)
@@ -426,7 +490,35 @@ class ForwardPlan:
     def schedule_name(self) -> str:
         if self.pipeline:
             return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
+        if self.graph_mode:
+            return "HIP graph replay (IoU counts | normalise + cosine in parallel -> solver -> mix)" \
+                if self._graph is not None else "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
         return "single stream"
+
+    def _launch_forked(self, L, masks_p, masks_t, feat_p, feat_t, score_p, dt, strides, n_valid, m_valid, cfg):
+        """Granular launches with the feature branch on the side stream (fork / join by stream waits): the form that
+        is captured into the HIP graph."""
+        B, N, M, D, Pp, HW = self.B, self.N, self.M, self.D, self.Pp, self.H * self.W
+        sp_b, sp_n, st_b, st_m = strides
+        score_weight, max_iter, proj_iter, lr, is_test = cfg
+        main = torch.cuda.current_stream(self.device)
+        side = self.side
+        inter, ap, at = self._tables(0)
+        side.wait_stream(main)
+        ss, ms = side.cuda_stream, main.cuda_stream
+        rc = L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ss)
+        rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ss)
+        rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid), _ptr(self.cos), ss)
+        rc |= L.dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), dt, B, N, M, HW, sp_b, sp_n, st_b, st_m, _ptr(n_valid),
+                               _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
+        main.wait_stream(side)
+        rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
+                                    _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
+                                    float(lr), int(is_test), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),
+                                    _ptr(self.match_score), _ptr(self.det_score), _ptr(self.iters), None, ms)
+        rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
+                                _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], M * HW, HW, ms)
+        _lib.check(rc, "ForwardPlan.run (forked)")
 
     def _mark(self, name, stream, begin):
         """HIP event on ``stream`` before / after a kernel launch when bench.py asked for kernel timing."""
@@ -458,6 +550,25 @@ class ForwardPlan:
         assert feat_p.dtype == torch.float32 and feat_t.dtype == torch.float32 and score_p.dtype == torch.float32
         L = _lib.load()
         dt = _DT[self.mask_dtype]
+        if self.graph_mode and not torch.cuda.is_current_stream_capturing():
+            cfg = (float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test))
+            key = (masks_p.data_ptr(), masks_t.data_ptr(), feat_p.data_ptr(), feat_t.data_ptr(), score_p.data_ptr(),
+                   sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), cfg)
+            if self._graph is not None and key == self._graph_key:
+                self._graph.replay()
+                return self.full_outmask, self.match_score, self.det_score
+            if key == self._last_key:
+                # second call in a row on the same tensors: capture (the first one ran directly = the warm-up)
+                with _CAPTURE_LOCK, torch.cuda.device(self.device):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._launch_forked(L, masks_p, masks_t, feat_p, feat_t, score_p, dt, (sp_b, sp_n, st_b, st_m),
+                                            n_valid, m_valid, cfg)
+                self._graph, self._graph_key = g, key
+                self._keep = (masks_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid)   # the graph holds raw addresses
+                g.replay()
+                return self.full_outmask, self.match_score, self.det_score
+            self._last_key = key
         if not self.pipeline and self.time_kernels:
             with torch.cuda.device(self.device):
                 main = torch.cuda.current_stream(self.device)
@@ -479,8 +590,8 @@ class ForwardPlan:
                                             _ptr(self.iters), None, ms)
                 self._mark("solver", main, False)
                 self._mark("mix", main, True)
-                rc |= L.dmm_mask_mix(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
-                                     _ptr(m_valid), _ptr(self.full_outmask), M * HW, HW, ms)
+                rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
+                                        _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], M * HW, HW, ms)
                 self._mark("mix", main, False)
             _lib.check(rc, "ForwardPlan.run (granular, timed)")
             return self.full_outmask, self.match_score, self.det_score
@@ -533,9 +644,10 @@ class ForwardPlan:
             for h, (b, e) in enumerate(self.halves):
                 main.wait_event(self.ev_solved[h])
                 self._mark("mix", main, True)
-                rc |= L.dmm_mask_mix(self.Rb.data_ptr() + 4 * b * M * Pp, masks_p.data_ptr() + es * b * sp_b, dt, e - b,
-                                     N, M, Pp, HW, sp_b, sp_n, nv(n_valid, b), nv(m_valid, b),
-                                     self.full_outmask.data_ptr() + 4 * b * M * HW, M * HW, HW, ms)
+                rc |= L.dmm_mask_mix_to(self.Rb.data_ptr() + 4 * b * M * Pp, masks_p.data_ptr() + es * b * sp_b, dt,
+                                        e - b, N, M, Pp, HW, sp_b, sp_n, nv(n_valid, b), nv(m_valid, b),
+                                        self.full_outmask.data_ptr() + self.full_outmask.element_size() * b * M * HW,
+                                        _DT[self.out_dtype], M * HW, HW, ms)
                 self._mark("mix", main, False)
         _lib.check(rc, "ForwardPlan.run (pipelined)")
         return self.full_outmask, self.match_score, self.det_score

@@ -202,6 +202,14 @@ DMM_API int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B,
                  int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
                  float *out, int64_t so_b, int64_t so_m, dmm_stream_t stream);
 
+/* (4a) Same with a choice of the output element type: DMM_F32, or the planes' own 16-bit type (dtype) -- BASELINE
+ * config 5 keeps the masks in fp16: the matched masks are the next frame's templates (mask_last_occurence,
+ * dmm_model.py:78-80), so they are written back in the storage type (the fp32 result rounded once, nearest-even).
+ * out strides so_b / so_m are in OUTPUT elements. */
+DMM_API int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                            int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, void *out,
+                            int out_dtype, int64_t so_b, int64_t so_m, dmm_stream_t stream);
+
 /* (4b) Backward of (4) w.r.t. Rb: dRb[b,m,n] = <dout[b,m,:], masks_p[b,n,:]> on the support of Rb (entries with
  * Rb == 0 were masked by the constant logic mask, match_model.py:124-130, and get 0).  dout: [B,M,HW] fp32
  * contiguous; dRb: [B,M,Pp] fp32, overwritten.  Only the selected planes are read. */

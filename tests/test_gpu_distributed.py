@@ -65,8 +65,9 @@ def test_rccl_grad_bucketer_over_resnet101_gradients(rccl_world1):
         return sum(t.float().pow(2).mean() for t in f["backbone_feature"]) + \
             sum(t.float().abs().mean() for t in f["refine_input_feat"])
 
-    # reference gradients: plain backward, no bucketer (MIOpen's weight-gradient kernels accumulate with atomics: two
-    # backward passes agree to rounding, not bit for bit -- the exact comparison below uses the SAME backward)
+    # a plain backward first: which parameters get a gradient at all.  (Values are compared within ONE backward below:
+    # MIOpen's weight-gradient kernels accumulate with atomics and a random-init 101-layer net in train-mode BatchNorm at
+    # batch 2 amplifies that to ~1e-2 relative between two backward passes.)
     loss_of(enc(x)).backward()
     ref = [None if p.grad is None else p.grad.clone() for p in params]
     idle = [p for p, g in zip(params, ref) if g is None]
@@ -91,9 +92,6 @@ def test_rccl_grad_bucketer_over_resnet101_gradients(rccl_world1):
                 assert r is None and p.grad is None                   # idle everywhere: no zero gradient for Adam
             else:
                 assert p.grad.is_cuda and torch.equal(p.grad, g)      # world 1: mean == the local gradient, bit exact
-                # (vs the separate plain backward: equal up to MIOpen's atomics; biases in front of a train-mode
-                # BatchNorm have mathematically zero gradients, i.e. pure rounding noise -> absolute floor)
-                assert float((p.grad - r).norm()) <= 1e-3 * float(r.norm()) + 1e-6
     gb.remove_hooks()
     # non-overlapped path + the loss-dict reduce + a device barrier as bench.py's fence
     local = [None if p.grad is None else p.grad.clone() for p in params]

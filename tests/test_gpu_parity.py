@@ -941,3 +941,29 @@ def test_dmm_model_does_not_copy_the_proposal_planes():
     assert torch.equal(out, ref)
     for b in range(B):
         assert float(losses[b]) == float(rloss[b])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mask_mix_16bit_output_is_the_fp32_result_rounded_once(dtype):
+    """dmm_mask_mix_to with the planes' own 16-bit type as output (config 5: matched masks stay fp16): exactly the fp32
+    result rounded to nearest-even, for one-plane rows (test mode), multi-plane rows (train mode), empty rows, ragged
+    batches and row starts of every alignment (odd H*W)."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    for (B, N, M, H, W) in [(3, 50, 10, 255, 255), (2, 200, 20, 33, 47), (5, 7, 3, 1, 9), (1, 9, 4, 64, 64)]:
+        pm = torch.from_numpy(rng.random((B, N, H, W), dtype=np.float32)).to(DEV).to(dtype)
+        Pp = ops.padded_width(N, M)
+        Rb = torch.zeros((B, M, Pp), device=DEV)
+        for b in range(B):
+            for m in range(M):
+                k = (m + b) % 4                                  # 0..3 weighted planes in this row
+                for j in range(k):
+                    Rb[b, m, (7 * m + 3 * j + b) % N] = 0.1 + 0.2 * j + 0.01 * m
+        nv = torch.tensor([N, max(N - 2, 1), N, 1, N][:B], dtype=torch.int32, device=DEV)
+        mv = torch.tensor([M, M, max(M - 1, 1), M, M][:B], dtype=torch.int32, device=DEV)
+        f32 = ops.mask_mix(Rb, pm, nv, mv)
+        low = ops.mask_mix(Rb, pm, nv, mv, out_dtype=dtype)
+        assert low.dtype == dtype and torch.equal(low, f32.to(dtype)), (B, N, M, H, W)
+        # and the fp32 result itself: weighted sum of the (rounded) planes
+        ref = torch.einsum("bmn,bnhw->bmhw", Rb[:, :, :N] * (torch.arange(N, device=DEV)[None, None, :] < nv[:, None, None]),
+                           pm.float()) * (torch.arange(M, device=DEV)[None, :, None, None] < mv[:, None, None, None])
+        assert float((f32 - ref).abs().max()) <= 1e-6
