@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream schedule")
     ap.add_argument("--pipeline", action="store_true", help="force the 2-lane schedule")
     ap.add_argument("--parts", type=int, default=0, help="slices of the batch in the 2-lane schedule (default 2)")
+    ap.add_argument("--nchw-encoder", action="store_true", help="config 3: the round-1 NCHW / all-MIOpen encoder")
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="no cpu_baseline / batch_sweep / in-run PMC traffic")
@@ -322,7 +323,7 @@ def bench_layer(R, ci):
         for b in (1, 4, 8, 64, 512, 1024):
             if b > B:
                 continue
-            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt)
+            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt, graph=b <= 32)
             inp = inputs if b == B else tuple(t[:b] for t in inputs)
             ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
             sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}
@@ -374,7 +375,7 @@ def conv_flops(module, x):
 
 def bench_config3(R):
     from dmm_net_amd import _lib, ops, synth
-    from dmm_net_amd.encoder import FeatureEncoder, GraphedEncoder, fold_batchnorm
+    from dmm_net_amd.encoder import FastEncoder, FeatureEncoder, GraphedEncoder, fold_batchnorm
     from dmm_net_amd.proposals import SimpleBoxList
     from dmm_net_amd.roi_features import FeatureExtractor
     args, dev, rank, world = R.args, R.dev, R.rank, R.world
@@ -385,7 +386,10 @@ def bench_config3(R):
     enc_fp32 = fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval())
     img = torch.randn(B, 3, H, W, device=dev)
     flops = conv_flops(enc_fp32, img)
-    enc = GraphedEncoder(enc_fp32, weights_dtype=torch.bfloat16)
+    if args.nchw_encoder:        # round-1 form: NCHW, every convolution through MIOpen
+        enc = GraphedEncoder(enc_fp32, weights_dtype=torch.bfloat16)
+    else:
+        enc = GraphedEncoder(FastEncoder(enc_fp32))
     fe = FeatureExtractor()
     pm = torch.rand((B, P, H, W), generator=g, device=dev)
     tm = torch.rand((B, O, H, W), generator=g, device=dev)
@@ -436,7 +440,7 @@ def bench_config3(R):
                    "frames_per_gpu_per_step": B, "sharding": f"frames x{world}",
                    "stage_ms": {"encoder": round(enc_ms, 4), "roi_features": round(roi_ms, 4),
                                 "matching_layer": round(lay_ms, 4)}, "schedule": plan.schedule_name()},
-        "roofline": {"bound": "mfma", "kernel": "MIOpen convolutions of the encoder graph (all kernels of the replay)",
+        "roofline": {"bound": "mfma", "kernel": "encoder graph replay: hipBLASLt GEMMs (1x1) + MIOpen implicit-GEMM (3x3, 7x7) + fused epilogues",
                      "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
                      "algorithmic_flops_per_launch": int(flops), "avg_launch_ms": round(enc_ms, 4),

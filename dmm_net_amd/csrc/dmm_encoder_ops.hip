@@ -1,0 +1,76 @@
+// dmm_encoder_ops.hip -- the elementwise epilogue of the inference encoder on gfx950 (channels-last bf16).
+//
+// Reference: the conv -> BatchNorm -> ReLU stacks of the encoder, dmm/modules/base.py:43-54 (prop heads), :35-42
+// (skip projections + bn, model_encoder.py:137-140) and the torchvision Bottleneck / BasicBlock tails reached through
+// dmm/modules/vision.py:6-38 (out = relu(bn3(conv3(x)) + identity)).  With BatchNorm folded into the convolution
+// (encoder.fold_batchnorm) what is left after each MIOpen / hipBLASLt contraction is
+//     y = act(x + bias[c] (+ residual))
+// which eager PyTorch runs as 2-3 separate launches (bias add, residual add, clamp): 134 of the 349 launches and 29 %
+// of the device time of the ResNet-50 forward at 8 x 255 x 255 (profiles/r02_encoder_kernel_table_nchw_eager.md).
+// Here it is ONE in-place pass: 16-byte lane loads (8 bf16), fp32 arithmetic, one rounding.
+//
+// Roofline: HBM (2-3 x rows*C*2 bytes); the tensors are small (<= 16 MB), so it is launch / L2 bound in practice.
+#include "dmm_common.h"
+
+namespace dmm {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float v) {
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x: [rows, C] bf16 (channels-last activation viewed 2-D), C % 8 == 0.  One thread = 8 consecutive channels.
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_bf16_kernel(uint16_t *__restrict__ x, const float *__restrict__ bias,
+                                                            const uint16_t *__restrict__ res, int64_t n8, int c8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c = (int)(i % c8) * 8;
+    u32x4 v = reinterpret_cast<const u32x4 *>(x)[i];
+    u32x4 r;
+    if (RES) r = reinterpret_cast<const u32x4 *>(res)[i];
+    const float4 b0 = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b1 = bias ? *reinterpret_cast<const float4 *>(bias + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float lo = __uint_as_float(v[k] << 16) + bb[2 * k];
+        float hi = __uint_as_float(v[k] & 0xFFFF0000u) + bb[2 * k + 1];
+        if (RES) {
+            lo = lo + __uint_as_float(r[k] << 16);
+            hi = hi + __uint_as_float(r[k] & 0xFFFF0000u);
+        }
+        if (RELU) {
+            lo = lo > 0.0f ? lo : 0.0f;
+            hi = hi > 0.0f ? hi : 0.0f;
+        }
+        o[k] = bf16_rne(lo) | (bf16_rne(hi) << 16);
+    }
+    reinterpret_cast<u32x4 *>(x)[i] = o;
+}
+
+}  // namespace dmm
+
+extern "C" int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
+                                 dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || (C & 7)) return DMM_ERR_BAD_ARG;
+    if (rows == 0) return DMM_OK;
+    if (!x) return DMM_ERR_BAD_ARG;
+    const int64_t n8 = rows * (int64_t)(C / 8);
+    const int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t *xp = (uint16_t *)x;
+    const uint16_t *rp = (const uint16_t *)residual;
+#define DMM_BA(RES_, RELU_)                                                                                          \
+    hipLaunchKernelGGL((dmm::bias_act_bf16_kernel<RES_, RELU_>), dim3((unsigned)blocks), dim3(256), 0, s, xp, bias, rp, \
+                       n8, C / 8)
+    if (residual) { if (relu) DMM_BA(true, true); else DMM_BA(true, false); }
+    else { if (relu) DMM_BA(false, true); else DMM_BA(false, false); }
+#undef DMM_BA
+    return dmm::check_launch();
+}

@@ -247,6 +247,7 @@ class GraphedEncoder:
         assert not encoder.training, "capture needs eval() mode"
         assert autocast_dtype is None or weights_dtype is None
         if weights_dtype is not None:
+            assert not isinstance(encoder, FastEncoder), "FastEncoder carries its own bf16 weights"
             assert not any(isinstance(m, nn.BatchNorm2d) for m in encoder.modules()), \
                 "fold_batchnorm() first: BatchNorm statistics should not be rounded to a 16-bit type"
             encoder = encoder.to(weights_dtype)
@@ -281,3 +282,129 @@ class GraphedEncoder:
         static_in.copy_(img)
         graph.replay()
         return static_out
+
+
+# ---- channels-last inference encoder: 1x1 convolutions as hipBLASLt GEMMs, fused epilogues ----------------------
+def _bias_act_(x: torch.Tensor, bias, residual=None, relu: bool = True) -> torch.Tensor:
+    """In place on a channels-last bf16 activation [B,C,H,W] (memory [B,H,W,C]): x = act(x + bias[c] (+ residual)) --
+    ONE HIP launch (``dmm_bias_act_bf16``) instead of eager's bias add + residual add + clamp."""
+    from . import _lib
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+    B, C, H, W = x.shape
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+        assert residual.is_contiguous(memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dmm_bias_act_bf16(x.data_ptr(), None if bias is None else bias.data_ptr(),
+                                           None if residual is None else residual.data_ptr(), B * H * W, C, int(relu),
+                                           torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dmm_bias_act_bf16")
+    return x
+
+
+def _as_rows(x: torch.Tensor) -> torch.Tensor:
+    """channels-last [B,C,H,W] -> its [B*H*W, C] matrix (a view: the memory already is that matrix)."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _from_rows(y: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    return y.view(B, H, W, y.shape[1]).permute(0, 3, 1, 2)          # channels-last [B,C,H,W] view
+
+
+class FastEncoder(nn.Module):
+    """Inference form of ``FeatureEncoder`` for MI355X (BASELINE config 3: bf16).  Same function as
+    ``fold_batchnorm(encoder)`` -- same parameters, BatchNorm folded -- evaluated differently:
+
+    * activations stay channels-last bf16 end to end.  In NCHW, MIOpen wraps every implicit-GEMM convolution in a
+      pair of layout transposes + cast / zero helper kernels (112 + 56 of the 349 launches of one ResNet-50 forward at
+      8 x 255 x 255, 27 % of its device time; profiles/r02_encoder_kernel_table_nchw_eager.md);
+    * the 1x1 convolutions (2/3 of a bottleneck) ARE matrix products of the [B*H*W, Cin] activation matrix: they go to
+      hipBLASLt through ``torch.addmm`` / ``torch._addmm_activation`` with the bias (+ ReLU) in the GEMM epilogue;
+    * what is left after the 3x3 / 7x7 MIOpen convolutions -- bias, residual, ReLU -- is one in-place HIP launch
+      (``dmm_bias_act_bf16``) instead of two or three eager ones.
+
+    ``backbone_feature`` comes back NCHW-contiguous (what the fused ROIAlign kernel reads); ``refine_input_feat`` /
+    ``body_feature`` stay channels-last views.  Wrap in ``GraphedEncoder(FastEncoder(enc))`` to replay from one HIP
+    graph.  Reference: vision.py:6-38 (body), base.py:35-54 + model_encoder.py:136-146 (heads)."""
+
+    def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
+        super().__init__()
+        assert not encoder.training, "FastEncoder is an inference form: eval() first"
+        enc = encoder if not any(isinstance(m, nn.BatchNorm2d) for m in encoder.modules()) else fold_batchnorm(encoder)
+        assert dtype == torch.bfloat16, "the fused epilogue kernel is bf16"
+        self.dtype = dtype
+        self.src = enc                       # folded fp32 parameters stay the source of truth (state_dict)
+        self._p = {}                         # id(conv) -> prepared (weight, bias)
+
+        def prep(conv: nn.Conv2d):
+            w = conv.weight.detach()
+            b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+            if conv.kernel_size == (1, 1):
+                wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous().to(dtype)          # [Cin, Cout]
+                self._p[id(conv)] = (wt, b, None if b is None else b.to(dtype))
+            else:
+                self._p[id(conv)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, None)
+        for m in enc.modules():
+            if isinstance(m, nn.Conv2d):
+                prep(m)
+        self.eval()
+
+    # -- building blocks --------------------------------------------------------------------------------------
+    def _conv1x1(self, x, conv, relu, residual=None):
+        """y = act(x @ W^T + b (+ residual)) on the activation matrix.  stride 2 = a row subsample first."""
+        wt, b32, bl = self._p[id(conv)]
+        if conv.stride != (1, 1):
+            x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous(memory_format=torch.channels_last)
+        B, _, H, W = x.shape
+        rows = _as_rows(x)
+        if residual is not None:
+            # (torch.addmm(residual, rows, wt) would first COPY the residual into the output -- a DtoD memcpy per
+            # block, 16 per ResNet-50 forward -- so the residual rides in the epilogue launch instead)
+            return _bias_act_(_from_rows(torch.mm(rows, wt), B, H, W), b32, residual, relu)
+        if relu:
+            y = torch._addmm_activation(bl, rows, wt, use_gelu=False)  # bias + ReLU in the GEMM epilogue
+        else:
+            y = torch.addmm(bl, rows, wt)
+        return _from_rows(y, B, H, W)
+
+    def _convkxk(self, x, conv, relu, residual=None):
+        w, b32, _ = self._p[id(conv)]
+        y = torch.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return _bias_act_(y, b32, residual, relu)
+
+    def _conv(self, x, conv, relu, residual=None):
+        if conv.kernel_size == (1, 1) and conv.groups == 1:
+            return self._conv1x1(x, conv, relu, residual)
+        return self._convkxk(x, conv, relu, residual)
+
+    def _block(self, x, blk):
+        idt = x if blk.downsample is None else self._conv(x, blk.downsample[0], relu=False)
+        if isinstance(blk, Bottleneck):
+            out = self._conv(x, blk.conv1, relu=True)
+            out = self._conv(out, blk.conv2, relu=True)
+            return self._conv(out, blk.conv3, relu=True, residual=idt)
+        out = self._conv(x, blk.conv1, relu=True)
+        return self._conv(out, blk.conv2, relu=True, residual=idt)
+
+    def _head(self, x, head):
+        out = self._conv(x, head[0], relu=True)                        # conv -> (folded BN) -> ReLU
+        return self._conv(out, head[3], relu=False)                    # conv -> (folded BN)
+
+    def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
+        assert img.dim() == 4 and img.shape[1] == 3, img.shape
+        enc, body = self.src, self.src.base
+        with torch.no_grad():
+            x = img.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            x1 = self._conv(x, body.conv1, relu=True)
+            x = body.maxpool(x1)
+            feats = []
+            for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
+                for blk in layer:
+                    x = self._block(x, blk)
+                feats.append(x)
+            x2, x3, x4, x5 = feats
+            skips = tuple(self._conv(f, getattr(enc, f"sk{k}"), relu=False) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
+            p5, p4, p3, p2 = (self._head(f, getattr(enc, f"prop{k}")) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
+            backbone = tuple(p.contiguous() for p in (p2, p3, p4, p5))   # NCHW for the fused ROIAlign kernel
+        return {"backbone_feature": backbone, "refine_input_feat": skips, "body_feature": (x2, x3, x4, x5)}

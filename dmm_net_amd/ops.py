@@ -407,11 +407,11 @@ class ForwardPlan:
     Two execution shapes:
 
     * ``pipeline=False`` -- one ``dmm_match_forward`` C call, all kernels back to back on the current stream;
-      With ``graph`` (default for B <= 32: the product's sizes, where a frame step is launch / latency bound) the
-      sequence is captured ONCE into a HIP graph the second time ``run`` sees the same tensors (same addresses and
-      strides) and replayed from then on: one graph launch instead of 7 kernel launches, and the two independent
-      branches of the layer -- IoU counts (masks) | normalise + cosine (features) -- run side by side before the
-      solver joins them.  Callers that hand in fresh tensors every step simply never trigger the capture.
+      With ``graph=True`` (small batches, where a frame step is launch / latency bound) the sequence is captured into
+      a HIP graph the second time in a row ``run`` sees the same tensors (same addresses and strides) and replayed
+      from then on -- one graph launch instead of 7 kernel launches, and the two independent branches of the layer,
+      IoU counts (masks) | normalise + cosine (features), run side by side before the solver joins them.  Up to 4
+      tensor sets are kept (each captured graph holds references to its tensors); other calls launch directly.
     * ``pipeline=True``  -- "streaming lane + latency lane".  The batch is split in two halves A, B.  The
       current stream runs only the HBM-bound kernels, serialised at full bandwidth:
       cost(A) -> cost(B) -> mix(A) -> mix(B)  (A, B = the two halves of the batch).  A side stream runs the latency-bound ones:
@@ -439,9 +439,10 @@ class ForwardPlan:
         assert self.out_dtype in (torch.float32, mask_dtype)
         self.time_kernels = bool(time_kernels) or self.out_dtype != torch.float32
         self.kernel_events = None
-        self.graph_mode = (B <= 32 and not self.pipeline and not self.time_kernels) if graph is None else \
-            (bool(graph) and not self.pipeline and not self.time_kernels)
-        self._graph = self._graph_key = self._last_key = None
+        # opt-in: it only pays for callers that present the SAME tensors again (static buffers: bench loops, serving
+        # loops over GraphedEncoder outputs); a frame loop with fresh proposal tensors would capture and never replay
+        self.graph_mode = bool(graph) and not self.pipeline and not self.time_kernels
+        self._graphs, self._last_key = {}, None                   # key -> (graph, tensors it holds addresses of)
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
@@ -492,7 +493,7 @@ class ForwardPlan:
             return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
         if self.graph_mode:
             return "HIP graph replay (IoU counts | normalise + cosine in parallel -> solver -> mix)" \
-                if self._graph is not None else "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
+                if self._graphs else "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
         return "single stream"
 
     def _launch_forked(self, L, masks_p, masks_t, feat_p, feat_t, score_p, dt, strides, n_valid, m_valid, cfg):
@@ -554,18 +555,19 @@ class ForwardPlan:
             cfg = (float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test))
             key = (masks_p.data_ptr(), masks_t.data_ptr(), feat_p.data_ptr(), feat_t.data_ptr(), score_p.data_ptr(),
                    sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), cfg)
-            if self._graph is not None and key == self._graph_key:
-                self._graph.replay()
+            hit = self._graphs.get(key)
+            if hit is not None:
+                hit[0].replay()
                 return self.full_outmask, self.match_score, self.det_score
-            if key == self._last_key:
+            if key == self._last_key and len(self._graphs) < 4:
                 # second call in a row on the same tensors: capture (the first one ran directly = the warm-up)
                 with _CAPTURE_LOCK, torch.cuda.device(self.device):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._launch_forked(L, masks_p, masks_t, feat_p, feat_t, score_p, dt, (sp_b, sp_n, st_b, st_m),
                                             n_valid, m_valid, cfg)
-                self._graph, self._graph_key = g, key
-                self._keep = (masks_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid)   # the graph holds raw addresses
+                # the graph holds raw addresses: keep the tensors alive with it
+                self._graphs[key] = (g, (masks_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid))
                 g.replay()
                 return self.full_outmask, self.match_score, self.det_score
             self._last_key = key

@@ -284,6 +284,15 @@ DMM_API int dmm_mask_boxes_f32(const float *masks, int R, int H, int W, int64_t 
 DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64_t stride_b, int64_t stride_o,
                                  const int32_t *o_valid, uint8_t *labels, dmm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (9) Encoder epilogue (inference, channels-last bf16): x[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])) in place,
+ * one pass, fp32 arithmetic, one rounding.  What remains of conv -> BatchNorm -> ReLU (dmm/modules/base.py:43-54,
+ * model_encoder.py:137-146) and of the residual tails of the torchvision blocks (dmm/modules/vision.py:6-38) once the
+ * BatchNorm is folded into the contraction.  x, residual: [rows, C] bfloat16, C % 8 == 0; bias: [C] fp32 or NULL.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
+                              dmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

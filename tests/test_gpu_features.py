@@ -279,3 +279,57 @@ def test_folded_graphed_encoder_matches_eager():
                 assert x.shape == y.shape
                 assert float((x - y).abs().max()) <= 5e-4 * max(1.0, float(x.abs().max())), (seed, k)
     assert len(genc._graphs) == 2
+
+
+# ------------------------------------------------------------------------------------ round 2: channels-last encoder
+def test_bias_act_bf16_kernel_matches_fp32_reference():
+    """dmm_bias_act_bf16: x = act(x + bias (+ residual)) in place on channels-last bf16 == the same in fp32, rounded once."""
+    from dmm_net_amd.encoder import _bias_act_
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for (B, C, H, W) in [(2, 64, 17, 23), (1, 8, 3, 5), (8, 256, 64, 64), (3, 2048, 8, 8)]:
+        for use_res in (False, True):
+            for relu in (False, True):
+                x = torch.randn((B, C, H, W), generator=g, device=DEV).to(torch.bfloat16).contiguous(
+                    memory_format=torch.channels_last)
+                r = torch.randn((B, C, H, W), generator=g, device=DEV).to(torch.bfloat16).contiguous(
+                    memory_format=torch.channels_last) if use_res else None
+                b = torch.randn((C,), generator=g, device=DEV)
+                ref = x.float() + b.view(1, C, 1, 1) + (r.float() if use_res else 0.0)
+                if relu:
+                    ref = ref.clamp_min(0.0)
+                y = _bias_act_(x.clone(memory_format=torch.preserve_format), b, r, relu)
+                assert torch.equal(y, ref.to(torch.bfloat16)), (B, C, H, W, use_res, relu)
+
+
+@pytest.mark.parametrize("arch,hw", [("resnet50", (96, 128)), ("resnet34", (64, 96))])
+def test_fast_channels_last_encoder_matches_the_folded_encoder(arch, hw):
+    """FastEncoder (channels-last bf16, 1x1 convolutions as hipBLASLt GEMMs with fused epilogues, one HIP launch for
+    bias + residual + ReLU) computes the function of fold_batchnorm(encoder): its distance to the fp32 result is that
+    of the same network run eagerly in bf16 (both carry bf16 rounding of every layer), and it replays from a graph."""
+    from dmm_net_amd.encoder import FastEncoder, GraphedEncoder, fold_batchnorm
+    torch.manual_seed(7)
+    enc = FeatureEncoder(arch, hidden_size=64).to(DEV)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    enc.eval()
+    folded = fold_batchnorm(enc)
+    img = torch.randn(2, 3, *hw, device=DEV)
+    with torch.no_grad():
+        ref = folded(img)
+        import copy
+        eager16 = copy.deepcopy(folded).to(torch.bfloat16)(img.to(torch.bfloat16))
+    fast = FastEncoder(folded)
+    out = fast(img)
+    gout = GraphedEncoder(fast)(img)
+    for k in ("backbone_feature", "refine_input_feat", "body_feature"):
+        for x, y16, y, yg in zip(ref[k], eager16[k], out[k], gout[k]):
+            assert x.shape == y.shape == yg.shape
+            scale = max(1.0, float(x.abs().max()))
+            e_eager = float((x - y16.float()).abs().max()) / scale
+            e_fast = float((x - y.float()).abs().max()) / scale
+            assert e_fast <= 2.0 * e_eager + 2e-2, (k, e_fast, e_eager)
+            # graph replay == direct launches (MIOpen's split-K convolutions accumulate with atomics: rounding noise only)
+            assert float((y.float() - yg.float()).abs().max()) <= 2e-2 * scale
+    assert all(p.is_contiguous() for p in out["backbone_feature"])      # NCHW for the ROIAlign kernel

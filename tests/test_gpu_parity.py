@@ -967,3 +967,34 @@ def test_mask_mix_16bit_output_is_the_fp32_result_rounded_once(dtype):
         ref = torch.einsum("bmn,bnhw->bmhw", Rb[:, :, :N] * (torch.arange(N, device=DEV)[None, None, :] < nv[:, None, None]),
                            pm.float()) * (torch.arange(M, device=DEV)[None, :, None, None] < mv[:, None, None, None])
         assert float((f32 - ref).abs().max()) <= 1e-6
+
+
+def test_forward_plan_graph_mode_replays_on_static_buffers():
+    """ForwardPlan(graph=True): the second call in a row on the same tensors captures a HIP graph (counts | normalise +
+    cosine as parallel branches), later calls replay it -- also after the buffers were refilled in place -- and calls
+    with other tensors launch directly; every result equals the plain single-stream plan."""
+    c = synth.CONFIGS[1]
+    B = 3
+    g = torch.Generator(device=DEV).manual_seed(21)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    bufs = [mk(B, c["P"], c["H"], c["W"]), mk(B, c["O"], c["H"], c["W"]), mk(B, c["P"], c["D"]) - 0.5,
+            mk(B, c["O"], c["D"]) - 0.5, mk(B, c["P"])]
+    plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, graph=True)
+    ref = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
+    kw = dict(max_iter=20, proj_iter=5, is_test=1)
+
+    def same(inputs):
+        plan.run(*inputs, **kw)
+        ref.run(*inputs, **kw)
+        torch.cuda.synchronize()
+        return all(torch.equal(a, b) for a, b in zip((plan.full_outmask, plan.match_score, plan.det_score, plan.R, plan.iters),
+                                                     (ref.full_outmask, ref.match_score, ref.det_score, ref.R, ref.iters)))
+    assert same(bufs) and len(plan._graphs) == 0                  # 1st call: direct
+    assert same(bufs) and len(plan._graphs) == 1                  # 2nd call on the same tensors: captured + replayed
+    for k in range(3):                                            # refill in place, replay
+        for t in bufs:
+            t.copy_(mk(*t.shape) - (0.5 if t.dim() == 3 else 0.0))
+        assert same(bufs) and len(plan._graphs) == 1
+    other = [t.clone() for t in bufs]
+    assert same(other) and len(plan._graphs) == 1                 # other tensors: direct launch, no new graph yet
+    assert "graph replay" in plan.schedule_name()

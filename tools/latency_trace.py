@@ -17,7 +17,7 @@ tm = torch.rand((B, M, H, W), generator=g, device=dev)
 pf = torch.randn((B, N, D), generator=g, device=dev)
 tf = torch.randn((B, M, D), generator=g, device=dev)
 sc = torch.rand((B, N), generator=g, device=dev)
-plan = ops.ForwardPlan(B, N, M, H, W, D, dev)
+plan = ops.ForwardPlan(B, N, M, H, W, D, dev, graph=True)
 for _ in range(30):
     plan.run(pm, tm, pf, tf, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
 torch.cuda.synchronize()
