@@ -389,7 +389,7 @@ def bench_config3(R):
     if args.nchw_encoder:        # round-1 form: NCHW, every convolution through MIOpen
         enc = GraphedEncoder(enc_fp32, weights_dtype=torch.bfloat16)
     else:
-        enc = GraphedEncoder(FastEncoder(enc_fp32))
+        enc = GraphedEncoder(FastEncoder(enc_fp32), miopen_find=True)   # find-db shipped in dmm_net_amd/miopen_db
     fe = FeatureExtractor()
     pm = torch.rand((B, P, H, W), generator=g, device=dev)
     tm = torch.rand((B, O, H, W), generator=g, device=dev)

@@ -240,7 +240,8 @@ class GraphedEncoder:
 
     static_outputs = True      # outputs alias the graph's buffers (video.FrameLoop clones what it keeps across frames)
 
-    def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3, weights_dtype=None):
+    def __init__(self, encoder: "FeatureEncoder", autocast_dtype=None, warmup: int = 3, weights_dtype=None,
+                 miopen_find: bool = False):
         """``weights_dtype=torch.bfloat16`` converts the (BatchNorm-folded) encoder's parameters ONCE and runs the whole
         forward in that dtype; ``autocast_dtype`` keeps fp32 parameters and lets autocast re-cast all of them on every
         replay (131 cast kernels per ResNet-50 forward, ~15 % of the graph).  Use one or the other."""
@@ -252,6 +253,13 @@ class GraphedEncoder:
                 "fold_batchnorm() first: BatchNorm statistics should not be rounded to a 16-bit type"
             encoder = encoder.to(weights_dtype)
         self.encoder, self.dtype, self.warmup, self.wdtype = encoder, autocast_dtype, int(warmup), weights_dtype
+        # miopen_find: run the warm-up of every new input shape with torch.backends.cudnn.benchmark = True, i.e. let
+        # MIOpen time all applicable solvers once per convolution shape instead of taking its heuristic pick (ResNet-50
+        # at 8 x 255 x 255, channels-last bf16: device time per forward 1.61 -> 1.25 ms, the search replaces the
+        # split-K implicit-GEMM kernels and their cast / zero helpers by CK kernels).  The results land in MIOpen's
+        # user find-db: dmm_net_amd/miopen_db ships the entries of BASELINE configs 3 and 4, so on those shapes the
+        # "search" is a lookup; a new shape costs a one-time search of some tens of seconds.
+        self.miopen_find = bool(miopen_find)
         self._graphs = {}
 
     def _forward(self, x):
@@ -271,8 +279,13 @@ class GraphedEncoder:
             side = torch.cuda.Stream(device=img.device)
             side.wait_stream(torch.cuda.current_stream(img.device))
             with torch.cuda.stream(side):                         # warm-up off the capture: MIOpen picks its kernels
-                for _ in range(self.warmup):
-                    self._forward(static_in)
+                old = torch.backends.cudnn.benchmark
+                torch.backends.cudnn.benchmark = old or self.miopen_find
+                try:
+                    for _ in range(self.warmup):
+                        self._forward(static_in)
+                finally:
+                    torch.backends.cudnn.benchmark = old
             torch.cuda.current_stream(img.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

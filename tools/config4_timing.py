@@ -18,12 +18,17 @@ B, F, P, H, W = 12, 5, 50, 255, 448
 torch.manual_seed(0)
 g = torch.Generator(device=dev).manual_seed(0)
 enc = FeatureEncoder("resnet101").to(dev).train()
+CL = bool(os.environ.get("CHANNELS_LAST"))
+if CL:
+    enc = enc.to(memory_format=torch.channels_last)
 fe = FeatureExtractor()
 cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
         "score_weight": 0.3}
 model = DMM_Model(cfgs, is_test=0, feature_extractor=fe)
 opt = torch.optim.Adam(list(enc.get_skip_params()) + list(enc.get_backbone_para()), lr=1e-4)
 img = torch.randn(B, 3, H, W, device=dev)
+if CL:
+    img = img.contiguous(memory_format=torch.channels_last)
 
 
 def boxes(n):

@@ -95,7 +95,7 @@ elif mode == "step4":
     mask_last = torch.rand((B, F, H, W), generator=g, device=dev)
     targets = (torch.rand((B, F, H, W), generator=g, device=dev) > 0.5).float()
     valid = torch.ones(B, F, device=dev)
-    for it in range(5):
+    for it in range(int(os.environ.get('STEPS', '5'))):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             feats = enc(img)
         tplt = model.fill_template_dict(None, tboxes, feats, None, valid)

@@ -8,6 +8,8 @@ import torch
 from dmm_net_amd.encoder import FastEncoder, FeatureEncoder, GraphedEncoder, fold_batchnorm
 
 dev = "cuda:0"
+if os.environ.get("BENCH"):
+    torch.backends.cudnn.benchmark = True      # MIOpen "find": time every applicable solver once per shape
 torch.manual_seed(0)
 enc = FastEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()))
 img = torch.randn(8, 3, 255, 255, device=dev)
