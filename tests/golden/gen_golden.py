@@ -33,6 +33,8 @@ are data only -- no reference source text is stored.  Groups follow SURVEY.md se
   G13 NMS + top-k through the REFERENCE's ``filter_results`` (dmm/utils/boxlist_ops.py:15-29, imported) with the
      third-party ``nms`` symbol bound to a plain-Python greedy NMS from the published definition (+1 box extents,
      IoU > thresh suppresses as in nms.cu, stable order for ties): duplicates, exact-threshold pairs, score ties.
+  G16 encoder heads first hand: the reference's FeatureExtractorBase (base.py:18-69, plain torch.nn behind the stubs)
+     + the head calls of model_encoder.py:136-146 on seeded body features, train and eval mode, all parameters.
   G14 algo 'hun' through the imported MatchModel (hungarian_matching with its hard-coded .cuda() patched to a
      no-op on this CPU-only box): outputs + gradients of cost_loss (the only differentiable term under 'hun').
 """
@@ -126,6 +128,14 @@ def _install_third_party_stubs():
     mod("maskrcnn_benchmark.structures")
     mod("maskrcnn_benchmark.structures.bounding_box", BoxList=BoxList)
     mod("torchvision", transforms=types.SimpleNamespace())
+    # symbols dmm/modules/base.py imports at module level and FeatureExtractorBase never touches
+    mod("maskrcnn_benchmark.modeling")
+    mod("maskrcnn_benchmark.modeling.detector", build_detection_model=None)
+    mod("maskrcnn_benchmark.config", cfg=None)
+    mod("maskrcnn_benchmark.utils")
+    mod("maskrcnn_benchmark.utils.checkpoint", DetectronCheckpointer=None)
+    mod("maskrcnn_benchmark.structures.image_list", to_image_list=None)
+    mod("maskrcnn_benchmark.data", transforms=types.SimpleNamespace())
     return BoxList
 
 
@@ -868,8 +878,61 @@ def g15():
     save("g15_nonprefix_valid", d)
 
 
+# ------------------------------------------------------------------------------------------ G16
+def g16():
+    """Encoder heads FIRST HAND: the reference's FeatureExtractorBase (dmm/modules/base.py:18-69, imported behind the
+    third-party stubs; its __init__ builds sk2-5 / bn2-5 / prop2-5 from plain torch.nn) under a fixed seed, applied to
+    seeded body features exactly as FeatureExtractor.forward does (model_encoder.py:136-146).  Stored: every parameter
+    and buffer (the state-dict schema a reference checkpoint has for these keys), the inputs, and the outputs in
+    train() and eval() mode.  (The ResNet body is torchvision's, absent here: its parity stays un-pinned.)"""
+    import types
+    _install_third_party_stubs()
+    from dmm.modules.base import FeatureExtractorBase       # noqa: E402  (reference)
+    d = {}
+    # small hidden sizes + parameters defined as fp16-representable values keep the fixture at ~1.5 MB
+    for name, (arch, hid, hw) in {"r50": ("resnet50", 8, (24, 32)), "r34": ("resnet34", 16, (16, 24))}.items():
+        torch.manual_seed(1600 + hid)
+        args = types.SimpleNamespace(base_model=arch, hidden_size=hid, kernel_size=3)
+        ref = FeatureExtractorBase(args)
+        with torch.no_grad():                               # non-trivial BatchNorm statistics
+            for m in ref.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.3)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.2)
+            for t in list(ref.parameters()) + list(ref.buffers()):
+                if t.dtype == torch.float32:
+                    t.copy_(t.half().float())               # stored as fp16, exactly
+        from dmm.utils.utils import get_skip_dims           # noqa: E402  (reference)
+        dims = get_skip_dims(arch)
+        gen = torch.Generator().manual_seed(16)
+        H, W = hw
+        body = {5: torch.randn(2, dims[0], H // 8, W // 8, generator=gen), 4: torch.randn(2, dims[1], H // 4, W // 4, generator=gen),
+                3: torch.randn(2, dims[2], H // 2, W // 2, generator=gen), 2: torch.randn(2, dims[3], H, W, generator=gen)}
+        for k, v in ref.state_dict().items():
+            d[f"{name}/sd/{k}"] = v.numpy().astype(np.float16) if v.dtype == torch.float32 else v.numpy()
+        # inputs by seed: torch.Generator().manual_seed(16), randn in the order x5, x4, x3, x2 (shapes below)
+        d[f"{name}/body_shapes"] = np.array([list(body[l].shape) for l in (5, 4, 3, 2)], np.int32)
+        d[f"{name}/body_checksum"] = np.array([float(body[l].double().sum()) for l in (5, 4, 3, 2)])
+        for mode in ("eval", "train"):
+            ref.train(mode == "train")
+            sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+            with torch.no_grad():
+                outs = {"x5_skip": ref.bn5(ref.sk5(body[5])), "x4_skip": ref.bn4(ref.sk4(body[4])),
+                        "x3_skip": ref.bn3(ref.sk3(body[3])), "x2_skip": ref.bn2(ref.sk2(body[2])),
+                        "p5": ref.prop5(body[5]), "p4": ref.prop4(body[4]), "p3": ref.prop3(body[3]),
+                        "p2": ref.prop2(body[2])}
+            ref.load_state_dict(sd0)                        # train mode moved the running statistics: restore
+            for k, v in outs.items():
+                d[f"{name}/{mode}/{k}"] = v.numpy()
+        d[f"{name}/cfg"] = np.array([hid, 3, H, W], np.int32)
+        d[f"{name}/n_skip_params"] = np.int64(sum(p.numel() for p in ref.get_skip_params()))
+    save("g16_encoder_heads", d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
-                             "g15"]
+                             "g15", "g16"]
     for w in which:
         globals()[w]()

@@ -1,4 +1,5 @@
 """Encoder structure (no GPU needed): published parameter counts, checkpoint key names, strides, gradient flow."""
+import pytest
 import torch
 
 from dmm_net_amd.encoder import FeatureEncoder
@@ -52,3 +53,46 @@ def test_fold_batchnorm_same_outputs_cpu():
                 assert x.shape == y.shape
                 assert float((x - y).abs().max()) <= 2e-4 * max(1.0, float(x.abs().max())), (name, k)
         assert any(isinstance(m, torch.nn.BatchNorm2d) for m in enc.modules())     # the original is untouched
+
+
+def _g16_case(name):
+    import numpy as np
+    from conftest import golden
+    g = golden("g16_encoder_heads")
+    hid, ker, H, W = [int(v) for v in g[f"{name}/cfg"]]
+    gen = torch.Generator().manual_seed(16)
+    shapes = g[f"{name}/body_shapes"]
+    body = [torch.randn(*[int(v) for v in shp], generator=gen) for shp in shapes]          # x5, x4, x3, x2
+    for t, c in zip(body, g[f"{name}/body_checksum"]):
+        assert abs(float(t.double().sum()) - float(c)) < 1e-6, "torch's CPU randn stream changed: regenerate G16"
+    sd = {k[len(name) + 4:]: torch.from_numpy(np.asarray(g[k])) for k in g.keys() if k.startswith(f"{name}/sd/")}
+    sd = {k: (v.float() if v.dtype == torch.float16 else v) for k, v in sd.items()}
+    return g, hid, ker, body, sd
+
+
+@pytest.mark.parametrize("name,arch", [("r50", "resnet50"), ("r34", "resnet34")])
+def test_encoder_heads_match_the_reference_feature_extractor_base(name, arch):
+    """G16: the sk / bn / prop heads against the reference's own FeatureExtractorBase (dmm/modules/base.py:18-69,
+    imported) driven like model_encoder.py:136-146 -- the reference's state dict loads into FeatureEncoder by key
+    (strict for the head keys) and the outputs agree in eval() and train() mode; get_skip_params covers the same
+    parameters."""
+    g, hid, ker, body, sd = _g16_case(name)
+    enc = FeatureEncoder(arch, hidden_size=hid, kernel_size=ker)
+    own = {k for k in enc.state_dict().keys() if not k.startswith("base.")}
+    assert own == set(sd.keys()), (sorted(own - set(sd.keys())), sorted(set(sd.keys()) - own))
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("base.") for k in missing)
+    assert sum(p.numel() for p in enc.get_skip_params()) == int(g[f"{name}/n_skip_params"])
+    x5, x4, x3, x2 = body
+    for mode in ("eval", "train"):
+        enc.train(mode == "train")
+        keep = {k: v.clone() for k, v in enc.state_dict().items()}
+        with torch.no_grad():
+            outs = {"x5_skip": enc.bn5(enc.sk5(x5)), "x4_skip": enc.bn4(enc.sk4(x4)), "x3_skip": enc.bn3(enc.sk3(x3)),
+                    "x2_skip": enc.bn2(enc.sk2(x2)), "p5": enc.prop5(x5), "p4": enc.prop4(x4), "p3": enc.prop3(x3),
+                    "p2": enc.prop2(x2)}
+        enc.load_state_dict(keep)
+        for k, v in outs.items():
+            exp = torch.from_numpy(g[f"{name}/{mode}/{k}"])
+            assert v.shape == exp.shape, k
+            assert float((v - exp).abs().max()) <= 1e-5 * max(1.0, float(exp.abs().max())), (mode, k)

@@ -333,3 +333,24 @@ def test_fast_channels_last_encoder_matches_the_folded_encoder(arch, hw):
             # graph replay == direct launches (MIOpen's split-K convolutions accumulate with atomics: rounding noise only)
             assert float((y.float() - yg.float()).abs().max()) <= 2e-2 * scale
     assert all(p.is_contiguous() for p in out["backbone_feature"])      # NCHW for the ROIAlign kernel
+
+
+@pytest.mark.parametrize("name,arch", [("r50", "resnet50"), ("r34", "resnet34")])
+def test_fast_encoder_heads_match_reference_g16(name, arch):
+    """G16 on the device: the reference's FeatureExtractorBase outputs (eval mode) against FastEncoder's head path --
+    BatchNorm folded, channels-last bf16, MIOpen convolution + dmm_bias_act_bf16 epilogue -- within bf16 rounding."""
+    from test_encoder_cpu import _g16_case
+    from dmm_net_amd.encoder import FastEncoder
+    g, hid, ker, body, sd = _g16_case(name)
+    enc = FeatureEncoder(arch, hidden_size=hid, kernel_size=ker)
+    enc.load_state_dict(sd, strict=False)
+    fast = FastEncoder(enc.to(DEV).eval())
+    cl = lambda t: t.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = {5: cl(body[0]), 4: cl(body[1]), 3: cl(body[2]), 2: cl(body[3])}
+    for lvl in (5, 4, 3, 2):
+        outs = {f"x{lvl}_skip": fast._conv(x[lvl], getattr(fast.src, f"sk{lvl}"), relu=False),
+                f"p{lvl}": fast._head(x[lvl], getattr(fast.src, f"prop{lvl}"))}
+        for k, v in outs.items():
+            exp = torch.from_numpy(g[f"{name}/eval/{k}"]).to(DEV)
+            err = float((v.float() - exp).abs().max()) / max(1.0, float(exp.abs().max()))
+            assert err <= 3e-2, (k, err)                      # bf16 inputs, weights and outputs; fp32 accumulation
