@@ -81,13 +81,17 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
     int rc = dmm_iou_counts(masks_p, masks_t, mask_dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid,
                             w.inter, w.area_p, w.area_t, stream);
     if (rc != DMM_OK) return rc;
-    rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
-    if (rc != DMM_OK) return rc;
-    rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
-    if (rc != DMM_OK) return rc;
     float *sim = sim_out ? sim_out : w.sim;
     float *Rb = Rb_out ? Rb_out : w.Rb;
-    rc = dmm_cosine_f32(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, stream);
+    // feature similarity: one launch when the batch is dense and the shape fits the fused kernel's LDS envelope
+    rc = (!n_valid && !m_valid) ? dmm_cosine_features_f32(feat_t, feat_p, B, N, M, D, w.cosv, stream) : DMM_ERR_UNSUPPORTED;
+    if (rc == DMM_ERR_UNSUPPORTED) {
+        rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_cosine_f32(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, stream);
+    }
     if (rc != DMM_OK) return rc;
     rc = dmm_relax_match_f32(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid, score_weight,
                              max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,

@@ -317,6 +317,132 @@ __global__ __launch_bounds__(256, 2) void cosine_rows_kernel(const float *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// get_cosine_score in ONE launch (dense batches, 2 <= N <= 64, M <= 16, D % 64 == 0): the frame's raw feature rows --
+// N proposals + M templates, (N + M) * D * 4 bytes = 123 KB at the BASELINE shape -- are staged into LDS ONCE with
+// every load in flight at the same time, normalised in place (ATen 2-norm order, clamp, IEEE division: the arithmetic
+// of feature_normalize_kernel), and thread (m, n) then walks its whole D-long product chain out of LDS.  The three-
+// launch path above stages the proposal rows once per D-chunk and template slot with a barrier pair per chunk: one
+// block lives ~30 us for ~1 us of dependent adds.  Here the independent 16-element blocks of ATen's cascade
+// (level_step 16) are accumulated four at a time, so the chain's add latency is hidden too.  Same products, same
+// association as cosine_kernel: bit identical.  grid = B, block = 64 * M threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restrict__ feat_t,
+                                                           const float *__restrict__ feat_p, int N, int M, int D,
+                                                           float *__restrict__ cos_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, nthreads = blockDim.x;
+    const int LDW = D + 4;                                   // row stride: 16-B aligned, lanes 0..7 cover all banks
+    float *P = lds;                                          // [N][LDW]
+    float *Q = lds + (size_t)N * LDW;                        // [M][LDW]
+    float *nrm = Q + (size_t)M * LDW;                        // [N + M]
+    const int rows = N + M, d4 = D >> 2;
+    // ---- stage the raw rows: 8 x 16-byte loads in flight per thread and pass ----
+    const int total4 = rows * d4;
+    for (int base = threadIdx.x; base < total4; base += 8 * nthreads) {
+        float4u v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthreads;
+            if (i < total4) {
+                const int r = i / d4, c4 = (i - r * d4) * 4;
+                const float *src = r < N ? feat_p + ((int64_t)b * N + r) * D : feat_t + ((int64_t)b * M + (r - N)) * D;
+                v[u] = *reinterpret_cast<const float4u *>(src + c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthreads;
+            if (i < total4) {
+                const int r = i / d4, c4 = (i - r * d4) * 4;
+                *reinterpret_cast<float4 *>(lds + (size_t)r * LDW + c4) = make_float4(v[u].x, v[u].y, v[u].z, v[u].w);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- norms: one aligned 8-lane group per row (ATen's 2-norm fast path), clamp_min(eps) ----
+    for (int r = threadIdx.x >> 3; r < rows; r += nthreads >> 3) {
+        const float *x = lds + (size_t)r * LDW;
+        float nr = torder::norm2_group8(D, threadIdx.x & 7, [&](long i) { return x[i]; });
+        nr = nr > 1e-8f ? nr : 1e-8f;
+        if ((threadIdx.x & 7) == 0) nrm[r] = nr;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total4; i += nthreads) {
+        const int r = i / d4, c4 = (i - r * d4) * 4;
+        float4 *p = reinterpret_cast<float4 *>(lds + (size_t)r * LDW + c4);
+        const float nr = nrm[r];
+        float4 v = *p;
+        v.x = v.x / nr; v.y = v.y / nr; v.z = v.z / nr; v.w = v.w / nr;
+        *p = v;
+    }
+    __syncthreads();
+    // ---- cos[m, n] ----
+    const int m = threadIdx.x >> 6, n = threadIdx.x & 63;
+    if (m >= M || n >= N) return;
+    const float *row = P + (size_t)n * LDW, *qq = Q + (size_t)m * LDW;
+    float res;
+    if (n < torder::outer_class_bound(N)) {                  // one cascade chain over d (multi_row_sum column)
+        torder::Cascade ca;
+        ca.init(D);
+        for (int d0 = 0; d0 < D; d0 += 64) {                 // 4 independent 16-element blocks at a time
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float4 qv[4], rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    qv[k] = *reinterpret_cast<const float4 *>(qq + d0 + 16 * k + 4 * t);
+                    rv[k] = *reinterpret_cast<const float4 *>(row + d0 + 16 * k + 4 * t);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] = a[k] + qv[k].x * rv[k].x;
+                    a[k] = a[k] + qv[k].y * rv[k].y;
+                    a[k] = a[k] + qv[k].z * rv[k].z;
+                    a[k] = a[k] + qv[k].w * rv[k].w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ca.a0 = a[k]; ca.block16_done(); }
+        }
+        res = ca.finish();
+    } else {                                                  // ILP-4 row_sum: chain j takes d = 4 k + j
+        torder::Cascade c0, c1, c2, c3;
+        const long g4 = D / 4;
+        c0.init(g4); c1.init(g4); c2.init(g4); c3.init(g4);
+        for (int d0 = 0; d0 < D; d0 += 128) {                // two 64-d segments (= one block of 16 per chain) at a time
+            float a[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+            const bool two = d0 + 64 < D;
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const float4 q0 = *reinterpret_cast<const float4 *>(qq + d0 + 4 * t);
+                const float4 r0 = *reinterpret_cast<const float4 *>(row + d0 + 4 * t);
+                a[0][0] = a[0][0] + q0.x * r0.x; a[0][1] = a[0][1] + q0.y * r0.y;
+                a[0][2] = a[0][2] + q0.z * r0.z; a[0][3] = a[0][3] + q0.w * r0.w;
+                if (two) {
+                    const float4 q1 = *reinterpret_cast<const float4 *>(qq + d0 + 64 + 4 * t);
+                    const float4 r1 = *reinterpret_cast<const float4 *>(row + d0 + 64 + 4 * t);
+                    a[1][0] = a[1][0] + q1.x * r1.x; a[1][1] = a[1][1] + q1.y * r1.y;
+                    a[1][2] = a[1][2] + q1.z * r1.z; a[1][3] = a[1][3] + q1.w * r1.w;
+                }
+            }
+            c0.a0 = a[0][0]; c1.a0 = a[0][1]; c2.a0 = a[0][2]; c3.a0 = a[0][3];
+            c0.block16_done(); c1.block16_done(); c2.block16_done(); c3.block16_done();
+            if (two) {
+                c0.a0 = a[1][0]; c1.a0 = a[1][1]; c2.a0 = a[1][2]; c3.a0 = a[1][3];
+                c0.block16_done(); c1.block16_done(); c2.block16_done(); c3.block16_done();
+            }
+        }
+        res = c0.finish();
+        const float p1 = c1.finish(), p2 = c2.finish(), p3 = c3.finish();
+        res = res + p1;
+        res = res + p2;
+        res = res + p3;
+    }
+    cos_out[((int64_t)b * M + m) * N + n] = res;
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, float *out, float *norms,
@@ -365,5 +491,24 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     }
     hipLaunchKernelGGL(dmm::cosine_kernel, dim3((M + slots - 1) / slots, B), dim3(256), lds, (hipStream_t)stream,
                        featn_t, featn_p, N, M, D, tpm, n_valid, m_valid, cos_out);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p, int B, int N, int M, int D,
+                                       float *cos_out, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || N == 0 || M == 0) return DMM_OK;
+    if (!feat_t || !feat_p || !cos_out) return DMM_ERR_BAD_ARG;
+    // envelope of the one-launch form; callers fall back to normalise + normalise + cosine outside it
+    if (N < 2 || N > 64 || M > 16 || D <= 0 || (D % 64) != 0 || D > (1 << 19)) return DMM_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)(N + M) * (D + 4) + (size_t)(N + M));
+    if (lds > 160 * 1024 - 512) return DMM_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_fused_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(dmm::cosine_fused_kernel, dim3(B), dim3(64 * M), lds, (hipStream_t)stream, feat_t, feat_p, N, M,
+                       D, cos_out);
     return dmm::check_launch();
 }

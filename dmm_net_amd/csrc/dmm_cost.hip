@@ -199,13 +199,20 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
     int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
     int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t,
-    int xcd_remap) {
+    int xcd_remap, int sub_count, int n_sub) {
     int b, range;
     xcd_frame_range(xcd_remap, b, range);
+    // small batches: the proposal tile is cut into sub_count sub-tiles of n_sub planes, one workgroup each, so that a
+    // handful of frames still spreads over the chip (the templates are re-read per sub-tile: latency, not bandwidth,
+    // is what a B = 1 launch pays for)
+    const int sub = range % sub_count;
+    range /= sub_count;
+    n0 += sub * n_sub;
+    if (sub != 0) write_area_t = 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
-    Nb = min(Nb - n0, NG * kWave);
+    Nb = min(min(Nb - n0, NG * kWave - sub * n_sub), n_sub);
     Mb = min(Mb - m0, masks_t2 ? MT / 2 : MT);
     if (Nb <= 0 || Mb <= 0) return;
     const int Mrows = masks_t2 ? 2 * Mb : Mb;                    // rows of the (template | target) tile
@@ -279,17 +286,31 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
     // ~8192 workgroups, at least 1 chunk per wave: small workgroups keep the tail of the launch short and measured
     // best (B = 1024: 5.8 / 6.0 / 6.3 / 6.6 / 6.4 TB/s at 1k / 2k / 4k / 8k / 16k workgroups)
     static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
+    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 1024; }();
     int splits = (target_wgs + B - 1) / B;
-    const int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
+    int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
+    // a few frames only (the product's B = 1 / B = 4 calls): one chunk per workgroup (waves 1-3 of it idle) ...
+    if ((int64_t)B * max_splits < small_wgs) max_splits = nchunks;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
+    // ... and sub-tiles of >= 8 proposals until ~1024 workgroups exist (B = 1, N = 50: 16 workgroups took 33 us,
+    // 448 take 17; B = 4: 53 us with 64)
+    const int ntile = (N - n0) < NG * kWave ? (N - n0) : NG * kWave;
+    int sub_count = 1, n_sub = NG * kWave;
+    if ((int64_t)B * splits < small_wgs && ntile > 8) {
+        sub_count = (int)((small_wgs + (int64_t)B * splits - 1) / ((int64_t)B * splits));
+        const int max_sub = (ntile + 7) / 8;
+        if (sub_count > max_sub) sub_count = max_sub;
+        n_sub = (ntile + sub_count - 1) / sub_count;
+        sub_count = (ntile + n_sub - 1) / n_sub;
+    }
     static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
-    dim3 grid(splits, B);
+    dim3 grid(splits * sub_count, B);
     hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, masks_t2, N,
                        M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,
-                       area_t2, n0, m0, chunks_per_wg, wap, wat, xcd_remap);
+                       area_t2, n0, m0, chunks_per_wg, wap, wat, xcd_remap, sub_count, n_sub);
     return check_launch();
 }
 

@@ -53,19 +53,42 @@ __global__ __launch_bounds__(256) void bias_act_bf16_kernel(uint16_t *__restrict
     reinterpret_cast<u32x4 *>(x)[i] = o;
 }
 
+// C not a multiple of 8 (tiny heads, e.g. hidden_size 8 -> 2-channel skips): one element per thread.
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_bf16_scalar_kernel(uint16_t *__restrict__ x, const float *__restrict__ bias,
+                                                                   const uint16_t *__restrict__ res, int64_t n, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = __uint_as_float((uint32_t)x[i] << 16) + (bias ? bias[i % C] : 0.0f);
+    if (RES) v = v + __uint_as_float((uint32_t)res[i] << 16);
+    if (RELU) v = v > 0.0f ? v : 0.0f;
+    x[i] = (uint16_t)bf16_rne(v);
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                                  dmm_stream_t stream) {
-    if (rows < 0 || C <= 0 || (C & 7)) return DMM_ERR_BAD_ARG;
+    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!x) return DMM_ERR_BAD_ARG;
-    const int64_t n8 = rows * (int64_t)(C / 8);
-    const int64_t blocks = (n8 + 255) / 256;
-    if (blocks > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     uint16_t *xp = (uint16_t *)x;
     const uint16_t *rp = (const uint16_t *)residual;
+    if (C & 7) {
+        const int64_t n = rows * (int64_t)C, nb = (n + 255) / 256;
+        if (nb > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+#define DMM_BAS(RES_, RELU_)                                                                                         \
+    hipLaunchKernelGGL((dmm::bias_act_bf16_scalar_kernel<RES_, RELU_>), dim3((unsigned)nb), dim3(256), 0, s, xp, bias, \
+                       rp, n, C)
+        if (residual) { if (relu) DMM_BAS(true, true); else DMM_BAS(true, false); }
+        else { if (relu) DMM_BAS(false, true); else DMM_BAS(false, false); }
+#undef DMM_BAS
+        return dmm::check_launch();
+    }
+    const int64_t n8 = rows * (int64_t)(C / 8);
+    const int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
 #define DMM_BA(RES_, RELU_)                                                                                          \
     hipLaunchKernelGGL((dmm::bias_act_bf16_kernel<RES_, RELU_>), dim3((unsigned)blocks), dim3(256), 0, s, xp, bias, rp, \
                        n8, C / 8)

@@ -238,6 +238,23 @@ def cosine(featn_t: torch.Tensor, featn_p: torch.Tensor, n_valid=None, m_valid=N
     return out
 
 
+def cosine_features(feat_t: torch.Tensor, feat_p: torch.Tensor) -> torch.Tensor:
+    """get_cosine_score (match_helper.py:51-64) from RAW features feat_t [B,M,D], feat_p [B,N,D] -> cos [B,M,N]: one
+    fused launch inside its envelope (dense, 2 <= N <= 64, M <= 16, D % 64 == 0), else normalise x 2 + cosine.
+    Bit identical either way."""
+    _need_gpu(feat_t, feat_p)
+    feat_t, feat_p = feat_t.contiguous().float(), feat_p.contiguous().float()
+    B, M, D = feat_t.shape
+    N = feat_p.shape[1]
+    out = torch.empty((B, M, N), dtype=torch.float32, device=feat_t.device)
+    with torch.cuda.device(feat_t.device):
+        rc = _lib.load().dmm_cosine_features_f32(_ptr(feat_t), _ptr(feat_p), B, N, M, D, _ptr(out), _stream(feat_t))
+    if rc == 2:                                               # DMM_ERR_UNSUPPORTED: outside the fused kernel's envelope
+        return cosine(feature_normalize(feat_t), feature_normalize(feat_p))
+    _lib.check(rc, "dmm_cosine_features_f32")
+    return out
+
+
 def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test,
                 n_valid=None, m_valid=None, want_x=False):
     """Similarity mix + relaxed assignment + scores for B frames.  cos [B,M,N] = feature_sim.
@@ -507,9 +524,7 @@ class ForwardPlan:
         inter, ap, at = self._tables(0)
         side.wait_stream(main)
         ss, ms = side.cuda_stream, main.cuda_stream
-        rc = L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ss)
-        rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ss)
-        rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid), _ptr(self.cos), ss)
+        rc = self._feature_sim(L, feat_p, feat_t, n_valid, m_valid, ss)
         rc |= L.dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), dt, B, N, M, HW, sp_b, sp_n, st_b, st_m, _ptr(n_valid),
                                _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
         main.wait_stream(side)
@@ -531,6 +546,20 @@ class ForwardPlan:
             self.kernel_events.setdefault(name, []).append([e, None])
         else:
             self.kernel_events[name][-1][1] = e
+
+    def _feature_sim(self, L, feat_p, feat_t, n_valid, m_valid, stream) -> int:
+        """cos[B,M,N] into self.cos on ``stream``: the fused one-launch kernel for dense batches inside its envelope,
+        normalise + normalise + cosine otherwise."""
+        B, N, M, D = self.B, self.N, self.M, self.D
+        if n_valid is None and m_valid is None:
+            rc = L.dmm_cosine_features_f32(_ptr(feat_t), _ptr(feat_p), B, N, M, D, _ptr(self.cos), stream)
+            if rc != 2:
+                return rc
+        rc = L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, stream)
+        rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, stream)
+        rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid), _ptr(self.cos),
+                               stream)
+        return rc
 
     def _tables(self, h):
         (b, e) = self.halves[h]
@@ -580,10 +609,7 @@ class ForwardPlan:
                 rc = L.dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), dt, B, N, M, HW, sp_b, sp_n, st_b, st_m,
                                       _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
                 self._mark("cost", main, False)
-                rc |= L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ms)
-                rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ms)
-                rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
-                                       _ptr(self.cos), ms)
+                rc |= self._feature_sim(L, feat_p, feat_t, n_valid, m_valid, ms)
                 self._mark("solver", main, True)
                 rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
                                             _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter),
@@ -617,10 +643,7 @@ class ForwardPlan:
             self.ev_start.record(main)
             # ---- latency lane: normalise + cosine for every frame --------------------------------------------
             side.wait_event(self.ev_start)
-            rc = L.dmm_feature_normalize_f32(_ptr(feat_p), B * N, D, _ptr(self.pn), None, ss)
-            rc |= L.dmm_feature_normalize_f32(_ptr(feat_t), B * M, D, _ptr(self.tn), None, ss)
-            rc |= L.dmm_cosine_f32(_ptr(self.tn), _ptr(self.pn), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
-                                   _ptr(self.cos), ss)
+            rc = self._feature_sim(L, feat_p, feat_t, n_valid, m_valid, ss)
             # ---- streaming lane: cost(A), cost(B) ------------------------------------------------------------
             for h, (b, e) in enumerate(self.halves):
                 inter, ap, at = self._tables(h)

@@ -129,6 +129,12 @@ DMM_API int dmm_mask_mix_bwd_frames(const float *Rb, const void *const *masks_p_
 DMM_API int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, float *out /*[rows,D]*/,
                               float *norms /*[rows] or NULL*/, dmm_stream_t stream);
 
+/* (2c) get_cosine_score (match_helper.py:51-64) from the RAW features in one launch: (2) for both inputs + (2b), bit
+ * identical to that sequence.  Dense batches only, 2 <= N <= 64, M <= 16, D % 64 == 0, (N + M) * (D + 4) * 4 bytes of
+ * LDS (<= 160 KB): DMM_ERR_UNSUPPORTED outside that envelope (callers then run (2), (2), (2b)).  Used by (5). */
+DMM_API int dmm_cosine_features_f32(const float *feat_t /*[B,M,D]*/, const float *feat_p /*[B,N,D]*/, int B, int N,
+                                    int M, int D, float *cos_out /*[B,M,N]*/, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (2b) Cosine table of normalised rows: cos[b,m,n] = <featn_t[b,m,:], featn_p[b,n,:]>
  * (second half of F.cosine_similarity, match_helper.py:59-63; == MatchModel's feature_sim for a
@@ -288,7 +294,7 @@ DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64
  * (9) Encoder epilogue (inference, channels-last bf16): x[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])) in place,
  * one pass, fp32 arithmetic, one rounding.  What remains of conv -> BatchNorm -> ReLU (dmm/modules/base.py:43-54,
  * model_encoder.py:137-146) and of the residual tails of the torchvision blocks (dmm/modules/vision.py:6-38) once the
- * BatchNorm is folded into the contraction.  x, residual: [rows, C] bfloat16, C % 8 == 0; bias: [C] fp32 or NULL.
+ * BatchNorm is folded into the contraction.  x, residual: [rows, C] bfloat16 (16-byte lane accesses when C % 8 == 0); bias: [C] fp32 or NULL.
  * ------------------------------------------------------------------------------------------- */
 DMM_API int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                               dmm_stream_t stream);

@@ -286,7 +286,7 @@ def test_bias_act_bf16_kernel_matches_fp32_reference():
     """dmm_bias_act_bf16: x = act(x + bias (+ residual)) in place on channels-last bf16 == the same in fp32, rounded once."""
     from dmm_net_amd.encoder import _bias_act_
     g = torch.Generator(device=DEV).manual_seed(9)
-    for (B, C, H, W) in [(2, 64, 17, 23), (1, 8, 3, 5), (8, 256, 64, 64), (3, 2048, 8, 8)]:
+    for (B, C, H, W) in [(2, 64, 17, 23), (1, 8, 3, 5), (8, 256, 64, 64), (3, 2048, 8, 8), (2, 4, 9, 7), (1, 2, 5, 5)]:
         for use_res in (False, True):
             for relu in (False, True):
                 x = torch.randn((B, C, H, W), generator=g, device=DEV).to(torch.bfloat16).contiguous(

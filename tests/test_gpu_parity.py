@@ -998,3 +998,35 @@ def test_forward_plan_graph_mode_replays_on_static_buffers():
     other = [t.clone() for t in bufs]
     assert same(other) and len(plan._graphs) == 1                 # other tensors: direct launch, no new graph yet
     assert "graph replay" in plan.schedule_name()
+
+
+def test_fused_normalise_cosine_kernel_is_bit_identical():
+    """dmm_cosine_features_f32 (one launch: stage, normalise, D-long chains with 4 blocks in flight) against the
+    three-launch path and the reference goldens (G7 cosine shapes inside its envelope), incl. zero rows (eps clamp)."""
+    g = golden("g7_shapes")
+    seen = 0
+    for j in range(int(g["n_cos"])):
+        c = g.group(f"cos{j}")
+        q, k = c["q"], c["k"]
+        if not (2 <= k.shape[0] <= 64 and q.shape[0] <= 16 and q.shape[1] % 64 == 0):
+            continue
+        seen += 1
+        out = ops.cosine_features(dev(q)[None], dev(k)[None])[0].cpu().numpy()
+        assert np.array_equal(out, c["cos"]), (j, q.shape, k.shape)
+    rng = np.random.Generator(np.random.PCG64(404))
+    for (B, N, M, D) in [(3, 50, 10, 512), (2, 64, 16, 512), (4, 2, 1, 64), (1, 33, 5, 1024), (2, 8, 3, 128), (2, 31, 16, 256)]:
+        tf = torch.from_numpy(rng.standard_normal((B, M, D), dtype=np.float32)).to(DEV)
+        pf = torch.from_numpy(rng.standard_normal((B, N, D), dtype=np.float32)).to(DEV)
+        tf[0, 0] = 0.0                                           # zero-norm rows: clamp_min(1e-8)
+        pf[-1, -1] = 0.0
+        a = ops.cosine_features(tf, pf)
+        b = ops.cosine(ops.feature_normalize(tf), ops.feature_normalize(pf))
+        assert torch.equal(a, b), (B, N, M, D)
+        o = oracle.cosine(tf[0].cpu().numpy(), pf[0].cpu().numpy())
+        assert np.array_equal(a[0].cpu().numpy(), o), (B, N, M, D)
+        seen += 1
+    assert seen >= 6
+    # outside the envelope: transparently the three-launch path
+    tf = torch.from_numpy(rng.standard_normal((1, 20, 96), dtype=np.float32)).to(DEV)
+    pf = torch.from_numpy(rng.standard_normal((1, 200, 96), dtype=np.float32)).to(DEV)
+    assert torch.equal(ops.cosine_features(tf, pf), ops.cosine(ops.feature_normalize(tf), ops.feature_normalize(pf)))
