@@ -57,10 +57,13 @@ class _MatchLayerFn(torch.autograd.Function):
     sc [B,P], targets [B,O,H,W] | None."""
 
     @staticmethod
-    def forward(ctx, pf, tf, pm, tm, sc, targets, n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test):
+    def forward(ctx, pf, tf, pm, tm, sc, targets, n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test,
+                counts=None):
         T = tf.shape[0]
         tcounts = None
-        if targets is not None and tm.shape[1] <= 16:
+        if counts is not None:                       # integer tables from elsewhere (1-bit planes of the paste kernel)
+            inter, ap, at = counts
+        elif targets is not None and tm.shape[1] <= 16:
             # training: one pass over the proposal planes for both IoU tables (templates and targets)
             (inter, ap, at), (gi, gat) = ops.iou_counts_dual(pm, tm, targets.to(tm.dtype), n_valid, m_valid)
             tcounts = (gi, ap, gat)
@@ -105,7 +108,7 @@ class _MatchLayerFn(torch.autograd.Function):
 
 
 def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
-                        proj_iter, lr, is_test):
+                        proj_iter, lr, is_test, counts=None):
     """B frames through the layer with autograd.  ``tf`` is [B,O,D] or, for several template-feature entries,
     [T,B,O,D].  Returns (full_outmask [B,O,H,W], match_score [B,O], det_score [B,O], cost_loss [B], iters [B])."""
     if tf.dim() == 3:
@@ -124,14 +127,14 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
             if targets is not None:
                 targets = targets.to(pm.dtype)
             return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
-                                       float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test))
+                                       float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
     # 16-bit mask planes go to the kernels as they are (half the bytes of the cost pass; values are only thresholded and
     # scaled); anything else is matched in fp32 like the reference
     if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
         pm, tm = pm.float(), tm.float()
     return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(),
                                None if targets is None else targets.float(), n_valid, m_valid, float(score_weight),
-                               int(max_iter), int(proj_iter), float(lr), int(is_test))
+                               int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
 
 
 def match_layer_function(proposed_feature, proposed_mask, template_feature: List[torch.Tensor], mask_last_occurence,

@@ -45,7 +45,7 @@ def match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss):
     Pp = Rb.shape[-1]
     need_pf, need_tf, need_pm = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
     g_pf = g_tf = g_pm = None
-    none = (None,) * 10
+    none = (None,) * 11
     if not (need_pf or need_tf or need_pm):
         return (None, None, None) + none
     dOut = None if d_full is None else d_full.reshape(B, O, H * W).float()

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void cosine_rows_kernel(const float *__rest
 // launch path above stages the proposal rows once per D-chunk and template slot with a barrier pair per chunk: one
 // block lives ~30 us for ~1 us of dependent adds.  Here the independent 16-element blocks of ATen's cascade
 // (level_step 16) are accumulated four at a time, so the chain's add latency is hidden too.  Same products, same
-// association as cosine_kernel: bit identical.  grid = B, block = 64 * M threads.
+// association as cosine_kernel: bit identical.  grid = B, block = roundup64(M*A) + roundup64(M*(N-A)) threads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restrict__ feat_t,
                                                            const float *__restrict__ feat_p, int N, int M, int D,
@@ -377,9 +377,22 @@ __global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restr
         *p = v;
     }
     __syncthreads();
-    // ---- cos[m, n] ----
-    const int m = threadIdx.x >> 6, n = threadIdx.x & 63;
-    if (m >= M || n >= N) return;
+    // ---- cos[m, n]: a wave holds outputs of ONE reduction class only (the two classes run different code; mixed in a
+    // wave -- columns 0..31 | 32..49 at N = 50 -- both paths would execute back to back).  Threads [0, M*A) take the
+    // class-A outputs (columns < A = outer_class_bound(N)), threads [TA, TA + M*(N-A)) the class-B ones. ----
+    const int A = torder::outer_class_bound(N), Bn = N - A;
+    const int TA = (M * A + 63) & ~63;
+    int m, n;
+    if ((int)threadIdx.x < TA) {
+        if ((int)threadIdx.x >= M * A) return;
+        m = threadIdx.x / A;
+        n = threadIdx.x - m * A;
+    } else {
+        const int t = threadIdx.x - TA;
+        if (t >= M * Bn) return;
+        m = t / Bn;
+        n = A + (t - m * Bn);
+    }
     const float *row = P + (size_t)n * LDW, *qq = Q + (size_t)m * LDW;
     float res;
     if (n < torder::outer_class_bound(N)) {                  // one cascade chain over d (multi_row_sum column)
@@ -508,7 +521,9 @@ extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(dmm::cosine_fused_kernel, dim3(B), dim3(64 * M), lds, (hipStream_t)stream, feat_t, feat_p, N, M,
+    const int A = N >= 8 ? 32 * (N / 32) : 4 * (N / 4);         // torder::outer_class_bound(N)
+    const int threads = ((M * A + 63) & ~63) + ((M * (N - A) + 63) & ~63);
+    hipLaunchKernelGGL(dmm::cosine_fused_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, feat_t, feat_p, N, M,
                        D, cos_out);
     return dmm::check_launch();
 }

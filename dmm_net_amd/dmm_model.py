@@ -61,7 +61,7 @@ class DMM_Model(nn.Module):
     # ---- shared batched core -----------------------------------------------------------------------
     def _match_batch(self, prop_feat: List[torch.Tensor], prop_m: List[torch.Tensor], prop_score: List[torch.Tensor],
                      tplt_feat: List[torch.Tensor], mask_last_occurence, n_tplt: List[int], targets, skip: List[bool],
-                     row_scale=None):
+                     row_scale=None, packed: Optional[List[torch.Tensor]] = None):
         """prop_feat[b] [P_b,D], prop_m[b] [P_b,H,W], tplt_feat[b] [F,D]; returns (full [B,F,H,W], loss [B])."""
         B, F, H, W = CHECK4D(mask_last_occurence)
         dev = mask_last_occurence.device
@@ -87,10 +87,22 @@ class DMM_Model(nn.Module):
             tf = tf * row_scale[:, :, None]
         n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
         m_valid = torch.tensor([0 if skip[b] else n_tplt[b] for b in range(B)], dtype=torch.int32, device=dev)
+        counts = None
+        if packed is not None and targets is None:
+            # the proposals come with their 1-bit (mask > 0.5) planes (emitted by the paste kernel): the cost pass
+            # counts on those -- 1/32 of the proposal bytes, identical integer tables -- and the templates are packed
+            # on the fly (one read of the F planes, what the float kernel would have read anyway)
+            from . import ops
+            wd = ops.pack_words(H * W)
+            pk = packed[0].new_zeros((B, Pmax, wd))
+            for b in range(B):
+                pk[b, :packed[b].shape[0]] = packed[b]
+            counts = ops.iou_counts_packed(pk, ops.pack_masks(mask_last_occurence.float()), H * W, n_valid, m_valid)
         cfg = self.match_layer
         full, ms, ds, loss, _ = match_layer_batched(
             pf, pm, tf, mask_last_occurence, sc, targets, n_valid, m_valid, score_weight=cfg.cfgs["score_weight"],
-            max_iter=cfg.max_iter, proj_iter=cfg.proj_iter, lr=cfg.relax_lr, is_test=int(bool(cfg.is_test)))
+            max_iter=cfg.max_iter, proj_iter=cfg.proj_iter, lr=cfg.relax_lr, is_test=int(bool(cfg.is_test)),
+            counts=counts)
         if row_scale is not None:
             full = full * row_scale[:, :, None, None]
         return full, loss
@@ -157,8 +169,11 @@ class DMM_Model(nn.Module):
             full, _ = self._per_video(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                       tplt_valid_batch, n_tplt, tg, skip)
         else:
+            packed = None
+            if all("mask_packed" in p.fields() for p in proposals):
+                packed = [p.get_field("mask_packed") for p in proposals]
             full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
-                                        tg, skip, row_scale)
+                                        tg, skip, row_scale, packed)
         out_last = full.clone()
         for b in range(B):
             if skip[b]:

@@ -117,24 +117,30 @@ def filter_results(boxlists: List, nms_thresh: float = 0.8, max_proposals: int =
     return boxlists
 
 
-def forward_mask_prop(mask_prob: Sequence[torch.Tensor], boxlists: Sequence, thresh: float = 0.4, padding: int = 1):
+def forward_mask_prop(mask_prob: Sequence[torch.Tensor], boxlists: Sequence, thresh: float = 0.4, padding: int = 1,
+                      want_packed: bool = False):
     """MaskPostProcessor.forward_mask_prop (masker.py:27-50): paste every image's masks, re-box tightly, carry the fields.
-    Images of one size (the usual case: one clip) go through ONE paste launch; the per-image planes are views of it."""
+    Images of one size (the usual case: one clip) go through ONE paste launch; the per-image planes are views of it.
+    ``want_packed``: the paste kernel also emits the 1-bit (mask > 0.5) planes as field 'mask_packed' ([P, words]
+    int64) -- all the cost pass ever looks at; ``DMM_Model.inference`` then counts on 1/32 of the proposal bytes."""
     sizes = {tuple(bl.size) for bl in boxlists}
     counts = [len(bl) for bl in boxlists]
     if len(sizes) == 1 and len(boxlists) > 1 and sum(counts) > 0:
         im_w, im_h = boxlists[0].size
-        planes, tight = paste_masks(torch.cat(list(mask_prob), 0), torch.cat([bl.bbox for bl in boxlists], 0), im_h, im_w,
-                                    thresh, padding)
-        per_image = list(zip(planes.split(counts, 0), tight.split(counts, 0)))
+        res = paste_masks(torch.cat(list(mask_prob), 0), torch.cat([bl.bbox for bl in boxlists], 0), im_h, im_w,
+                          thresh, padding, want_packed=want_packed)
+        per_image = list(zip(*[t.split(counts, 0) for t in res]))
     else:
-        per_image = [paste_masks(prob, bl.bbox, bl.size[1], bl.size[0], thresh, padding)
+        per_image = [paste_masks(prob, bl.bbox, bl.size[1], bl.size[0], thresh, padding, want_packed=want_packed)
                      for prob, bl in zip(mask_prob, boxlists)]
     out = []
-    for (planes, tight), bl in zip(per_image, boxlists):
+    for res, bl in zip(per_image, boxlists):
+        planes, tight = res[0], res[1]
         nb = SimpleBoxList(tight, bl.size, "xyxy")
         for f in bl.fields():
             nb.add_field(f, bl.get_field(f))
         nb.add_field("mask", planes)
+        if want_packed:
+            nb.add_field("mask_packed", res[2])
         out.append(nb)
     return out

@@ -192,7 +192,9 @@ class FrameLoop:
             q = p.resize((im_w, im_h)) if tuple(p.size) != (im_w, im_h) else p
             props.append(q.to(device))
         if not self.pasted:
-            props = forward_mask_prop([p.get_field("mask") for p in props], props, self.mask_thresh, self.padding)
+            # the paste kernel emits the 1-bit planes along with the soft ones: DMM_Model.inference counts on those
+            props = forward_mask_prop([p.get_field("mask") for p in props], props, self.mask_thresh, self.padding,
+                                      want_packed=True)
         score_field = "scores" if "scores" in props[0].fields() else "objectness"
         return filter_results(list(props), self.nms_thresh, self.max_proposals, score_field)
 
