@@ -3,10 +3,11 @@
 
     python tools/collect_profiles.py r01 gpurun_out/profiles_new
 
-  <tag>_bench.json                  python bench.py
-  <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-cpu-baseline
-  <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-cpu-baseline
-  <tag>_kernel_stats_single_stream.csv   same with --no-pipeline
+  <tag>_bench.json                  python bench.py                      (all extras: cpu baseline, sweep, in-run traffic)
+  <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-extras
+  <tag>_bench_config5.json / _config3.json     python bench.py --config 5 / 3
+  <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-extras
+  <tag>_kernel_stats_single_stream.csv / _config5.csv / _config3.csv   same with --no-pipeline / --config 5 / --config 3
   <tag>_pmc_traffic.json            two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), per-kernel averages;
                                     bytes = KiB * 1024, FETCH x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section)
   <tag>_agent_info.csv
@@ -39,13 +40,18 @@ def last_json(stdout):
 if not only_pmc:
     open(os.path.join(out, f"{tag}_bench.json"), "w").write(last_json(run(bench).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_single_stream.json"), "w").write(
-        last_json(run(bench + ["--no-pipeline", "--no-cpu-baseline"]).stdout) + "\n")
+        last_json(run(bench + ["--no-pipeline", "--no-extras"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_config5.json"), "w").write(
+        last_json(run(bench + ["--config", "5", "--no-cpu-baseline"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_config3.json"), "w").write(
+        last_json(run(bench + ["--config", "3"]).stdout) + "\n")
 
-for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]))):
+for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]), ("_config5", ["--config", "5"]),
+                                           ("_config3", ["--config", "3", "--steps", "50"]))):
     d = f"/tmp/prof_stats{suffix}"
     shutil.rmtree(d, ignore_errors=True)
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench +
-        ["--no-cpu-baseline"] + extra)
+        ["--no-extras"] + extra)
     for f in glob.glob(d + "/**/*_kernel_stats.csv", recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats{suffix}.csv"))
     for f in glob.glob(d + "/**/*_agent_info.csv", recursive=True):
@@ -56,7 +62,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = f"/tmp/prof_{ctr}"
     shutil.rmtree(d, ignore_errors=True)
     run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + bench +
-        ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+        ["--steps", "3", "--warmup", "1", "--no-extras"])
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"].split("(")[0]

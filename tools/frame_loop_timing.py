@@ -10,7 +10,7 @@ import numpy as np
 import torch
 from dmm_net_amd import video
 from dmm_net_amd.dmm_model import DMM_Model
-from dmm_net_amd.encoder import FeatureEncoder, GraphedEncoder, fold_batchnorm
+from dmm_net_amd.encoder import FastEncoder, FeatureEncoder, GraphedEncoder, fold_batchnorm
 from dmm_net_amd.proposals import SimpleBoxList
 from dmm_net_amd.roi_features import FeatureExtractor
 
@@ -26,8 +26,11 @@ if os.environ.get("NOENC"):                                 # isolate this packa
         g = x.mean(1, keepdim=True)
         lv = tuple(F.avg_pool2d(g, s, ceil_mode=True).expand(-1, 128, -1, -1).contiguous() for s in (4, 8, 16, 32))
         return {"backbone_feature": lv, "refine_input_feat": lv}
-else:
+elif os.environ.get("NCHW"):                                # round-1 encoder form: NCHW, every convolution through MIOpen
     enc = GraphedEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval()), weights_dtype=torch.bfloat16)
+else:                                                       # channels-last bf16, 1x1 convolutions on hipBLASLt, fused epilogues
+    enc = GraphedEncoder(FastEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval())),
+                         miopen_find=bool(os.environ.get("FIND")))
 
 
 def raw(n):
