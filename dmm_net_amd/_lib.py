@@ -22,7 +22,7 @@ MAX_PROPOSALS = 256
 # every symbol include/dmm_match.h declares
 SYMBOLS = (
     "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
-    "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
+    "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_feature_sim_bwd_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
@@ -78,6 +78,9 @@ def load():
     L.dmm_mask_mix_bwd_frames.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_i64, vp, vp, vp, vp]
     L.dmm_feature_normalize_f32.argtypes = [vp, c_i64, c_int, vp, vp, vp]
     L.dmm_cosine_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
+    L.dmm_feature_sim_bwd_f32.argtypes = [vp, vp, vp, vp, c_float, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp,
+                                          vp, vp, vp]
+    L.dmm_feature_sim_bwd_f32.restype = c_int
     L.dmm_cosine_features_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     L.dmm_cosine_features_f32.restype = c_int
     L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,

@@ -181,12 +181,10 @@ class _CosineFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcos):
-        from .backward import _normalize_backward
         pn, tn, pnorm, tnorm, pf, tf = ctx.saved_tensors
-        dcos = dcos.contiguous().float()
-        g_tf = _normalize_backward(torch.bmm(dcos, pn), tnorm, tf) if ctx.needs_input_grad[0] else None
-        g_pf = _normalize_backward(torch.bmm(dcos.transpose(1, 2), tn), pnorm, pf) if ctx.needs_input_grad[1] else None
-        return g_tf, g_pf
+        # dmm_feature_sim_bwd_f32 with weight (1 - 0) = 1 and no loss term: both contractions + normalisation backward
+        g_tf, g_pf = ops.feature_sim_bwd(dcos, None, None, None, 0.0, tf, pf, tn, pn, tnorm, pnorm)
+        return (g_tf if ctx.needs_input_grad[0] else None), (g_pf if ctx.needs_input_grad[1] else None)
 
 
 def _hungarian_forward(pf, tf, pm, tm, sc, targets, score_weight, is_test):

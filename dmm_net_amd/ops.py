@@ -300,6 +300,31 @@ def relax_match_bwd(sim, score_p, dRb, d_match_score, d_det_score, *, max_iter, 
     return out
 
 
+def feature_sim_bwd(dsim, cos, gt, d_loss, score_weight, feat_t, feat_p, featn_t, featn_p, norm_t, norm_p,
+                    n_valid=None, m_valid=None):
+    """-> (g_feat_t [B,M,D], g_feat_p [B,N,D]): backward of cosine + (1 - w) mix + matching-loss mse in one launch
+    (``dmm_feature_sim_bwd_f32``).  gt / d_loss None = no matching loss."""
+    _need_gpu(dsim, feat_t, feat_p)
+    cf = lambda t: None if t is None else t.contiguous().float()
+    dsim, cos, gt, d_loss = cf(dsim), cf(cos), cf(gt), cf(d_loss)
+    feat_t, feat_p, featn_t, featn_p = cf(feat_t), cf(feat_p), cf(featn_t), cf(featn_p)
+    norm_t, norm_p = cf(norm_t), cf(norm_p)
+    B, M, N = dsim.shape
+    D = feat_p.shape[-1]
+    g_t, g_p = torch.empty_like(feat_t), torch.empty_like(feat_p)
+    if gt is None or d_loss is None:
+        gt = d_loss = cos_arg = None
+    else:
+        cos_arg = cos
+    with torch.cuda.device(dsim.device):
+        rc = _lib.load().dmm_feature_sim_bwd_f32(_ptr(dsim), _ptr(cos_arg), _ptr(gt), _ptr(d_loss), float(score_weight),
+                                                 _ptr(feat_t), _ptr(feat_p), _ptr(featn_t), _ptr(featn_p), _ptr(norm_t),
+                                                 _ptr(norm_p), B, N, M, D, _ptr(n_valid), _ptr(m_valid), _ptr(g_t),
+                                                 _ptr(g_p), _stream(dsim))
+    _lib.check(rc, "dmm_feature_sim_bwd_f32")
+    return g_t, g_p
+
+
 def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_valid=None, cols_valid=None):
     """relax_matching on cost matrices C [B,n,m] -> dict(X, R, cost [B,max_iter+1], iters [B]).
     rows_valid / cols_valid (int32 [B]) restrict each frame to its top-left live block."""

@@ -135,6 +135,17 @@ DMM_API int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, floa
 DMM_API int dmm_cosine_features_f32(const float *feat_t /*[B,M,D]*/, const float *feat_p /*[B,N,D]*/, int B, int N,
                                     int M, int D, float *cos_out /*[B,M,N]*/, dmm_stream_t stream);
 
+/* (2d) Backward of the feature similarity: d/d feat_t, d/d feat_p of  sum(dsim * sim) + sum_b d_loss[b] * cost_loss[b],
+ * i.e. torch autograd through get_cosine_score (match_helper.py:51-64), the (1 - score_weight) mix (match_model.py:90)
+ * and compute_matching_loss's mse (match_helper.py:48).  featn_* / norm_* are the outputs of (2) saved by the forward;
+ * gt [B,M,N] (greedy one-hot, no gradient), cos and d_loss [B] may be NULL together (inference-style loss-free call).
+ * One launch; compared with the reference's autograd at 2e-4 relative. */
+DMM_API int dmm_feature_sim_bwd_f32(const float *dsim /*[B,M,N]*/, const float *cos /*[B,M,N]*/, const float *gt,
+                                    const float *d_loss, float score_weight, const float *feat_t, const float *feat_p,
+                                    const float *featn_t, const float *featn_p, const float *norm_t, const float *norm_p,
+                                    int B, int N, int M, int D, const int32_t *n_valid, const int32_t *m_valid,
+                                    float *g_feat_t /*[B,M,D]*/, float *g_feat_p /*[B,N,D]*/, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (2b) Cosine table of normalised rows: cos[b,m,n] = <featn_t[b,m,:], featn_p[b,n,:]>
  * (second half of F.cosine_similarity, match_helper.py:59-63; == MatchModel's feature_sim for a

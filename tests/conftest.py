@@ -43,3 +43,16 @@ def golden(name):
 @pytest.fixture(scope="session")
 def load_golden():
     return golden
+
+
+def record_achieved(name, value):
+    """Append an achieved error of a toleranced comparison to gpurun_out/parity_achieved.jsonl (scratch, merged back by
+    gpurun): the tolerances in the tests are bounds, this is what the kernels actually reached on the box."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_achieved.jsonl"), "a") as f:
+            f.write(json.dumps({"name": name, "value": float(value)}) + "\n")
+    except OSError:
+        pass

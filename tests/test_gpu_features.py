@@ -66,11 +66,14 @@ def test_roialign4_mean_forward_and_backward_match_g12_fixture():
         out = FeatureExtractor()(tuple(feats), boxes)
         exp = c["out"][order]
         err = float(np.abs(out.detach().cpu().numpy() - exp).max())
+        from conftest import record_achieved
+        record_achieved(f"g12_roialign/c{k}/fwd_rel_err", err / max(1.0, float(np.abs(exp).max())))
         assert err <= 1e-5 * max(1.0, float(np.abs(exp).max())), (k, err)
         out.backward(torch.from_numpy(c["wgt"][order]).to(DEV))
         for l in range(4):
             ge = c[f"grad{l}"]
             gerr = float(np.abs(feats[l].grad.cpu().numpy() - ge).max())
+            record_achieved(f"g12_roialign/c{k}/grad{l}_rel_err", gerr / max(1.0, float(np.abs(ge).max())))
             assert gerr <= 1e-5 * max(1.0, float(np.abs(ge).max())), (k, l, gerr)
 
 

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import golden
+from conftest import golden, record_achieved
 from dmm_net_amd import ops, synth
 from dmm_net_amd.match_model import MatchModel
 
@@ -393,6 +393,7 @@ def test_g6_backward_matches_reference_autograd(name):
     for mine, ref in ((gp, c["grad_pf"]), (gt_, c["grad_tf"])):
         scale = max(float(np.abs(ref).max()), 1e-12)
         err = float(np.abs(mine - ref).max())
+        record_achieved(f"g6_backward/{name}/rel_err", err / scale)
         assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
 
 
@@ -764,6 +765,7 @@ def test_g10_template_feature_list(is_test):
     for mine, ref in ((pf.grad, c["grad_pf"]), (tfs[0].grad, c["grad_tf0"]), (tfs[1].grad, c["grad_tf1"]),
                       (tfs[2].grad, c["grad_tf2"])):
         scale = max(float(np.abs(ref).max()), 1e-12)
+        record_achieved("g10_backward/rel_err", float(np.abs(mine.cpu().numpy() - ref).max()) / scale)
         assert float(np.abs(mine.cpu().numpy() - ref).max()) <= 2e-4 * scale + 1e-7
 
 
@@ -791,6 +793,7 @@ def test_g14_hungarian_matches_reference(name):
     loss["cost_loss"].backward()
     for got, exp in ((pf.grad, g[f"{name}/grad_pf"]), (tf.grad, g[f"{name}/grad_tf"])):
         err = float(np.abs(got.cpu().numpy() - exp).max())
+        record_achieved(f"g14_hungarian_grad/{name}/rel_err", err / max(float(np.abs(exp).max()), 1e-12))
         assert err <= 1e-4 * float(np.abs(exp).max()) + 1e-8, err
 
 
