@@ -394,7 +394,7 @@ def test_g6_backward_matches_reference_autograd(name):
         scale = max(float(np.abs(ref).max()), 1e-12)
         err = float(np.abs(mine - ref).max())
         record_achieved(f"g6_backward/{name}/rel_err", err / scale)
-        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)         # achieved: <= 1.9e-6 (profiles/r02_parity_achieved.jsonl)
 
 
 def test_backward_mask_gradient_and_no_grad_paths():
@@ -766,7 +766,7 @@ def test_g10_template_feature_list(is_test):
                       (tfs[2].grad, c["grad_tf2"])):
         scale = max(float(np.abs(ref).max()), 1e-12)
         record_achieved("g10_backward/rel_err", float(np.abs(mine.cpu().numpy() - ref).max()) / scale)
-        assert float(np.abs(mine.cpu().numpy() - ref).max()) <= 2e-4 * scale + 1e-7
+        assert float(np.abs(mine.cpu().numpy() - ref).max()) <= 2e-5 * scale + 1e-7     # achieved: <= 4.6e-7
 
 
 # ------------------------------------------------------------------------------------ round 2: 'hun', non-prefix valid
