@@ -182,6 +182,7 @@ template <> struct MaskIO<float> {
     typedef float4u Raw;                                   // one 16-byte lane load, kept raw until it is consumed
     static __device__ __forceinline__ Raw load_raw(const float *p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw *>(p)); }
     static __device__ __forceinline__ float elem(const Raw &r, int k) { return r[k]; }
+    static __device__ __forceinline__ bool gt_half(const Raw &r, int k) { return r[k] > 0.5f; }   // x > 0.5 (strict)
     static __device__ __forceinline__ void loadv(const float *p, float (&v)[4]) { load4(p, v); }
     template <bool NT = true> static __device__ __forceinline__ void load4(const float *p, float (&v)[4]) {
         const float4u *q = reinterpret_cast<const float4u *>(p);
@@ -197,6 +198,9 @@ template <> struct MaskIO<f16_t> {
     typedef half8u Raw;
     static __device__ __forceinline__ Raw load_raw(const f16_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw *>(p)); }
     static __device__ __forceinline__ float elem(const Raw &r, int k) { return (float)r[k]; }
+    // native half compare (v_cmp_gt_f16): half -> float is exact and 0.5 is a half, so this IS (float)x > 0.5f, minus
+    // one v_cvt per pixel in the threshold / ballot step of the count kernels
+    static __device__ __forceinline__ bool gt_half(const Raw &r, int k) { return r[k] > (_Float16)0.5f; }
     static __device__ __forceinline__ void loadv(const f16_t *p, float (&v)[8]) {
         half8u t = __builtin_nontemporal_load(reinterpret_cast<const half8u *>(p));
 #pragma unroll
@@ -218,6 +222,7 @@ template <> struct MaskIO<bf16_t> {
     static __device__ __forceinline__ float elem(const Raw &r, int k) {
         return __uint_as_float((k & 1) ? (r[k >> 1] & 0xFFFF0000u) : (r[k >> 1] << 16));
     }
+    static __device__ __forceinline__ bool gt_half(const Raw &r, int k) { return elem(r, k) > 0.5f; }
     static __device__ __forceinline__ void loadv(const bf16_t *p, float (&v)[8]) {
         uint4u t = __builtin_nontemporal_load(reinterpret_cast<const uint4u *>(p));
 #pragma unroll

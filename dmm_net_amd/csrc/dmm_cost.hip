@@ -120,7 +120,7 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
                 for (int j = 0; j < SUB; ++j)
 #pragma unroll
                     for (int k = 0; k < E; ++k) {
-                        const unsigned long long b = __ballot(MaskIO<T>::elem(v[u][j], k) > 0.5f);
+                        const unsigned long long b = __ballot(MaskIO<T>::gt_half(v[u][j], k));
                         w.lo[E * j + k] = mine ? (int)(unsigned)b : w.lo[E * j + k];
                         w.hi[E * j + k] = mine ? (int)(unsigned)(b >> 32) : w.hi[E * j + k];
                     }
@@ -343,35 +343,50 @@ __device__ __forceinline__ void tl_chunk(const T *Pb, const T *Tb, const T *T2b,
         for (int k = 0; k < kWords; ++k) { tw.lo[k] = -1; tw.hi[k] = -1; }
     }
     const int x = x0 + lane * E;
-    for (int p0 = 0; p0 < Nb; p0 += kUnroll) {
-        typename MaskIO<T>::Raw v[kUnroll][SUB];
+    typedef typename MaskIO<T>::Raw Raw;
+    // Software pipeline: the loads of the NEXT kUnroll planes are in flight while the current ones are thresholded
+    // and counted (ping-pong register sets A / B, no copies); without it a wave issued its next loads only after ~400
+    // VALU instructions on the previous group.
+    auto load_group = [&](Raw (&v)[kUnroll][SUB], int p0) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int p = p0 + u < Nb ? p0 + u : Nb - 1;
 #pragma unroll
             for (int j = 0; j < SUB; ++j) v[u][j] = load_pixels<T, TAIL>(Pb + (int64_t)p * sp_n, x + j * 64 * E, HW);
         }
+    };
+    auto count_group = [&](const Raw (&v)[kUnroll][SUB], int p0) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             if (p0 + u < Nb) {
-                unsigned a = 0;
+                unsigned a0 = 0, a1 = 0;                     // two chains of accumulating v_bcnt (dst = popc(src) + acc)
 #pragma unroll
                 for (int j = 0; j < SUB; ++j)
 #pragma unroll
                     for (int k = 0; k < E; ++k) {
-                        const unsigned long long b = __ballot(MaskIO<T>::elem(v[u][j], k) > 0.5f);
-                        a += __builtin_popcount(tw.lo[E * j + k] & (int)(unsigned)b) +
-                             __builtin_popcount(tw.hi[E * j + k] & (int)(unsigned)(b >> 32));
+                        const unsigned long long b = __ballot(MaskIO<T>::gt_half(v[u][j], k));
+                        const int lo = tw.lo[E * j + k] & (int)(unsigned)b, hi = tw.hi[E * j + k] & (int)(unsigned)(b >> 32);
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(lo));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(hi));
                     }
-                if (lane <= Mrows) atomicAdd(&red[(p0 + u) * RS + lane], a);
+                if (lane <= Mrows) atomicAdd(&red[(p0 + u) * RS + lane], a0 + a1);
             }
         }
+    };
+    Raw va[kUnroll][SUB], vb[kUnroll][SUB];
+    load_group(va, 0);
+    for (int p0 = 0; p0 < Nb; p0 += 2 * kUnroll) {
+        if (p0 + kUnroll < Nb) load_group(vb, p0 + kUnroll);
+        count_group(va, p0);
+        if (p0 + kUnroll >= Nb) break;
+        if (p0 + 2 * kUnroll < Nb) load_group(va, p0 + 2 * kUnroll);
+        count_group(vb, p0 + kUnroll);
     }
 }
 
 // grid = (splits, B); block = 256; dynamic LDS = (nt * RS + 64) * 4 bytes, RS = Mrows_max + 1.
 template <typename T>
-__global__ __launch_bounds__(kCostThreads) void iou_counts_tl_kernel(
+__global__ __launch_bounds__(kCostThreads, 4) void iou_counts_tl_kernel(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
     int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
