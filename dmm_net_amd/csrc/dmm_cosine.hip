@@ -318,25 +318,33 @@ __global__ __launch_bounds__(256, 2) void cosine_rows_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// get_cosine_score in ONE launch (dense batches, 2 <= N <= 64, M <= 16, D % 64 == 0): the frame's raw feature rows --
-// N proposals + M templates, (N + M) * D * 4 bytes = 123 KB at the BASELINE shape -- are staged into LDS ONCE with
-// every load in flight at the same time, normalised in place (ATen 2-norm order, clamp, IEEE division: the arithmetic
-// of feature_normalize_kernel), and thread (m, n) then walks its whole D-long product chain out of LDS.  The three-
-// launch path above stages the proposal rows once per D-chunk and template slot with a barrier pair per chunk: one
-// block lives ~30 us for ~1 us of dependent adds.  Here the independent 16-element blocks of ATen's cascade
-// (level_step 16) are accumulated four at a time, so the chain's add latency is hidden too.  Same products, same
-// association as cosine_kernel: bit identical.  grid = B, block = roundup64(M*A) + roundup64(M*(N-A)) threads.
+// get_cosine_score in ONE launch (dense batches, N >= 2, D % 64 == 0).  The proposal columns are cut into tiles that
+// never straddle the boundary A = outer_class_bound(N) between ATen's two reduction classes; a block takes one tile
+// of one frame: it stages the tile's raw proposal rows + all M template rows into LDS ONCE with every load in flight
+// at the same time ((nt + M) * (D + 4) * 4 bytes; 87 KB for the 32-column tile of the BASELINE shape), normalises
+// them in place (ATen 2-norm order, clamp, IEEE division: the arithmetic of feature_normalize_kernel), and thread
+// (m, j) then walks its whole D-long product chain out of LDS.  The three-launch path above stages the proposal rows
+// once per D-chunk and template slot with a barrier pair per chunk: one block lives ~30 us for ~1 us of dependent
+// adds.  Here the independent 16-element blocks of ATen's cascade (level_step 16) are accumulated four at a time, so
+// the chain's add latency is hidden too, and every wave runs ONE class's code.  Same products, same association as
+// cosine_kernel: bit identical.  grid = (tiles, B), block = roundup64(M * nt) threads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restrict__ feat_t,
                                                            const float *__restrict__ feat_p, int N, int M, int D,
-                                                           float *__restrict__ cos_out) {
+                                                           int nt, float *__restrict__ cos_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, nthreads = blockDim.x;
+    const int b = blockIdx.y, nthreads = blockDim.x;
+    const int A = torder::outer_class_bound(N);
+    const int tiles_a = (A + nt - 1) / nt;
+    const bool class_a = (int)blockIdx.x < tiles_a;
+    const int c0 = class_a ? blockIdx.x * nt : A + ((int)blockIdx.x - tiles_a) * nt;
+    const int c1 = min(class_a ? A : N, c0 + nt);
+    const int w = c1 - c0;                                   // columns of this tile
     const int LDW = D + 4;                                   // row stride: 16-B aligned, lanes 0..7 cover all banks
-    float *P = lds;                                          // [N][LDW]
-    float *Q = lds + (size_t)N * LDW;                        // [M][LDW]
-    float *nrm = Q + (size_t)M * LDW;                        // [N + M]
-    const int rows = N + M, d4 = D >> 2;
+    float *P = lds;                                          // [w][LDW]
+    float *Q = lds + (size_t)w * LDW;                        // [M][LDW]
+    float *nrm = Q + (size_t)M * LDW;                        // [w + M]
+    const int rows = w + M, d4 = D >> 2;
     // ---- stage the raw rows: 8 x 16-byte loads in flight per thread and pass ----
     const int total4 = rows * d4;
     for (int base = threadIdx.x; base < total4; base += 8 * nthreads) {
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restr
             const int i = base + u * nthreads;
             if (i < total4) {
                 const int r = i / d4, c4 = (i - r * d4) * 4;
-                const float *src = r < N ? feat_p + ((int64_t)b * N + r) * D : feat_t + ((int64_t)b * M + (r - N)) * D;
+                const float *src = r < w ? feat_p + ((int64_t)b * N + c0 + r) * D : feat_t + ((int64_t)b * M + (r - w)) * D;
                 v[u] = *reinterpret_cast<const float4u *>(src + c4);
             }
         }
@@ -377,25 +385,13 @@ __global__ __launch_bounds__(1024) void cosine_fused_kernel(const float *__restr
         *p = v;
     }
     __syncthreads();
-    // ---- cos[m, n]: a wave holds outputs of ONE reduction class only (the two classes run different code; mixed in a
-    // wave -- columns 0..31 | 32..49 at N = 50 -- both paths would execute back to back).  Threads [0, M*A) take the
-    // class-A outputs (columns < A = outer_class_bound(N)), threads [TA, TA + M*(N-A)) the class-B ones. ----
-    const int A = torder::outer_class_bound(N), Bn = N - A;
-    const int TA = (M * A + 63) & ~63;
-    int m, n;
-    if ((int)threadIdx.x < TA) {
-        if ((int)threadIdx.x >= M * A) return;
-        m = threadIdx.x / A;
-        n = threadIdx.x - m * A;
-    } else {
-        const int t = threadIdx.x - TA;
-        if (t >= M * Bn) return;
-        m = t / Bn;
-        n = A + (t - m * Bn);
-    }
-    const float *row = P + (size_t)n * LDW, *qq = Q + (size_t)m * LDW;
+    // ---- cos[m, c0 + j] ----
+    if ((int)threadIdx.x >= M * w) return;
+    const int m = threadIdx.x / w, j = threadIdx.x - m * w;
+    const int n = c0 + j;
+    const float *row = P + (size_t)j * LDW, *qq = Q + (size_t)m * LDW;
     float res;
-    if (n < torder::outer_class_bound(N)) {                  // one cascade chain over d (multi_row_sum column)
+    if (class_a) {                  // one cascade chain over d (multi_row_sum column)
         torder::Cascade ca;
         ca.init(D);
         for (int d0 = 0; d0 < D; d0 += 64) {                 // 4 independent 16-element blocks at a time
@@ -513,18 +509,34 @@ extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p,
     if (B == 0 || N == 0 || M == 0) return DMM_OK;
     if (!feat_t || !feat_p || !cos_out) return DMM_ERR_BAD_ARG;
     // envelope of the one-launch form; callers fall back to normalise + normalise + cosine outside it
-    if (N < 2 || N > 64 || M > 16 || D <= 0 || (D % 64) != 0 || D > (1 << 19)) return DMM_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)(N + M) * (D + 4) + (size_t)(N + M));
+    if (N < 2 || N > DMM_MAX_PROPOSALS || M > DMM_MAX_TEMPLATES || D <= 0 || (D % 64) != 0 || D > (1 << 19) || B > 65535)
+        return DMM_ERR_UNSUPPORTED;
+    // tile width: as many columns as fit the block (M * nt <= 1024 threads) and the LDS ((nt + M) rows of D + 4 floats)
+    const size_t row_bytes = sizeof(float) * (size_t)(D + 4);
+    const long lds_rows = (long)((160 * 1024 - 1024) / (row_bytes + sizeof(float))) - M;
+    int nt = 1024 / M;
+    if (nt > 64) nt = 64;
+    if (nt > lds_rows) nt = (int)lds_rows;
+    if (nt < 1) return DMM_ERR_UNSUPPORTED;
+    const int A = N >= 8 ? 32 * (N / 32) : 4 * (N / 4);         // torder::outer_class_bound(N)
+    // balance the tiles inside each class (e.g. A = 192, nt = 51 -> 4 tiles of 48)
+    const int tiles_a = (A + nt - 1) / nt, tiles_b = (N - A + nt - 1) / nt;
+    int wmax = 0;
+    if (tiles_a) wmax = (A + tiles_a - 1) / tiles_a;
+    if (tiles_b) { const int wb = (N - A + tiles_b - 1) / tiles_b; wmax = wb > wmax ? wb : wmax; }
+    // one common width keeps the in-kernel tile arithmetic trivial: use the larger of the two balanced widths
+    nt = wmax;
+    const int ta = (A + nt - 1) / nt, tb = (N - A + nt - 1) / nt;
+    const size_t lds = sizeof(float) * ((size_t)(nt + M) * (D + 4) + (size_t)(nt + M));
     if (lds > 160 * 1024 - 512) return DMM_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_fused_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { dmm::set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
-    const int A = N >= 8 ? 32 * (N / 32) : 4 * (N / 4);         // torder::outer_class_bound(N)
-    const int threads = ((M * A + 63) & ~63) + ((M * (N - A) + 63) & ~63);
-    hipLaunchKernelGGL(dmm::cosine_fused_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, feat_t, feat_p, N, M,
-                       D, cos_out);
+    const int threads = (M * nt + 63) & ~63;
+    hipLaunchKernelGGL(dmm::cosine_fused_kernel, dim3(ta + tb, B), dim3(threads), lds, (hipStream_t)stream, feat_t, feat_p,
+                       N, M, D, nt, cos_out);
     return dmm::check_launch();
 }
 

@@ -1011,13 +1011,14 @@ def test_fused_normalise_cosine_kernel_is_bit_identical():
     for j in range(int(g["n_cos"])):
         c = g.group(f"cos{j}")
         q, k = c["q"], c["k"]
-        if not (2 <= k.shape[0] <= 64 and q.shape[0] <= 16 and q.shape[1] % 64 == 0):
+        if not (k.shape[0] >= 2 and q.shape[1] % 64 == 0):
             continue
         seen += 1
         out = ops.cosine_features(dev(q)[None], dev(k)[None])[0].cpu().numpy()
         assert np.array_equal(out, c["cos"]), (j, q.shape, k.shape)
     rng = np.random.Generator(np.random.PCG64(404))
-    for (B, N, M, D) in [(3, 50, 10, 512), (2, 64, 16, 512), (4, 2, 1, 64), (1, 33, 5, 1024), (2, 8, 3, 128), (2, 31, 16, 256)]:
+    for (B, N, M, D) in [(3, 50, 10, 512), (2, 64, 16, 512), (4, 2, 1, 64), (1, 33, 5, 1024), (2, 8, 3, 128), (2, 31, 16, 256),
+                         (2, 200, 20, 512), (1, 256, 32, 512), (2, 130, 20, 256), (1, 97, 7, 64), (1, 5, 32, 128)]:
         tf = torch.from_numpy(rng.standard_normal((B, M, D), dtype=np.float32)).to(DEV)
         pf = torch.from_numpy(rng.standard_normal((B, N, D), dtype=np.float32)).to(DEV)
         tf[0, 0] = 0.0                                           # zero-norm rows: clamp_min(1e-8)
@@ -1028,7 +1029,7 @@ def test_fused_normalise_cosine_kernel_is_bit_identical():
         o = oracle.cosine(tf[0].cpu().numpy(), pf[0].cpu().numpy())
         assert np.array_equal(a[0].cpu().numpy(), o), (B, N, M, D)
         seen += 1
-    assert seen >= 6
+    assert seen >= 11
     # outside the envelope: transparently the three-launch path
     tf = torch.from_numpy(rng.standard_normal((1, 20, 96), dtype=np.float32)).to(DEV)
     pf = torch.from_numpy(rng.standard_normal((1, 200, 96), dtype=np.float32)).to(DEV)
