@@ -115,6 +115,36 @@ __global__ __launch_bounds__(256) void read_planes_run_kernel(const float *__res
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
 }
 
+// config-5 geometry: a wave visit takes ONE 2 KiB run (two 16-byte loads per lane) of the plane -- what a 1024-pixel
+// chunk of a 16-bit plane is -- with UNR planes in flight
+template <int UNR>
+__global__ __launch_bounds__(256) void read_planes_half_kernel(const float *__restrict__ src, int planes, int HW,
+                                                               int chunks_per_wg, float *sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *fb = src + (int64_t)blockIdx.y * planes * HW;
+    const int full = HW / 512;
+    const int c_begin = blockIdx.x * chunks_per_wg, c_end = min(full, c_begin + chunks_per_wg);
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        const float *x = fb + (int64_t)c * 512 + lane * 4;
+        for (int p0 = 0; p0 < planes; p0 += UNR) {
+            f4u v[UNR][2];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = p0 + u < planes ? p0 + u : planes - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(x + (int64_t)p * HW + j * 256));
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc += v[u][j];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
 // the cost-kernel pattern with every 4 KiB run moved down to its 128-byte line boundary (what per-plane aligned loads
 // + funnel-shifted ballot words would read): is the odd plane size or the plane pattern the limit?
 template <int ALIGN>
@@ -233,5 +263,18 @@ extern "C" __attribute__((visibility("default"))) int probe_copy(const void *src
     const int64_t vec_per_wg = bytes / 16 / wgs;
     if (unroll == 4) hipLaunchKernelGGL(copy_kernel<4>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, (f4 *)dst, vec_per_wg);
     else hipLaunchKernelGGL(copy_kernel<1>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const f4 *)src, (f4 *)dst, vec_per_wg);
+    return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default"))) int probe_read_planes_half(const void *src, int B, int planes, int HW,
+                                                                             int wgs, int unr, float *sink, void *stream) {
+    const int nchunks = HW / 512;
+    int splits = (wgs + B - 1) / B;
+    if (splits > (nchunks + 3) / 4) splits = (nchunks + 3) / 4;
+    const int cpw = (nchunks + splits - 1) / splits;
+    splits = (nchunks + cpw - 1) / cpw;
+    dim3 grid(splits, B);
+    if (unr == 4) hipLaunchKernelGGL(read_planes_half_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
+    else hipLaunchKernelGGL(read_planes_half_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
     return (int)hipGetLastError();
 }
