@@ -17,7 +17,9 @@ tag, out = sys.argv[1], os.path.abspath(sys.argv[2])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-bench = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+bench = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"] + \
+    os.environ.get("BENCH_ARGS", "").split()
+suffix = os.environ.get("SUFFIX", "")
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
           ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_WAVES"],
           ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]]
@@ -35,9 +37,9 @@ for i, ctrs in enumerate(PASSES):
                 continue
             kernels.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 res = {"round": tag, "command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 3 --warmup 1 "
-                                "--no-cpu-baseline (three separate passes)", "passes": PASSES, "kernels": {}}
+                                "--no-extras " + os.environ.get("BENCH_ARGS", "") + " (three separate passes)", "passes": PASSES, "kernels": {}}
 for name, cs in kernels.items():
     res["kernels"][name] = {c: {"avg_per_launch": sum(v) / len(v), "samples": len(v)} for c, v in cs.items()}
-json.dump(res, open(os.path.join(out, f"{tag}_pmc_instruction_mix.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, f"{tag}_pmc_instruction_mix{suffix}.json"), "w"), indent=1)
 for name, cs in res["kernels"].items():
     print(name, {c: round(v["avg_per_launch"]) for c, v in cs.items()})
