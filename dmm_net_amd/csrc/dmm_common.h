@@ -16,7 +16,10 @@ constexpr int kWave = 64;
 constexpr int64_t kFrameTable = INT64_MIN;
 template <typename T>
 __device__ __forceinline__ const T *frame_base(const T *base, int b, int64_t stride_b) {
-    if (stride_b == kFrameTable) return reinterpret_cast<const T *const *>(base)[b];
+    // (the table is read AS an array of global-address-space pointers: the value then carries its address space into
+    // the IR and the plane loads stay global_load; read as generic pointers they all became flat_load)
+    typedef const __attribute__((address_space(1))) T *gptr_t;
+    if (stride_b == kFrameTable) return (const T *)(reinterpret_cast<const gptr_t *>(base)[b]);
     return base + (int64_t)b * stride_b;
 }
 

@@ -1034,3 +1034,42 @@ def test_fused_normalise_cosine_kernel_is_bit_identical():
     tf = torch.from_numpy(rng.standard_normal((1, 20, 96), dtype=np.float32)).to(DEV)
     pf = torch.from_numpy(rng.standard_normal((1, 200, 96), dtype=np.float32)).to(DEV)
     assert torch.equal(ops.cosine_features(tf, pf), ops.cosine(ops.feature_normalize(tf), ops.feature_normalize(pf)))
+
+
+def test_round2_entry_points_reject_bad_arguments_loudly():
+    """Status codes of the round-2 C-ABI entries: bad output type / null pointers -> DMM_ERR_BAD_ARG (1), shapes outside
+    an envelope -> DMM_ERR_UNSUPPORTED (2), empty batches -> DMM_OK without touching anything."""
+    from dmm_net_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros((1, 2, 8, 8), device=DEV)
+    rb = torch.zeros((1, 1, 2), device=DEV)
+    out = torch.zeros((1, 1, 8, 8), device=DEV)
+    # fp32 planes cannot be written back as fp16; fp16 planes can only go to fp32 or fp16
+    assert L.dmm_mask_mix_to(rb.data_ptr(), x.data_ptr(), _lib.DTYPE_F32, 1, 2, 1, 2, 64, 128, 64, None, None,
+                             out.data_ptr(), _lib.DTYPE_F16, 64, 64, st) == 1
+    assert L.dmm_mask_mix_to(rb.data_ptr(), x.half().data_ptr(), _lib.DTYPE_F16, 1, 2, 1, 2, 64, 128, 64, None, None,
+                             out.data_ptr(), _lib.DTYPE_BF16, 64, 64, st) == 1
+    assert L.dmm_mask_mix_to(rb.data_ptr(), None, _lib.DTYPE_F32, 1, 2, 1, 2, 64, 128, 64, None, None, out.data_ptr(),
+                             _lib.DTYPE_F32, 64, 64, st) == 1
+    f = torch.zeros((1, 4, 96), device=DEV)
+    c = torch.zeros((1, 4, 4), device=DEV)
+    assert L.dmm_cosine_features_f32(f.data_ptr(), f.data_ptr(), 1, 4, 4, 96, c.data_ptr(), st) == 2      # D % 64 != 0
+    assert L.dmm_cosine_features_f32(f.data_ptr(), f.data_ptr(), 1, 1, 4, 64, c.data_ptr(), st) == 2      # N == 1
+    assert L.dmm_cosine_features_f32(f.data_ptr(), f.data_ptr(), 0, 4, 4, 64, c.data_ptr(), st) == 0      # empty batch
+    assert L.dmm_cosine_features_f32(None, f.data_ptr(), 1, 4, 4, 64, c.data_ptr(), st) == 1
+    assert L.dmm_bias_act_bf16(None, None, None, 4, 8, 1, st) == 1
+    assert L.dmm_bias_act_bf16(f.data_ptr(), None, None, 0, 8, 1, st) == 0
+    assert L.dmm_feature_sim_bwd_f32(c.data_ptr(), None, c.data_ptr(), None, 0.3, f.data_ptr(), f.data_ptr(),
+                                     f.data_ptr(), f.data_ptr(), c.data_ptr(), c.data_ptr(), 1, 4, 4, 96, None, None,
+                                     f.data_ptr(), f.data_ptr(), st) == 1                                    # gt without d_loss
+    tab = torch.zeros((1,), dtype=torch.int64, device=DEV)
+    i32 = torch.zeros((16,), dtype=torch.int32, device=DEV)
+    assert L.dmm_iou_counts_frames(tab.data_ptr(), x.data_ptr(), _lib.DTYPE_F32, 1, 2, 1, 64, 32, 64, 64, None, None,
+                                   i32.data_ptr(), i32.data_ptr(), i32.data_ptr(), st) == 1                  # plane stride < HW
+    assert L.dmm_iou_counts_frames(tab.data_ptr(), x.data_ptr(), _lib.DTYPE_F32, 0, 2, 1, 64, 64, 64, 64, None, None,
+                                   i32.data_ptr(), i32.data_ptr(), i32.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    # an empty frame list is refused on the host side
+    with pytest.raises(AssertionError):
+        ops.FramePlanes([])
