@@ -452,10 +452,7 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
     static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
     const int RS = (masks_t2 ? 2 * mt : mt) + 1;
-    // DMM_COST_TL_LDS_PAD (bytes, experiment): extra dynamic LDS per workgroup = an occupancy throttle, so that the
-    // latency-lane kernels of a concurrent stream always find free VGPRs / wave slots next to this kernel
-    const char *pad_env = getenv("DMM_COST_TL_LDS_PAD");
-    const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave) + (pad_env ? (size_t)atoi(pad_env) : 0);
+    const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave);
     hipLaunchKernelGGL((iou_counts_tl_kernel<T>), dim3(splits, B), dim3(kCostThreads), lds, stream, masks_p, masks_t,
                        masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t,
                        inter2, area_t2, n0, m0, nt, mt, chunks_per_wg, wap, wat, RS, xcd_remap);

@@ -17,8 +17,7 @@ tm = torch.rand((B, M, H, W), generator=g, device=dev).half()
 pf = torch.randn((B, N, D), generator=g, device=dev)
 tf = torch.randn((B, M, D), generator=g, device=dev)
 sc = torch.rand((B, N), generator=g, device=dev)
-for pipe, pad in ((False, 0), (True, 0), (True, 16384), (True, 24576), (True, 32768), (False, 24576)):
-    os.environ['DMM_COST_TL_LDS_PAD'] = str(pad)
+for pipe, pad in ((False, 0), (True, 0)):
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=torch.float16, pipeline=pipe)
     run = lambda: plan.run(pm, tm, pf, tf, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
     for _ in range(3):
