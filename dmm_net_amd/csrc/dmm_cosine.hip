@@ -503,6 +503,11 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     return dmm::check_launch();
 }
 
+namespace dmm {
+int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
+                        hipStream_t stream);
+}
+
 extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p, int B, int N, int M, int D,
                                        float *cos_out, dmm_stream_t stream) {
     if (B < 0 || N < 0 || M < 0 || D < 0) return DMM_ERR_BAD_ARG;
@@ -511,6 +516,13 @@ extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p,
     // envelope of the one-launch form; callers fall back to normalise + normalise + cosine outside it
     if (N < 2 || N > DMM_MAX_PROPOSALS || M > DMM_MAX_TEMPLATES || D <= 0 || (D % 64) != 0 || D > (1 << 19) || B > 65535)
         return DMM_ERR_UNSUPPORTED;
+    // D spread over the lanes (dmm_cosine_lanes.hip) where its envelope holds; DMM_COSINE_KERNEL=tile keeps the
+    // one-thread-per-output tile kernel below (A/B timing, and every other D)
+    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    if (!force_tile) {
+        const int rc = dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, cos_out, (hipStream_t)stream);
+        if (rc != DMM_ERR_UNSUPPORTED) return rc;
+    }
     // tile width: as many columns as fit the block (M * nt <= 1024 threads) and the LDS ((nt + M) rows of D + 4 floats)
     const size_t row_bytes = sizeof(float) * (size_t)(D + 4);
     const long lds_rows = (long)((160 * 1024 - 1024) / (row_bytes + sizeof(float))) - M;

@@ -1030,6 +1030,28 @@ def test_fused_normalise_cosine_kernel_is_bit_identical():
         assert np.array_equal(a[0].cpu().numpy(), o), (B, N, M, D)
         seen += 1
     assert seen >= 11
+    # the hoisted-reciprocal division of the lanes kernel (RowDiv): sparse rows, tiny / huge / denormal / non-finite values
+    for k, (B, N, M, D) in enumerate([(2, 50, 10, 512), (1, 40, 20, 256), (1, 19, 9, 1024)]):
+        tf = rng.standard_normal((B, M, D), dtype=np.float32)
+        pf = np.maximum(rng.standard_normal((B, N, D), dtype=np.float32), 0.0)
+        pf[0, 1] *= np.float32(1e-33)                            # every element below 2^-100
+        pf[0, 2, ::3] *= np.float32(1e-36)                       # a few tiny ones in a normal row
+        pf[0, 3] *= np.float32(1e-42)                            # denormal row
+        pf[0, 4] *= np.float32(3e30)                             # norm above 2^25
+        pf[0, 5, 7] = np.float32(1e20)
+        pf[0, 6] = np.exp(rng.uniform(-80, 30, D)).astype(np.float32)
+        tf[0, 1] *= np.float32(1e-35)
+        tf[0, 2, 5] = np.float32(2e-41)
+        tf[-1, -1] *= np.float32(1e12)
+        if k == 0:
+            pf[1, 0, 3] = np.inf
+            tf[1, 2, 0] = np.nan
+        tf, pf = torch.from_numpy(tf).to(DEV), torch.from_numpy(pf).to(DEV)
+        a = ops.cosine_features(tf, pf).cpu().numpy()
+        b = ops.cosine(ops.feature_normalize(tf), ops.feature_normalize(pf)).cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), (B, N, M, D, np.argwhere(a != b)[:5])
+        o = oracle.cosine(tf[0].cpu().numpy(), pf[0].cpu().numpy())
+        assert np.array_equal(a[0], o, equal_nan=True), (B, N, M, D)
     # outside the envelope: transparently the three-launch path
     tf = torch.from_numpy(rng.standard_normal((1, 20, 96), dtype=np.float32)).to(DEV)
     pf = torch.from_numpy(rng.standard_normal((1, 200, 96), dtype=np.float32)).to(DEV)
