@@ -60,27 +60,30 @@ __device__ __forceinline__ typename MaskIO<T>::Raw load_pixels(const T *plane, i
 }
 
 // Bit tile of one group of <= 64 planes for one chunk: lane p holds the kWords words of plane p.
-struct BitTile {
-    int lo[kWords], hi[kWords];
+template <int CH>
+struct BitTileT {
+    static constexpr int kW = CH / 64;
+    int lo[kW], hi[kW];
 };
+typedef BitTileT<kChunk> BitTile;
 
 // DMM_PACKED1 planes: the words ARE the tile -- lane lane0+p loads the 16 words (128 B) of its plane's chunk.
-template <bool TAIL>
-__device__ __forceinline__ void fill_tile_packed(BitTile &w, const packed_t *base, int64_t plane_stride, int nplanes,
+template <bool TAIL, int CH = kChunk>
+__device__ __forceinline__ void fill_tile_packed(BitTileT<CH> &w, const packed_t *base, int64_t plane_stride, int nplanes,
                                                  int x0, int HW, int lane0, bool clear) {
     const int lane = threadIdx.x & 63;
     const int p = lane - lane0;
     const bool mine = p >= 0 && p < nplanes;
     if (clear) {
 #pragma unroll
-        for (int k = 0; k < kWords; ++k) { w.lo[k] = 0; w.hi[k] = 0; }
+        for (int k = 0; k < (CH / 64); ++k) { w.lo[k] = 0; w.hi[k] = 0; }
     }
     if (mine) {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(base + (int64_t)p * plane_stride)
                                         + (x0 >> 6);
         const int nwords = 4 * ((HW + 255) / 256);
 #pragma unroll
-        for (int k = 0; k < kWords; ++k) {
+        for (int k = 0; k < (CH / 64); ++k) {
             unsigned long long v = 0;
             if (!TAIL || (x0 >> 6) + k < nwords) v = src[k];
             w.lo[k] = (int)(unsigned)v;
@@ -89,12 +92,13 @@ __device__ __forceinline__ void fill_tile_packed(BitTile &w, const packed_t *bas
     }
 }
 
-template <typename T, bool TAIL>
-__device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t plane_stride, int nplanes,
+template <typename T, bool TAIL, int CH = kChunk, int LB = kLoadBytes>
+__device__ __forceinline__ void fill_tile(BitTileT<CH> &w, const T *base, int64_t plane_stride, int nplanes,
                                           int x0, int HW, int lane0 = 0, bool clear = true) {
     constexpr int E = MaskIO<T>::kVec;
-    constexpr int SUB = kChunk / (64 * E);
-    constexpr int kUnroll = kLoadBytes / (kChunk * (int)sizeof(T));
+    constexpr int SUB = CH / (64 * E);
+    constexpr int kUnroll = LB / (CH * (int)sizeof(T));
+    constexpr int kWords = CH / 64;
     const int lane = threadIdx.x & 63;
     const int x = x0 + lane * E;
     if (clear) {
@@ -129,21 +133,22 @@ __device__ __forceinline__ void fill_tile(BitTile &w, const T *base, int64_t pla
     }
 }
 
-template <typename T, bool TAIL>
-__device__ __forceinline__ void fill_any(BitTile &w, const T *base, int64_t plane_stride, int nplanes, int x0, int HW,
+template <typename T, bool TAIL, int CH = kChunk, int LB = kLoadBytes>
+__device__ __forceinline__ void fill_any(BitTileT<CH> &w, const T *base, int64_t plane_stride, int nplanes, int x0, int HW,
                                          int lane0, bool clear) {
-    if constexpr (std::is_same<T, packed_t>::value) fill_tile_packed<TAIL>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
-    else fill_tile<T, TAIL>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
+    if constexpr (std::is_same<T, packed_t>::value) fill_tile_packed<TAIL, CH>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
+    else fill_tile<T, TAIL, CH, LB>(w, base, plane_stride, nplanes, x0, HW, lane0, clear);
 }
 
-template <typename T, int MT, int NG, bool TAIL>
+template <typename T, int MT, int NG, bool TAIL, int CH = kChunk, int LB = kLoadBytes>
 __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T *T2b, int64_t sp_n, int64_t st_m,
                                               int64_t st2_m, int Nb, int Mb, int Mrows, int x0, int HW,
                                               unsigned (&acc)[NG][MT], unsigned (&area_p)[NG], unsigned &area_t) {
     // template tile: lanes [0, Mb) = planes of set 1, lanes [Mb, 2*Mb) = planes of set 2 (training: the targets)
-    BitTile tw;
-    fill_any<T, TAIL>(tw, Tb, st_m, Mb, x0, HW, 0, true);
-    if (T2b) fill_any<T, TAIL>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
+    constexpr int kWords = CH / 64;
+    BitTileT<CH> tw;
+    fill_any<T, TAIL, CH, LB>(tw, Tb, st_m, Mb, x0, HW, 0, true);
+    if (T2b) fill_any<T, TAIL, CH, LB>(tw, T2b, st2_m, Mb, x0, HW, Mb, false);
 #pragma unroll
     for (int k = 0; k < kWords; ++k) area_t += __builtin_popcount(tw.lo[k]) + __builtin_popcount(tw.hi[k]);
 #pragma unroll
@@ -151,8 +156,8 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
         int nn = Nb - g * kWave;
         if (nn > kWave) nn = kWave;
         if (nn > 0) {
-        BitTile pw;
-        fill_any<T, TAIL>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW, 0, true);
+        BitTileT<CH> pw;
+        fill_any<T, TAIL, CH, LB>(pw, Pb + (int64_t)g * kWave * sp_n, sp_n, nn, x0, HW, 0, true);
 #pragma unroll
         for (int k = 0; k < kWords; ++k) area_p[g] += __builtin_popcount(pw.lo[k]) + __builtin_popcount(pw.hi[k]);
 #pragma unroll
@@ -192,7 +197,7 @@ __device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &rang
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
 
 
-template <typename T, int MT, int NG>
+template <typename T, int MT, int NG, int CH = kChunk, int LB = kLoadBytes>
 __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
     int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
@@ -230,16 +235,16 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
         for (int m = 0; m < MT; ++m) acc[g][m] = 0;
     }
 
-    const int full_chunks = HW / kChunk;
-    const int nchunks = (HW + kChunk - 1) / kChunk;
+    const int full_chunks = HW / CH;
+    const int nchunks = (HW + CH - 1) / CH;
     const int c_begin = range * chunks_per_wg;
     const int c_end = min(nchunks, c_begin + chunks_per_wg);
     for (int c = c_begin + wave; c < c_end; c += kCostThreads / kWave) {
-        const int x0 = c * kChunk;
+        const int x0 = c * CH;
         if (c < full_chunks)
-            process_chunk<T, MT, NG, false>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
+            process_chunk<T, MT, NG, false, CH, LB>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
         else
-            process_chunk<T, MT, NG, true>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
+            process_chunk<T, MT, NG, true, CH, LB>(Pb, Tb, T2b, sp_n, st_m, st2_m, Nb, Mb, Mrows, x0, HW, acc, ap, at);
     }
 
     // fold the 4 waves (integer LDS atomics), then one global atomic per entry
@@ -282,11 +287,40 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
                        int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
                        const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
                        int32_t *area_t2, int n0, int m0, int wap, int wat, hipStream_t stream) {
+    static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
+    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 1024; }();
+    const char *tiny_env = getenv("DMM_COST_TINY_FRAMES");       // read per call: tests flip it
+    const int tiny_frames = tiny_env ? atoi(tiny_env) : 8;      // B = 8: 0.162 ms per sequence with it, 0.191 without
+    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
+    // A handful of frames (the product's B = 1 / B = 4 calls) is a LATENCY problem: with 1024-pixel chunks one frame
+    // has 64 of them, one per workgroup, so three waves of every workgroup idled and the working one went through 9
+    // dependent load batches (10 template planes + 8 proposals, 2 planes in flight): 19 us at B = 1.  The same kernel
+    // with one 16-byte lane load per plane and chunk (256 / 512 pixels) and 16 planes in flight gives all four waves a
+    // chunk and needs 2 batches: 11 us at B = 1, 24 us at B = 4 (profiles/r02_latency_B*_timeline.txt).
+    if constexpr (NG == 1 && MT <= 16 && !std::is_same<T, packed_t>::value) {
+        if (B <= tiny_frames) {
+            constexpr int CHS = 64 * MaskIO<T>::kVec, LBS = 16384;
+            const int nch = (HW + CHS - 1) / CHS;
+            const int splits_s = (nch + kCostThreads / kWave - 1) / (kCostThreads / kWave);
+            const int ntile_s = (N - n0) < kWave ? (N - n0) : kWave;
+            int sub_count = 1, n_sub = kWave;
+            if ((int64_t)B * splits_s < small_wgs && ntile_s > 8) {
+                sub_count = (int)((small_wgs + (int64_t)B * splits_s - 1) / ((int64_t)B * splits_s));
+                const int max_sub = (ntile_s + 7) / 8;
+                if (sub_count > max_sub) sub_count = max_sub;
+                n_sub = (ntile_s + sub_count - 1) / sub_count;
+                sub_count = (ntile_s + n_sub - 1) / n_sub;
+            }
+            hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG, CHS, LBS>), dim3(splits_s * sub_count, B), dim3(kCostThreads), 0,
+                               stream, masks_p, masks_t, masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid,
+                               m_valid, inter, area_p, area_t, inter2, area_t2, n0, m0, kCostThreads / kWave, wap, wat,
+                               xcd_remap, sub_count, n_sub);
+            return check_launch();
+        }
+    }
     const int nchunks = (HW + kChunk - 1) / kChunk;
     // ~8192 workgroups, at least 1 chunk per wave: small workgroups keep the tail of the launch short and measured
     // best (B = 1024: 5.8 / 6.0 / 6.3 / 6.6 / 6.4 TB/s at 1k / 2k / 4k / 8k / 16k workgroups)
-    static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
-    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 1024; }();
     int splits = (target_wgs + B - 1) / B;
     int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
     // a few frames only (the product's B = 1 / B = 4 calls): one chunk per workgroup (waves 1-3 of it idle) ...
@@ -306,7 +340,6 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
         n_sub = (ntile + sub_count - 1) / sub_count;
         sub_count = (ntile + n_sub - 1) / n_sub;
     }
-    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
     dim3 grid(splits * sub_count, B);
     hipLaunchKernelGGL((iou_counts_kernel<T, MT, NG>), grid, dim3(kCostThreads), 0, stream, masks_p, masks_t, masks_t2, N,
                        M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid, m_valid, inter, area_p, area_t, inter2,

@@ -451,9 +451,9 @@ class ForwardPlan:
     * ``pipeline=False`` -- one ``dmm_match_forward`` C call, all kernels back to back on the current stream;
       With ``graph=True`` (small batches, where a frame step is launch / latency bound) the sequence is captured into
       a HIP graph the second time in a row ``run`` sees the same tensors (same addresses and strides) and replayed
-      from then on -- one graph launch instead of 7 kernel launches, and the two independent branches of the layer,
-      IoU counts (masks) | normalise + cosine (features), run side by side before the solver joins them.  Up to 4
-      tensor sets are kept (each captured graph holds references to its tensors); other calls launch directly.
+      from then on -- one graph launch instead of 7 kernel launches (``graph_fork=True`` also runs the two independent
+      branches of the layer, IoU counts (masks) | feature similarity, side by side before the solver joins them).
+      Up to 4 tensor sets are kept (each captured graph holds references to its tensors); other calls launch directly.
     * ``pipeline=True``  -- "streaming lane + latency lane".  The batch is split in two halves A, B.  The
       current stream runs only the HBM-bound kernels, serialised at full bandwidth:
       cost(A) -> cost(B) -> mix(A) -> mix(B)  (A, B = the two halves of the batch).  A side stream runs the latency-bound ones:
@@ -463,7 +463,7 @@ class ForwardPlan:
     """
 
     def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None,
-                 split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2):
+                 split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2, graph_fork=False):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
@@ -484,6 +484,10 @@ class ForwardPlan:
         # opt-in: it only pays for callers that present the SAME tensors again (static buffers: bench loops, serving
         # loops over GraphedEncoder outputs); a frame loop with fresh proposal tensors would capture and never replay
         self.graph_mode = bool(graph) and not self.pipeline and not self.time_kernels
+        # graph_fork: feature branch on a second stream inside the captured graph.  It paid while the feature similarity
+        # took as long as the counts (18 us vs 19 us at B = 1); with the lanes kernel (10 us) and the small-chunk count
+        # launch (round 2) the ~18 us a cross-queue fork + join costs is more than the branch saves: default off
+        self.graph_fork = bool(graph_fork)
         self._graphs, self._last_key = {}, None                   # key -> (graph, tensors it holds addresses of)
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -534,25 +538,29 @@ class ForwardPlan:
         if self.pipeline:
             return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
         if self.graph_mode:
-            return "HIP graph replay (IoU counts | normalise + cosine in parallel -> solver -> mix)" \
-                if self._graphs else "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
+            if not self._graphs:
+                return "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
+            return "HIP graph replay (IoU counts | feature similarity in parallel -> solver -> mix)" if self.graph_fork \
+                else "HIP graph replay (feature similarity -> IoU counts -> solver -> mix, one chain)"
         return "single stream"
 
     def _launch_forked(self, L, masks_p, masks_t, feat_p, feat_t, score_p, dt, strides, n_valid, m_valid, cfg):
-        """Granular launches with the feature branch on the side stream (fork / join by stream waits): the form that
-        is captured into the HIP graph."""
+        """Granular launches, the form that is captured into the HIP graph (``graph_fork``: feature branch on the side
+        stream, fork / join by stream waits)."""
         B, N, M, D, Pp, HW = self.B, self.N, self.M, self.D, self.Pp, self.H * self.W
         sp_b, sp_n, st_b, st_m = strides
         score_weight, max_iter, proj_iter, lr, is_test = cfg
         main = torch.cuda.current_stream(self.device)
-        side = self.side
+        side = self.side if self.graph_fork else main
         inter, ap, at = self._tables(0)
-        side.wait_stream(main)
+        if self.graph_fork:
+            side.wait_stream(main)
         ss, ms = side.cuda_stream, main.cuda_stream
         rc = self._feature_sim(L, feat_p, feat_t, n_valid, m_valid, ss)
         rc |= L.dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), dt, B, N, M, HW, sp_b, sp_n, st_b, st_m, _ptr(n_valid),
                                _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
-        main.wait_stream(side)
+        if self.graph_fork:
+            main.wait_stream(side)
         rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
                                     _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
                                     float(lr), int(is_test), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),

@@ -88,13 +88,18 @@ def check_against_golden(o, g, is_test, big=False):
 
 
 # ------------------------------------------------------------------------------------ cost kernel
-@pytest.fixture(params=["auto", "register-tiles", "template-lanes"])
+@pytest.fixture(params=["auto", "register-tiles", "register-tiles-small-chunks", "template-lanes"])
 def cost_kernel(request, monkeypatch):
-    """The IoU-count entry point has two kernels (dmm_cost.hip); DMM_COST_KERNEL pins one (read per call)."""
+    """The IoU-count entry point has two kernels (dmm_cost.hip); DMM_COST_KERNEL pins one (read per call).  The register-
+    tile kernel has a second instantiation for a handful of frames (one 16-byte lane load per plane and chunk, 16 planes
+    in flight; B <= DMM_COST_TINY_FRAMES, default 8): pinned off (0) and on for every batch size (64) here."""
     if request.param != "auto":
-        monkeypatch.setenv("DMM_COST_KERNEL", "0" if request.param == "register-tiles" else "1")
+        monkeypatch.setenv("DMM_COST_KERNEL", "1" if request.param == "template-lanes" else "0")
+        if request.param != "template-lanes":
+            monkeypatch.setenv("DMM_COST_TINY_FRAMES", "0" if request.param == "register-tiles" else "64")
     else:
         monkeypatch.delenv("DMM_COST_KERNEL", raising=False)
+        monkeypatch.delenv("DMM_COST_TINY_FRAMES", raising=False)
     return request.param
 
 
@@ -972,17 +977,18 @@ def test_mask_mix_16bit_output_is_the_fp32_result_rounded_once(dtype):
         assert float((f32 - ref).abs().max()) <= 1e-6
 
 
-def test_forward_plan_graph_mode_replays_on_static_buffers():
-    """ForwardPlan(graph=True): the second call in a row on the same tensors captures a HIP graph (counts | normalise +
-    cosine as parallel branches), later calls replay it -- also after the buffers were refilled in place -- and calls
-    with other tensors launch directly; every result equals the plain single-stream plan."""
+@pytest.mark.parametrize("fork", [False, True])
+def test_forward_plan_graph_mode_replays_on_static_buffers(fork):
+    """ForwardPlan(graph=True): the second call in a row on the same tensors captures a HIP graph (one chain, or with
+    graph_fork counts | feature similarity as parallel branches), later calls replay it -- also after the buffers were
+    refilled in place -- and calls with other tensors launch directly; every result equals the plain single-stream plan."""
     c = synth.CONFIGS[1]
     B = 3
     g = torch.Generator(device=DEV).manual_seed(21)
     mk = lambda *s: torch.rand(s, generator=g, device=DEV)
     bufs = [mk(B, c["P"], c["H"], c["W"]), mk(B, c["O"], c["H"], c["W"]), mk(B, c["P"], c["D"]) - 0.5,
             mk(B, c["O"], c["D"]) - 0.5, mk(B, c["P"])]
-    plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, graph=True)
+    plan = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, graph=True, graph_fork=fork)
     ref = ops.ForwardPlan(B, c["P"], c["O"], c["H"], c["W"], c["D"], DEV, want_tables=True, pipeline=False)
     kw = dict(max_iter=20, proj_iter=5, is_test=1)
 
