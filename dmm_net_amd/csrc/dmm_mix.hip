@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     constexpr int E = 16 / (int)sizeof(T);
     __shared__ float w_s[DMM_MAX_PROPOSALS];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
-    __shared__ int cnt_s;
+    __shared__ int wcnt_s[kMixThreads / 64];
     // XCD-aware mapping (workgroups go round-robin over the 8 XCDs by linear id): every complete group of 8 output rows
     // gives each XCD one whole row, so the misaligned source lines neighbouring pixel ranges share stay in one L2
     int b = blockIdx.z, m = blockIdx.y, range = blockIdx.x;
@@ -193,26 +193,28 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_rows_kernel(const float 
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
     if (Nb <= 0) Mb = 0;
-    if (threadIdx.x < 64) {
+    // The row's non-zero weights, compacted in column order.  ONE global round trip: thread n reads Rb[m, n] (N <=
+    // DMM_MAX_PROPOSALS = the workgroup size), a ballot per wave and the wave counts through LDS give the positions.
+    // (A 64-lane loop over the row was 4 dependent round trips at N = 200 in front of 16 KB of streaming per
+    // workgroup: config 5's mix ran at 0.63 of peak against 0.78 for the N = 50 rows of config 2.)
+    static_assert(kMixThreads >= DMM_MAX_PROPOSALS, "one thread per proposal column");
+    {
+        const int n = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const float w = (m < Mb && n < Nb) ? Rb[((int64_t)b * M + m) * Pp + n] : 0.0f;
+        const unsigned long long bal = __ballot(w != 0.0f);
+        if (lane == 0) wcnt_s[wave] = __builtin_popcountll(bal);
+        __syncthreads();
         int base = 0;
-        if (m < Mb) {
-            const float *Rrow = Rb + ((int64_t)b * M + m) * Pp;
-            for (int n0 = 0; n0 < Nb; n0 += 64) {
-                const int n = n0 + threadIdx.x;
-                const float w = n < Nb ? Rrow[n] : 0.0f;
-                const unsigned long long bal = __ballot(w != 0.0f);
-                if (w != 0.0f) {
-                    const int pos = base + __builtin_popcountll(bal & ((1ull << threadIdx.x) - 1ull));
-                    col_s[pos] = n;
-                    w_s[pos] = w;
-                }
-                base += __builtin_popcountll(bal);
-            }
+#pragma unroll
+        for (int k = 0; k < kMixThreads / 64; ++k) base += k < wave ? wcnt_s[k] : 0;
+        if (w != 0.0f) {
+            const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            col_s[pos] = n;
+            w_s[pos] = w;
         }
-        if (threadIdx.x == 0) cnt_s = base;
     }
     __syncthreads();
-    const int cnt = cnt_s;
+    const int cnt = wcnt_s[0] + wcnt_s[1] + wcnt_s[2] + wcnt_s[3];
     const T *Pb = frame_base(masks_p, b, sp_b);
     TO *orow = out + (int64_t)b * so_b + (int64_t)m * so_m;
     // row start = 128-byte boundary + pre elements (align_mask = elements per aligned unit - 1)
