@@ -35,6 +35,10 @@ constexpr int kChunk = 1024;          // pixels a wave takes from one plane per 
                                       // shares those lines (measured HBM over-fetch 8.6 % -> 1.3 % for fp32)
 constexpr int kLoadBytes = 8192;      // bytes of plane loads a wave keeps in flight: 2 fp32 planes or 4 16-bit planes
 constexpr int kWords = kChunk / 64;   // 64-bit words per plane and chunk (16)
+#ifndef DMM_TL_LOAD_BYTES
+#define DMM_TL_LOAD_BYTES 8192
+#define DMM_TL_MIN_WAVES 4
+#endif
 constexpr int kCostThreads = 256;     // 4 waves; 1- and 2-wave workgroups measured 2-4 % slower
 
 // One 16-byte load per lane: E = 4 (fp32) or 8 (half / bfloat16) consecutive pixels, kept RAW in 4 VGPRs until the
@@ -364,7 +368,7 @@ __device__ __forceinline__ void tl_chunk(const T *Pb, const T *Tb, const T *T2b,
                                          unsigned &area_t) {
     constexpr int E = MaskIO<T>::kVec;
     constexpr int SUB = kChunk / (64 * E);
-    constexpr int kUnroll = kLoadBytes / (kChunk * (int)sizeof(T));
+    constexpr int kUnroll = DMM_TL_LOAD_BYTES / (kChunk * (int)sizeof(T));
     const int lane = threadIdx.x & 63;
     BitTile tw;
     fill_tile<T, TAIL>(tw, Tb, st_m, Mb, x0, HW, 0, true);
@@ -419,7 +423,7 @@ __device__ __forceinline__ void tl_chunk(const T *Pb, const T *Tb, const T *T2b,
 
 // grid = (splits, B); block = 256; dynamic LDS = (nt * RS + 64) * 4 bytes, RS = Mrows_max + 1.
 template <typename T>
-__global__ __launch_bounds__(kCostThreads, 4) void iou_counts_tl_kernel(
+__global__ __launch_bounds__(kCostThreads, DMM_TL_MIN_WAVES) void iou_counts_tl_kernel(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
     int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
