@@ -240,8 +240,8 @@ def cosine(featn_t: torch.Tensor, featn_p: torch.Tensor, n_valid=None, m_valid=N
 
 def cosine_features(feat_t: torch.Tensor, feat_p: torch.Tensor) -> torch.Tensor:
     """get_cosine_score (match_helper.py:51-64) from RAW features feat_t [B,M,D], feat_p [B,N,D] -> cos [B,M,N]: one
-    fused launch inside its envelope (dense, 2 <= N <= 64, M <= 16, D % 64 == 0), else normalise x 2 + cosine.
-    Bit identical either way."""
+    fused launch inside its envelope (dense, N >= 2, D % 64 == 0; D = 256 / 512 / 1024 with the D axis over the lanes),
+    else normalise x 2 + cosine.  Bit identical either way."""
     _need_gpu(feat_t, feat_p)
     feat_t, feat_p = feat_t.contiguous().float(), feat_p.contiguous().float()
     B, M, D = feat_t.shape

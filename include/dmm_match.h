@@ -130,9 +130,10 @@ DMM_API int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, floa
                               float *norms /*[rows] or NULL*/, dmm_stream_t stream);
 
 /* (2c) get_cosine_score (match_helper.py:51-64) from the RAW features in one launch: (2) for both inputs + (2b), bit
- * identical to that sequence.  Dense batches only, N >= 2, D % 64 == 0; the proposal columns are tiled so that a tile
- * plus the M template rows fit the LDS ((nt + M) * (D + 4) * 4 bytes <= 160 KB): DMM_ERR_UNSUPPORTED when not even one
- * column does (callers then run (2), (2), (2b)).  Used by (5). */
+ * identical to that sequence.  Dense batches only, N >= 2, D % 64 == 0.  D = 256 / 512 / 1024 (the product's 4 x
+ * hidden_size) runs with the D axis spread over the lanes of a wave (dmm_cosine_lanes.hip); any other D with one thread
+ * per output, the proposal columns tiled so that a tile plus the M template rows fit the LDS ((nt + M) * (D + 4) * 4
+ * bytes <= 160 KB).  DMM_ERR_UNSUPPORTED when not even one column does (callers then run (2), (2), (2b)).  Used by (5). */
 DMM_API int dmm_cosine_features_f32(const float *feat_t /*[B,M,D]*/, const float *feat_p /*[B,N,D]*/, int B, int N,
                                     int M, int D, float *cos_out /*[B,M,N]*/, dmm_stream_t stream);
 

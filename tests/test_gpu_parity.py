@@ -1058,6 +1058,15 @@ def test_fused_normalise_cosine_kernel_is_bit_identical():
         assert np.array_equal(a, b, equal_nan=True), (B, N, M, D, np.argwhere(a != b)[:5])
         o = oracle.cosine(tf[0].cpu().numpy(), pf[0].cpu().numpy())
         assert np.array_equal(a[0], o, equal_nan=True), (B, N, M, D)
+    # random shapes through the lanes kernel: every step width (1..8 columns), both classes, partial template groups
+    for D in (256, 512, 1024):
+        for _ in range(6):
+            B, N, M = int(rng.integers(1, 4)), int(rng.integers(2, 257)), int(rng.integers(1, 33))
+            tf = torch.from_numpy(rng.standard_normal((B, M, D), dtype=np.float32)).to(DEV)
+            pf = torch.from_numpy(np.maximum(rng.standard_normal((B, N, D), dtype=np.float32), 0.0)).to(DEV)
+            a = ops.cosine_features(tf, pf)
+            assert torch.equal(a, ops.cosine(ops.feature_normalize(tf), ops.feature_normalize(pf))), (B, N, M, D)
+            assert np.array_equal(a[-1].cpu().numpy(), oracle.cosine(tf[-1].cpu().numpy(), pf[-1].cpu().numpy())), (B, N, M, D)
     # outside the envelope: transparently the three-launch path
     tf = torch.from_numpy(rng.standard_normal((1, 20, 96), dtype=np.float32)).to(DEV)
     pf = torch.from_numpy(rng.standard_normal((1, 200, 96), dtype=np.float32)).to(DEV)
