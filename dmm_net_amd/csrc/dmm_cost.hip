@@ -460,13 +460,17 @@ __global__ __launch_bounds__(kCostThreads, DMM_TL_MIN_WAVES) void iou_counts_tl_
     __syncthreads();
     int32_t *inter_b = inter + (int64_t)b * M * N;
     int32_t *inter2_b = inter2 ? inter2 + (int64_t)b * M * N : nullptr;
-    for (int i = threadIdx.x; i < Nb * RS; i += kCostThreads) {
-        const unsigned v = tl_red[i];
+    // row-major over the OUTPUT tables (consecutive threads = consecutive proposals of one row): a wave's 64 atomics
+    // then fall into 2-3 lines instead of 64 (the [proposal][row] order of tl_red made every one its own L2
+    // transaction: 4200 per workgroup at config 5, and the launch slowed with every extra workgroup);
+    // RS is odd or coprime with the 64 banks for the shipped shapes, the strided LDS reads stay cheap
+    for (int i = threadIdx.x; i < (Mrows + 1) * Nb; i += kCostThreads) {
+        const int r = i / Nb, p = i - r * Nb;
+        const unsigned v = tl_red[p * RS + r];
         if (!v) continue;
-        const int p = i / RS, r = i - p * RS;
         if (r < Mb) atomicAdd(&inter_b[(int64_t)(m0 + r) * N + n0 + p], (int)v);
         else if (r < Mrows) atomicAdd(&inter2_b[(int64_t)(m0 + r - Mb) * N + n0 + p], (int)v);
-        else if (r == Mrows && write_area_p) atomicAdd(&area_p[(int64_t)b * N + n0 + p], (int)v);
+        else if (write_area_p) atomicAdd(&area_p[(int64_t)b * N + n0 + p], (int)v);
     }
     if (write_area_t && threadIdx.x < Mrows && red_at[threadIdx.x]) {
         if (threadIdx.x < Mb) atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);

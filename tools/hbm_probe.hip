@@ -278,3 +278,98 @@ extern "C" __attribute__((visibility("default"))) int probe_read_planes_half(con
     else hipLaunchKernelGGL(read_planes_half_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, planes, HW, cpw, sink);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Skeleton of iou_counts_tl_kernel (config 5) with its ingredients switchable, to find what separates it from the
+// bare read loop: MODE bit 0 = the thresholding / ballot / and / bcnt work against a parked 32-register tile,
+// bit 1 = the LDS atomic per plane; HWh = plane size in HALVES (65025: odd, planes 2 bytes off; 65024: line aligned);
+// dynamic LDS caps the workgroups per CU (40 KB -> 4 workgroups = 4 waves per SIMD, like the kernel's 128 VGPRs).
+// Ping-pong groups of 4 planes x 2 KiB, 1024-pixel chunks, 4 waves per workgroup: the kernel's loop structure.
+typedef _Float16 h8u __attribute__((ext_vector_type(8), aligned(2)));
+template <int MODE>
+__global__ __launch_bounds__(256) void tl_skeleton_kernel(const _Float16 *__restrict__ src, int planes, int HWh,
+                                                           int chunks_per_wg, unsigned *sink) {
+    extern __shared__ unsigned red[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const _Float16 *fb = src + (int64_t)blockIdx.y * planes * HWh;
+    const int full = HWh / 1024;
+    const int c_begin = blockIdx.x * chunks_per_wg, c_end = min(full, c_begin + chunks_per_wg);
+    for (int i = threadIdx.x; i < 256 * 22; i += 256) red[i] = 0;
+    __syncthreads();
+    unsigned tot = 0;
+    int tlo[16], thi[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tlo[k] = 0x5a5a5a5a ^ (lane * 0x01010101) ^ k; thi[k] = 0xa5a5a5a5 ^ (lane * 0x10101010) ^ k; }
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        const _Float16 *x = fb + (int64_t)c * 1024 + lane * 8;
+        auto load_group = [&](h8u (&v)[4][2], int p0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u < planes ? p0 + u : planes - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const h8u *>(x + (int64_t)p * HWh + j * 512));
+            }
+        };
+        auto count_group = [&](const h8u (&v)[4][2], int p0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u < planes) {
+                    unsigned a0 = 0, a1 = 0;
+                    if (MODE & 1) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const unsigned long long b = __ballot(v[u][j][k] > (_Float16)0.5f);
+                                const int lo = tlo[8 * j + k] & (int)(unsigned)b, hi = thi[8 * j + k] & (int)(unsigned)(b >> 32);
+                                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a0) : "v"(lo));
+                                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a1) : "v"(hi));
+                            }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const unsigned *w = reinterpret_cast<const unsigned *>(&v[u][j]);
+                            a0 |= w[0] | w[1];
+                            a1 |= w[2] | w[3];
+                        }
+                    }
+                    if (MODE & 2) { if (lane <= 20) atomicAdd(&red[(p0 + u) * 22 + lane], a0 + a1); }
+                    else tot += a0 + a1;
+                }
+            }
+        };
+        h8u va[4][2], vb[4][2];
+        load_group(va, 0);
+        for (int p0 = 0; p0 < planes; p0 += 8) {
+            if (p0 + 4 < planes) load_group(vb, p0 + 4);
+            count_group(va, p0);
+            if (p0 + 4 >= planes) break;
+            if (p0 + 8 < planes) load_group(va, p0 + 8);
+            count_group(vb, p0 + 4);
+        }
+    }
+    __syncthreads();
+    if (MODE & 2) tot += red[threadIdx.x];
+    if (tot == 0x12345678u) sink[blockIdx.x] = tot;
+}
+extern "C" __attribute__((visibility("default"))) int probe_tl_skeleton(const void *src, int B, int planes, int HWh, int wgs,
+                                                                        int mode, int lds_bytes, void *sink, void *stream) {
+    const int nchunks = HWh / 1024;
+    int splits = (wgs + B - 1) / B;
+    if (splits > (nchunks + 3) / 4) splits = (nchunks + 3) / 4;
+    const int cpw = (nchunks + splits - 1) / splits;
+    splits = (nchunks + cpw - 1) / cpw;
+    dim3 grid(splits, B);
+    if (lds_bytes < 256 * 22 * 4) lds_bytes = 256 * 22 * 4;
+#define TLS(M)                                                                                                      \
+    case M:                                                                                                         \
+        if (lds_bytes > 65536) hipFuncSetAttribute((const void *)tl_skeleton_kernel<M>,                             \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);          \
+        hipLaunchKernelGGL(tl_skeleton_kernel<M>, grid, dim3(256), lds_bytes, (hipStream_t)stream,                  \
+                           (const _Float16 *)src, planes, HWh, cpw, (unsigned *)sink);                              \
+        break;
+    switch (mode) { TLS(0) TLS(1) TLS(2) TLS(3) }
+#undef TLS
+    return (int)hipGetLastError();
+}
