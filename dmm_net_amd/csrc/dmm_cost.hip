@@ -484,7 +484,10 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
                      const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
                      int32_t *area_t2, int n0, int m0, int nt, int mt, int wap, int wat, hipStream_t stream) {
     const int nchunks = (HW + kChunk - 1) / kChunk;
-    static const int target_wgs = [] { const char *e = getenv("DMM_COST_TL_WGS"); return e ? atoi(e) : 2048; }();
+    // FEW, long-lived workgroups: every one zeroes and flushes its own [proposal][row] table (4200 entries at config 5),
+    // and this kernel's rate does not follow its occupancy (2 waves per SIMD stream as fast as 4).  Measured at config 5,
+    // ms per launch at 512 / 2048 / 8192 workgroups: 512 frames 2.42 / 2.48 / 2.53, 128 frames 0.68 / 0.71 / 0.71.
+    static const int target_wgs = [] { const char *e = getenv("DMM_COST_TL_WGS"); return e ? atoi(e) : 512; }();
     int splits = (target_wgs + B - 1) / B;
     const int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
     if (splits > max_splits) splits = max_splits;
