@@ -27,6 +27,7 @@ from typing import Callable, List, Optional
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .autograd import match_layer_batched
 from .match_model import MatchModel
 
@@ -85,8 +86,8 @@ class DMM_Model(nn.Module):
             # zeroes the feature rows -- and, transposed, the scattered output rows (:78-80) -- of slots i < O with
             # valid[i] == 0
             tf = tf * row_scale[:, :, None]
-        n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
-        m_valid = torch.tensor([0 if skip[b] else n_tplt[b] for b in range(B)], dtype=torch.int32, device=dev)
+        n_valid = _lib.small_to_device([int(p.shape[0]) for p in prop_m], torch.int32, dev)
+        m_valid = _lib.small_to_device([0 if skip[b] else n_tplt[b] for b in range(B)], torch.int32, dev)
         counts = None
         if packed is not None and targets is None:
             # the proposals come with their 1-bit (mask > 0.5) planes (emitted by the paste kernel): the cost pass
@@ -119,7 +120,7 @@ class DMM_Model(nn.Module):
         if all(all(v == 1 for v in r[:o]) for r, o in zip(rows, n_tplt)):
             return n_tplt, None
         scale = [[float(v) if i < o else 0.0 for i, v in enumerate(r)] for r, o in zip(rows, n_tplt)]
-        return n_tplt, torch.tensor(scale, dtype=torch.float32, device=tplt_valid_batch.device)
+        return n_tplt, _lib.small_to_device(scale, torch.float32, tplt_valid_batch.device)
 
     def _per_video(self, prop_feat, prop_m, prop_score, tplt_feat, mask_last_occurence, tplt_valid_batch, n_tplt,
                    targets, skip):

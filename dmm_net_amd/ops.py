@@ -72,11 +72,10 @@ class FramePlanes:
         self.counts = [int(t.shape[0]) for t in fixed]
         # one small H2D copy; frames without planes get a valid dummy address (never dereferenced: n_valid = 0)
         any_ptr = next((t.data_ptr() for t in fixed if t.shape[0]), 0)
-        self.table = torch.tensor([t.data_ptr() if t.shape[0] else any_ptr for t in fixed], dtype=torch.int64,
-                                  device=self.device)
+        self.table = _lib.small_to_device([t.data_ptr() if t.shape[0] else any_ptr for t in fixed], torch.int64, self.device)
 
     def n_valid(self) -> torch.Tensor:
-        return torch.tensor(self.counts, dtype=torch.int32, device=self.device)
+        return _lib.small_to_device(self.counts, torch.int32, self.device)
 
     def stacked(self) -> torch.Tensor:
         """[B, N, H, W] copy (zero planes beyond a frame's count) -- only for paths without a pointer-table kernel."""

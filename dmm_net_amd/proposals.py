@@ -90,7 +90,7 @@ def nms_batched(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor], t
     """Per-image NMS in one launch -> list of kept index tensors (descending score order)."""
     dev = boxes[0].device
     counts = [int(b.shape[0]) for b in boxes]
-    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+    offs = _lib.small_to_device([sum(counts[:i]) for i in range(len(counts) + 1)], torch.int32, dev)
     allb = torch.cat([b.float() for b in boxes], 0).contiguous()
     alls = torch.cat([s.float() for s in scores], 0).contiguous()
     keep = torch.empty((max(int(allb.shape[0]), 1),), dtype=torch.int32, device=dev)

@@ -28,8 +28,8 @@ def convert_to_roi_format(boxes: Sequence) -> torch.Tensor:
     (the per-image full + cat of the reference costs ~17 launches at 8 images, more than the ROI kernel itself)."""
     bbs = [(b.bbox if hasattr(b, "bbox") else b) for b in boxes]
     allb = (torch.cat(bbs, dim=0) if len(bbs) > 1 else bbs[0]).float()
-    ids = torch.tensor([float(i) for i, bb in enumerate(bbs) for _ in range(bb.shape[0])], dtype=torch.float32)
-    return torch.cat([ids.to(allb.device, non_blocking=True).unsqueeze(1), allb], dim=1)
+    ids = _lib.small_to_device([float(i) for i, bb in enumerate(bbs) for _ in range(bb.shape[0])], torch.float32, allb.device)
+    return torch.cat([ids.unsqueeze(1), allb], dim=1)
 
 
 def _arrays(feats):
