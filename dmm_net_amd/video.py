@@ -184,6 +184,14 @@ class FrameLoop:
         self.encoder, self.dmm, self.refine = encoder, dmm, refine
         self.nms_thresh, self.max_proposals = float(nms_thresh), int(max_proposals)
         self.mask_thresh, self.padding, self.pasted = float(mask_thresh), int(padding), bool(pasted)
+        self.lookahead = True                                    # proposals of frame t + 1 on a side stream (see run)
+        self._side = {}
+
+    def _side_stream(self, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
 
     # model_encoder.py:115-134
     def prepare_proposals(self, raw: Sequence, im_h: int, im_w: int, device):
@@ -212,9 +220,31 @@ class FrameLoop:
         n_frames = list(n_frames) if n_frames is not None else [T] * B
         history, state, mask_hist = [], None, None
         tplt_dict = tplt_valid = prev_mask = n_tplt = row_scale = None
+        # Proposal look-ahead.  A frame's proposals (paste, tight boxes, NMS, top-k) depend on nothing the loop computes,
+        # and their NMS ends in the step's only host sync (the kept counts).  On the main stream that sync drained
+        # the whole step and the GPU idled while the host enqueued the next one; here the proposals of frame t + 1 are
+        # prepared on a side stream AFTER frame t's work has been enqueued, so the sync waits for a few short kernels
+        # only and the main stream never runs dry.
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        side = self._side_stream(dev) if main is not None and self.lookahead else None
+
+        def prepare(tt):
+            raw = [proposals[b][tt] if len(proposals[b]) > tt else proposals[b][-1] for b in range(B)]
+            if side is None:
+                return self.prepare_proposals(raw, H, W, dev), None
+            with torch.cuda.stream(side):
+                out = self.prepare_proposals(raw, H, W, dev)
+                for bl in out:                                   # allocated on `side`, consumed on `main`
+                    for v in [bl.bbox] + [bl.get_field(f) for f in bl.fields()]:
+                        if isinstance(v, torch.Tensor) and v.is_cuda:
+                            v.record_stream(main)
+                return out, side.record_event()
+
+        if side is not None:
+            side.wait_stream(main)                               # inputs the caller produced on the main stream
+        ahead = prepare(0) if T > 0 else None
         for t in range(T):
             extra = [n <= t for n in n_frames]
-            raw = [proposals[b][t] if len(proposals[b]) > t else proposals[b][-1] for b in range(B)]
             x = frames[:, t]
             if t == 0:
                 y_mask = first_masks.float().view(B, O, H * W)
@@ -222,9 +252,9 @@ class FrameLoop:
                 y_mask = targets[:, t].float().view(B, O, H * W)
             else:
                 y_mask = first_masks.new_zeros((B, O, H * W), dtype=torch.float32)
-            # proposals first: their NMS ends in the step's only host sync (kept counts), which then waits for a few
-            # short kernels instead of the encoder; everything after it is enqueued without another sync
-            props = self.prepare_proposals(raw, H, W, dev)
+            props, ready = ahead
+            if ready is not None:
+                main.wait_event(ready)
             features = self.encoder(x)
             if t == 0:                                                   # forward_timestep_init, :215-225
                 tpl, valid = [], []
@@ -264,4 +294,6 @@ class FrameLoop:
                     if not extra[b]:
                         on_labels(b, t, labels[b])
             history.append(outs)
+            if t + 1 < T:
+                ahead = prepare(t + 1)                           # host sync inside: frame t's work is already queued
         return history

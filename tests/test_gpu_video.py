@@ -125,6 +125,13 @@ def test_frame_loop_batched_equals_per_video_and_writes_labels(tmp_path):
             assert torch.equal(h1[t][0], hist[t][b]), (b, t)
         for t in range(n_frames[b]):
             assert torch.equal(solo[t], got[(b, t)])
+    # the proposal look-ahead (frame t + 1 prepared on a side stream) changes no result
+    plain = make_loop()
+    plain.lookahead = False
+    for rep in range(3):                                                 # a race would not show every time
+        h0 = plain.run(frames, first, props, n_frames)
+        h2 = make_loop().run(frames, first, props, n_frames)
+        assert all(torch.equal(a, c) and torch.equal(a, d) for a, c, d in zip(hist, h0, h2)), rep
     # output format: one palette PNG per frame, read back identically
     Image = pytest.importorskip("PIL.Image")
     f = tmp_path / "merged" / "v0" / "00001.png"
