@@ -378,19 +378,15 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
 // ---------------------------------------------------------------------------------------------
 // Layer kernel: iou + mix with the cosine table + pad + solver + scores.  grid = B, block = 64*NG.
 // ---------------------------------------------------------------------------------------------
+// One frame: red_buf [2 * NG * (MT + 1)], xbuf [MT * 64 * NG], rsbuf [MT + 1] floats of LDS.
 template <int MT, int NG, bool EXACT>
-// (4-wave instantiations up to 20 rows are capped at 256 registers -- 4 spilled -- so that two frames share a CU:
-// 20 x 200 needed 256 VGPRs + 12 AGPRs = one wave per SIMD, i.e. 256 frames filled the chip and 512 took twice as long)
-__global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_match_kernel(
+__device__ __forceinline__ void relax_match_body(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final) {
-    __shared__ float red_buf[2 * NG * (MT + 1)];
-    __shared__ float xbuf[MT * 64 * NG];
-    __shared__ float rsbuf[MT + 1];
+    float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf) {
     const int b = blockIdx.x;
     const int col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
@@ -499,6 +495,57 @@ __global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_
     // live rows, dead proposal columns of sim: zeros
     if (!has_prop && col < N)
         for (int i = 0; i < Mb; ++i) sim_b[(int64_t)i * N + col] = 0.0f;
+}
+
+template <int MT, int NG, bool EXACT>
+// (4-wave instantiations up to 20 rows are capped at 256 registers -- 4 spilled -- so that two frames share a CU:
+// 20 x 200 needed 256 VGPRs + 12 AGPRs = one wave per SIMD, i.e. 256 frames filled the chip and 512 took twice as long)
+__global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_match_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final) {
+    __shared__ float red_buf[2 * NG * (MT + 1)];
+    __shared__ float xbuf[MT * 64 * NG];
+    __shared__ float rsbuf[MT + 1];
+    relax_match_body<MT, NG, EXACT>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
+                                    is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, red_buf,
+                                    xbuf, rsbuf);
+}
+
+// Ragged batches of small problems (the product: up to maxseqlen = 5 templates per video, a different count per video):
+// one wave per frame picks the EXACT-row-count body of ITS frame.  The guarded MT = 8 instantiation carried 8 rows and a
+// row guard on every element for every frame (5 templates, eval setting 40 x 5: 183 us per solve; exact: ~120).
+template <int MTMAX>
+__global__ __launch_bounds__(64) void relax_match_ragged_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final) {
+    __shared__ float red_buf[2 * (MTMAX + 1)];
+    __shared__ float xbuf[MTMAX * 64];
+    __shared__ float rsbuf[MTMAX + 1];
+    const int Mb = m_valid ? m_valid[blockIdx.x] : M;
+#define DMM_BODY(K)                                                                                                     \
+    case K:                                                                                                             \
+        if constexpr (K <= MTMAX)                                                                                       \
+            relax_match_body<K, 1, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, \
+                                         prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,       \
+                                         X_final, red_buf, xbuf, rsbuf);                                                \
+        break;
+    switch (Mb) {
+        DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
+        default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
+            relax_match_body<1, 1, false>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
+                                          is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final,
+                                          red_buf, xbuf, rsbuf);
+            break;
+    }
+#undef DMM_BODY
 }
 
 // Solver-only kernel on a caller-provided C [B, n, m].
@@ -750,6 +797,12 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
                                           w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,
                                           iters_out, X_final, (hipStream_t)stream);
     const bool exact_ok = (m_valid == nullptr);   // every frame has exactly M templates
+    if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
+        hipLaunchKernelGGL((dmm::relax_match_ragged_kernel<8>), dim3(B), dim3(64), 0, (hipStream_t)stream, cos_in, inter,
+                           area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out,
+                           Rb_out, match_score, det_score, iters_out, X_final);
+        return dmm::check_launch();
+    }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                    \
     hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
                        cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, \

@@ -222,6 +222,46 @@ def test_solver_batch_matches_oracle(solver_kernel):
             assert np.array_equal(r["X"][b].cpu().numpy(), o["X"]), (n, m, b)
 
 
+@pytest.mark.parametrize("is_test", [0, 1])
+def test_ragged_template_counts_equal_dense_single_frame_calls(is_test):
+    """dmm_relax_match_f32 on a ragged batch of small problems (M <= 8, a different live template / proposal count per
+    frame: the per-frame exact-body kernel) == one dense call per frame on its live [Mb, Nb] block, bit for bit --
+    including dead frames (zeros) and the rows / columns beyond the live block."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for (M, N, mi, pi) in [(5, 50, 40, 5), (8, 20, 20, 5), (3, 7, 10, 3), (5, 4, 20, 5)]:
+        mv = [5, 3, 0, 1, 8, 2, 4, 7, 6, 5]
+        mv = [min(v, M) for v in mv]
+        nv = [N, max(N - 3, 1), N, 1, N, 0, 2, N, max(N // 2, 1), N]
+        B = len(mv)
+        cos = torch.from_numpy(rng.uniform(-1, 1, (B, M, N)).astype(np.float32)).to(DEV)
+        area_p = torch.from_numpy(rng.integers(50, 400, (B, N)).astype(np.int32)).to(DEV)
+        area_t = torch.from_numpy(rng.integers(50, 400, (B, M)).astype(np.int32)).to(DEV)
+        inter = (torch.minimum(area_p[:, None, :], area_t[:, :, None]).float()
+                 * torch.from_numpy(rng.random((B, M, N), dtype=np.float32)).to(DEV)).to(torch.int32)
+        sc = torch.from_numpy(rng.random((B, N), dtype=np.float32)).to(DEV)
+        kw = dict(score_weight=0.3, max_iter=mi, proj_iter=pi, lr=0.1, is_test=is_test)
+        r = ops.relax_match(cos, inter, area_p, area_t, sc, n_valid=torch.tensor(nv, dtype=torch.int32, device=DEV),
+                            m_valid=torch.tensor(mv, dtype=torch.int32, device=DEV), **kw)
+        Pp = ops.padded_width(N, M)
+        for b in range(B):
+            mb, nb = mv[b], nv[b]
+            if mb == 0 or nb == 0:
+                assert float(r["Rb"][b].abs().sum()) == 0.0 and float(r["sim"][b].abs().sum()) == 0.0, (M, N, b)
+                assert float(r["match_score"][b].abs().sum()) == 0.0 and int(r["iters"][b]) == 0, (M, N, b)
+                continue
+            d = ops.relax_match(cos[b:b + 1, :mb, :nb].contiguous(), inter[b:b + 1, :mb, :nb].contiguous(),
+                                area_p[b:b + 1, :nb].contiguous(), area_t[b:b + 1, :mb].contiguous(),
+                                sc[b:b + 1, :nb].contiguous(), **kw)
+            pp = ops.padded_width(nb, mb)
+            assert int(r["iters"][b]) == int(d["iters"][0]), (M, N, b)
+            assert torch.equal(r["sim"][b, :mb, :nb], d["sim"][0]), (M, N, b)
+            assert torch.equal(r["R"][b, :mb, :pp], d["R"][0]) and torch.equal(r["Rb"][b, :mb, :pp], d["Rb"][0]), (M, N, b)
+            assert torch.equal(r["match_score"][b, :mb], d["match_score"][0]), (M, N, b)
+            assert torch.equal(r["det_score"][b, :mb], d["det_score"][0]), (M, N, b)
+            assert float(r["Rb"][b, mb:].abs().sum()) == 0.0 and float(r["Rb"][b, :, pp:].abs().sum()) == 0.0, (M, N, b)
+            assert float(r["match_score"][b, mb:].abs().sum()) == 0.0
+
+
 # ------------------------------------------------------------------------------------ whole layer
 @pytest.mark.parametrize("kind", ["structured", "uniform"])
 def test_g2_config1(kind, solver_kernel):
