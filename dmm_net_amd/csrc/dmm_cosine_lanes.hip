@@ -218,13 +218,22 @@ __device__ __forceinline__ void cf_step(const float *__restrict__ pp, const floa
 }
 
 // grid = (parts, B), block = 64 * nw threads; wave (part, wave) takes the steps part * nw + wave, + parts * nw, ...
+// zero_ptr / zero_words: an unrelated buffer the launch clears on the side (dmm_match_forward: the IoU count tables the
+// next kernel accumulates into -- saves the memset node in front of it)
 template <int LPC>
 __global__ __launch_bounds__(512) void cosine_lanes_kernel(const float *__restrict__ feat_t,
                                                            const float *__restrict__ feat_p, int N, int M,
-                                                           float *__restrict__ cos_out) {
+                                                           float *__restrict__ cos_out, int32_t *__restrict__ zero_ptr,
+                                                           int64_t zero_words) {
     typedef CfGeom<LPC> G;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (zero_ptr) {
+        const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = blockIdx.x + (int64_t)gridDim.x * blockIdx.y;
+        const int64_t per = (zero_words + nblk - 1) / nblk, lo = blk * per;
+        const int64_t hi = lo + per < zero_words ? lo + per : zero_words;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) zero_ptr[i] = 0;
+    }
     float *Q = lds;                                          // [M][PITCH] normalised templates
     float *nq = Q + (size_t)M * G::PITCH;                    // [32] their clamped norms
     float *wb = nq + 32 + (size_t)wave * G::WAVE_FLOATS;     // this wave's buffer
@@ -272,7 +281,8 @@ __global__ __launch_bounds__(512) void cosine_lanes_kernel(const float *__restri
 }
 
 template <int LPC>
-static int launch_lanes(const float *feat_t, const float *feat_p, int B, int N, int M, float *cos_out, hipStream_t stream) {
+static int launch_lanes(const float *feat_t, const float *feat_p, int B, int N, int M, float *cos_out, int32_t *zero_ptr,
+                        int64_t zero_words, hipStream_t stream) {
     typedef CfGeom<LPC> G;
     const int A = N >= 8 ? 32 * (N / 32) : 4 * (N / 4);     // torder::outer_class_bound(N)
     const int S = (A + 7) / 8 + (N - A + 7) / 8;
@@ -293,18 +303,19 @@ static int launch_lanes(const float *feat_t, const float *feat_p, int B, int N, 
                                            (int)lds);
         if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL((cosine_lanes_kernel<LPC>), dim3(parts, B), dim3(64 * nw), lds, stream, feat_t, feat_p, N, M, cos_out);
+    hipLaunchKernelGGL((cosine_lanes_kernel<LPC>), dim3(parts, B), dim3(64 * nw), lds, stream, feat_t, feat_p, N, M, cos_out,
+                       zero_ptr, zero_words);
     return check_launch();
 }
 
 // DMM_ERR_UNSUPPORTED outside the envelope (D in {256, 512, 1024}); the caller then takes the tile kernel.
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
-                        hipStream_t stream) {
+                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words) {
     if (N < 2 || M < 1 || M > 32 || B > 65535) return DMM_ERR_UNSUPPORTED;
     switch (D) {
-        case 256: return launch_lanes<16>(feat_t, feat_p, B, N, M, cos_out, stream);
-        case 512: return launch_lanes<32>(feat_t, feat_p, B, N, M, cos_out, stream);
-        case 1024: return launch_lanes<64>(feat_t, feat_p, B, N, M, cos_out, stream);
+        case 256: return launch_lanes<16>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
+        case 512: return launch_lanes<32>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
+        case 1024: return launch_lanes<64>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
         default: return DMM_ERR_UNSUPPORTED;
     }
 }

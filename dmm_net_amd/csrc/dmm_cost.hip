@@ -503,12 +503,17 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     return check_launch();
 }
 
+// set (per thread, for the duration of one call) by iou_counts_prezeroed
+static thread_local bool g_tables_prezeroed = false;
+
 template <typename T>
 static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t2, int B, int N, int M, int HW,
                             int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
                             const int32_t *n_valid, const int32_t *m_valid, int32_t *inter, int32_t *area_p,
                             int32_t *area_t, int32_t *inter2, int32_t *area_t2, hipStream_t stream) {
-    if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
+    if (g_tables_prezeroed && !masks_t2) {
+        // dmm_match_forward: the feature-similarity launch in front of this one already cleared the three tables
+    } else if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
         // the three tables are one contiguous block (dmm_match_forward's workspace): one memset node
         DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
     } else {
@@ -641,6 +646,20 @@ extern "C" int dmm_iou_counts(const void *masks_p, const void *masks_t, int dtyp
     return iou_counts_dispatch(masks_p, masks_t, nullptr, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, 0, 0, n_valid,
                                m_valid, inter, area_p, area_t, nullptr, nullptr, stream);
 }
+
+// dmm_iou_counts for a caller that has ALREADY zeroed inter / area_p / area_t on this stream (dmm_match_forward: the
+// feature-similarity kernel clears them, one memset node less in front of the solver's dependent chain)
+namespace dmm {
+int iou_counts_prezeroed(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW, int64_t sp_b,
+                         int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid,
+                         int32_t *inter, int32_t *area_p, int32_t *area_t, dmm_stream_t stream) {
+    g_tables_prezeroed = true;
+    const int rc = dmm_iou_counts(masks_p, masks_t, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter,
+                                  area_p, area_t, stream);
+    g_tables_prezeroed = false;
+    return rc;
+}
+}  // namespace dmm
 
 extern "C" int dmm_iou_counts_dual(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, int B,
                                    int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,

@@ -550,7 +550,16 @@ class ForwardPlan:
         sp_b, sp_n, st_b, st_m = strides
         score_weight, max_iter, proj_iter, lr, is_test = cfg
         main = torch.cuda.current_stream(self.device)
-        side = self.side if self.graph_fork else main
+        if not self.graph_fork:
+            # one chain: the fused C call (its feature-similarity launch also clears the count tables: no memset node)
+            _lib.check(L.dmm_match_forward(
+                _ptr(masks_p), _ptr(masks_t), dt, _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M, HW, D, sp_b, sp_n,
+                st_b, st_m, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter), float(lr),
+                int(is_test), _ptr(self.full_outmask), _ptr(self.match_score), _ptr(self.det_score), _ptr(self.sim),
+                _ptr(self.R), _ptr(self.Rb), _ptr(self.iters), _ptr(self.workspace), self.ws_bytes, main.cuda_stream),
+                "dmm_match_forward (graph capture)")
+            return
+        side = self.side
         inter, ap, at = self._tables(0)
         if self.graph_fork:
             side.wait_stream(main)
