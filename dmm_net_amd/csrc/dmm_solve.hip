@@ -126,57 +126,71 @@ __device__ __forceinline__ void row_sums_torch_order(const float *xbuf, int n, i
     }
     __syncthreads();                                   // rsbuf complete, xbuf free again
 }
-// Single-wave variant (NG == 1): the 8 group results of a pass are picked out of the wave with v_readlane, so the
-// second LDS round trip (store rs, barrier, reload) disappears; rs[] comes back wave-uniform in registers.
-template <int MT>
-__device__ __forceinline__ void row_sums_torch_order_wave(const float *xbuf, int n, int m, float (&rs)[MT]) {
-    __syncthreads();                                   // xbuf complete (one wave: just drains the LDS queue)
+// Single-wave variant (NG == 1).  The rows live in their OWN buffer with a fixed stride of kRowStride = 72 floats: every
+// lane writes its column (dead columns carry exact zeros) and slots 64..71 are zeroed once, so a row is zero-padded up
+// to its stride.  That makes every address a compile-time constant and lets the tail of ATen's inner sum (the m % 8
+// scalars behind the vectorised part) be 7 unconditional adds -- the slots past column m add exact zeros.  The shape
+// of the vectorised part (m / 8 vectors: which go to the four ILP accumulators, which are appended to the first)
+// is a compile-time parameter VS picked by ONE wave-uniform switch; a version with m as a run-time value throughout
+// spent 60 of a sweep's 370 instructions on selects and read 15 words per row where 8 are needed (with m = 50 known
+// at compile time the sweep is 239 instructions).  The 8 group results of a pass are picked out of the wave with
+// v_readlane: rs[] comes back wave-uniform in registers.  Same add order as torder::inner_sum_group8_small.
+constexpr int kRowStride = 72;
+
+template <int MT, int VS>
+__device__ __forceinline__ void row_sums_wave_vs(const float *rowbuf, int n, int m, float (&rs)[MT]) {
     const int lane = threadIdx.x & 63, l = lane & 7, g = lane >> 3;
-    // m <= 64 here (one wave).  Same order as torder::inner_sum_group8_small, but every LDS word a group can need --
-    // the 8 vector slots x[8 i + l] and up to 7 tail scalars -- is fetched up front in one batch (the loop form kept
-    // ONE ds_read in flight per step: ~5 serialized LDS round trips per pass); the adds then follow the ATen order
-    // under wave-uniform conditions on m.  Reads beyond the row stay inside xbuf and are never used.
-    const int vs = m >> 3, gq = vs >> 2, tail0 = vs << 3, ntail = m - tail0;
 #pragma unroll
     for (int p = 0; p < (MT + 7) / 8; ++p) {
         const int r = p * 8 + g;
-        const int rr = r < n ? r : n - 1;
-        const float *x = xbuf + rr * m;
-        float v[8], t[7];
+        const float *x = rowbuf + (r < n ? r : n - 1) * kRowStride;
+        float v[VS > 0 ? VS : 1], t[7];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = x[8 * i + l];
+        for (int i = 0; i < VS; ++i) v[i] = x[8 * i + l];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int idx = rr * m + tail0 + k;
-            t[k] = xbuf[idx < MT * 64 ? idx : MT * 64 - 1];
-        }
+        for (int k = 0; k < 7; ++k) t[k] = x[8 * VS + k];        // zero from column m on
         float s;
-        if (m < torder::TV) {                          // scalar_inner_sum: ILP-4 over single elements (= the tail array)
+        if (VS == 0) {                                 // scalar_inner_sum (m < 8): ILP-4 over single elements
             float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-            if (m >= 4) { p0 = p0 + t[0]; p1 = p1 + t[1]; p2 = p2 + t[2]; p3 = p3 + t[3]; }
-            const int b4 = m & ~3;
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-                if (k >= b4 && k < m) p0 = p0 + t[k];
+            if (m >= 4) {
+                p0 = p0 + t[0]; p1 = p1 + t[1]; p2 = p2 + t[2]; p3 = p3 + t[3];
+                p0 = p0 + t[4]; p0 = p0 + t[5]; p0 = p0 + t[6];
+            } else {
+                p0 = p0 + t[0]; p0 = p0 + t[1]; p0 = p0 + t[2];
+            }
             p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
             s = p0;
         } else {
+            constexpr int GQ = VS / 4;
             float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-            if (gq >= 1) { p0 = p0 + v[0]; p1 = p1 + v[1]; p2 = p2 + v[2]; p3 = p3 + v[3]; }
-            if (gq >= 2) { p0 = p0 + v[4]; p1 = p1 + v[5]; p2 = p2 + v[6]; p3 = p3 + v[7]; }
+            if (GQ >= 1) { p0 = p0 + v[0]; p1 = p1 + v[1]; p2 = p2 + v[2]; p3 = p3 + v[3]; }
+            if (GQ >= 2) { p0 = p0 + v[4]; p1 = p1 + v[5]; p2 = p2 + v[6]; p3 = p3 + v[7]; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i >= 4 * gq && i < vs) p0 = p0 + v[i];
+            for (int i = 4 * GQ; i < VS; ++i) p0 = p0 + v[i];
             p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;   // vec[l]
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
-                if (k < ntail) acc = acc + t[k];
+            for (int k = 0; k < 7; ++k) acc = acc + t[k];
             s = torder::add_group8_seq(acc, p0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (p * 8 + k < MT) rs[p * 8 + k] = readlane_f32(s, 8 * k);
+    }
+}
+template <int MT>
+__device__ __forceinline__ void row_sums_torch_order_wave(const float *rowbuf, int n, int m, float (&rs)[MT]) {
+    __syncthreads();                                   // rowbuf complete (one wave: just drains the LDS queue)
+    switch (m >> 3) {                                  // m <= 64 here (one wave)
+        case 0: row_sums_wave_vs<MT, 0>(rowbuf, n, m, rs); break;
+        case 1: row_sums_wave_vs<MT, 1>(rowbuf, n, m, rs); break;
+        case 2: row_sums_wave_vs<MT, 2>(rowbuf, n, m, rs); break;
+        case 3: row_sums_wave_vs<MT, 3>(rowbuf, n, m, rs); break;
+        case 4: row_sums_wave_vs<MT, 4>(rowbuf, n, m, rs); break;
+        case 5: row_sums_wave_vs<MT, 5>(rowbuf, n, m, rs); break;
+        case 6: row_sums_wave_vs<MT, 6>(rowbuf, n, m, rs); break;
+        case 7: row_sums_wave_vs<MT, 7>(rowbuf, n, m, rs); break;
+        default: row_sums_wave_vs<MT, 8>(rowbuf, n, m, rs); break;
     }
 }
 __device__ __forceinline__ float norm_torch_order(const float *xbuf, int cnt, float *slot) {
@@ -210,6 +224,12 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                                           RelaxTape tape = RelaxTape{nullptr, nullptr}) {
     int tape_pos = 0;
     const int n = EXACT ? MT : n_rt;
+    // NG == 1: the zero-padded row buffer of row_sums_torch_order_wave
+    __shared__ float rowbuf[NG == 1 ? MT * kRowStride : 1];
+    if (NG == 1 && threadIdx.x < 8) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rowbuf[i * kRowStride + 64 + threadIdx.x] = 0.0f;
+    }
 #define DMM_ROW(i) (EXACT || (i) < n)
     const bool live = col < m;
     const float fn = (float)n, fm = (float)m;
@@ -334,14 +354,17 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 x = y + P2[i];
                 X[i] = x;
             }
-            if (live) {
+            if (NG == 1) {                                        // every lane: dead columns hold exact zeros
+#pragma unroll
+                for (int i = 0; i < MT; ++i) rowbuf[i * kRowStride + col] = X[i];
+            } else if (live) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) xbuf[i * m + col] = X[i];
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
             float rsv[MT];
             if (NG == 1) {
-                row_sums_torch_order_wave<MT>(xbuf, n, m, rsv);
+                row_sums_torch_order_wave<MT>(rowbuf, n, m, rsv);
             } else {
                 row_sums_torch_order<NG>(xbuf, n, m, rsbuf);
 #pragma unroll
