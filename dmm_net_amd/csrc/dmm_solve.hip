@@ -33,8 +33,8 @@ bool use_row_split(int B, int M, int Pp) {
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
     // measured (tools/solver_timing.py, 20 x 5 iterations, us per solve of one frame, thread-per-column vs row-split):
-    // 5 x 50: 61 vs 82, 10 x 50: 102 vs 99, 16 x 64: 124 vs 112; beyond ~256 frames in flight the 4x waves of the
-    // row-split form cost throughput (10 x 50, B = 1024: 109 vs 162 us per launch)
+    // 5 x 50: 61 vs 83, 10 x 50: 89 vs 99 (102 before the zero-padded row buffer), 16 x 64: 115 vs 112; beyond ~256
+    // frames in flight the 4x waves of the row-split form cost throughput (10 x 50, B = 1024: 95 vs 162 us per launch)
     return M >= 12 && B <= 256;
 }
 
