@@ -26,7 +26,7 @@ SYMBOLS = (
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
-    "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32",
+    "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad",
 )
 
 _lib = None
@@ -99,6 +99,7 @@ def load():
     L.dmm_nms_f32.argtypes = [vp, vp, vp, c_int, c_int, c_float, c_int, vp, vp, vp]
     L.dmm_mask_boxes_f32.argtypes = [vp, c_int, c_int, c_int, c_i64, c_float, vp, vp, vp]
     L.dmm_merge_labels_f32.argtypes = [vp, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp]
+    L.dmm_ragged_pad.argtypes = [vp, vp, c_int, c_int, c_i64, vp, vp]
     L.dmm_mask_mix.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_i64,
                                c_i64, vp]
     L.dmm_bias_act_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp]
@@ -116,7 +117,7 @@ def load():
               "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
               "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks",
-              "dmm_mask_boxes_f32", "dmm_merge_labels_f32"):
+              "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad"):
         getattr(L, f).restype = c_int
     if L.dmm_abi_version() != 1:
         raise DmmError("libdmm_match.so ABI version mismatch")

@@ -137,3 +137,39 @@ extern "C" int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, in
                        HW, stride_b, stride_o, o_valid, labels);
     return dmm::check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// ragged_pad_kernel: out[b, i, :] = src_b[i, :] for i < counts[b], zeros up to P_max -- the batching step of the
+// per-video driver (reference: one MatchModel call per video, dmm/modules/dmm_model.py:62-82; here the videos of a step
+// run as one ragged launch and their per-video feature / score / packed-plane blocks are stacked first).  One launch
+// for the whole batch instead of a zero fill + one copy per video (12 launches per frame step in the frame loop).
+// Rows are moved as dwords; src_b = table[b] (device pointer table, like the *_frames entries).
+// ---------------------------------------------------------------------------------------------
+namespace dmm {
+__global__ __launch_bounds__(256) void ragged_pad_kernel(const uint32_t *const *__restrict__ table,
+                                                         const int32_t *__restrict__ counts, int P_max,
+                                                         int64_t row_dwords, uint32_t *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int64_t per_frame = (int64_t)P_max * row_dwords;
+    const int64_t live = (int64_t)min(counts[b], P_max) * row_dwords;
+    typedef const __attribute__((address_space(1))) uint32_t *gptr;
+    const gptr src = (gptr)table[b];
+    uint32_t *dst = out + (int64_t)b * per_frame;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = i < live ? src[i] : 0u;
+}
+}  // namespace dmm
+
+extern "C" int dmm_ragged_pad(const void *const *src_table, const int32_t *counts, int B, int P_max, int64_t row_bytes,
+                              void *out, dmm_stream_t stream) {
+    if (B < 0 || P_max < 0 || row_bytes < 0 || (row_bytes & 3)) return DMM_ERR_BAD_ARG;
+    if (B == 0 || P_max == 0 || row_bytes == 0) return DMM_OK;
+    if (!src_table || !counts || !out) return DMM_ERR_BAD_ARG;
+    if (B > 65535) return DMM_ERR_UNSUPPORTED;
+    const int64_t per_frame = (int64_t)P_max * (row_bytes / 4);
+    int64_t blocks = (per_frame + 1023) / 1024;                 // ~4 dwords per thread
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dmm::ragged_pad_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t *const *)src_table, counts, P_max, row_bytes / 4, (uint32_t *)out);
+    return dmm::check_launch();
+}

@@ -68,15 +68,24 @@ class DMM_Model(nn.Module):
         dev = mask_last_occurence.device
         D = prop_feat[0].shape[1]
         Pmax = max(int(p.shape[0]) for p in prop_m)
-        pf = prop_feat[0].new_zeros((B, Pmax, D))
-        sc = mask_last_occurence.new_zeros((B, Pmax))
         for b in range(B):
             P = prop_m[b].shape[0]
             assert prop_m[b].shape[-2:] == mask_last_occurence[b].shape[-2:], \
                 "get {} {}".format(prop_m[b].shape[-2:], mask_last_occurence[b].shape[-2:])
             assert prop_feat[b].shape[0] == P, "get {} {}".format(P, prop_feat[b].shape[0])
-            pf[b, :P] = prop_feat[b]
-            sc[b, :P] = prop_score[b]
+        n_valid = _lib.small_to_device([int(p.shape[0]) for p in prop_m], torch.int32, dev)
+        if dev.type == "cuda" and not any(t.requires_grad for t in prop_feat):
+            # inference: the per-video blocks are stacked by one launch each (a zero fill + one copy per video before)
+            from . import ops
+            pf = ops.ragged_pad([f.float() for f in prop_feat], Pmax, n_valid)
+            sc = ops.ragged_pad([s_.float().reshape(-1, 1) for s_ in prop_score], Pmax, n_valid).view(B, Pmax)
+        else:
+            pf = prop_feat[0].new_zeros((B, Pmax, D))
+            sc = mask_last_occurence.new_zeros((B, Pmax))
+            for b in range(B):
+                P = prop_m[b].shape[0]
+                pf[b, :P] = prop_feat[b]
+                sc[b, :P] = prop_score[b]
         # the mask planes stay where they are: one tensor per video, handed to the kernels as a pointer table (the
         # round-1 driver copied them into a [B, Pmax, H, W] batch: 2 x 13 MB per video in front of a 15.6 MB cost pass)
         pm = list(prop_m)
@@ -86,7 +95,6 @@ class DMM_Model(nn.Module):
             # zeroes the feature rows -- and, transposed, the scattered output rows (:78-80) -- of slots i < O with
             # valid[i] == 0
             tf = tf * row_scale[:, :, None]
-        n_valid = _lib.small_to_device([int(p.shape[0]) for p in prop_m], torch.int32, dev)
         m_valid = _lib.small_to_device([0 if skip[b] else n_tplt[b] for b in range(B)], torch.int32, dev)
         counts = None
         if packed is not None and targets is None:
@@ -94,10 +102,7 @@ class DMM_Model(nn.Module):
             # counts on those -- 1/32 of the proposal bytes, identical integer tables -- and the templates are packed
             # on the fly (one read of the F planes, what the float kernel would have read anyway)
             from . import ops
-            wd = ops.pack_words(H * W)
-            pk = packed[0].new_zeros((B, Pmax, wd))
-            for b in range(B):
-                pk[b, :packed[b].shape[0]] = packed[b]
+            pk = ops.ragged_pad(list(packed), Pmax, n_valid)
             counts = ops.iou_counts_packed(pk, ops.pack_masks(mask_last_occurence.float()), H * W, n_valid, m_valid)
         cfg = self.match_layer
         full, ms, ds, loss, _ = match_layer_batched(

@@ -133,6 +133,29 @@ def pack_words(HW: int) -> int:
     return 4 * ((HW + 255) // 256)
 
 
+def ragged_pad(blocks, P_max: int, counts: torch.Tensor) -> torch.Tensor:
+    """Per-video blocks [P_b, ...] (same trailing shape and dtype, 4-byte multiples per row) -> [B, P_max, ...] with
+    zeros from row P_b on, in ONE launch (``dmm_ragged_pad``): the batching step of the per-video driver.
+    counts: [B] int32 on the device (= the n_valid the ragged kernels take anyway)."""
+    blocks = [b.contiguous() for b in blocks]
+    first = blocks[0]
+    _need_gpu(first, counts)
+    tail = tuple(first.shape[1:])
+    row_bytes = first.element_size()
+    for d in tail:
+        row_bytes *= int(d)
+    out = torch.empty((len(blocks), int(P_max)) + tail, dtype=first.dtype, device=first.device)
+    if row_bytes % 4 != 0 or any(tuple(b.shape[1:]) != tail or b.dtype != first.dtype for b in blocks):
+        raise ValueError("ragged_pad: blocks must share dtype and trailing shape, rows of a multiple of 4 bytes")
+    any_ptr = next((b.data_ptr() for b in blocks if b.shape[0]), 0)
+    table = _lib.small_to_device([b.data_ptr() if b.shape[0] else any_ptr for b in blocks], torch.int64, first.device)
+    with torch.cuda.device(first.device):
+        rc = _lib.load().dmm_ragged_pad(_ptr(table), _ptr(counts), len(blocks), int(P_max), row_bytes, _ptr(out),
+                                        _stream(first))
+    _lib.check(rc, "dmm_ragged_pad")
+    return out                                        # (the blocks are read in stream order: no keep-alive needed)
+
+
 def pack_masks(masks: torch.Tensor) -> torch.Tensor:
     """[B,K,H,W] soft masks -> [B,K,words] int64 bit planes of (x > 0.5) in the library's ballot layout."""
     _need_gpu(masks)

@@ -303,6 +303,13 @@ DMM_API int dmm_mask_boxes_f32(const float *masks, int R, int H, int W, int64_t 
 DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64_t stride_b, int64_t stride_o,
                                  const int32_t *o_valid, uint8_t *labels, dmm_stream_t stream);
 
+/* dmm_ragged_pad: the batching step of the per-video driver (the reference loops MatchModel over the videos,
+ *   dmm/modules/dmm_model.py:62-82 / :115-139; here they run as one ragged launch): out[b, i, :] = src_table[b][i, :] for
+ *   i < counts[b], zeros up to P_max.  src_table: B device pointers (device memory) to contiguous [counts[b], row_bytes]
+ *   blocks; counts [B] int32 (device); row_bytes % 4 == 0; out [B, P_max, row_bytes]. */
+DMM_API int dmm_ragged_pad(const void *const *src_table, const int32_t *counts, int B, int P_max, int64_t row_bytes,
+                           void *out, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (9) Encoder epilogue (inference, channels-last bf16): x[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])) in place,
  * one pass, fp32 arithmetic, one rounding.  What remains of conv -> BatchNorm -> ReLU (dmm/modules/base.py:43-54,

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 import oracle
 from conftest import golden
 from dmm_net_amd import proposals as prop
-from dmm_net_amd import synth, video
+from dmm_net_amd import _lib, ops, synth, video
 from dmm_net_amd.dmm_model import DMM_Model
 from dmm_net_amd.roi_features import FeatureExtractor
 
@@ -137,3 +137,30 @@ def test_frame_loop_batched_equals_per_video_and_writes_labels(tmp_path):
     f = tmp_path / "merged" / "v0" / "00001.png"
     video.save_label_png(got[(0, 1)], str(f))
     assert np.array_equal(np.array(Image.open(str(f))), got[(0, 1)].cpu().numpy())
+
+
+def test_ragged_pad_stacks_per_video_blocks_in_one_launch():
+    """dmm_ragged_pad: out[b, i] = block_b[i] for i < counts[b], zeros up to P_max -- feature rows (fp32), scores (one
+    float per row), packed planes (int64 words), empty videos, and the status codes of bad arguments."""
+    rng = np.random.default_rng(3)
+    for (tail, dtype) in [((512,), torch.float32), ((1,), torch.float32), ((1017,), torch.int64), ((3, 5), torch.float32),
+                          ((2,), torch.bfloat16)]:
+        counts = [7, 0, 50, 1, 23]
+        blocks = []
+        for c in counts:
+            a = rng.standard_normal((c,) + tail).astype(np.float32) * 100
+            blocks.append(torch.from_numpy(a).to(DEV).to(dtype))
+        cd = torch.tensor(counts, dtype=torch.int32, device=DEV)
+        for P_max in (50, 64):
+            out = ops.ragged_pad(blocks, P_max, cd)
+            assert out.shape == (len(counts), P_max) + tail and out.dtype == dtype
+            for b, c in enumerate(counts):
+                assert torch.equal(out[b, :c], blocks[b]) and not out[b, c:].to(torch.float32).abs().sum().item(), (tail, b)
+    L = _lib.load()
+    t = torch.zeros(8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.dmm_ragged_pad(t.data_ptr(), t.data_ptr(), 2, 4, 6, t.data_ptr(), st) == 1        # row_bytes % 4 != 0
+    assert L.dmm_ragged_pad(None, t.data_ptr(), 2, 4, 8, t.data_ptr(), st) == 1                # null table
+    assert L.dmm_ragged_pad(t.data_ptr(), t.data_ptr(), 0, 4, 8, t.data_ptr(), st) == 0         # empty batch
+    with pytest.raises(ValueError):
+        ops.ragged_pad([torch.zeros(2, 3, device=DEV, dtype=torch.float16)], 4, torch.tensor([2], dtype=torch.int32, device=DEV))
