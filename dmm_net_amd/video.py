@@ -162,6 +162,17 @@ def load_offline_proposals(path: str, map_location="cpu"):
 # ------------------------------------------------------------------------------------------------------------------
 # frame loop
 # ------------------------------------------------------------------------------------------------------------------
+def _slice_batch(out, lo: int, hi: int):
+    """Rows lo..hi of every tensor in an encoder's output (dict / tuple / list nesting kept)."""
+    if isinstance(out, torch.Tensor):
+        return out[lo:hi]
+    if isinstance(out, dict):
+        return {k: _slice_batch(v, lo, hi) for k, v in out.items()}
+    if isinstance(out, (tuple, list)):
+        return type(out)(_slice_batch(v, lo, hi) for v in out)
+    return out
+
+
 class FrameLoop:
     """Frame loop of the evaluator for a batch of B videos (evaluator.py:63-213).
 
@@ -185,6 +196,7 @@ class FrameLoop:
         self.nms_thresh, self.max_proposals = float(nms_thresh), int(max_proposals)
         self.mask_thresh, self.padding, self.pasted = float(mask_thresh), int(padding), bool(pasted)
         self.lookahead = True                                    # proposals of frame t + 1 on a side stream (see run)
+        self.encode_ahead = 4                                    # frames per encoder batch (see run); 1 = the reference's order
         self._side = {}
 
     def _side_stream(self, dev):
@@ -255,7 +267,16 @@ class FrameLoop:
             props, ready = ahead
             if ready is not None:
                 main.wait_event(ready)
-            features = self.encoder(x)
+            # The encoder has no temporal state (the templates and the decoder carry it), so `encode_ahead` frames of
+            # the clip go through it as ONE batch, time-major: G x B images per launch sequence instead of B -- the
+            # ResNet at 4 x 255 x 448 is launch bound (~90 kernels of 5-20 us), at 16-48 images it is not.
+            G = max(1, min(int(self.encode_ahead), T))
+            if t % G == 0:
+                g = min(G, T - t)
+                xs = frames[:, t:t + g].transpose(0, 1).reshape(g * B, C, H, W)
+                chunk = self.encoder(xs) if g > 1 else self.encoder(x)
+            j = t % G
+            features = chunk if min(G, T - (t - j)) == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
             if t == 0:                                                   # forward_timestep_init, :215-225
                 tpl, valid = [], []
                 for b in range(B):
