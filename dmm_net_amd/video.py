@@ -188,6 +188,14 @@ class FrameLoop:
     buffers and are overwritten by the next frame's replay.  Everything this loop keeps ACROSS frames is copied out
     (template vectors are fresh tensors from the ROI kernel; ``refine_input_feat`` of frame 0 is cloned); a ``refine``
     callable that keeps feature maps in its ``state`` must clone them likewise.
+
+    Two reorderings against the reference's strictly sequential loop, neither changes a result for a feed-forward
+    encoder (``lookahead = False`` / ``encode_ahead = 1`` restore the reference's order):
+    ``lookahead``: the proposals of frame t + 1 (paste, NMS, top-k -- they depend on nothing the loop computes) are
+    prepared on a side stream after frame t's work has been enqueued, so the step's one host sync does not drain the main
+    stream; ``encode_ahead``: that many frames of the clip go through the encoder as one time-major batch (the encoder
+    has no temporal state; the templates, the mask history and the decoder carry it).  An encoder whose output for an
+    image depends on the rest of the batch (BatchNorm in train mode) needs ``encode_ahead = 1``.
     """
 
     def __init__(self, encoder: Callable, dmm, refine: Optional[Callable] = None, nms_thresh: float = 0.4,
