@@ -162,15 +162,20 @@ def load_offline_proposals(path: str, map_location="cpu"):
 # ------------------------------------------------------------------------------------------------------------------
 # frame loop
 # ------------------------------------------------------------------------------------------------------------------
-def _slice_batch(out, lo: int, hi: int):
-    """Rows lo..hi of every tensor in an encoder's output (dict / tuple / list nesting kept)."""
+def _map_tensors(out, fn):
+    """fn over every tensor in an encoder's output (dict / tuple / list nesting kept)."""
     if isinstance(out, torch.Tensor):
-        return out[lo:hi]
+        return fn(out)
     if isinstance(out, dict):
-        return {k: _slice_batch(v, lo, hi) for k, v in out.items()}
+        return {k: _map_tensors(v, fn) for k, v in out.items()}
     if isinstance(out, (tuple, list)):
-        return type(out)(_slice_batch(v, lo, hi) for v in out)
+        return type(out)(_map_tensors(v, fn) for v in out)
     return out
+
+
+def _slice_batch(out, lo: int, hi: int):
+    """Rows lo..hi of every tensor in an encoder's output."""
+    return _map_tensors(out, lambda v: v[lo:hi])
 
 
 class FrameLoop:
@@ -190,12 +195,14 @@ class FrameLoop:
     callable that keeps feature maps in its ``state`` must clone them likewise.
 
     Two reorderings against the reference's strictly sequential loop, neither changes a result for a feed-forward
-    encoder (``lookahead = False`` / ``encode_ahead = 1`` restore the reference's order):
+    encoder (``lookahead = False``, ``encode_ahead = 1``, ``encode_overlap = False`` restore the reference's order):
     ``lookahead``: the proposals of frame t + 1 (paste, NMS, top-k -- they depend on nothing the loop computes) are
     prepared on a side stream after frame t's work has been enqueued, so the step's one host sync does not drain the main
     stream; ``encode_ahead``: that many frames of the clip go through the encoder as one time-major batch (the encoder
-    has no temporal state; the templates, the mask history and the decoder carry it).  An encoder whose output for an
-    image depends on the rest of the batch (BatchNorm in train mode) needs ``encode_ahead = 1``.
+    has no temporal state; the templates, the mask history and the decoder carry it), and with ``encode_overlap`` the
+    NEXT batch is encoded on its own stream while this one's steps run (outputs of a static-buffer encoder are cloned).
+    An encoder whose output for an image depends on the rest of the batch (BatchNorm in train mode) needs
+    ``encode_ahead = 1``.
     """
 
     def __init__(self, encoder: Callable, dmm, refine: Optional[Callable] = None, nms_thresh: float = 0.4,
@@ -205,10 +212,11 @@ class FrameLoop:
         self.mask_thresh, self.padding, self.pasted = float(mask_thresh), int(padding), bool(pasted)
         self.lookahead = True                                    # proposals of frame t + 1 on a side stream (see run)
         self.encode_ahead = 4                                    # frames per encoder batch (see run); 1 = the reference's order
+        self.encode_overlap = True                               # next chunk's encoder on its own stream (see run)
         self._side = {}
 
-    def _side_stream(self, dev):
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
+    def _side_stream(self, dev, role="proposals"):
+        key = (role, dev.index if dev.index is not None else torch.cuda.current_device())
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
@@ -260,9 +268,32 @@ class FrameLoop:
                             v.record_stream(main)
                 return out, side.record_event()
 
+        G = max(1, min(int(self.encode_ahead), T))
+        enc_side = self._side_stream(dev, "encoder") if main is not None and self.encode_overlap else None
+
+        def encode(t0):
+            g = min(G, T - t0)
+
+            def go():
+                xs = frames[:, t0] if g == 1 else frames[:, t0:t0 + g].transpose(0, 1).reshape(g * B, C, H, W)
+                return self.encoder(xs)
+            if enc_side is None:
+                return go(), None
+            with torch.cuda.stream(enc_side):
+                out = go()
+                if getattr(self.encoder, "static_outputs", False):
+                    # views of a graph's static buffers: the next replay (issued while this chunk is still in use)
+                    # would overwrite them
+                    out = _map_tensors(out, lambda v: v.clone())
+                _map_tensors(out, lambda v: (v.record_stream(main), v)[1])
+                return out, enc_side.record_event()
+
         if side is not None:
             side.wait_stream(main)                               # inputs the caller produced on the main stream
+        if enc_side is not None:
+            enc_side.wait_stream(main)
         ahead = prepare(0) if T > 0 else None
+        next_chunk = encode(0) if T > 0 else None
         for t in range(T):
             extra = [n <= t for n in n_frames]
             x = frames[:, t]
@@ -278,11 +309,14 @@ class FrameLoop:
             # The encoder has no temporal state (the templates and the decoder carry it), so `encode_ahead` frames of
             # the clip go through it as ONE batch, time-major: G x B images per launch sequence instead of B -- the
             # ResNet at 4 x 255 x 448 is launch bound (~90 kernels of 5-20 us), at 16-48 images it is not.
-            G = max(1, min(int(self.encode_ahead), T))
+            # `encode_overlap`: the chunk AFTER this one is encoded on its own stream while this chunk's steps -- a
+            # dependent chain of small kernels that leaves most of the chip idle -- run on the main stream.
             if t % G == 0:
-                g = min(G, T - t)
-                xs = frames[:, t:t + g].transpose(0, 1).reshape(g * B, C, H, W)
-                chunk = self.encoder(xs) if g > 1 else self.encoder(x)
+                chunk, enc_ready = next_chunk
+                if enc_ready is not None:
+                    main.wait_event(enc_ready)
+                if t + G < T:
+                    next_chunk = encode(t + G)
             j = t % G
             features = chunk if min(G, T - (t - j)) == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
             if t == 0:                                                   # forward_timestep_init, :215-225

@@ -125,13 +125,18 @@ def test_frame_loop_batched_equals_per_video_and_writes_labels(tmp_path):
             assert torch.equal(h1[t][0], hist[t][b]), (b, t)
         for t in range(n_frames[b]):
             assert torch.equal(solo[t], got[(b, t)])
-    # the proposal look-ahead (frame t + 1 prepared on a side stream) changes no result
+    # the reorderings of the loop -- proposal look-ahead on a side stream, several frames per encoder batch, the next
+    # chunk's encoder on its own stream -- change no result (the reference's strictly sequential order: all off)
     plain = make_loop()
-    plain.lookahead = False
+    plain.lookahead, plain.encode_ahead, plain.encode_overlap = False, 1, False
     for rep in range(3):                                                 # a race would not show every time
         h0 = plain.run(frames, first, props, n_frames)
         h2 = make_loop().run(frames, first, props, n_frames)
         assert all(torch.equal(a, c) and torch.equal(a, d) for a, c, d in zip(hist, h0, h2)), rep
+        for (la, ea, eo) in [(True, 1, True), (False, 3, False), (True, 2, True), (False, 4, True)]:
+            lp = make_loop()
+            lp.lookahead, lp.encode_ahead, lp.encode_overlap = la, ea, eo
+            assert all(torch.equal(a, c) for a, c in zip(hist, lp.run(frames, first, props, n_frames))), (rep, la, ea, eo)
     # output format: one palette PNG per frame, read back identically
     Image = pytest.importorskip("PIL.Image")
     f = tmp_path / "merged" / "v0" / "00001.png"
