@@ -68,7 +68,7 @@ if os.environ.get("PROFILE"):
     loop.run(frames, first, props, on_labels=lambda b, t, lab: None)
     torch.cuda.synchronize()
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(32)
 if os.environ.get("KERNELS"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
