@@ -143,3 +143,22 @@ def small_to_device(values, dtype, device):
     if torch.device(device).type != "cuda":
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
+
+
+_NULL_CTX = None
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)`` only when ``device`` is not already the current one: the launchers run under a
+    device guard so that the HIP runtime targets the tensors' GPU, but pushing and popping the guard costs several
+    microseconds per op -- with ~20 ops per frame step in a host-bound loop -- and almost every call is on the
+    current device already."""
+    global _NULL_CTX
+    import contextlib
+    import torch
+    if _NULL_CTX is None:
+        _NULL_CTX = contextlib.nullcontext()
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NULL_CTX
+    return torch.cuda.device(dev)

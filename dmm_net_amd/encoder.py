@@ -307,7 +307,7 @@ def _bias_act_(x: torch.Tensor, bias, residual=None, relu: bool = True) -> torch
     if residual is not None:
         assert residual.shape == x.shape and residual.dtype == x.dtype
         assert residual.is_contiguous(memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = _lib.load().dmm_bias_act_bf16(x.data_ptr(), None if bias is None else bias.data_ptr(),
                                            None if residual is None else residual.data_ptr(), B * H * W, C, int(relu),
                                            torch.cuda.current_stream(x.device).cuda_stream)

@@ -103,7 +103,7 @@ def iou_counts(masks_p: torch.Tensor, masks_t: torch.Tensor, n_valid=None, m_val
         inter = torch.empty((B, M, N), dtype=torch.int32, device=dev)
         ap = torch.empty((B, N), dtype=torch.int32, device=dev)
         at = torch.empty((B, M), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.load().dmm_iou_counts_frames(_ptr(fp.table), _ptr(masks_t), _DT[fp.dtype], B, N, M, H * W,
                                                    fp.plane_stride, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
                                                    _ptr(inter), _ptr(ap), _ptr(at), _stream(masks_t))
@@ -120,7 +120,7 @@ def iou_counts(masks_p: torch.Tensor, masks_t: torch.Tensor, n_valid=None, m_val
     inter = torch.empty((B, M, N), dtype=torch.int32, device=dev)
     ap = torch.empty((B, N), dtype=torch.int32, device=dev)
     at = torch.empty((B, M), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().dmm_iou_counts(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], B, N, M, H * W, sp_b, sp_n,
                                         st_b, st_m, _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at),
                                         _stream(masks_p))
@@ -149,7 +149,7 @@ def ragged_pad(blocks, P_max: int, counts: torch.Tensor) -> torch.Tensor:
         raise ValueError("ragged_pad: blocks must share dtype and trailing shape, rows of a multiple of 4 bytes")
     any_ptr = next((b.data_ptr() for b in blocks if b.shape[0]), 0)
     table = _lib.small_to_device([b.data_ptr() if b.shape[0] else any_ptr for b in blocks], torch.int64, first.device)
-    with torch.cuda.device(first.device):
+    with _lib.device_guard(first.device):
         rc = _lib.load().dmm_ragged_pad(_ptr(table), _ptr(counts), len(blocks), int(P_max), row_bytes, _ptr(out),
                                         _stream(first))
     _lib.check(rc, "dmm_ragged_pad")
@@ -166,7 +166,7 @@ def pack_masks(masks: torch.Tensor) -> torch.Tensor:
         s_k = H * W
     wd = pack_words(H * W)
     out = torch.empty((B, K, wd), dtype=torch.int64, device=masks.device)
-    with torch.cuda.device(masks.device):
+    with _lib.device_guard(masks.device):
         rc = _lib.load().dmm_pack_masks(_ptr(masks), _DT[masks.dtype], B * K, H * W, s_k, _ptr(out), wd, _stream(masks))
     _lib.check(rc, "dmm_pack_masks")
     return out
@@ -184,7 +184,7 @@ def iou_counts_packed(packed_p: torch.Tensor, packed_t: torch.Tensor, HW: int, n
     inter = torch.empty((B, M, N), dtype=torch.int32, device=dev)
     ap = torch.empty((B, N), dtype=torch.int32, device=dev)
     at = torch.empty((B, M), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().dmm_iou_counts(_ptr(packed_p), _ptr(packed_t), _lib.DTYPE_PACKED1, B, N, M, HW, N * wd, wd,
                                         M * wd, wd, _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at),
                                         _stream(packed_p))
@@ -205,7 +205,7 @@ def iou_counts_dual(masks_p: torch.Tensor, masks_t: torch.Tensor, masks_t2: torc
         i32 = dict(dtype=torch.int32, device=fp.device)
         inter, inter2 = torch.empty((B, M, N), **i32), torch.empty((B, M, N), **i32)
         ap, at, at2 = torch.empty((B, N), **i32), torch.empty((B, M), **i32), torch.empty((B, M), **i32)
-        with torch.cuda.device(fp.device):
+        with _lib.device_guard(fp.device):
             rc = _lib.load().dmm_iou_counts_dual_frames(_ptr(fp.table), _ptr(masks_t), _ptr(masks_t2), _DT[fp.dtype], B,
                                                         N, M, H * W, fp.plane_stride, st_b, st_m, st2_b, st2_m,
                                                         _ptr(n_valid), _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at),
@@ -224,7 +224,7 @@ def iou_counts_dual(masks_p: torch.Tensor, masks_t: torch.Tensor, masks_t2: torc
     i32 = dict(dtype=torch.int32, device=dev)
     inter, inter2 = torch.empty((B, M, N), **i32), torch.empty((B, M, N), **i32)
     ap, at, at2 = torch.empty((B, N), **i32), torch.empty((B, M), **i32), torch.empty((B, M), **i32)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().dmm_iou_counts_dual(_ptr(masks_p), _ptr(masks_t), _ptr(masks_t2), _DT[masks_p.dtype], B, N, M,
                                              H * W, sp_b, sp_n, st_b, st_m, st2_b, st2_m, _ptr(n_valid), _ptr(m_valid),
                                              _ptr(inter), _ptr(ap), _ptr(at), _ptr(inter2), _ptr(at2), _stream(masks_p))
@@ -240,7 +240,7 @@ def feature_normalize(x: torch.Tensor, want_norms: bool = False):
     rows = x.numel() // max(D, 1)
     out = torch.empty_like(x)
     norms = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if want_norms else None
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         rc = _lib.load().dmm_feature_normalize_f32(_ptr(x), rows, D, _ptr(out), _ptr(norms), _stream(x))
     _lib.check(rc, "dmm_feature_normalize_f32")
     return (out, norms) if want_norms else out
@@ -253,7 +253,7 @@ def cosine(featn_t: torch.Tensor, featn_p: torch.Tensor, n_valid=None, m_valid=N
     B, M, D = featn_t.shape
     N = featn_p.shape[1]
     out = torch.empty((B, M, N), dtype=torch.float32, device=featn_t.device)
-    with torch.cuda.device(featn_t.device):
+    with _lib.device_guard(featn_t.device):
         rc = _lib.load().dmm_cosine_f32(_ptr(featn_t), _ptr(featn_p), B, N, M, D, _ptr(n_valid), _ptr(m_valid),
                                         _ptr(out), _stream(featn_t))
     _lib.check(rc, "dmm_cosine_f32")
@@ -269,7 +269,7 @@ def cosine_features(feat_t: torch.Tensor, feat_p: torch.Tensor) -> torch.Tensor:
     B, M, D = feat_t.shape
     N = feat_p.shape[1]
     out = torch.empty((B, M, N), dtype=torch.float32, device=feat_t.device)
-    with torch.cuda.device(feat_t.device):
+    with _lib.device_guard(feat_t.device):
         rc = _lib.load().dmm_cosine_features_f32(_ptr(feat_t), _ptr(feat_p), B, N, M, D, _ptr(out), _stream(feat_t))
     if rc == 2:                                               # DMM_ERR_UNSUPPORTED: outside the fused kernel's envelope
         return cosine(feature_normalize(feat_t), feature_normalize(feat_p))
@@ -291,7 +291,7 @@ def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, 
                iters=torch.empty((B,), dtype=torch.int32, device=dev),
                X=torch.empty((B, M, Pp), **f32) if want_x else None)
     cos, score_p = cos.contiguous().float(), score_p.contiguous().float()
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().dmm_relax_match_f32(
             _ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
             float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
@@ -314,7 +314,7 @@ def relax_match_bwd(sim, score_p, dRb, d_match_score, d_det_score, *, max_iter, 
     nbytes = int(L.dmm_relax_bwd_workspace_bytes(B, N, M, int(max_iter), int(proj_iter)))
     ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=dev)
     out = torch.empty((B, M, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = L.dmm_relax_match_bwd_f32(_ptr(sim), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid), int(max_iter),
                                        int(proj_iter), float(lr), int(is_test), _ptr(dRb), _ptr(d_match_score),
                                        _ptr(d_det_score), _ptr(out), _ptr(ws), ws.numel(), _stream(sim))
@@ -338,7 +338,7 @@ def feature_sim_bwd(dsim, cos, gt, d_loss, score_weight, feat_t, feat_p, featn_t
         gt = d_loss = cos_arg = None
     else:
         cos_arg = cos
-    with torch.cuda.device(dsim.device):
+    with _lib.device_guard(dsim.device):
         rc = _lib.load().dmm_feature_sim_bwd_f32(_ptr(dsim), _ptr(cos_arg), _ptr(gt), _ptr(d_loss), float(score_weight),
                                                  _ptr(feat_t), _ptr(feat_p), _ptr(featn_t), _ptr(featn_p), _ptr(norm_t),
                                                  _ptr(norm_p), B, N, M, D, _ptr(n_valid), _ptr(m_valid), _ptr(g_t),
@@ -357,7 +357,7 @@ def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_
     R = torch.empty_like(C)
     cost = torch.zeros((B, max_iter + 1), dtype=torch.float32, device=C.device)
     iters = torch.empty((B,), dtype=torch.int32, device=C.device)
-    with torch.cuda.device(C.device):
+    with _lib.device_guard(C.device):
         rc = _lib.load().dmm_relax_solve_f32(_ptr(C), B, n, m, _ptr(rows_valid), _ptr(cols_valid), int(max_iter),
                                              int(proj_iter), float(lr), _ptr(X), _ptr(R), _ptr(cost), _ptr(iters),
                                              _stream(C))
@@ -374,7 +374,7 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
         M, Pp = Rb.shape[1], Rb.shape[2]
         Rb = Rb.contiguous().float()
         out = torch.empty((B, M, H, W), dtype=torch.float32, device=Rb.device)
-        with torch.cuda.device(Rb.device):
+        with _lib.device_guard(Rb.device):
             rc = _lib.load().dmm_mask_mix_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], B, N, M, Pp, H * W,
                                                  fp.plane_stride, _ptr(n_valid), _ptr(m_valid), _ptr(out), M * H * W,
                                                  H * W, _stream(Rb))
@@ -387,7 +387,7 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
     Rb = Rb.contiguous().float()
     out_dtype = out_dtype or torch.float32
     out = torch.empty((B, M, H, W), dtype=out_dtype, device=Rb.device)
-    with torch.cuda.device(Rb.device):
+    with _lib.device_guard(Rb.device):
         rc = _lib.load().dmm_mask_mix_to(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], B, N, M, Pp, H * W, sp_b, sp_n,
                                          _ptr(n_valid), _ptr(m_valid), _ptr(out), _DT[out_dtype], M * H * W, H * W,
                                          _stream(Rb))
@@ -405,7 +405,7 @@ def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_
         Rb = Rb.contiguous().float()
         dout = dout.contiguous().float().view(B, M, H * W)
         dRb = torch.empty((B, M, Pp), dtype=torch.float32, device=Rb.device)
-        with torch.cuda.device(Rb.device):
+        with _lib.device_guard(Rb.device):
             rc = _lib.load().dmm_mask_mix_bwd_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], _ptr(dout), B, N, M, Pp,
                                                      H * W, fp.plane_stride, _ptr(n_valid), _ptr(m_valid), _ptr(dRb),
                                                      _stream(Rb))
@@ -418,7 +418,7 @@ def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_
     Rb = Rb.contiguous().float()
     dout = dout.contiguous().float().view(B, M, H * W)
     dRb = torch.empty((B, M, Pp), dtype=torch.float32, device=Rb.device)
-    with torch.cuda.device(Rb.device):
+    with _lib.device_guard(Rb.device):
         rc = _lib.load().dmm_mask_mix_bwd(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], _ptr(dout), B, N, M, Pp, H * W,
                                           sp_b, sp_n, _ptr(n_valid), _ptr(m_valid), _ptr(dRb), _stream(Rb))
     _lib.check(rc, "dmm_mask_mix_bwd")
@@ -456,7 +456,7 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
     full = torch.empty((B, M, H, W), **f32)
     ms, ds = torch.empty((B, M), **f32), torch.empty((B, M), **f32)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = L.dmm_match_forward(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p), _ptr(feat_t),
                                  _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
                                  float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(full),
@@ -526,7 +526,7 @@ class ForwardPlan:
             self.workspace = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=self.device)
             if self.time_kernels or self.graph_mode:
                 if self.graph_mode:
-                    with torch.cuda.device(self.device):
+                    with _lib.device_guard(self.device):
                         self.side = torch.cuda.Stream(device=self.device)
                 self.counts = [torch.empty((B * (M * N + N + M),), **i32)]
                 self.halves = [(0, B)]
@@ -549,7 +549,7 @@ class ForwardPlan:
         self.pn = torch.empty((B, N, D), **f32)
         self.tn = torch.empty((B, M, D), **f32)
         self.cos = torch.empty((B, M, N), **f32)
-        with torch.cuda.device(self.device):
+        with _lib.device_guard(self.device):
             # (stream priorities make no measurable difference here: 261.1 / 262.0 k frames/s at priority 0 / -1)
             self.side = torch.cuda.Stream(device=self.device)
             self.ev_start = torch.cuda.Event()
@@ -665,7 +665,7 @@ class ForwardPlan:
                 return self.full_outmask, self.match_score, self.det_score
             self._last_key = key
         if not self.pipeline and self.time_kernels:
-            with torch.cuda.device(self.device):
+            with _lib.device_guard(self.device):
                 main = torch.cuda.current_stream(self.device)
                 ms = main.cuda_stream
                 inter, ap, at = self._tables(0)
@@ -688,7 +688,7 @@ class ForwardPlan:
             _lib.check(rc, "ForwardPlan.run (granular, timed)")
             return self.full_outmask, self.match_score, self.det_score
         if not self.pipeline:
-            with torch.cuda.device(self.device):
+            with _lib.device_guard(self.device):
                 rc = L.dmm_match_forward(
                     _ptr(masks_p), _ptr(masks_t), dt, _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M, HW, D, sp_b,
                     sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
@@ -700,7 +700,7 @@ class ForwardPlan:
 
         es = masks_p.element_size()
         nv = lambda t, b: None if t is None else t.data_ptr() + 4 * b
-        with torch.cuda.device(self.device):
+        with _lib.device_guard(self.device):
             main = torch.cuda.current_stream(self.device)
             side = self.side
             ms, ss = main.cuda_stream, side.cuda_stream

@@ -77,7 +77,7 @@ def paste_masks(mask_prob: torch.Tensor, boxes: torch.Tensor, im_h: int, im_w: i
     packed = None
     if want_packed:
         packed = torch.empty((P, 4 * ((im_h * im_w + 255) // 256)), dtype=torch.int64, device=prob.device)
-    with torch.cuda.device(prob.device):
+    with _lib.device_guard(prob.device):
         rc = _lib.load().dmm_paste_masks_f32(prob.data_ptr(), P, M, boxes.data_ptr(), int(im_h), int(im_w), float(thresh),
                                              int(padding), planes.data_ptr(), im_h * im_w, nb.data_ptr(),
                                              None if packed is None else packed.data_ptr(),
@@ -95,7 +95,7 @@ def nms_batched(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor], t
     alls = torch.cat([s.float() for s in scores], 0).contiguous()
     keep = torch.empty((max(int(allb.shape[0]), 1),), dtype=torch.int32, device=dev)
     cnt = torch.empty((len(boxes),), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.load().dmm_nms_f32(allb.data_ptr(), alls.data_ptr(), offs.data_ptr(), len(boxes), max(counts + [0]),
                                      float(thresh), int(max_keep), keep.data_ptr(), cnt.data_ptr(),
                                      torch.cuda.current_stream(dev).cuda_stream)

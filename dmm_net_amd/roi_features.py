@@ -53,7 +53,7 @@ class _RoiAlign4Mean(torch.autograd.Function):
         out = torch.empty((R, 4 * C), dtype=torch.float32, device=rois.device)
         Hs, Ws, sc = _arrays(feats)
         ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        with torch.cuda.device(rois.device):
+        with _lib.device_guard(rois.device):
             rc = _lib.load().dmm_roialign4_mean_fwd(ptrs, _DT[feats[0].dtype], B, C, Hs, Ws, sc, rois.data_ptr(), R,
                                                     out.data_ptr(), torch.cuda.current_stream(rois.device).cuda_stream)
         _lib.check(rc, "dmm_roialign4_mean_fwd")
@@ -72,7 +72,7 @@ class _RoiAlign4Mean(torch.autograd.Function):
         Ws = (ctypes.c_int * 4)(*[s[3] for s in ctx.shapes])
         sc = (ctypes.c_float * 4)(*SCALES)
         ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dfs])
-        with torch.cuda.device(dout.device):
+        with _lib.device_guard(dout.device):
             rc = _lib.load().dmm_roialign4_mean_bwd(dout.data_ptr(), B, C, Hs, Ws, sc, rois.data_ptr(), rois.shape[0],
                                                     ptrs, torch.cuda.current_stream(dout.device).cuda_stream)
         _lib.check(rc, "dmm_roialign4_mean_bwd")

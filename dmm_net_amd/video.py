@@ -46,7 +46,7 @@ def mask_boxes(masks: torch.Tensor, thresh: float = 0.0):
         masks = masks.contiguous()
     boxes = torch.empty((R, 4), dtype=torch.float32, device=masks.device)
     valid = torch.empty((R,), dtype=torch.int32, device=masks.device)
-    with torch.cuda.device(masks.device):
+    with _lib.device_guard(masks.device):
         rc = _lib.load().dmm_mask_boxes_f32(masks.data_ptr(), R, H, W, masks.stride(0) if R else H * W, float(thresh),
                                             boxes.data_ptr(), valid.data_ptr(),
                                             torch.cuda.current_stream(masks.device).cuda_stream)
@@ -83,7 +83,7 @@ def merge_labels(outs: torch.Tensor, tplt_valid_batch: Optional[torch.Tensor] = 
         ov = tplt_valid_batch if tplt_valid_batch.dim() == 1 else tplt_valid_batch.sum(1)
         ov = ov.to(device=m.device, dtype=torch.int32).contiguous()
     labels = torch.empty((B, HW), dtype=torch.uint8, device=m.device)
-    with torch.cuda.device(m.device):
+    with _lib.device_guard(m.device):
         rc = _lib.load().dmm_merge_labels_f32(m.data_ptr(), B, O, HW, m.stride(0), m.stride(1),
                                               None if ov is None else ov.data_ptr(), labels.data_ptr(),
                                               torch.cuda.current_stream(m.device).cuda_stream)
