@@ -30,3 +30,20 @@ def test_synth_is_deterministic_and_structured():
     o = oracle.match_forward(a.proposed_mask, a.mask_last_occurence, a.proposed_feature, a.template_feature,
                              a.proposal_score, max_iter=20, proj_iter=5, is_test=1, want_outmask=False)
     assert np.array_equal(o["R"].argmax(1), a.perm)
+
+
+def test_small_host_helpers_on_cpu():
+    """_lib.small_to_device / device_guard degrade to plain tensors / a null context off the GPU, and the frame loop's
+    output helpers keep the nesting of an encoder's output."""
+    import contextlib
+
+    import torch
+
+    from dmm_net_amd import _lib, video
+    t = _lib.small_to_device([3, 1, 2], torch.int32, torch.device("cpu"))
+    assert t.dtype == torch.int32 and t.tolist() == [3, 1, 2] and t.device.type == "cpu"
+    assert isinstance(_lib.device_guard(torch.device("cpu")), contextlib.nullcontext)
+    out = {"a": (torch.arange(12).view(6, 2), torch.arange(6)), "b": [torch.arange(6).view(6, 1)], "c": "tag"}
+    s = video._slice_batch(out, 2, 4)
+    assert s["a"][0].tolist() == [[4, 5], [6, 7]] and s["a"][1].tolist() == [2, 3] and s["b"][0].tolist() == [[2], [3]]
+    assert isinstance(s["a"], tuple) and isinstance(s["b"], list) and s["c"] == "tag"
