@@ -27,6 +27,8 @@ SYMBOLS = (
     "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
     "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad",
+    "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
+    "dmm_paste_kept_f32", "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32",
 )
 
 _lib = None
@@ -113,6 +115,21 @@ def load():
     L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                     c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]
+    L.dmm_workspace_bytes_packed.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    L.dmm_workspace_bytes_packed.restype = sz
+    L.dmm_match_forward_packed.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
+                                           c_i64, c_i64, c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp,
+                                           vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.dmm_proposal_boxes_f32.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_float, c_int, vp, vp, vp]
+    L.dmm_nms_slots_f32.argtypes = [vp, vp, vp, c_int, c_int, c_float, c_int, vp, vp, vp, vp]
+    L.dmm_paste_kept_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,
+                                     c_i64, vp, vp, vp, vp, vp]
+    L.dmm_step_select_i32.argtypes = [vp, vp, c_int, vp, vp]
+    L.dmm_step_advance.argtypes = [vp, vp]
+    L.dmm_commit_masks_f32.argtypes = [vp, vp, vp, c_int, c_i64, vp]
+    for f in ("dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32", "dmm_paste_kept_f32",
+              "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32"):
+        getattr(L, f).restype = c_int
     for f in ("dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
               "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
               "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",

@@ -123,3 +123,75 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
     return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
                         (int64_t)M * HW, HW, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// (5b) The same forward with the proposal side of the cost pass on 1-bit planes (DMM_PACKED1) that the caller already
+// holds -- dmm_paste_masks_f32 / dmm_paste_kept_f32 emit them next to the soft planes.  The M template planes of each
+// frame are packed here (one read of them, what the float count kernel would have read anyway), the counts run on the
+// words (1/32 of the proposal bytes, identical integer tables), the mix reads the soft planes.
+// ---------------------------------------------------------------------------------------------
+static size_t packed_t_bytes(int B, int M, int HW) {
+    return dmm::align_up(sizeof(uint64_t) * (size_t)B * M * (size_t)dmm_pack_words(HW), 256);
+}
+
+extern "C" size_t dmm_workspace_bytes_packed(int B, int N, int M, int D, int HW) {
+    if (B <= 0 || N <= 0 || M <= 0 || D < 0 || HW < 0) return 0;
+    return dmm::carve(nullptr, B, N, M, D).bytes + packed_t_bytes(B, M, HW);
+}
+
+extern "C" int dmm_match_forward_packed(const void *masks_p, const uint64_t *packed_p, const void *masks_t, int mask_dtype,
+                                        const float *feat_p, const float *feat_t, const float *score_p, int B, int N, int M,
+                                        int HW, int D, int64_t sp_b, int64_t sp_n, int64_t pk_b, int64_t pk_n, int64_t st_b,
+                                        int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, float score_weight,
+                                        int max_iter, int proj_iter, float lr, int is_test, float *full_outmask,
+                                        float *match_score, float *det_score, float *sim_out, float *R_out, float *Rb_out,
+                                        int32_t *iters_out, void *workspace, size_t workspace_bytes, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    if (!masks_p || !packed_p || !masks_t || !feat_p || !feat_t || !score_p || !full_outmask || !match_score ||
+        !det_score || !workspace)
+        return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    if (mask_dtype != DMM_F32 && mask_dtype != DMM_F16 && mask_dtype != DMM_BF16) return DMM_ERR_BAD_ARG;
+    if (st_b != (int64_t)M * st_m) return DMM_ERR_UNSUPPORTED;          // templates: one plane stride over the batch
+    dmm::Workspace w = dmm::carve(workspace, B, N, M, D);
+    const int64_t wd = dmm_pack_words(HW);
+    if (workspace_bytes < w.bytes + packed_t_bytes(B, M, HW)) return DMM_ERR_WORKSPACE;
+    uint64_t *packed_t = (uint64_t *)((char *)workspace + w.bytes);
+    float *sim = sim_out ? sim_out : w.sim;
+    float *Rb = Rb_out ? Rb_out : w.Rb;
+    int rc = dmm_pack_masks(masks_t, mask_dtype, (int64_t)B * M, HW, st_m, packed_t, wd, stream);
+    if (rc != DMM_OK) return rc;
+    // Feature similarity of ALL slots as a dense batch (rows past a frame's n_valid / m_valid are computed and never
+    // read: the solver masks them) -- the one-launch kernel, which also clears the count tables; bit identical to the
+    // ragged three-launch form on every live entry.
+    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    rc = force_tile ? DMM_ERR_UNSUPPORTED
+                    : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
+                                               (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
+    if (rc == DMM_OK) {
+        rc = dmm::iou_counts_prezeroed(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, pk_b, pk_n, (int64_t)M * wd, wd,
+                                       n_valid, m_valid, w.inter, w.area_p, w.area_t, stream);
+        if (rc != DMM_OK) return rc;
+    } else if (rc != DMM_ERR_UNSUPPORTED) {
+        return rc;
+    } else {
+        rc = dmm_iou_counts(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, pk_b, pk_n, (int64_t)M * wd, wd, n_valid,
+                            m_valid, w.inter, w.area_p, w.area_t, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_cosine_f32(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, stream);
+        if (rc != DMM_OK) return rc;
+    }
+    rc = dmm_relax_match_f32(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid, score_weight,
+                             max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,
+                             nullptr, stream);
+    if (rc != DMM_OK) return rc;
+    return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                        (int64_t)M * HW, HW, stream);
+}

@@ -8,6 +8,15 @@
 //    A proposal's plane is cut into bands of 4096 pixels, one workgroup each (a first one-workgroup-per-proposal version
 //    kept 50 CUs busy and wrote at 0.27 TB/s); the (M+2)^2 padded mask sits in LDS, 16-byte stores, the whole plane is
 //    produced (zeros outside the box) so no separate memset is needed.  HBM bound (plane writes).
+//  * Two-phase form on FIXED SLOTS (the per-frame step of the evaluator without host round trips,
+//    model_encoder.py:115-134 + boxlist_ops.py:15-29): proposal_boxes_kernel evaluates the pasted values of every RAW
+//    proposal only for its tight box (no plane is written), nms_slots_kernel ranks / suppresses / truncates per image
+//    into K slots, paste_kept_kernel then pastes ONLY the kept proposals straight into planes [images, K, H*W] (+ 1-bit
+//    planes, kept boxes / scores, the ROIAlign roi rows) in score order.  Same arithmetic (paste_value below), so the
+//    planes and boxes are bit identical to paste-everything + NMS + gather -- without the gather copy, with the kept
+//    counts left on the device (n_valid of the matching entry points).  Raw inputs may be CLIP RESIDENT ([T, images,
+//    R, ...]) with the frame index read from a device scalar (`step`): a captured HIP graph then replays the whole
+//    frame step with no host input.
 //  * nms_kernel: filter_results' NMS + top-k (dmm/utils/boxlist_ops.py:15-29; maskrcnn_benchmark nms semantics:
 //    descending score, legacy +1 areas, IoU > thresh suppresses).  One workgroup per image, <= 1024 boxes: rank by
 //    counting (stable), pairwise suppression bitmask in LDS, serial greedy scan by one lane.
@@ -18,6 +27,61 @@ namespace dmm {
 constexpr int kNmsMax = 1024;
 
 constexpr int kPasteIters = 4;       // 1024-pixel steps per workgroup (a band of the plane)
+
+// Geometry of one paste (masker.py:110-150): pad the M x M probabilities, expand the box about its centre by
+// (M + 2 pad) / M, truncate to int, clip to the image.  paste_value = one pixel of F.interpolate(bilinear,
+// align_corners=False) of the padded mask resized to the box -- every kernel that needs a pasted value calls THIS, so
+// planes, tight boxes and 1-bit planes agree bit for bit whichever kernel produced them.
+struct PasteGeom {
+    int Mp, bx0, by0, x_0, y_0, x_1, y_1;
+    float sh, sw;
+    __device__ __forceinline__ bool inside(int y, int x) const { return y >= y_0 && y < y_1 && x >= x_0 && x < x_1; }
+};
+__device__ __forceinline__ PasteGeom paste_geom(const float *__restrict__ box, int M, int padding, int im_h, int im_w) {
+    PasteGeom g;
+    g.Mp = M + 2 * padding;
+    const float scale = (float)((double)g.Mp / (double)M);
+    float w_half = (box[2] - box[0]) * 0.5f, h_half = (box[3] - box[1]) * 0.5f;
+    const float x_c = (box[2] + box[0]) * 0.5f, y_c = (box[3] + box[1]) * 0.5f;
+    w_half = w_half * scale;
+    h_half = h_half * scale;
+    g.bx0 = (int)(x_c - w_half);
+    g.by0 = (int)(y_c - h_half);
+    const int bx1 = (int)(x_c + w_half), by1 = (int)(y_c + h_half);
+    int w = bx1 - g.bx0 + 1, h = by1 - g.by0 + 1;
+    w = w < 1 ? 1 : w;
+    h = h < 1 ? 1 : h;
+    g.x_0 = max(g.bx0, 0);
+    g.y_0 = max(g.by0, 0);
+    g.x_1 = min(bx1 + 1, im_w);
+    g.y_1 = min(by1 + 1, im_h);
+    g.sh = (float)g.Mp / (float)h;
+    g.sw = (float)g.Mp / (float)w;
+    return g;
+}
+__device__ __forceinline__ float paste_value(const PasteGeom &g, const float *pad_s, int y, int x) {
+    const int Mp = g.Mp;
+    float ry = __builtin_fmaf(g.sh, (float)(y - g.by0) + 0.5f, -0.5f);
+    ry = ry < 0.0f ? 0.0f : ry;
+    const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
+    const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
+    float rx = __builtin_fmaf(g.sw, (float)(x - g.bx0) + 0.5f, -0.5f);
+    rx = rx < 0.0f ? 0.0f : rx;
+    const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
+    const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
+    const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
+    const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
+    const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
+    const float lb = ly1 * bot;
+    return __builtin_fmaf(ly0, top, lb);
+}
+__device__ __forceinline__ void stage_padded(const float *__restrict__ prob_p, int M, int padding, float *pad_s) {
+    const int Mp = M + 2 * padding;
+    for (int i = threadIdx.x; i < Mp * Mp; i += 256) {
+        const int y = i / Mp - padding, x = i % Mp - padding;
+        pad_s[i] = (y >= 0 && y < M && x >= 0 && x < M) ? prob_p[y * M + x] : 0.0f;
+    }
+}
 
 // Tight boxes are reduced ACROSS the band workgroups of a proposal with integer atomics on the bit patterns of the
 // (non-negative, integer-valued) float coordinates in new_boxes itself: init = [W, H, -1, -1], atomicMin / atomicMax as
@@ -46,27 +110,10 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
     __shared__ float pad_s[64 * 64];
     __shared__ int box_s[4];
     const int p = blockIdx.y;
-    const int Mp = M + 2 * padding;
-    for (int i = threadIdx.x; i < Mp * Mp; i += 256) {
-        const int y = i / Mp - padding, x = i % Mp - padding;
-        pad_s[i] = (y >= 0 && y < M && x >= 0 && x < M) ? prob[(int64_t)p * M * M + y * M + x] : 0.0f;
-    }
+    stage_padded(prob + (int64_t)p * M * M, M, padding, pad_s);
     if (threadIdx.x == 0) { box_s[0] = im_w; box_s[1] = im_h; box_s[2] = -1; box_s[3] = -1; }
     __syncthreads();
-    const float *box = boxes + (int64_t)p * 4;
-    const float scale = (float)((double)Mp / (double)M);
-    float w_half = (box[2] - box[0]) * 0.5f, h_half = (box[3] - box[1]) * 0.5f;
-    const float x_c = (box[2] + box[0]) * 0.5f, y_c = (box[3] + box[1]) * 0.5f;
-    w_half = w_half * scale;
-    h_half = h_half * scale;
-    const int bx0 = (int)(x_c - w_half), by0 = (int)(y_c - h_half);
-    const int bx1 = (int)(x_c + w_half), by1 = (int)(y_c + h_half);
-    int w = bx1 - bx0 + 1, h = by1 - by0 + 1;
-    w = w < 1 ? 1 : w;
-    h = h < 1 ? 1 : h;
-    const int x_0 = max(bx0, 0), y_0 = max(by0, 0);
-    const int x_1 = min(bx1 + 1, im_w), y_1 = min(by1 + 1, im_h);
-    const float sh = (float)Mp / (float)h, sw = (float)Mp / (float)w;
+    const PasteGeom g = paste_geom(boxes + (int64_t)p * 4, M, padding, im_h, im_w);
     float *plane = planes + (int64_t)p * plane_stride;
     int xmin = im_w, ymin = im_h, xmax = -1, ymax = -1;
     // each thread produces 4 consecutive pixels per step, a wave 256: exactly one block of the packed ballot layout
@@ -79,20 +126,8 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float v = 0.0f;
-            if (i4 + k < HW && y >= y_0 && y < y_1 && x >= x_0 && x < x_1) {
-                float ry = __builtin_fmaf(sh, (float)(y - by0) + 0.5f, -0.5f);
-                ry = ry < 0.0f ? 0.0f : ry;
-                const int iy0 = (int)ry, iy1 = iy0 + (iy0 < Mp - 1 ? 1 : 0);
-                const float ly1 = ry - (float)iy0, ly0 = 1.0f - ly1;
-                float rx = __builtin_fmaf(sw, (float)(x - bx0) + 0.5f, -0.5f);
-                rx = rx < 0.0f ? 0.0f : rx;
-                const int ix0 = (int)rx, ix1 = ix0 + (ix0 < Mp - 1 ? 1 : 0);
-                const float lx1 = rx - (float)ix0, lx0 = 1.0f - lx1;
-                const float t1 = lx1 * pad_s[iy0 * Mp + ix1], b1 = lx1 * pad_s[iy1 * Mp + ix1];
-                const float top = __builtin_fmaf(lx0, pad_s[iy0 * Mp + ix0], t1);
-                const float bot = __builtin_fmaf(lx0, pad_s[iy1 * Mp + ix0], b1);
-                const float lb = ly1 * bot;
-                v = __builtin_fmaf(ly0, top, lb);
+            if (i4 + k < HW && g.inside(y, x)) {
+                v = paste_value(g, pad_s, y, x);
                 if (v > thresh) {
                     xmin = min(xmin, x); xmax = max(xmax, x);
                     ymin = min(ymin, y); ymax = max(ymax, y);
@@ -134,16 +169,11 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
     }
 }
 
-// grid = images; boxes [sum n, 4], scores [sum n], offsets [images + 1] (device int32).
-__global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
-                                                  const int32_t *__restrict__ offsets, float thresh, int max_keep,
-                                                  int32_t *__restrict__ keep, int32_t *__restrict__ keep_count) {
-    __shared__ int order_s[kNmsMax];
-    __shared__ unsigned supp_s[kNmsMax * (kNmsMax / 32)];   // [ranked i][word of ranked j]
-    const int img = blockIdx.x;
-    const int beg = offsets[img], n = offsets[img + 1] - beg;
-    const float *bx = boxes + (int64_t)beg * 4;
-    const float *sc = scores + beg;
+// NMS + top-k of one image by one workgroup (256 threads): bx [n,4], sc [n] -> keep_out[0 .. cnt) = kept local indices in
+// descending score order, *count_out = cnt.  order_s [kNmsMax], supp_s [kNmsMax * kNmsMax / 32] are the caller's LDS.
+__device__ __forceinline__ void nms_image(const float *__restrict__ bx, const float *__restrict__ sc, int n, float thresh,
+                                          int max_keep, int32_t *__restrict__ keep_out, int32_t *__restrict__ count_out,
+                                          int *order_s, unsigned *supp_s) {
     const int words = (n + 31) / 32;
     // rank by counting: position = #boxes with a higher score (or equal score and lower index) -> stable
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -179,12 +209,150 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ boxe
         int cnt = 0;
         for (int a = 0; a < n; ++a) {
             if (dead[a >> 5] & (1u << (a & 31))) continue;
-            keep[beg + cnt] = order_s[a];
+            keep_out[cnt] = order_s[a];
             ++cnt;
             if (max_keep > 0 && cnt >= max_keep) break;
             for (int wd = a >> 5; wd < words; ++wd) dead[wd] |= supp_s[a * (kNmsMax / 32) + wd];
         }
-        keep_count[img] = cnt;
+        *count_out = cnt;
+    }
+}
+
+// grid = images; boxes [sum n, 4], scores [sum n], offsets [images + 1] (device int32).
+__global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                  const int32_t *__restrict__ offsets, float thresh, int max_keep,
+                                                  int32_t *__restrict__ keep, int32_t *__restrict__ keep_count) {
+    __shared__ int order_s[kNmsMax];
+    __shared__ unsigned supp_s[kNmsMax * (kNmsMax / 32)];   // [ranked i][word of ranked j]
+    const int img = blockIdx.x;
+    const int beg = offsets[img], n = offsets[img + 1] - beg;
+    nms_image(boxes + (int64_t)beg * 4, scores + beg, n, thresh, max_keep, keep + beg, keep_count + img, order_s, supp_s);
+}
+
+// ---- two-phase form on fixed slots -------------------------------------------------------------------------------
+// Raw proposals of `images` images, R slots each: prob [.., images, R, M, M], boxes [.., images, R, 4], scores / counts
+// [.., images, R] / [.., images]; the leading axis is the frame of a clip, selected by the DEVICE scalar *step (NULL = 0).
+__device__ __forceinline__ int64_t step_of(const int32_t *__restrict__ step) { return step ? (int64_t)step[0] : 0; }
+
+// Phase 1.  grid = images * R; block = 256: tight box of (pasted value > thresh) of one raw proposal, by evaluating the
+// pasted values inside its (clipped) box only -- nothing outside can pass (the plane is zero there and the reference
+// tests v > thresh on the pasted region's values only through the same branch, paste_masks_kernel above).
+__global__ __launch_bounds__(256) void proposal_boxes_kernel(const float *__restrict__ prob, const float *__restrict__ boxes,
+                                                             const int32_t *__restrict__ counts, int images, int R, int M,
+                                                             int im_h, int im_w, float thresh, int padding,
+                                                             const int32_t *__restrict__ step,
+                                                             float *__restrict__ tight /*[images,R,4]*/) {
+    __shared__ float pad_s[64 * 64];
+    __shared__ int box_s[4];
+    const int img = blockIdx.x / R, r = blockIdx.x - img * R;
+    const int64_t fi = step_of(step) * images + img;
+    float *o = tight + (int64_t)blockIdx.x * 4;
+    if (counts && r >= counts[fi]) {                                  // empty raw slot
+        if (threadIdx.x < 4) o[threadIdx.x] = 0.0f;
+        return;
+    }
+    const int64_t p = fi * R + r;
+    stage_padded(prob + p * M * M, M, padding, pad_s);
+    if (threadIdx.x == 0) { box_s[0] = im_w; box_s[1] = im_h; box_s[2] = -1; box_s[3] = -1; }
+    __syncthreads();
+    const PasteGeom g = paste_geom(boxes + p * 4, M, padding, im_h, im_w);
+    const int rw = g.x_1 - g.x_0, rh = g.y_1 - g.y_0;
+    int xmin = im_w, ymin = im_h, xmax = -1, ymax = -1;
+    if (rw > 0 && rh > 0) {
+        for (int i = threadIdx.x; i < rw * rh; i += 256) {
+            const int yy = i / rw, y = g.y_0 + yy, x = g.x_0 + (i - yy * rw);
+            if (paste_value(g, pad_s, y, x) > thresh) {
+                xmin = min(xmin, x); xmax = max(xmax, x);
+                ymin = min(ymin, y); ymax = max(ymax, y);
+            }
+        }
+    }
+    if (xmax >= 0) {
+        atomicMin(&box_s[0], xmin);
+        atomicMin(&box_s[1], ymin);
+        atomicMax(&box_s[2], xmax);
+        atomicMax(&box_s[3], ymax);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (box_s[2] < 0) { o[0] = 0.0f; o[1] = 0.0f; o[2] = (float)im_h; o[3] = (float)im_w; }       // masker.py:164
+        else { o[0] = (float)box_s[0]; o[1] = (float)box_s[1]; o[2] = (float)box_s[2]; o[3] = (float)box_s[3]; }
+    }
+}
+
+// Phase 2.  grid = images: NMS + top-K on the tight boxes; keep [images, K], keep_count [images].
+__global__ __launch_bounds__(256) void nms_slots_kernel(const float *__restrict__ tight, const float *__restrict__ scores,
+                                                        const int32_t *__restrict__ counts, int images, int R, float thresh,
+                                                        int K, const int32_t *__restrict__ step,
+                                                        int32_t *__restrict__ keep, int32_t *__restrict__ keep_count) {
+    __shared__ int order_s[kNmsMax];
+    __shared__ unsigned supp_s[kNmsMax * (kNmsMax / 32)];
+    const int img = blockIdx.x;
+    const int64_t fi = step_of(step) * images + img;
+    int n = counts ? counts[fi] : R;
+    n = n < 0 ? 0 : (n > R ? R : n);
+    nms_image(tight + (int64_t)img * R * 4, scores + fi * R, n, thresh, K, keep + (int64_t)img * K, keep_count + img,
+              order_s, supp_s);
+}
+
+// Phase 3.  grid = (bands, images * K); block = 256: slot (img, k) receives raw proposal keep[img, k] -- plane, 1-bit
+// plane, tight box, score and its ROIAlign row [image index in the feature batch, box]; slots k >= keep_count[img] are
+// dead: their plane is left alone (n_valid hides it), score 0, box 0, roi image index -1 (the ROI kernel then writes
+// a zero feature row).
+__global__ __launch_bounds__(256) void paste_kept_kernel(
+    const float *__restrict__ prob, const float *__restrict__ boxes, const float *__restrict__ scores,
+    const float *__restrict__ tight, const int32_t *__restrict__ keep, const int32_t *__restrict__ keep_count, int images,
+    int R, int M, int K, int im_h, int im_w, int padding, const int32_t *__restrict__ step,
+    const int32_t *__restrict__ img_base, float *__restrict__ planes, int64_t plane_stride,
+    unsigned long long *__restrict__ packed, int64_t packed_stride, float *__restrict__ kept_boxes,
+    float *__restrict__ kept_scores, float *__restrict__ rois) {
+    __shared__ float pad_s[64 * 64];
+    const int slot = blockIdx.y, img = slot / K, k = slot - img * K;
+    const int64_t st = step_of(step), fi = st * images + img;
+    const bool live = k < keep_count[img];
+    const int r = live ? keep[(int64_t)img * K + k] : 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        const float tb = live ? tight[((int64_t)img * R + r) * 4 + threadIdx.x] : 0.0f;
+        if (kept_boxes) kept_boxes[(int64_t)slot * 4 + threadIdx.x] = tb;
+        if (rois) rois[(int64_t)slot * 5 + 1 + threadIdx.x] = tb;
+        if (threadIdx.x == 0) {
+            if (kept_scores) kept_scores[slot] = live ? scores[fi * R + r] : 0.0f;
+            if (rois) rois[(int64_t)slot * 5] = live ? (float)((img_base ? img_base[st] : 0) + img) : -1.0f;
+        }
+    }
+    if (!live) return;
+    const int64_t p = fi * R + r;
+    stage_padded(prob + p * M * M, M, padding, pad_s);
+    __syncthreads();
+    const PasteGeom g = paste_geom(boxes + p * 4, M, padding, im_h, im_w);
+    float *plane = planes + (int64_t)slot * plane_stride;
+    const int HW = im_h * im_w;
+    const int lane = threadIdx.x & 63;
+    const int i_end = min(((HW + 255) / 256) * 256, (int)(blockIdx.x + 1) * kPasteIters * 1024);
+    for (int i4 = blockIdx.x * kPasteIters * 1024 + 4 * threadIdx.x; i4 < i_end; i4 += 1024) {
+        float vv[4];
+        int y = i4 / im_w, x = i4 - y * im_w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vv[q] = (i4 + q < HW && g.inside(y, x)) ? paste_value(g, pad_s, y, x) : 0.0f;
+            if (++x == im_w) { x = 0; ++y; }
+        }
+        if (i4 + 3 < HW) {
+            float4u t;
+            t.x = vv[0]; t.y = vv[1]; t.z = vv[2]; t.w = vv[3];
+            *reinterpret_cast<float4u *>(plane + i4) = t;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i4 + q < HW) plane[i4 + q] = vv[q];
+        }
+        if (packed) {
+            const unsigned long long b0 = __ballot(vv[0] > 0.5f), b1 = __ballot(vv[1] > 0.5f);
+            const unsigned long long b2 = __ballot(vv[2] > 0.5f), b3 = __ballot(vv[3] > 0.5f);
+            if (lane < 4)
+                packed[(int64_t)slot * packed_stride + (i4 - 4 * lane) / 64 + lane] =
+                    lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+        }
     }
 }
 
@@ -223,5 +391,53 @@ extern "C" int dmm_nms_f32(const float *boxes, const float *scores, const int32_
     if (max_per_image > dmm::kNmsMax) return DMM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dmm::nms_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, boxes, scores, offsets, thresh,
                        max_keep, keep, keep_count);
+    return dmm::check_launch();
+}
+
+// ---- two-phase proposal preparation on fixed slots (include/dmm_match.h (7b)) ----
+extern "C" int dmm_proposal_boxes_f32(const float *prob, const float *boxes, const int32_t *counts, int images, int R,
+                                      int M, int im_h, int im_w, float thresh, int padding, const int32_t *step,
+                                      float *tight, dmm_stream_t stream) {
+    if (images < 0 || R < 0 || M <= 0 || im_h < 0 || im_w < 0 || padding < 0) return DMM_ERR_BAD_ARG;
+    if (images == 0 || R == 0) return DMM_OK;
+    if (!prob || !boxes || !tight) return DMM_ERR_BAD_ARG;
+    if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
+    if ((int64_t)images * R > 0x7fffffff) return DMM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dmm::proposal_boxes_kernel, dim3(images * R), dim3(256), 0, (hipStream_t)stream, prob, boxes, counts,
+                       images, R, M, im_h, im_w, thresh, padding, step, tight);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_nms_slots_f32(const float *tight, const float *scores, const int32_t *counts, int images, int R,
+                                 float thresh, int K, const int32_t *step, int32_t *keep, int32_t *keep_count,
+                                 dmm_stream_t stream) {
+    if (images < 0 || R < 0 || K <= 0) return DMM_ERR_BAD_ARG;
+    if (images == 0) return DMM_OK;
+    if (!tight || !scores || !keep || !keep_count) return DMM_ERR_BAD_ARG;
+    if (R > dmm::kNmsMax) return DMM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dmm::nms_slots_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, tight, scores, counts,
+                       images, R, thresh, K, step, keep, keep_count);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_paste_kept_f32(const float *prob, const float *boxes, const float *scores, const float *tight,
+                                  const int32_t *keep, const int32_t *keep_count, int images, int R, int M, int K, int im_h,
+                                  int im_w, int padding, const int32_t *step, const int32_t *img_base, float *planes,
+                                  int64_t plane_stride, uint64_t *packed, float *kept_boxes, float *kept_scores,
+                                  float *rois, dmm_stream_t stream) {
+    if (images < 0 || R < 0 || M <= 0 || K <= 0 || im_h < 0 || im_w < 0 || padding < 0) return DMM_ERR_BAD_ARG;
+    if (images == 0) return DMM_OK;
+    if (!prob || !boxes || !scores || !tight || !keep || !keep_count || !planes ||
+        plane_stride < (int64_t)im_h * im_w)
+        return DMM_ERR_BAD_ARG;
+    if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
+    if ((int64_t)images * K > 65535) return DMM_ERR_UNSUPPORTED;                  // grid.y
+    const int nsteps = (im_h * im_w + 1023) / 1024;
+    int bands = (nsteps + dmm::kPasteIters - 1) / dmm::kPasteIters;
+    bands = bands < 1 ? 1 : bands;
+    hipLaunchKernelGGL(dmm::paste_kept_kernel, dim3(bands, images * K), dim3(256), 0, (hipStream_t)stream, prob, boxes,
+                       scores, tight, keep, keep_count, images, R, M, K, im_h, im_w, padding, step, img_base, planes,
+                       plane_stride, reinterpret_cast<unsigned long long *>(packed), dmm_pack_words(im_h * im_w),
+                       kept_boxes, kept_scores, rois);
     return dmm::check_launch();
 }

@@ -173,3 +173,68 @@ extern "C" int dmm_ragged_pad(const void *const *src_table, const int32_t *count
                        (const uint32_t *const *)src_table, counts, P_max, row_bytes / 4, (uint32_t *)out);
     return dmm::check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident frame cursor (include/dmm_match.h (8b)).  The evaluator's frame loop (dmm/modules/evaluator.py:63-213)
+// advances t on the host and rebuilds every per-frame argument there; with the raw proposals of a clip resident on the
+// device and the frame index in a DEVICE scalar, one captured HIP graph replays every frame step of the clip with no
+// host input: step_select copies row *step of a per-clip int table (live template counts / commit flags per video) to
+// a fixed address, step_advance increments the scalar as the graph's last node.
+// commit_masks: out_mask_last of the per-video driver (dmm/modules/dmm_model.py:66-69, :78-80) -- a video's template
+// planes are replaced by the matched masks unless the video was skipped this frame (no live template / 'extra' frame),
+// then they stay as they were.
+// ---------------------------------------------------------------------------------------------
+namespace dmm {
+__global__ void step_select_kernel(const int32_t *__restrict__ table, const int32_t *__restrict__ step, int n,
+                                   int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table[(int64_t)step[0] * n + i];
+}
+__global__ void step_advance_kernel(int32_t *step) { step[0] = step[0] + 1; }
+
+// grid = (blocks, B); block = 256; 16 bytes per thread and step.
+__global__ __launch_bounds__(256) void commit_masks_kernel(const float *__restrict__ full, float *__restrict__ hist,
+                                                           const int32_t *__restrict__ commit, int64_t per_video) {
+    const int b = blockIdx.y;
+    if (commit[b] == 0) return;
+    const float *src = full + (int64_t)b * per_video;
+    float *dst = hist + (int64_t)b * per_video;
+    const int64_t n4 = per_video >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float v[4];
+        MaskIO<float>::load4(src + 4 * i, v);
+        float4u t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        *reinterpret_cast<float4u *>(dst + 4 * i) = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (per_video & 3)) dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
+}
+}  // namespace dmm
+
+extern "C" int dmm_step_select_i32(const int32_t *table, const int32_t *step, int n, int32_t *out, dmm_stream_t stream) {
+    if (n < 0) return DMM_ERR_BAD_ARG;
+    if (n == 0) return DMM_OK;
+    if (!table || !step || !out) return DMM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dmm::step_select_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, step, n,
+                       out);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_step_advance(int32_t *step, dmm_stream_t stream) {
+    if (!step) return DMM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dmm::step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_commit_masks_f32(const float *full, float *hist, const int32_t *commit, int B, int64_t per_video,
+                                    dmm_stream_t stream) {
+    if (B < 0 || per_video < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || per_video == 0) return DMM_OK;
+    if (!full || !hist || !commit) return DMM_ERR_BAD_ARG;
+    if (B > 65535) return DMM_ERR_UNSUPPORTED;
+    int64_t blocks = (per_video / 4 + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(dmm::commit_masks_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, full, hist,
+                       commit, per_video);
+    return dmm::check_launch();
+}

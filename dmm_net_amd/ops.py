@@ -465,6 +465,47 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
     return full, ms, ds, iters
 
 
+def match_forward_packed(masks_p, packed_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid, *, score_weight, max_iter,
+                         proj_iter, lr, is_test, out=None, workspace=None):
+    """``match_forward`` with the proposal side of the cost pass on the 1-bit planes ``packed_p`` [B,N,words] the caller
+    holds next to the soft planes (``proposals.ProposalSlots``); ``dmm_match_forward_packed``.  ``out`` = (full [B,M,H,W],
+    match_score [B,M], det_score [B,M], iters [B]) and ``workspace`` (uint8) may be caller-owned: then nothing is
+    allocated (a captured frame step).  Returns the ``out`` tuple."""
+    _need_gpu(masks_p, packed_p, masks_t, feat_p, feat_t, score_p)
+    assert masks_p.dtype == masks_t.dtype and masks_p.dtype in _DT and packed_p.dtype == torch.int64
+    masks_p, sp_b, sp_n = _planes(masks_p)
+    masks_t, st_b, st_m = _planes(masks_t)
+    B, N, H, W = masks_p.shape
+    M, D = masks_t.shape[1], feat_p.shape[-1]
+    assert packed_p.is_contiguous() and packed_p.shape == (B, N, pack_words(H * W))
+    assert feat_p.is_contiguous() and feat_t.is_contiguous() and score_p.is_contiguous()
+    assert feat_p.dtype == feat_t.dtype == score_p.dtype == torch.float32
+    dev = masks_p.device
+    L = _lib.load()
+    need = int(L.dmm_workspace_bytes_packed(B, N, M, D, H * W))
+    if workspace is None:
+        key = (dev.index, _stream(masks_p), "packed")
+        workspace = _WORKSPACES.get(key)
+        if workspace is None or workspace.numel() < need:
+            workspace = _WORKSPACES[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    assert workspace.numel() >= need
+    if out is None:
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = (torch.empty((B, M, H, W), **f32), torch.empty((B, M), **f32), torch.empty((B, M), **f32),
+               torch.empty((B,), dtype=torch.int32, device=dev))
+    full, ms, ds, iters = out
+    assert full.is_contiguous() and full.shape == (B, M, H, W) and full.dtype == torch.float32
+    wd = packed_p.shape[2]
+    with _lib.device_guard(dev):
+        rc = L.dmm_match_forward_packed(_ptr(masks_p), _ptr(packed_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p),
+                                        _ptr(feat_t), _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, N * wd, wd, st_b, st_m,
+                                        _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
+                                        float(lr), int(is_test), _ptr(full), _ptr(ms), _ptr(ds), None, None, None,
+                                        _ptr(iters), _ptr(workspace), workspace.numel(), _stream(masks_p))
+    _lib.check(rc, "dmm_match_forward_packed")
+    return out
+
+
 class ForwardPlan:
     """Pre-allocated forward of B same-shaped frames: nothing is allocated or synchronised per call.
 

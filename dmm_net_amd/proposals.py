@@ -144,3 +144,125 @@ def forward_mask_prop(mask_prob: Sequence[torch.Tensor], boxlists: Sequence, thr
             nb.add_field("mask_packed", res[2])
         out.append(nb)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two-phase preparation on fixed slots: no plane of a dropped proposal is written, nothing is gathered, no host sync
+# ------------------------------------------------------------------------------------------------------------------
+class ClipProposals:
+    """The RAW proposals of a clip, resident on the device (what ``model_encoder.py:53-58`` loads per frame):
+    ``prob`` [T,B,R,M,M] mask probabilities, ``boxes`` [T,B,R,4] xyxy in image coordinates, ``scores`` [T,B,R],
+    ``counts`` [T,B] int32 (proposals of video b in frame t; rows past it are padding).  The per-frame kernels take the
+    frame index from a device scalar, so a captured graph can walk the clip without host input."""
+
+    def __init__(self, prob, boxes, scores, counts):
+        T, B, R = scores.shape
+        assert prob.shape[:3] == (T, B, R) and boxes.shape == (T, B, R, 4) and counts.shape == (T, B)
+        assert prob.dtype == boxes.dtype == scores.dtype == torch.float32 and counts.dtype == torch.int32
+        self.prob, self.boxes, self.scores, self.counts = prob, boxes, scores, counts
+        self.T, self.B, self.R, self.M = T, B, R, int(prob.shape[-1])
+
+    @classmethod
+    def from_boxlists(cls, proposals: Sequence[Sequence], T: int, im_h: int, im_w: int, device, R: int = 0,
+                      out: "ClipProposals" = None):
+        """proposals[b][t] BoxLists with the raw 'mask' ([P,1,M,M] or [P,M,M]) and 'scores' | 'objectness'; the last
+        entry of a video is reused for missing frames (evaluator.py:101-106); boxes are brought to the image size like
+        ``BoxList.resize``.  With ``out`` the clip is written into the first T frames of that (larger) buffer."""
+        B = len(proposals)
+        items = []
+        for t in range(T):
+            for b in range(B):
+                p = proposals[b][t] if len(proposals[b]) > t else proposals[b][-1]
+                if tuple(p.size) != (im_w, im_h):
+                    p = p.resize((im_w, im_h))
+                items.append(p)
+        field = "scores" if "scores" in items[0].fields() else "objectness"
+        cnt = [len(p) for p in items]
+        Rm = max(cnt + [1, int(R)])
+        if out is not None:
+            assert out.R >= Rm and out.T >= T and out.B == B
+            Rm = out.R
+        M = int(items[0].get_field("mask").shape[-1])
+        src_dev = items[0].bbox.device
+
+        def pack(get, tail, dtype=torch.float32):
+            ts = [get(p).reshape((len(p),) + tail).to(dtype) for p in items]
+            if all(c == Rm for c in cnt):
+                return torch.stack(ts, 0).view((T, B, Rm) + tail)
+            buf = torch.zeros((T * B, Rm) + tail, dtype=dtype, device=src_dev)
+            for i, x in enumerate(ts):
+                buf[i, :cnt[i]] = x
+            return buf.view((T, B, Rm) + tail)
+        prob = pack(lambda p: p.get_field("mask"), (M, M))
+        boxes = pack(lambda p: p.bbox, (4,))
+        scores = pack(lambda p: p.get_field(field), ())
+        counts = torch.tensor(cnt, dtype=torch.int32).view(T, B)
+        dev = torch.device(device)
+        # host-resident inputs (a loaded proposal file) go through pinned staging: an asynchronous copy out of pageable
+        # memory may still be reading it when these temporaries are freed
+        stage = lambda x: x.pin_memory() if (not x.is_cuda and dev.type == "cuda") else x
+        prob, boxes, scores, counts = stage(prob), stage(boxes), stage(scores), stage(counts)
+        if out is not None:
+            out.prob[:T].copy_(prob, non_blocking=True)
+            out.boxes[:T].copy_(boxes, non_blocking=True)
+            out.scores[:T].copy_(scores, non_blocking=True)
+            out.counts[:T].copy_(counts, non_blocking=True)
+            return out
+        return cls(prob.to(dev, non_blocking=True), boxes.to(dev, non_blocking=True), scores.to(dev, non_blocking=True),
+                   counts.to(dev, non_blocking=True))
+
+    @classmethod
+    def empty(cls, T, B, R, M, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        return cls(torch.zeros((T, B, R, M, M), **f32), torch.zeros((T, B, R, 4), **f32), torch.zeros((T, B, R), **f32),
+                   torch.zeros((T, B), dtype=torch.int32, device=device))
+
+
+class ProposalSlots:
+    """K fixed slots per image holding the proposals that survive NMS + top-k, in descending score order: soft planes
+    ``planes`` [B,K,H,W], their 1-bit form ``packed`` [B,K,words], tight ``boxes`` [B,K,4], ``scores`` [B,K], the live
+    count ``count`` [B] int32 (ON THE DEVICE: it is the ``n_valid`` of the matching kernels) and the ROIAlign rows
+    ``rois`` [B*K,5].  Slots past the count are dead (score 0, roi image index -1, stale plane never read)."""
+
+    def __init__(self, B: int, K: int, H: int, W: int, R: int, device):
+        from .ops import pack_words
+        f32 = dict(dtype=torch.float32, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.B, self.K, self.H, self.W, self.R = B, K, H, W, R
+        self.planes = torch.zeros((B, K, H, W), **f32)
+        self.packed = torch.zeros((B, K, pack_words(H * W)), dtype=torch.int64, device=device)
+        self.boxes, self.scores = torch.zeros((B, K, 4), **f32), torch.zeros((B, K), **f32)
+        self.rois = torch.zeros((B * K, 5), **f32)
+        self.count = torch.zeros((B,), **i32)
+        self.tight = torch.zeros((B, R, 4), **f32)               # phase-1 result: tight boxes of ALL raw proposals
+        self.keep = torch.zeros((B, K), **i32)
+
+
+def prepare_slots(clip: ClipProposals, slots: ProposalSlots, nms_thresh: float, mask_thresh: float = 0.4,
+                  padding: int = 1, step: torch.Tensor = None, img_base: torch.Tensor = None) -> ProposalSlots:
+    """Masker paste + ``filter_results`` + BoxList indexing of one frame of ``clip`` (model_encoder.py:115-134) as three
+    launches on fixed slots: tight boxes of every raw proposal (no plane written) -> NMS + top-K -> paste of the kept
+    proposals into their slots.  ``step`` (int32 [1] on the device, None = frame 0) selects the frame; ``img_base``
+    (int32 [T]) the image index of video 0 in the feature batch the roi rows refer to.  Nothing returns to the host."""
+    if not clip.prob.is_cuda:
+        raise _lib.DmmError("prepare_slots needs tensors on an MI355X device (no CPU fallback)")
+    assert clip.B == slots.B and clip.R == slots.R
+    L = _lib.load()
+    s = torch.cuda.current_stream(clip.prob.device).cuda_stream
+    sp = None if step is None else step.data_ptr()
+    with _lib.device_guard(clip.prob.device):
+        rc = L.dmm_proposal_boxes_f32(clip.prob.data_ptr(), clip.boxes.data_ptr(), clip.counts.data_ptr(), clip.B, clip.R,
+                                      clip.M, slots.H, slots.W, float(mask_thresh), int(padding), sp,
+                                      slots.tight.data_ptr(), s)
+        _lib.check(rc, "dmm_proposal_boxes_f32")
+        rc = L.dmm_nms_slots_f32(slots.tight.data_ptr(), clip.scores.data_ptr(), clip.counts.data_ptr(), clip.B, clip.R,
+                                 float(nms_thresh), slots.K, sp, slots.keep.data_ptr(), slots.count.data_ptr(), s)
+        _lib.check(rc, "dmm_nms_slots_f32")
+        rc = L.dmm_paste_kept_f32(clip.prob.data_ptr(), clip.boxes.data_ptr(), clip.scores.data_ptr(),
+                                  slots.tight.data_ptr(), slots.keep.data_ptr(), slots.count.data_ptr(), clip.B, clip.R,
+                                  clip.M, slots.K, slots.H, slots.W, int(padding), sp,
+                                  None if img_base is None else img_base.data_ptr(), slots.planes.data_ptr(),
+                                  slots.H * slots.W, slots.packed.data_ptr(), slots.boxes.data_ptr(),
+                                  slots.scores.data_ptr(), slots.rois.data_ptr(), s)
+        _lib.check(rc, "dmm_paste_kept_f32")
+    return slots

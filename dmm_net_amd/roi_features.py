@@ -7,7 +7,8 @@ spatially averaged, giving one ``[4*C]`` vector per box.  Here that is ONE fused
 (``dmm_roialign4_mean_fwd`` / ``_bwd``); the reference's ``[R, 4, C, 14, 14]`` intermediate is never formed.
 
 ``proposals`` are duck-typed BoxLists: ``len(p)`` and ``p.bbox`` ([P,4] xyxy in image coordinates).
-Parity: un-pinned upstream (third-party op without fixtures); checked against the oracle's literal restatement.
+Parity: no upstream fixture exists for this third-party op; forward and gradients are pinned against G12, an independent
+differentiable formulation of the published per-bin definition (tests/golden/gen_golden.py), and the oracle.
 """
 from __future__ import annotations
 
@@ -37,6 +38,24 @@ def _arrays(feats):
     Ws = (ctypes.c_int * 4)(*[int(f.shape[3]) for f in feats])
     sc = (ctypes.c_float * 4)(*SCALES)
     return Hs, Ws, sc
+
+
+def roialign4_mean_into(rois: torch.Tensor, feats, out: torch.Tensor) -> torch.Tensor:
+    """Inference form with a caller-owned result: rois [R,5] fp32 (image index < 0 = dead row -> zeros), feats = the four
+    NCHW-contiguous levels, out [R, 4*C] fp32.  Nothing is allocated: this is what a captured frame step replays."""
+    f0 = feats[0]
+    if not f0.is_cuda:
+        raise _lib.DmmError("roi features need tensors on an MI355X device (no CPU fallback)")
+    B, C, R = int(f0.shape[0]), int(f0.shape[1]), int(rois.shape[0])
+    assert all(f.is_contiguous() and f.dtype == f0.dtype and f.shape[:2] == f0.shape[:2] for f in feats)
+    assert rois.is_contiguous() and rois.dtype == torch.float32 and out.is_contiguous() and out.shape == (R, 4 * C)
+    Hs, Ws, sc = _arrays(feats)
+    ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+    with _lib.device_guard(rois.device):
+        rc = _lib.load().dmm_roialign4_mean_fwd(ptrs, _DT[f0.dtype], B, C, Hs, Ws, sc, rois.data_ptr(), R, out.data_ptr(),
+                                                torch.cuda.current_stream(rois.device).cuda_stream)
+    _lib.check(rc, "dmm_roialign4_mean_fwd")
+    return out
 
 
 class _RoiAlign4Mean(torch.autograd.Function):

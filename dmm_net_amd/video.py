@@ -30,7 +30,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import _lib
-from .proposals import SimpleBoxList, filter_results, forward_mask_prop
+from .proposals import ClipProposals, ProposalSlots, SimpleBoxList, filter_results, forward_mask_prop, prepare_slots
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -162,6 +162,10 @@ def load_offline_proposals(path: str, map_location="cpu"):
 # ------------------------------------------------------------------------------------------------------------------
 # frame loop
 # ------------------------------------------------------------------------------------------------------------------
+import contextlib
+_NULL = contextlib.nullcontext()
+
+
 def _map_tensors(out, fn):
     """fn over every tensor in an encoder's output (dict / tuple / list nesting kept)."""
     if isinstance(out, torch.Tensor):
@@ -177,6 +181,107 @@ def _slice_batch(out, lo: int, hi: int):
     """Rows lo..hi of every tensor in an encoder's output."""
     return _map_tensors(out, lambda v: v[lo:hi])
 
+
+
+class StepPlan:
+    """Everything ONE frame step of the evaluator needs (evaluator.py:151-213 around dmm_model.py:48-86), at fixed
+    device addresses, so that the step can be captured into a HIP graph once and replayed for every frame of every
+    clip of the same shape with NO host input:
+
+        step_select   row *step of the per-clip tables -> m_valid [B] (live templates, 0 = video skipped) / commit [B]
+        proposal_boxes -> nms_slots -> paste_kept     raw proposals of frame *step -> K slots (proposals.prepare_slots)
+        roialign4_mean                                slots' roi rows on the feature batch -> feat_p [B,K,D]
+        match_forward_packed                          counts on 1-bit planes, cosine, solver, mix -> full [B,O,H,W]
+        (x row_scale)                                 only when the live templates are not a prefix (dmm_model.py:151-156)
+        commit_masks                                  hist[b] = full[b] unless skipped          (out_mask_last, :78-80)
+        merge_labels                                  label map of the frame                       (evaluator.py:134-139)
+        step_advance                                  *step += 1
+
+    The clip's raw proposals live in ``clip`` ([T_cap,B,R,..]); the encoder's backbone features of two chunks of G frames
+    in ``feats[l]`` [2*G*B, C, H_l, W_l] (chunk k in half k % 2), addressed through the roi rows' image index
+    (``img_base[t]``).  ``hist`` is mask_last_occurence / mask_hist, ``tplt_feat`` the template features (fixed from
+    frame 0, dmm_model.py:44)."""
+
+    def __init__(self, B, O, H, W, R, Mm, K, G, T_cap, feat_like, device, cfg, nms_thresh, mask_thresh, padding,
+                 tail: bool):
+        from . import ops
+        self.B, self.O, self.H, self.W, self.R, self.K, self.G, self.T_cap = B, O, H, W, R, K, G, T_cap
+        self.cfg, self.tail = cfg, bool(tail)
+        self.nms_thresh, self.mask_thresh, self.padding = float(nms_thresh), float(mask_thresh), int(padding)
+        dev = torch.device(device)
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        self.clip = ClipProposals.empty(T_cap, B, R, Mm, dev)
+        self.slots = ProposalSlots(B, K, H, W, R, dev)
+        self.feats = [torch.zeros((2 * G * B,) + tuple(f.shape[1:]), dtype=f.dtype, device=dev) for f in feat_like]
+        C = int(feat_like[0].shape[1])
+        self.D = 4 * C
+        self.feat_p = torch.zeros((B * K, self.D), **f32)
+        self.tplt_feat = torch.zeros((B, O, self.D), **f32)
+        self.hist = torch.zeros((B, O, H, W), **f32)
+        self.full = torch.zeros((B, O, H, W), **f32)
+        self.out = (self.full, torch.zeros((B, O), **f32), torch.zeros((B, O), **f32), torch.zeros((B,), **i32))
+        self.workspace = torch.empty((int(_lib.load().dmm_workspace_bytes_packed(B, K, O, self.D, H * W)),),
+                                     dtype=torch.uint8, device=dev)
+        self.step = torch.zeros((1,), **i32)
+        self.tables = torch.zeros((T_cap, 2, B), **i32)          # [t, 0] = m_valid, [t, 1] = commit
+        self.cur = torch.zeros((2, B), **i32)
+        self.img_base = torch.zeros((T_cap,), **i32)
+        self.n_tplt = torch.zeros((B,), **i32)
+        self.row_scale_buf = torch.ones((B, O), **f32)           # fixed address: the captured step multiplies by it
+        self.row_scale = None                                    # = row_scale_buf when the live templates are not a prefix
+        self.labels = torch.zeros((B, H * W), dtype=torch.uint8, device=dev)
+        self.graphs = {}                                         # row_scale? -> captured graph
+        self.device = dev
+
+    def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail):
+        return ((self.B, self.O, self.H, self.W, self.R, self.clip.M, self.K, self.G, self.tail) ==
+                (B, O, H, W, R, Mm, K, G, bool(tail)) and T <= self.T_cap and
+                all(tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.dtype == b.dtype for a, b in zip(self.feats, feat_like)))
+
+    def body(self):
+        """The frame step as launches on the current stream (captured, or run directly)."""
+        from . import ops
+        from .roi_features import roialign4_mean_into
+        L = _lib.load()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(L.dmm_step_select_i32(self.tables.data_ptr(), self.step.data_ptr(), 2 * self.B, self.cur.data_ptr(), s),
+                   "dmm_step_select_i32")
+        prepare_slots(self.clip, self.slots, self.nms_thresh, self.mask_thresh, self.padding, step=self.step,
+                      img_base=self.img_base)
+        roialign4_mean_into(self.slots.rois, self.feats, self.feat_p)
+        score_weight, max_iter, proj_iter, lr, is_test = self.cfg
+        ops.match_forward_packed(self.slots.planes, self.slots.packed, self.hist, self.feat_p.view(self.B, self.K, self.D),
+                                 self.tplt_feat, self.slots.scores, self.slots.count, self.cur[0],
+                                 score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test,
+                                 out=self.out, workspace=self.workspace)
+        if self.row_scale is not None:
+            self.full.mul_(self.row_scale[:, :, None, None])
+        if self.tail:
+            _lib.check(L.dmm_commit_masks_f32(self.full.data_ptr(), self.hist.data_ptr(), self.cur[1].data_ptr(), self.B,
+                                              self.O * self.H * self.W, s), "dmm_commit_masks_f32")
+            _lib.check(L.dmm_merge_labels_f32(self.full.data_ptr(), self.B, self.O, self.H * self.W,
+                                              self.O * self.H * self.W, self.H * self.W, self.n_tplt.data_ptr(),
+                                              self.labels.data_ptr(), s), "dmm_merge_labels_f32")
+        _lib.check(L.dmm_step_advance(self.step.data_ptr(), s), "dmm_step_advance")
+
+    def run_step(self, graph: bool):
+        if not graph:
+            return self.body()
+        key = self.row_scale is not None
+        g = self.graphs.get(key)
+        if g is None:
+            # warm-up on the real buffers would advance the clip: save / restore the two pieces of state it touches
+            from .ops import _CAPTURE_LOCK
+            keep_step, keep_hist = self.step.clone(), self.hist.clone()
+            self.body()
+            self.step.copy_(keep_step)
+            self.hist.copy_(keep_hist)
+            with _CAPTURE_LOCK, torch.cuda.device(self.device):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.body()
+            self.graphs[key] = g
+        g.replay()
 
 class FrameLoop:
     """Frame loop of the evaluator for a batch of B videos (evaluator.py:63-213).
@@ -213,13 +318,177 @@ class FrameLoop:
         self.lookahead = True                                    # proposals of frame t + 1 on a side stream (see run)
         self.encode_ahead = 4                                    # frames per encoder batch (see run); 1 = the reference's order
         self.encode_overlap = True                               # next chunk's encoder on its own stream (see run)
+        # fixed-slot frame step (StepPlan): raw proposals of the whole clip on the device, two-phase paste, kept counts
+        # stay on the device, and -- ``graph`` -- the whole step replayed from one HIP graph.  Off = the BoxList path
+        # (paste every raw proposal, NMS, gather the kept ones, one host sync per frame).
+        self.slots = True
+        self.graph = True
         self._side = {}
+        self._plan = None
 
     def _side_stream(self, dev, role="proposals"):
         key = (role, dev.index if dev.index is not None else torch.cuda.current_device())
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
+
+
+    # ---- fixed-slot path ---------------------------------------------------------------------------------------------
+    def _slots_ok(self, frames, proposals, O) -> bool:
+        """The fixed-slot step covers the product's configuration: raw mask probabilities, the relaxed solver, shapes
+        inside the kernels' envelopes.  Anything else takes the BoxList path."""
+        if not (self.slots and frames.is_cuda and not self.pasted and self.dmm.match_algo == "relax"):
+            return False
+        if isinstance(proposals, ClipProposals):
+            R, Mm = proposals.R, proposals.M
+        else:
+            ps = [p for v in proposals for p in v]
+            if not ps or any("mask" not in p.fields() for p in ps):
+                return False
+            R, Mm = max(len(p) for p in ps), int(ps[0].get_field("mask").shape[-1])
+        K = self.max_proposals if self.max_proposals > 0 else R
+        return 0 < R <= 1024 and Mm + 2 * self.padding <= 64 and frames.shape[0] * K <= 65535 and O <= 32 and K <= 256
+
+    def _run_slots(self, frames, first_masks, proposals, n_frames, targets, on_labels):
+        """``run`` on the fixed-slot step: zero host syncs per frame, and with ``graph`` one graph replay per frame."""
+        B, T, C, H, W = frames.shape
+        O = first_masks.shape[1]
+        dev = frames.device
+        main = torch.cuda.current_stream(dev)
+        G = max(1, min(int(self.encode_ahead), T))
+        enc_side = self._side_stream(dev, "encoder") if self.encode_overlap else None
+        need_features = self.refine is not None                  # the decoder reads refine_input_feat of every frame
+        static = getattr(self.encoder, "static_outputs", False)
+        plan = None
+
+        def encode(k):
+            """chunk k = frames [k*G, k*G + g): encoder batch, time-major; its backbone features go to half k % 2 of the
+            plan's feature batch ON THE STREAM THAT PRODUCED THEM (a static-output encoder overwrites them on its next
+            call), after the steps that still read that half (chunk k - 2) have been passed on the main stream."""
+            t0 = k * G
+            g = min(G, T - t0)
+            ctx = torch.cuda.stream(enc_side) if enc_side is not None else _NULL
+            fence = main.record_event() if enc_side is not None else None
+            with ctx:
+                xs = frames[:, t0] if g == 1 else frames[:, t0:t0 + g].transpose(0, 1).reshape(g * B, C, H, W)
+                out = self.encoder(xs)
+                if need_features and static:
+                    out = _map_tensors(out, lambda v: v.clone())
+                if enc_side is not None:
+                    _map_tensors(out, lambda v: (v.record_stream(main), v)[1])
+                return out, fence
+
+        def land(k, out, fence):
+            """backbone features of chunk k -> the plan's feature batch (needs the plan, i.e. the first chunk's shapes)."""
+            ctx = torch.cuda.stream(enc_side) if enc_side is not None else _NULL
+            with ctx:
+                if fence is not None:
+                    enc_side.wait_event(fence)
+                lo = (k % 2) * G * B
+                for dst, src in zip(plan.feats, out["backbone_feature"]):
+                    dst[lo:lo + src.shape[0]].copy_(src)
+                return enc_side.record_event() if enc_side is not None else None
+
+        if enc_side is not None:
+            enc_side.wait_stream(main)
+        out0, fence0 = encode(0)
+        # ---- the plan (buffers + captured graph) for this shape --------------------------------------------------------
+        if isinstance(proposals, ClipProposals):
+            R, Mm = proposals.R, proposals.M
+        else:
+            R = max(len(p) for v in proposals for p in v)
+            Mm = int(proposals[0][0].get_field("mask").shape[-1])
+        K = self.max_proposals if self.max_proposals > 0 else R
+        cfg = self.dmm.match_layer
+        tail = self.refine is None
+        plan = self._plan
+        if plan is None or not plan.key_fits(B, O, H, W, R, Mm, K, G, T, out0["backbone_feature"], tail) \
+                or plan.device != dev:
+            plan = self._plan = StepPlan(B, O, H, W, R, Mm, K, G, max(T, 32), out0["backbone_feature"], dev,
+                                         (float(cfg.cfgs["score_weight"]), int(cfg.max_iter), int(cfg.proj_iter),
+                                          float(cfg.relax_lr), int(bool(cfg.is_test))),
+                                         self.nms_thresh, self.mask_thresh, self.padding, tail)
+        ready = land(0, out0, fence0)
+        chunk = out0
+        # ---- the clip's raw proposals and per-frame tables: one upload, before the loop ----------------------------
+        if isinstance(proposals, ClipProposals):
+            for dst, src in ((plan.clip.prob, proposals.prob), (plan.clip.boxes, proposals.boxes),
+                             (plan.clip.scores, proposals.scores), (plan.clip.counts, proposals.counts)):
+                dst[:T].copy_(src[:T], non_blocking=True)
+        else:
+            ClipProposals.from_boxlists(proposals, T, H, W, dev, out=plan.clip)
+        plan.img_base[:T].copy_(_lib.small_to_device([((t // G) % 2) * G * B + (t % G) * B for t in range(T)],
+                                                     torch.int32, dev))
+        plan.step.zero_()
+        y0 = first_masks.float().view(B, O, H * W)
+        plan.hist.copy_(y0.view(B, O, H, W))
+        history, state, prev_mask, tplt_valid = [], None, y0, None
+        hist_all = torch.empty((T, B, O, H * W), dtype=torch.float32, device=dev)
+        lab_all = torch.empty((T, B, H, W), dtype=torch.uint8, device=dev) if on_labels is not None else None
+        next_chunk = None
+        for t in range(T):
+            extra = [n <= t for n in n_frames]
+            if t == 0:
+                y_mask = y0
+            elif targets is not None:
+                y_mask = targets[:, t].float().view(B, O, H * W)
+            else:
+                y_mask = None                                            # zeros (only the decoder reads it)
+            j = t % G
+            if j == 0:
+                if t > 0:
+                    chunk, ready = next_chunk
+                if ready is not None:
+                    main.wait_event(ready)
+                if t + G < T:
+                    k = t // G + 1
+                    o, f = encode(k)
+                    next_chunk = (o, land(k, o, f))
+            if t == 0:                                                   # forward_timestep_init, :215-225
+                boxes, valid = mask_boxes(y0.view(B * O, H, W), 0.0)
+                tplt_valid = valid.view(B, O).long()
+                n_tplt, row_scale = self.dmm._valid_layout(tplt_valid)  # the clip's ONE host sync
+                ids = torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(O)
+                rois = torch.cat([ids[:, None], boxes], 1)
+                from .roi_features import roialign4_mean_into
+                roialign4_mean_into(rois, plan.feats, plan.tplt_feat.view(B * O, -1))
+                if row_scale is not None:
+                    plan.tplt_feat.mul_(row_scale[:, :, None])
+                if row_scale is not None:
+                    plan.row_scale_buf.copy_(row_scale)
+                plan.row_scale = plan.row_scale_buf if row_scale is not None else None
+                plan.n_tplt.copy_(_lib.small_to_device(n_tplt, torch.int32, dev))
+                rows = [[[0 if (n <= tt or n_tplt[b] == 0) else n_tplt[b] for b, n in enumerate(n_frames)],
+                         [0 if (tt == 0 or n <= tt or n_tplt[b] == 0) else 1 for b, n in enumerate(n_frames)]]
+                        for tt in range(T)]
+                plan.tables[:T].copy_(_lib.small_to_device(rows, torch.int32, dev))
+            plan.run_step(self.graph)
+            if self.refine is not None:
+                gb = min(G, T - (t - j))
+                features = chunk if gb == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
+                live = plan.cur[0] > 0
+                out_last = torch.where(live[:, None, None, None], plan.full, plan.hist)
+                zeros = first_masks.new_zeros((B, O, H * W), dtype=torch.float32) if y_mask is None else y_mask
+                outs, hist_new, state = self.refine(features, prev_mask, zeros, plan.full, out_last, tplt_valid, state)
+                if t > 0:
+                    plan.hist.copy_(hist_new.view(B, O, H, W))
+                outs = outs.reshape(B, O, H * W)
+            else:
+                outs = plan.full.view(B, O, H * W)
+            if t == 0:                                                   # frame 0 only warms the decoder state, :119-128
+                outs = y0
+            hist_all[t].copy_(outs)
+            prev_mask = hist_all[t]
+            if on_labels is not None:
+                if t == 0 or self.refine is not None:
+                    lab_all[t].copy_(merge_labels(hist_all[t].view(B, O, H, W), tplt_valid))
+                else:
+                    lab_all[t].copy_(plan.labels.view(B, H, W))
+                for b in range(B):
+                    if not extra[b]:
+                        on_labels(b, t, lab_all[t, b])
+            history.append(hist_all[t])
+        return history
 
     # model_encoder.py:115-134
     def prepare_proposals(self, raw: Sequence, im_h: int, im_w: int, device):
@@ -246,6 +515,8 @@ class FrameLoop:
         O = first_masks.shape[1]
         dev = frames.device
         n_frames = list(n_frames) if n_frames is not None else [T] * B
+        if self._slots_ok(frames, proposals, O):
+            return self._run_slots(frames, first_masks, proposals, n_frames, targets, on_labels)
         history, state, mask_hist = [], None, None
         tplt_dict = tplt_valid = prev_mask = n_tplt = row_scale = None
         # Proposal look-ahead.  A frame's proposals (paste, tight boxes, NMS, top-k) depend on nothing the loop computes,
@@ -278,7 +549,12 @@ class FrameLoop:
                 xs = frames[:, t0] if g == 1 else frames[:, t0:t0 + g].transpose(0, 1).reshape(g * B, C, H, W)
                 return self.encoder(xs)
             if enc_side is None:
-                return go(), None
+                out = go()
+                if getattr(self.encoder, "static_outputs", False):
+                    # views of a graph's static buffers: the NEXT chunk is encoded (same graph, same buffers) as soon as
+                    # this one has been taken, i.e. before its steps are enqueued -- they must not alias the buffers
+                    out = _map_tensors(out, lambda v: v.clone())
+                return out, None
             with torch.cuda.stream(enc_side):
                 out = go()
                 if getattr(self.encoder, "static_outputs", False):

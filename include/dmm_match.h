@@ -255,6 +255,22 @@ DMM_API int dmm_match_forward(const void *masks_p, const void *masks_t, int mask
                       int32_t *iters_out /*[B] or NULL*/,
                       void *workspace, size_t workspace_bytes, dmm_stream_t stream);
 
+/* (5b) The same forward with the proposal side of the cost pass on 1-bit planes the caller already holds
+ * (dmm_paste_masks_f32 / dmm_paste_kept_f32 emit them next to the soft planes): packed_p [B,N,words] uint64, strides
+ * pk_b / pk_n in WORDS.  The M template planes of every frame are packed inside (st_b == M * st_m required), the counts
+ * run on the words -- identical integer tables from 1/32 of the proposal bytes -- and the mix reads the soft planes.
+ * The feature similarity is computed for every slot as a dense batch (rows past n_valid / m_valid are never read).
+ * This is the per-frame call of the evaluator's loop (dmm_model.py:75-77 for all videos of the step at once).
+ * workspace >= dmm_workspace_bytes_packed(B, N, M, D, HW). */
+DMM_API size_t dmm_workspace_bytes_packed(int B, int N, int M, int D, int HW);
+DMM_API int dmm_match_forward_packed(const void *masks_p, const uint64_t *packed_p, const void *masks_t, int mask_dtype,
+                                     const float *feat_p, const float *feat_t, const float *score_p, int B, int N, int M,
+                                     int HW, int D, int64_t sp_b, int64_t sp_n, int64_t pk_b, int64_t pk_n, int64_t st_b,
+                                     int64_t st_m, const int32_t *n_valid, const int32_t *m_valid, float score_weight,
+                                     int max_iter, int proj_iter, float lr, int is_test, float *full_outmask,
+                                     float *match_score, float *det_score, float *sim_out, float *R_out, float *Rb_out,
+                                     int32_t *iters_out, void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (6) Fused 4-level ROIAlign + spatial mean: the reference's ROI feature extractor
  * (dmm/modules/feature_extractor.py:20-52: maskrcnn_benchmark legacy ROIAlign, 14x14 bins,
@@ -290,6 +306,37 @@ DMM_API int dmm_nms_f32(const float *boxes, const float *scores, const int32_t *
                         float thresh, int max_keep, int32_t *keep, int32_t *keep_count, dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (7b) The same preprocessing in TWO PHASES on FIXED SLOTS, with no host round trip: what the evaluator does per frame
+ * before the layer (dmm/modules/model_encoder.py:115-134: Masker paste of every raw proposal, then filter_results =
+ * NMS + top-k, dmm/utils/boxlist_ops.py:15-29, then BoxList indexing of the kept ones) without ever writing the planes
+ * of proposals NMS drops and without gathering the kept ones into a new tensor.
+ *   raw inputs: prob [.., images, R, M, M], boxes [.., images, R, 4] xyxy, scores [.., images, R], counts [.., images]
+ *   (NULL = R each) -- the leading axis is the FRAME of a clip-resident buffer, selected by the DEVICE scalar *step
+ *   (NULL = frame 0), so a captured graph can replay the frame step of every frame of a clip (see (8b));
+ * dmm_proposal_boxes_f32: tight [images, R, 4] = box of (pasted value > thresh) of every raw proposal, [0,0,im_h,im_w]
+ *   when nothing passes (masker.py:164), zeros for empty raw slots -- the values are evaluated, no plane is written;
+ * dmm_nms_slots_f32: NMS(thresh) + top-K on the tight boxes -> keep [images, K] raw indices in descending score order,
+ *   keep_count [images] (stays on the device: it is the n_valid of the matching entry points); R <= 1024;
+ * dmm_paste_kept_f32: slot (i, k), k < keep_count[i], receives raw proposal keep[i, k]: its soft plane
+ *   planes[(i*K + k) * plane_stride ..], its 1-bit plane packed [images, K, dmm_pack_words] (may be NULL), kept_boxes
+ *   [images, K, 4] (the tight box), kept_scores [images, K] and the ROIAlign row rois [images*K, 5] = (img_base[*step]
+ *   + i, tight box) (each may be NULL; img_base NULL = 0).  Dead slots: plane untouched, score 0, box 0, roi image
+ *   index -1 (dmm_roialign4_mean_fwd writes a zero feature row for it).
+ * Bit identical to dmm_paste_masks_f32 + dmm_nms_f32 + gather (same device function evaluates every pasted value).
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_proposal_boxes_f32(const float *prob, const float *boxes, const int32_t *counts, int images, int R, int M,
+                                   int im_h, int im_w, float thresh, int padding, const int32_t *step, float *tight,
+                                   dmm_stream_t stream);
+DMM_API int dmm_nms_slots_f32(const float *tight, const float *scores, const int32_t *counts, int images, int R,
+                              float thresh, int K, const int32_t *step, int32_t *keep, int32_t *keep_count,
+                              dmm_stream_t stream);
+DMM_API int dmm_paste_kept_f32(const float *prob, const float *boxes, const float *scores, const float *tight,
+                               const int32_t *keep, const int32_t *keep_count, int images, int R, int M, int K, int im_h,
+                               int im_w, int padding, const int32_t *step, const int32_t *img_base, float *planes,
+                               int64_t plane_stride, uint64_t *packed, float *kept_boxes, float *kept_scores, float *rois,
+                               dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (8) Frame-loop reductions (the step right after the path).
  * dmm_mask_boxes_f32: ohw_mask2boxlist (dmm/utils/utils.py:179-210, binmask_to_bbox_xyxy_pt :114-143) for R
  *   planes [R, H*W] (plane_stride elements apart): boxes [R,4] = tight xyxy box of (plane > thresh), or
@@ -302,6 +349,19 @@ DMM_API int dmm_mask_boxes_f32(const float *masks, int R, int H, int W, int64_t 
                                float *boxes, int32_t *valid, dmm_stream_t stream);
 DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64_t stride_b, int64_t stride_o,
                                  const int32_t *o_valid, uint8_t *labels, dmm_stream_t stream);
+
+/* (8b) Device-resident frame cursor of the evaluator's loop (dmm/modules/evaluator.py:63-213: `for t in range(T)` with
+ * every per-frame argument rebuilt on the host).  With the clip's raw proposals resident on the device ((7b)) and the
+ * frame index in a device scalar, ONE captured HIP graph replays every frame step of the clip without host input:
+ * dmm_step_select_i32: out[i] = table[*step * n + i] (a row of a per-clip table -- live template counts, commit flags
+ *   per video -- copied to a fixed address); dmm_step_advance: *step += 1 (the graph's last node).
+ * dmm_commit_masks_f32: out_mask_last of the per-video driver (dmm/modules/dmm_model.py:66-69 / :78-80): hist[b] =
+ *   full[b] ([per_video] floats each) where commit[b] != 0; a skipped video (no live template, 'extra' frame) keeps its
+ *   template planes. */
+DMM_API int dmm_step_select_i32(const int32_t *table, const int32_t *step, int n, int32_t *out, dmm_stream_t stream);
+DMM_API int dmm_step_advance(int32_t *step, dmm_stream_t stream);
+DMM_API int dmm_commit_masks_f32(const float *full, float *hist, const int32_t *commit, int B, int64_t per_video,
+                                 dmm_stream_t stream);
 
 /* dmm_ragged_pad: the batching step of the per-video driver (the reference loops MatchModel over the videos,
  *   dmm/modules/dmm_model.py:62-82 / :115-139; here they run as one ragged launch): out[b, i, :] = src_table[b][i, :] for

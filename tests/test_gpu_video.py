@@ -169,3 +169,124 @@ def test_ragged_pad_stacks_per_video_blocks_in_one_launch():
     assert L.dmm_ragged_pad(t.data_ptr(), t.data_ptr(), 0, 4, 8, t.data_ptr(), st) == 0         # empty batch
     with pytest.raises(ValueError):
         ops.ragged_pad([torch.zeros(2, 3, device=DEV, dtype=torch.float16)], 4, torch.tensor([2], dtype=torch.int32, device=DEV))
+
+
+def _count_host_syncs(fn):
+    """Run fn() counting the tensor methods that round-trip to the host (tolist / item / cpu / numpy on CUDA tensors)."""
+    calls = []
+    orig = {k: getattr(torch.Tensor, k) for k in ("tolist", "item", "cpu", "numpy")}
+
+    def wrap(name):
+        def f(self, *a, **kw):
+            if self.is_cuda:
+                calls.append(name)
+            return orig[name](self, *a, **kw)
+        return f
+    try:
+        for k in orig:
+            setattr(torch.Tensor, k, wrap(k))
+        out = fn()
+    finally:
+        for k, v in orig.items():
+            setattr(torch.Tensor, k, v)
+    return out, calls
+
+
+def test_two_phase_slots_equal_paste_nms_gather():
+    """dmm_proposal_boxes_f32 -> dmm_nms_slots_f32 -> dmm_paste_kept_f32 == paste every raw proposal, NMS + top-k, index the
+    kept ones (model_encoder.py:115-134 + boxlist_ops.py:15-29): planes, 1-bit planes, boxes, scores, counts bit for bit,
+    in score order; dead slots are marked; frames of a clip are selected by the device scalar."""
+    rng = np.random.default_rng(21)
+    T, B, H, W, K = 3, 3, 57, 83, 12
+    raw = [[_raw_proposals(rng, int(rng.integers(1, 30)), H, W) for _ in range(T)] for _ in range(B)]
+    raw[1][2] = _raw_proposals(rng, 1, H, W)
+    clip = prop.ClipProposals.from_boxlists(raw, T, H, W, DEV)
+    slots = prop.ProposalSlots(B, K, H, W, clip.R, DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    base = torch.tensor([0, 7, 14], dtype=torch.int32, device=DEV)
+    for t in range(T):
+        step.fill_(t)
+        prop.prepare_slots(clip, slots, 0.4, 0.4, 1, step=step, img_base=base)
+        ref = prop.forward_mask_prop([raw[b][t].get_field("mask").to(DEV) for b in range(B)],
+                                     [raw[b][t].to(DEV) for b in range(B)], 0.4, 1, want_packed=True)
+        ref = prop.filter_results(list(ref), 0.4, K, "scores")
+        cnt = slots.count.cpu().tolist()
+        for b in range(B):
+            n = len(ref[b])
+            assert cnt[b] == n and n <= K, (t, b)
+            assert torch.equal(slots.planes[b, :n], ref[b].get_field("mask").squeeze(1)), (t, b)
+            assert torch.equal(slots.packed[b, :n], ref[b].get_field("mask_packed")), (t, b)
+            assert torch.equal(slots.boxes[b, :n], ref[b].bbox) and torch.equal(slots.scores[b, :n], ref[b].get_field("scores"))
+            rois = slots.rois.view(B, K, 5)[b]
+            assert torch.equal(rois[:n, 1:], ref[b].bbox) and bool((rois[:n, 0] == 7 * t + b).all())
+            assert bool((rois[n:, 0] == -1).all()) and float(slots.scores[b, n:].abs().sum()) == 0.0
+
+
+def test_frame_loop_fixed_slots_and_graph_equal_boxlist_path_without_host_syncs():
+    """The fixed-slot frame step (two-phase paste, device-side counts, whole step in one HIP graph) reproduces the BoxList
+    path bit for bit -- histories and label maps, ragged proposal counts, videos without templates, 'extra' frames, a
+    non-prefix template layout, a decoder -- and does not touch the host per frame."""
+    rng = np.random.default_rng(12)
+    B, T, O, H, W = 3, 6, 5, 96, 128
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    frames = torch.randn(B, T, 3, H, W, device=DEV)
+    n_frames = [6, 3, 5]
+    props = [[_raw_proposals(rng, 22 + 6 * b + t, H, W) for t in range(n_frames[b])] for b in range(B)]
+    first = torch.zeros(B, O, H, W, device=DEV)
+    for b, objs in enumerate([(0, 1), (), (0, 2, 3)]):                     # video 2: object 1 empty in frame 0 (non-prefix)
+        for o in objs:
+            y0, x0 = int(rng.integers(0, H - 30)), int(rng.integers(0, W - 30))
+            first[b, o, y0:y0 + 25, x0:x0 + 28] = 1.0
+    first = first.view(B, O, H * W)
+
+    def make(slots, graph, refine=None, **kn):
+        lp = video.FrameLoop(_PoolEncoder(), DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()),
+                             refine=refine, nms_thresh=0.4, max_proposals=20)
+        lp.slots, lp.graph = slots, graph
+        for k, v in kn.items():
+            setattr(lp, k, v)
+        return lp
+
+    def run(lp, fr=frames, fi=first, pr=props, nf=n_frames):
+        labs = {}
+        h = lp.run(fr, fi, pr, nf, on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()))
+        return [x.clone() for x in h], labs
+
+    ref_h, ref_l = run(make(False, False))
+    for (slots, graph, kn) in [(True, False, {}), (True, True, {}), (True, True, dict(encode_ahead=1, encode_overlap=False)),
+                               (True, True, dict(encode_ahead=3))]:
+        lp = make(slots, graph, **kn)
+        for rep in range(3):                                             # replays of the captured step; races
+            h, l = run(lp)
+            assert sorted(l) == sorted(ref_l)
+            assert all(torch.equal(a, c) for a, c in zip(ref_h, h)), (slots, graph, kn, rep)
+            assert all(torch.equal(ref_l[k], l[k]) for k in ref_l), (slots, graph, kn, rep)
+    # the same plan on another clip of the same shape (graph reuse), and on a shorter one
+    lp = make(True, True)
+    run(lp)
+    props2 = [[_raw_proposals(rng, 25 + t, H, W) for t in range(T)] for b in range(B)]
+    fr2 = torch.randn(B, T, 3, H, W, device=DEV)
+    h2, l2 = run(lp, fr2, first, props2, [T] * B)
+    r2, rl2 = run(make(False, False), fr2, first, props2, [T] * B)
+    assert all(torch.equal(a, c) for a, c in zip(r2, h2)) and all(torch.equal(rl2[k], l2[k]) for k in rl2)
+    h3, _ = run(lp, fr2[:, :4], first, props2, [4] * B)
+    assert all(torch.equal(a, c) for a, c in zip(r2[:4], h3))
+    # a decoder (stand-in: blends the matched masks with the previous prediction and keeps a running state)
+    def refine(features, prev_mask, y_mask, init_pred, hist_new, valid, state):
+        Bq, Oq = init_pred.shape[:2]
+        outs = 0.75 * init_pred.reshape(Bq, Oq, -1) + 0.25 * prev_mask + 0.0 * y_mask
+        state = outs.mean() if state is None else state + outs.mean()
+        return outs, hist_new * 0.5 + 0.5 * outs.view_as(hist_new), state
+    rh, rl = run(make(False, False, refine=refine))
+    gh, gl = run(make(True, True, refine=refine))
+    assert all(torch.equal(a, c) for a, c in zip(rh, gh)) and all(torch.equal(rl[k], gl[k]) for k in rl)
+    # no host round trip per frame: the count does not grow with the clip length
+    lp = make(True, True)
+    run(lp)                                                              # capture
+    quiet = lambda b, t, lab: None
+    _, c6 = _count_host_syncs(lambda: lp.run(frames, first, props, n_frames, on_labels=quiet))
+    _, c3 = _count_host_syncs(lambda: lp.run(frames[:, :3], first, props, [3, 3, 3], on_labels=quiet))
+    assert len(c6) == len(c3) <= 2, (c6, c3)
+    _, old = _count_host_syncs(lambda: make(False, False).run(frames, first, props, n_frames, on_labels=quiet))
+    assert len(old) >= T
