@@ -20,6 +20,8 @@
 //  * nms_kernel: filter_results' NMS + top-k (dmm/utils/boxlist_ops.py:15-29; maskrcnn_benchmark nms semantics:
 //    descending score, legacy +1 areas, IoU > thresh suppresses).  One workgroup per image, <= 1024 boxes: rank by
 //    counting (stable), pairwise suppression bitmask in LDS, serial greedy scan by one lane.
+#include <stdlib.h>
+
 #include "dmm_common.h"
 
 namespace dmm {
@@ -77,7 +79,7 @@ __device__ __forceinline__ float paste_value(const PasteGeom &g, const float *pa
 }
 __device__ __forceinline__ void stage_padded(const float *__restrict__ prob_p, int M, int padding, float *pad_s) {
     const int Mp = M + 2 * padding;
-    for (int i = threadIdx.x; i < Mp * Mp; i += 256) {
+    for (int i = threadIdx.x; i < Mp * Mp; i += blockDim.x) {
         const int y = i / Mp - padding, x = i % Mp - padding;
         pad_s[i] = (y >= 0 && y < M && x >= 0 && x < M) ? prob_p[y * M + x] : 0.0f;
     }
@@ -153,7 +155,13 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float *__restric
                     lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
         }
     }
-    if (xmax >= 0) {
+    // one LDS atomic per wave and coordinate (64 lanes on one LDS address serialise: 4096 of them cost more than the
+    // whole evaluation loop)
+    xmin = wave_min_i32(xmin);
+    ymin = wave_min_i32(ymin);
+    xmax = -wave_min_i32(-xmax);
+    ymax = -wave_min_i32(-ymax);
+    if ((threadIdx.x & 63) == 0 && xmax >= 0) {
         atomicMin(&box_s[0], xmin);
         atomicMin(&box_s[1], ymin);
         atomicMax(&box_s[2], xmax);
@@ -234,10 +242,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ boxe
 // [.., images, R] / [.., images]; the leading axis is the frame of a clip, selected by the DEVICE scalar *step (NULL = 0).
 __device__ __forceinline__ int64_t step_of(const int32_t *__restrict__ step) { return step ? (int64_t)step[0] : 0; }
 
-// Phase 1.  grid = images * R; block = 256: tight box of (pasted value > thresh) of one raw proposal, by evaluating the
+// Phase 1.  grid = images * R; block = 1024: tight box of (pasted value > thresh) of one raw proposal, by evaluating the
 // pasted values inside its (clipped) box only -- nothing outside can pass (the plane is zero there and the reference
 // tests v > thresh on the pasted region's values only through the same branch, paste_masks_kernel above).
-__global__ __launch_bounds__(256) void proposal_boxes_kernel(const float *__restrict__ prob, const float *__restrict__ boxes,
+__global__ __launch_bounds__(1024) void proposal_boxes_kernel(const float *__restrict__ prob, const float *__restrict__ boxes,
                                                              const int32_t *__restrict__ counts, int images, int R, int M,
                                                              int im_h, int im_w, float thresh, int padding,
                                                              const int32_t *__restrict__ step,
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void proposal_boxes_kernel(const float *__rest
     const int rw = g.x_1 - g.x_0, rh = g.y_1 - g.y_0;
     int xmin = im_w, ymin = im_h, xmax = -1, ymax = -1;
     if (rw > 0 && rh > 0) {
-        for (int i = threadIdx.x; i < rw * rh; i += 256) {
+        for (int i = threadIdx.x; i < rw * rh; i += 1024) {
             const int yy = i / rw, y = g.y_0 + yy, x = g.x_0 + (i - yy * rw);
             if (paste_value(g, pad_s, y, x) > thresh) {
                 xmin = min(xmin, x); xmax = max(xmax, x);
@@ -267,7 +275,13 @@ __global__ __launch_bounds__(256) void proposal_boxes_kernel(const float *__rest
             }
         }
     }
-    if (xmax >= 0) {
+    // one LDS atomic per wave and coordinate (64 lanes on one LDS address serialise: 4096 of them cost more than the
+    // whole evaluation loop)
+    xmin = wave_min_i32(xmin);
+    ymin = wave_min_i32(ymin);
+    xmax = -wave_min_i32(-xmax);
+    ymax = -wave_min_i32(-ymax);
+    if ((threadIdx.x & 63) == 0 && xmax >= 0) {
         atomicMin(&box_s[0], xmin);
         atomicMin(&box_s[1], ymin);
         atomicMax(&box_s[2], xmax);
@@ -293,6 +307,93 @@ __global__ __launch_bounds__(256) void nms_slots_kernel(const float *__restrict_
     n = n < 0 ? 0 : (n > R ? R : n);
     nms_image(tight + (int64_t)img * R * 4, scores + fi * R, n, thresh, K, keep + (int64_t)img * K, keep_count + img,
               order_s, supp_s);
+}
+
+
+// NMS + top-k of one image with at most 64 boxes by ONE WORKGROUP OF 4 WAVES, no scratch memory: wave 0 ranks the boxes
+// by counting (lane i holds box i; scores broadcast with readlane) and leaves them in LDS in rank order; every wave
+// then builds a quarter of the suppression matrix -- lane a = ranked box a against ranked boxes c in its 16-column
+// slice, each c one broadcast LDS read -- and wave 0 walks the greedy scan over a wave-uniform 64-bit dead mask.  The
+// IoU arithmetic is nms_image's, operation for operation, so both give the same kept set.
+__device__ __forceinline__ void nms_image_small(const float *__restrict__ bx, const float *__restrict__ sc, int n,
+                                                float thresh, int max_keep, int32_t *__restrict__ keep_out,
+                                                int32_t *__restrict__ count_out, float *box_s /*[64*4]*/, int *order_s /*[64]*/,
+                                                unsigned *row_s /*[64*4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const bool live = lane < n;
+        float4a b = {0.0f, 0.0f, 0.0f, 0.0f};
+        float si = 0.0f;
+        if (live) {
+            b = *reinterpret_cast<const float4a *>(bx + 4 * lane);               // [n,4] rows: 16-byte aligned
+            si = sc[lane];
+        }
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float sj = readlane_f32(si, j);
+            rank += (sj > si) || (sj == si && j < lane);
+        }
+        if (live) {
+            order_s[rank] = lane;
+            *reinterpret_cast<float4a *>(box_s + 4 * rank) = b;
+        }
+    }
+    __syncthreads();
+    const int a = lane;
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+    if (a < n) {
+        const float4a t = *reinterpret_cast<const float4a *>(box_s + 4 * a);
+        r0 = t.x; r1 = t.y; r2 = t.z; r3 = t.w;
+    }
+    const float ai = (r2 - r0 + 1.0f) * (r3 - r1 + 1.0f);
+    unsigned bits = 0u;
+    const int c_lo = 16 * wave, c_hi = min(n, c_lo + 16);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float4a t = *reinterpret_cast<const float4a *>(box_s + 4 * c);    // one address for the wave: broadcast
+        const float l = fmaxf(r0, t.x), r = fminf(r2, t.z);
+        const float tp = fmaxf(r1, t.y), bt = fminf(r3, t.w);
+        const float iw = fmaxf(r - l + 1.0f, 0.0f), ih = fmaxf(bt - tp + 1.0f, 0.0f);
+        const float inter = iw * ih;
+        const float aj = (t.z - t.x + 1.0f) * (t.w - t.y + 1.0f);
+        if (c > a && inter / (ai + aj - inter) > thresh) bits |= 1u << (c - c_lo);
+    }
+    row_s[4 * a + wave] = bits;                                 // 16 bits per wave
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned long long row = (unsigned long long)row_s[4 * a] | ((unsigned long long)row_s[4 * a + 1] << 16) |
+                                       ((unsigned long long)row_s[4 * a + 2] << 32) |
+                                       ((unsigned long long)row_s[4 * a + 3] << 48);
+        const int src = a < n ? order_s[a] : 0;
+        unsigned long long dead = 0ull;
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            if ((dead >> k) & 1ull) continue;
+            const int idx = __builtin_amdgcn_readlane(src, k);
+            if (lane == 0) keep_out[cnt] = idx;
+            ++cnt;
+            if (max_keep > 0 && cnt >= max_keep) break;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)row, k);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(row >> 32), k);
+            dead |= ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) *count_out = cnt;
+    }
+}
+
+// grid = images; block = 256: nms_slots_kernel for R <= 64 (the product's 50 raw proposals per frame).
+__global__ __launch_bounds__(256) void nms_slots_small_kernel(const float *__restrict__ tight, const float *__restrict__ scores,
+                                                             const int32_t *__restrict__ counts, int images, int R,
+                                                             float thresh, int K, const int32_t *__restrict__ step,
+                                                             int32_t *__restrict__ keep, int32_t *__restrict__ keep_count) {
+    __shared__ __attribute__((aligned(16))) float box_s[64 * 4];
+    __shared__ int order_s[64];
+    __shared__ unsigned row_s[64 * 4];
+    const int img = blockIdx.x;
+    const int64_t fi = step_of(step) * images + img;
+    int n = counts ? counts[fi] : R;
+    n = n < 0 ? 0 : (n > R ? R : n);
+    nms_image_small(tight + (int64_t)img * R * 4, scores + fi * R, n, thresh, K, keep + (int64_t)img * K, keep_count + img,
+                    box_s, order_s, row_s);
 }
 
 // Phase 3.  grid = (bands, images * K); block = 256: slot (img, k) receives raw proposal keep[img, k] -- plane, 1-bit
@@ -403,7 +504,7 @@ extern "C" int dmm_proposal_boxes_f32(const float *prob, const float *boxes, con
     if (!prob || !boxes || !tight) return DMM_ERR_BAD_ARG;
     if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
     if ((int64_t)images * R > 0x7fffffff) return DMM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(dmm::proposal_boxes_kernel, dim3(images * R), dim3(256), 0, (hipStream_t)stream, prob, boxes, counts,
+    hipLaunchKernelGGL(dmm::proposal_boxes_kernel, dim3(images * R), dim3(1024), 0, (hipStream_t)stream, prob, boxes, counts,
                        images, R, M, im_h, im_w, thresh, padding, step, tight);
     return dmm::check_launch();
 }
@@ -415,8 +516,13 @@ extern "C" int dmm_nms_slots_f32(const float *tight, const float *scores, const 
     if (images == 0) return DMM_OK;
     if (!tight || !scores || !keep || !keep_count) return DMM_ERR_BAD_ARG;
     if (R > dmm::kNmsMax) return DMM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(dmm::nms_slots_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, tight, scores, counts,
-                       images, R, thresh, K, step, keep, keep_count);
+    static const bool no_wave = [] { const char *e = getenv("DMM_NMS_WAVE"); return e && e[0] == '0'; }();
+    if (R <= 64 && !no_wave)
+        hipLaunchKernelGGL(dmm::nms_slots_small_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, tight, scores,
+                           counts, images, R, thresh, K, step, keep, keep_count);
+    else
+        hipLaunchKernelGGL(dmm::nms_slots_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, tight, scores, counts,
+                           images, R, thresh, K, step, keep, keep_count);
     return dmm::check_launch();
 }
 

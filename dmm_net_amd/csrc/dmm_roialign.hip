@@ -6,7 +6,8 @@
 // materialised (:49) and then averaged over the 14x14 bins (:29) -> [R, 4*C].
 // Third-party arithmetic: maskrcnn_benchmark (github.com/ZENGXH/maskrcnn-benchmark, un-pinned HEAD,
 // INSTALL.md:24) is not vendored; its published ROIAlign definition is restated in oracle/dmm_oracle.c
-// (its roialign4_mean restatement) -- parity of this row is UN-PINNED (no reference fixtures exist for it).
+// (its roialign4_mean restatement); no reference fixture exists for it -- forward and gradients are pinned against
+// G12, an independent differentiable formulation of the published per-bin definition (tests/golden/gen_golden.py).
 //
 // The 2x2 samples of the 14x14 bins form a uniform 28x28 grid over the roi and bilinear weights are
 // separable, so   out[r, l, c] = sum_h wy[h] * sum_w wx[w] * feat_l[b, c, h, w]   with two 1-D weight
@@ -148,6 +149,122 @@ __global__ __launch_bounds__(256) void roialign4_mean_kernel(RoiLevels lv, int B
     }
 }
 
+
+// ---- channels-last (NHWC) features: what the inference encoder produces (encoder.FastEncoder keeps activations
+// [B,H,W,C] bf16 end to end).  A feature cell is C contiguous channels, so a lane takes 16 bytes (8 bf16 / 4 fp32
+// channels) of one cell, LPC = C / VEC lanes cover a cell and a wave takes 64 / LPC cells per load instruction -- every
+// load is a full 16-byte lane access of contiguous memory, where the NCHW form reads 2-byte elements H*W apart.  Each
+// lane accumulates its channels over its share of the roi's patch (weight wy[h] * wx[w], the same separable weights
+// as above); the partial sums of the cell groups of a wave and of the four waves are then added in a fixed order.
+// grid = (R, 4); block = 512.  Requires C % VEC == 0 and C / VEC a power of two <= 64 (or a multiple of 64).
+template <typename T> struct NhwcVec;
+template <> struct NhwcVec<float> {
+    static constexpr int kVec = 4;
+    static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
+        const float4a t = *reinterpret_cast<const float4a *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+template <> struct NhwcVec<bf16_t> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&v)[8]) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 t = *reinterpret_cast<const u4 *>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(t[k] << 16);
+            v[2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
+        }
+    }
+};
+template <> struct NhwcVec<f16_t> {
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ void load(const f16_t *p, float (&v)[8]) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 t = *reinterpret_cast<const h8 *>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+};
+
+constexpr int kNhwcWaves = 8;        // waves per (roi, level) workgroup
+constexpr int kNhwcUnroll = 4;       // cells in flight per lane
+
+template <typename T>
+__global__ __launch_bounds__(64 * kNhwcWaves) void roialign4_mean_nhwc_kernel(RoiLevels lv, int B, int C,
+                                                                              const float *__restrict__ rois, int R,
+                                                                              float *__restrict__ out) {
+    constexpr int VEC = NhwcVec<T>::kVec;
+    constexpr int NT = 64 * kNhwcWaves;
+    __shared__ float wy_s[kRoiMaxDim], wx_s[kRoiMaxDim];
+    __shared__ float red_s[kNhwcWaves][64 * VEC];
+    __shared__ int rng_s[4];
+    const int r = blockIdx.x, l = blockIdx.y;
+    const int H = lv.H[l], W = lv.W[l];
+    const float sc = lv.scale[l];
+    for (int i = threadIdx.x; i < H; i += NT) wy_s[i] = 0.0f;
+    for (int i = threadIdx.x; i < W; i += NT) wx_s[i] = 0.0f;
+    __syncthreads();
+    const float *roi = rois + (int64_t)r * 5;
+    const int b = (int)roi[0];
+    if (threadIdx.x == 0) axis_weights(roi[2] * sc, roi[4] * sc, H, wy_s, &rng_s[0], &rng_s[1]);
+    if (threadIdx.x == 64) axis_weights(roi[1] * sc, roi[3] * sc, W, wx_s, &rng_s[2], &rng_s[3]);
+    __syncthreads();
+    const int h0 = rng_s[0], h1 = rng_s[1], w0 = rng_s[2], w1 = rng_s[3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float norm = 1.0f / (float)(kRoiSamples * kRoiSamples);
+    float *orow = out + (int64_t)r * 4 * C + (int64_t)l * C;
+    if (h1 < h0 || w1 < w0 || b < 0 || b >= B) {
+        for (int c = threadIdx.x; c < C; c += NT) orow[c] = 0.0f;
+        return;
+    }
+    const T *f = (const T *)lv.feat[l] + (int64_t)b * H * W * C;
+    const int ph = h1 - h0 + 1, pw = w1 - w0 + 1, ncell = ph * pw;
+    const int cblk = C < 64 * VEC ? C : 64 * VEC;              // channels one pass of the wave covers
+    const int LPC = cblk / VEC, CPW = 64 / LPC;                // lanes per cell, cells per wave and load
+    const int cs = lane / LPC, co = (lane - cs * LPC) * VEC;
+    const int stride = kNhwcWaves * CPW;
+    for (int c0 = 0; c0 < C; c0 += cblk) {
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        // kNhwcUnroll independent cells in flight per lane: the loop is bound by load latency (a roi's patch is a few
+        // hundred to a few thousand cells), not by bandwidth; cells past the patch are clamped and weighted 0
+        for (int e = wave * CPW + cs; e < ncell; e += kNhwcUnroll * stride) {
+            float v[kNhwcUnroll][VEC], g[kNhwcUnroll];
+#pragma unroll
+            for (int u = 0; u < kNhwcUnroll; ++u) {
+                const int eu = e + u * stride;
+                const int ec = eu < ncell ? eu : ncell - 1;
+                const int rr = ec / pw, cc = ec - rr * pw;
+                NhwcVec<T>::load(f + ((int64_t)(h0 + rr) * W + (w0 + cc)) * C + c0 + co, v[u]);
+                g[u] = eu < ncell ? wy_s[h0 + rr] * wx_s[w0 + cc] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kNhwcUnroll; ++u)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(g[u], v[u][k], acc[k]);
+        }
+        // fold the cell groups of the wave (lanes LPC apart hold the same channels), then the waves
+        for (int d = LPC; d < 64; d <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], d);
+        }
+        __syncthreads();
+        if (cs == 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red_s[wave][co + k] = acc[k];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cblk; c += NT) {
+            float t = red_s[0][c];
+#pragma unroll
+            for (int w = 1; w < kNhwcWaves; ++w) t += red_s[w][c];
+            orow[c0 + c] = t * norm;
+        }
+    }
+}
+
 }  // namespace dmm
 
 static int roi_check(const void *const feat[4], const int H[4], const int W[4], const float scale[4], int B, int C,
@@ -204,5 +321,42 @@ extern "C" int dmm_roialign4_mean_bwd(const float *dout, int B, int C, const int
     }
     hipLaunchKernelGGL((dmm::roialign4_mean_kernel<float, true>), dim3(R, 4), dim3(256), 0, (hipStream_t)stream, lv, B, C,
                        rois, R, const_cast<float *>(dout));
+    return dmm::check_launch();
+}
+
+// Channels-last (NHWC) form of dmm_roialign4_mean_fwd: feat[l] is [B, H[l], W[l], C] contiguous (a torch channels_last
+// [B,C,H,W] tensor).  C % (16 / element size) == 0 and C / that a power of two (or a multiple of 64 x that).
+extern "C" int dmm_roialign4_mean_nhwc_fwd(const void *const feat[4], int dtype, int B, int C, const int H[4],
+                                           const int W[4], const float scale[4], const float *rois, int R, float *out,
+                                           dmm_stream_t stream) {
+    const int rc = roi_check(feat, H, W, scale, B, C, rois, R);
+    if (rc >= 0) return rc;
+    if (!out) return DMM_ERR_BAD_ARG;
+    const int vec = dtype == DMM_F32 ? 4 : 8;
+    if (C % vec != 0) return DMM_ERR_UNSUPPORTED;
+    const int lpc = C / vec;
+    if (!(lpc <= 64 ? (lpc & (lpc - 1)) == 0 : lpc % 64 == 0)) return DMM_ERR_UNSUPPORTED;
+    for (int l = 0; l < 4; ++l)
+        if (((uintptr_t)feat[l] & 15) != 0) return DMM_ERR_UNSUPPORTED;
+    dmm::RoiLevels lv;
+    for (int l = 0; l < 4; ++l) {
+        lv.feat[l] = feat[l]; lv.dfeat[l] = nullptr; lv.H[l] = H[l]; lv.W[l] = W[l]; lv.scale[l] = scale[l];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case DMM_F32:
+            hipLaunchKernelGGL((dmm::roialign4_mean_nhwc_kernel<float>), dim3(R, 4), dim3(64 * dmm::kNhwcWaves), 0, s, lv, B, C, rois, R, out);
+            break;
+        case DMM_F16:
+            hipLaunchKernelGGL((dmm::roialign4_mean_nhwc_kernel<dmm::f16_t>), dim3(R, 4), dim3(64 * dmm::kNhwcWaves), 0, s, lv, B, C, rois,
+                               R, out);
+            break;
+        case DMM_BF16:
+            hipLaunchKernelGGL((dmm::roialign4_mean_nhwc_kernel<dmm::bf16_t>), dim3(R, 4), dim3(64 * dmm::kNhwcWaves), 0, s, lv, B, C, rois,
+                               R, out);
+            break;
+        default:
+            return DMM_ERR_BAD_ARG;
+    }
     return dmm::check_launch();
 }

@@ -203,6 +203,403 @@ __device__ __forceinline__ float norm_torch_order(const float *xbuf, int cnt, fl
     return *slot;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// relax_matching core, ONE WAVE per frame (NG == 1, forward only): the latency form of the sweep.  Same operations in
+// the same order as relax_core below -- bit identical -- with the work a single wave has to ISSUE cut down, because for
+// one wave per SIMD a sweep costs (instructions x 4 cycles) + a few fixed latencies:
+//   * the element-wise Dykstra steps run on PAIRS of rows as packed fp32 (v_pk_add_f32 / v_pk_mul_f32: two IEEE ops
+//     per instruction, separate roundings); the relu is one v_max_f32 (max(-0, +0) = +0 and max(NaN, 0) = 0 are what
+//     `x > 0 ? x : 0` gives);
+//   * the column projection subtracts `over ? tc : 0` (x - 0 = x exactly) instead of selecting per row;
+//   * the row projection's (sum - 1) / m is computed ONCE per row, on the lanes that hold the row sums, before the
+//     readlane broadcast (it was recomputed by every lane for every row: 7 instructions x rows per sweep); dead columns
+//     are skipped under one exec mask instead of one select per row;
+//   * "did anything move" = some |y - X_start| > 2^-75, i.e. exactly "some square (y - X_start)^2 is non-zero in fp32"
+//     (d^2 rounds to zero iff |d| <= 2^-75; a NaN counts as moved), as one compare per row with the lane masks OR-ed on
+//     the scalar unit -- no multiplies, no integer ORs;
+//   * the trailing scalars of ATen's inner sum come as two 16-byte LDS reads per row instead of seven 4-byte ones, and
+//     the rows are read back without draining the LDS queue first (one wave's LDS operations execute in order).
+// C[i] = cost of (row i, this thread's column); n rows, m <= 64 columns live; threads with col >= m carry zeros.
+// On return X[] is the final projected iterate, acc[] = sum(X_list); returns len(X_list) - 1.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Helper wave of the one-wave solver (workgroups of 128 threads, used while few frames are in flight).  Per outer
+// iteration the reference evaluates cost = ||X * C||_F (relax_match.py:70) -- in ATen's order a chain of n*m/8 dependent
+// fmas on 8 lanes, 0.6-0.9 us -- but only LOOKS at it after the projection sweeps (:96-98).  So wave 0 posts the products
+// in LDS and goes on with its sweeps; wave 1 (another SIMD of the CU) computes the norm meanwhile and posts it back.
+// Handshake through LDS words (one wave's LDS operations execute in order; workgroup-scope acquire / release):
+//   hs[0] request: 0 = none yet, k = products of outer iteration k-1 are in xbuf (hs[3] = element count), -1 = stop
+//   hs[1] done:    k = the cost of request k is in hs[2]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hs_load(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void hs_store(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void norm_helper_wave(const float *xbuf, int *hs) {
+    const int lane = threadIdx.x & 63;
+    for (int seq = 1;; ++seq) {
+        int f;
+        while ((f = hs_load(&hs[0])) == seq - 1) __builtin_amdgcn_s_sleep(1);
+        if (f < 0) return;
+        if (lane < 8) {
+            const float c = torder::norm2_group8(hs[3], lane, [&](long i) { return xbuf[i]; });
+            if (lane == 0) hs[2] = __float_as_int(c);
+        }
+        hs_store(&hs[1], seq);
+    }
+}
+// Kernel prologue for the one-wave forms: clears the handshake words; in a 128-thread workgroup the second wave becomes
+// the helper and never returns to the caller's code (returns true: the caller must `return`).
+__device__ __forceinline__ bool solver_helper_entry(const float *xbuf, int *hs) {
+    if (blockDim.x <= 64) return false;
+    if (threadIdx.x == 0) { hs[0] = 0; hs[1] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) return false;
+    norm_helper_wave(xbuf, hs);
+    return true;
+}
+__device__ __forceinline__ void solver_helper_stop(int *hs) {
+    if (blockDim.x > 64 && threadIdx.x == 0) hs_store(&hs[0], -1);
+}
+
+// (row sum - 1) / m of the rows of rowbuf in ATen's vectorised inner-sum order (see row_sums_wave_vs), returned wave-uniform.
+// The aligned 8-lane group g of the wave takes row 8p + g in pass p; the passes (two for 9..16 rows) advance in LOCKSTEP --
+// the section is one dependent chain per pass (loads -> ILP partials -> tail -> 8-lane sequential combine -> step), a
+// dependent VALU op costs ~8 cycles while an independent one issues in ~2, so two interleaved chains cost what one does.
+template <int MT, int VS>
+__device__ __forceinline__ void row_steps_wave_vs(const float *rowbuf, int n, int m, float fm, float rcp_m, float (&tr)[MT]) {
+    constexpr int NP = (MT + 7) / 8;
+    const int lane = threadIdx.x & 63, l = lane & 7, g = lane >> 3;
+    float v[NP][VS > 0 ? VS : 1];
+    f32x4 ta[NP], tb[NP];
+    const bool long_tail = (m & 7) > 4;                // wave-uniform: more than 4 trailing scalars
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = p * 8 + g;
+        const float *x = rowbuf + (r < n ? r : n - 1) * kRowStride;
+#pragma unroll
+        for (int i = 0; i < VS; ++i) v[p][i] = x[8 * i + l];
+        ta[p] = *reinterpret_cast<const f32x4 *>(x + 8 * VS);                    // zero from column m on
+        tb[p] = *reinterpret_cast<const f32x4 *>(x + 8 * VS + 4);
+    }
+    float s[NP];
+    if (VS == 0) {                                     // scalar_inner_sum (m < 8): ILP-4 over single elements
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+            if (m >= 4) {
+                p0 = p0 + ta[p].x; p1 = p1 + ta[p].y; p2 = p2 + ta[p].z; p3 = p3 + ta[p].w;
+                p0 = p0 + tb[p].x; p0 = p0 + tb[p].y; p0 = p0 + tb[p].z;
+            } else {
+                p0 = p0 + ta[p].x; p0 = p0 + ta[p].y; p0 = p0 + ta[p].z;
+            }
+            p0 = p0 + p1; p0 = p0 + p2; p0 = p0 + p3;
+            s[p] = p0;
+        }
+    } else {
+        constexpr int GQ = VS / 4;
+        float p0[NP], p1[NP], p2[NP], p3[NP], a[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { p0[p] = 0.0f; p1[p] = 0.0f; p2[p] = 0.0f; p3[p] = 0.0f; }
+        if (GQ >= 1) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { p0[p] = p0[p] + v[p][0]; p1[p] = p1[p] + v[p][1]; p2[p] = p2[p] + v[p][2]; p3[p] = p3[p] + v[p][3]; }
+        }
+        if (GQ >= 2) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { p0[p] = p0[p] + v[p][4]; p1[p] = p1[p] + v[p][5]; p2[p] = p2[p] + v[p][6]; p3[p] = p3[p] + v[p][7]; }
+        }
+#pragma unroll
+        for (int i = 4 * GQ; i < VS; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) p0[p] = p0[p] + v[p][i];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p1[p];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p2[p];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p3[p];                      // vec[l]
+        // trailing scalars, sequential from 0; adding the zeros past column m is exact, so with <= 4 of them the chain
+        // stops after the fourth
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = 0.0f + ta[p].x;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].y;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].z;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].w;
+        if (long_tail) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].x;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].y;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].z;
+        }
+        // acc + vec[0] + vec[1] + ... + vec[7] in that order (torder::add_group8_seq), the passes in lockstep
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = a[p] + p0[p];
+#if !(defined(DMM_DBG) && (DMM_DBG & 4))
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<1>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<2>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<3>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<4>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<5>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<6>(p0[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<7>(p0[p]);
+#endif
+    }
+    // (row sum - 1) / m once per row, where the sum lives (div_by_const, the passes in lockstep)
+    float q0[NP], rr[NP], step[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] - 1.0f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) q0[p] = s[p] * rcp_m;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) rr[p] = __builtin_fmaf(-q0[p], fm, s[p]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) step[p] = __builtin_fmaf(rr[p], rcp_m, q0[p]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (p * 8 + k < MT) tr[p * 8 + k] = readlane_f32(step[p], 8 * k);
+}
+template <int MT>
+__device__ __forceinline__ void row_steps_wave(const float *rowbuf, int n, int m, float fm, float rcp_m, float (&tr)[MT]) {
+    __builtin_amdgcn_wave_barrier();                   // scheduling fence only: the wave's own LDS writes are ordered
+    switch (m >> 3) {
+        case 0: row_steps_wave_vs<MT, 0>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 1: row_steps_wave_vs<MT, 1>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 2: row_steps_wave_vs<MT, 2>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 3: row_steps_wave_vs<MT, 3>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 4: row_steps_wave_vs<MT, 4>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 5: row_steps_wave_vs<MT, 5>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 6: row_steps_wave_vs<MT, 6>(rowbuf, n, m, fm, rcp_m, tr); break;
+        case 7: row_steps_wave_vs<MT, 7>(rowbuf, n, m, fm, rcp_m, tr); break;
+        default: row_steps_wave_vs<MT, 8>(rowbuf, n, m, fm, rcp_m, tr); break;
+    }
+}
+
+template <int MT, bool EXACT>
+__device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
+                                             float *xbuf, float *rsbuf, int *hs, float (&X)[MT], float (&acc)[MT],
+                                             float *cost_out) {
+    constexpr int MP = (MT + 1) / 2;                   // row pairs; an odd MT leaves a dummy slot that stays zero
+    const int n = EXACT ? MT : n_rt;
+    const bool with_helper = blockDim.x > 64;          // wave 1 computes the cost norms (norm_helper_wave)
+    if (with_helper && threadIdx.x == 0) hs[3] = n * m;
+    __shared__ __attribute__((aligned(16))) float rowbuf[MT * kRowStride + 8];
+    if (threadIdx.x < 8) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rowbuf[i * kRowStride + 64 + threadIdx.x] = 0.0f;
+        rowbuf[MT * kRowStride + threadIdx.x] = 0.0f;
+    }
+#define DMM_ROW(i) (EXACT || (i) < n)
+    const bool live = col < m;
+    const float fn = (float)n, fm = (float)m;
+    const float rcp_n = 1.0f / fn, rcp_m = 1.0f / fm;
+    const bool col_class_a = col < torder::outer_class_bound(m);
+    const int n4 = 4 * (n / 4);
+
+    // ---- greedy row-min initialisation (relax_match.py:45-55); max / first-argmin are order free ----
+    float cmax = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        if (DMM_ROW(i) && live) cmax = C[i] > cmax ? C[i] : cmax;
+    cmax = wave_max(cmax);
+    int best_row = 0;
+    {
+        float bv = C[0];
+#pragma unroll
+        for (int i = 1; i < MT; ++i)
+            if (DMM_ROW(i) && C[i] < bv) { bv = C[i]; best_row = i; }   // first argmin over rows
+    }
+    {
+        float crm[MT], vmin[MT];
+        int cand[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            crm[i] = (live && DMM_ROW(i)) ? (i == best_row ? C[i] : cmax) : __builtin_inff();
+            vmin[i] = crm[i];
+        }
+        wave_min_rows<MT>(vmin);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) cand[i] = (live && crm[i] == vmin[i]) ? col : 0x7fffffff;
+        wave_min_rows_i32<MT>(cand);                                 // first argmin over columns
+#pragma unroll
+        for (int i = 0; i < MT; ++i) X[i] = (DMM_ROW(i) && col == cand[i]) ? 1.0f : 0.0f;
+    }
+    f32x2 Xp[MP], Cp[MP], P0[MP], P1[MP], P2[MP], ap[MP];
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        Xp[k] = f32x2{X[2 * k], 2 * k + 1 < MT ? X[2 * k + 1] : 0.0f};
+        Cp[k] = f32x2{C[2 * k], 2 * k + 1 < MT ? C[2 * k + 1] : 0.0f};
+        P0[k] = f32x2{0.0f, 0.0f}; P1[k] = P0[k]; P2[k] = P0[k];
+        ap[k] = f32x2{0.0f, 0.0f} + Xp[k];                        // sum(X_list) starts at 0 + X0
+    }
+    if (cost_out && threadIdx.x == 0) cost_out[0] = 0.0f;
+    const f32x2 lr2 = f32x2{prm.lr, prm.lr};
+    constexpr float kMoveThr = 0x1p-75f;               // d*d != 0 in fp32  <=>  !(|d| <= 2^-75)
+
+    int len = 1;
+    float cost_prev = 0.0f;
+    for (int it = 0; it < prm.max_iter; ++it) {
+        // gradient step X = X - lr*C (:69); cost = ||X*C||_F (:70); X_list.append(X) (:71)
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const f32x2 g = lr2 * Cp[k];
+            Xp[k] = Xp[k] - g;
+            ap[k] = ap[k] + Xp[k];
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const f32x2 pr = Xp[k] * Cp[k];
+                xbuf[(2 * k) * m + col] = pr.x;                      // rows >= n land past the n x m matrix
+                if (2 * k + 1 < MT) xbuf[(2 * k + 1) * m + col] = pr.y;
+            }
+        }
+        float cost = 0.0f;
+        if (with_helper) {
+            if (threadIdx.x == 0) hs_store(&hs[0], it + 1);     // after this wave's product writes (LDS is in order)
+        } else {
+            cost = norm_torch_order(xbuf, n * m, rsbuf + MT);
+        }
+        ++len;
+
+        // `if ||X - X_start|| == 0: break` (:88-89) is decided ONE PHASE LATE: the lane masks of sweep j are tested after
+        // the relu step and the column sums of sweep j + 1 have been issued (a branch right behind the compares stalled
+        // the wave for the whole compare -> scalar -> branch latency, ~0.1 us per sweep); when sweep j turns out to have
+        // moved nothing, the relu step of sweep j + 1 -- all that was done since: it only touches X and P0 -- is undone.
+        unsigned long long moved_prev = ~0ull;
+        for (int j = 0; j < prm.proj_iter; ++j) {
+            f32x2 Xs[MP], P0s[MP];
+            // {X >= 0} (:74-76) then X = Y + P1 (:78)
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                Xs[k] = Xp[k];
+                P0s[k] = P0[k];
+                const f32x2 x = Xp[k] + P0[k];
+                const f32x2 y = f32x2{__builtin_fmaxf(x.x, 0.0f), __builtin_fmaxf(x.y, 0.0f)};
+                P0[k] = x - y;
+                Xp[k] = y + P1[k];
+            }
+            // X.sum(dim=0) in ATen's outer-sum order for this column's class (in-lane)
+            float cs;
+            {
+                float a0 = 0.0f, a1 = 0.0f;                 // class A: one cascade chain, 16-row blocks
+                float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;   // class B: ILP-4 row_sum
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float xi = (i & 1) ? Xp[i >> 1].y : Xp[i >> 1].x;
+                    a0 = a0 + xi;
+                    if (((i + 1) & 15) == 0) { a1 = a1 + a0; a0 = 0.0f; }
+                    const float xm = (EXACT ? i < 4 * (MT / 4) : i < n4) ? xi : 0.0f;
+                    if ((i & 3) == 0) p0 = p0 + xm;
+                    else if ((i & 3) == 1) p1 = p1 + xm;
+                    else if ((i & 3) == 2) p2 = p2 + xm;
+                    else p3 = p3 + xm;
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float xi = (i & 1) ? Xp[i >> 1].y : Xp[i >> 1].x;
+                    if (EXACT) { if (i >= 4 * (MT / 4)) p0 = p0 + xi; }
+                    else p0 = p0 + (i >= n4 ? xi : 0.0f);
+                }
+                p0 = p0 + p1;
+                p0 = p0 + p2;
+                p0 = p0 + p3;
+                cs = col_class_a ? a0 + a1 : p0;
+#if defined(DMM_DBG) && (DMM_DBG & 2)
+                cs = Xp[0].x + Xp[MP - 1].y;                    // timing experiment: no column-sum chains
+#endif
+            }
+#if !(defined(DMM_DBG) && (DMM_DBG & 8))
+            if (moved_prev == 0ull) {                          // sweep j - 1 was the last one (:88-89)
+#pragma unroll
+                for (int k = 0; k < MP; ++k) { Xp[k] = Xs[k]; P0[k] = P0s[k]; }
+                break;
+            }
+#endif
+            // {column sums <= 1}: project_col (:21-34, :79-80); then X = Y + P2 (:82)
+            const bool over = cs > 1.0f;                       // mask = (X_col_sum <= 1)
+            float tc = div_by_const(cs - 1.0f, fn, rcp_n);
+            tc = over ? tc : 0.0f;                             // x - 0 = x: the reference's `Y = X` branch, exactly
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const f32x2 tcp = f32x2{DMM_ROW(2 * k) ? tc : 0.0f, (2 * k + 1 < MT && DMM_ROW(2 * k + 1)) ? tc : 0.0f};
+                const f32x2 x = Xp[k];
+                const f32x2 y = x - tcp;
+                P1[k] = x - y;
+                Xp[k] = y + P2[k];
+            }
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {                     // every lane: dead columns hold exact zeros
+                rowbuf[(2 * k) * kRowStride + col] = Xp[k].x;
+                if (2 * k + 1 < MT) rowbuf[(2 * k + 1) * kRowStride + col] = Xp[k].y;
+            }
+            // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
+            float tr[MT];
+#if defined(DMM_DBG) && (DMM_DBG & 1)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) tr[i] = readlane_f32(tc, i);       // timing experiment: no row sums
+#else
+            row_steps_wave<MT>(rowbuf, n, m, fm, rcp_m, tr);
+#endif
+            bool moved = false;
+            if (live) {                                        // dead columns keep their zeros
+#pragma unroll
+                for (int k = 0; k < MP; ++k) {
+                    const f32x2 trp = f32x2{DMM_ROW(2 * k) ? tr[2 * k] : 0.0f,
+                                            (2 * k + 1 < MT && DMM_ROW(2 * k + 1)) ? tr[2 * k + 1 < MT ? 2 * k + 1 : 0] : 0.0f};
+                    const f32x2 x = Xp[k];
+                    const f32x2 y = x - trp;
+                    P2[k] = x - y;
+                    Xp[k] = y;                                  // :86
+                    const f32x2 d = y - Xs[k];
+                    moved |= !(__builtin_fabsf(d.x) <= kMoveThr);
+                    moved |= !(__builtin_fabsf(d.y) <= kMoveThr);
+                }
+            }
+            // a sum of squares is zero iff every square rounds to zero: "no lane saw a move" is the reference's test
+            moved_prev = __ballot(moved);
+        }
+        if (with_helper) {
+            while (hs_load(&hs[1]) != it + 1) {}
+            cost = __int_as_float(hs[2]);
+        }
+        if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
+#if !(defined(DMM_DBG) && (DMM_DBG & 16))
+        if (cost_prev == cost) break;                           // :96-98
+#endif
+        cost_prev = cost;
+    }
+    solver_helper_stop(hs);
+#undef DMM_ROW
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        X[2 * k] = Xp[k].x;
+        acc[2 * k] = ap[k].x;
+        if (2 * k + 1 < MT) { X[2 * k + 1] = Xp[k].y; acc[2 * k + 1] = ap[k].y; }
+    }
+    return len - 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // relax_matching core.  C[i] = cost of (row i, this thread's column); n rows, m columns live.
 // Threads with col >= m carry zeros everywhere and never change.  On return X[] is the final
@@ -221,7 +618,13 @@ template <int MT, int NG, bool EXACT, bool TAPE = false>
 __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                           BlockRed<MT, NG> &red, float *xbuf, float *rsbuf, float (&X)[MT],
                                           float (&acc)[MT], float *cost_out /* global [max_iter+1] or null */,
-                                          RelaxTape tape = RelaxTape{nullptr, nullptr}) {
+                                          RelaxTape tape = RelaxTape{nullptr, nullptr}, int *hs = nullptr) {
+#ifndef DMM_SOLVER_NO_W1
+    if constexpr (NG == 1 && !TAPE) {                  // forward, one wave per frame: the latency form
+        (void)red;
+        return relax_core_w1<MT, EXACT>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out);
+    }
+#endif
     int tape_pos = 0;
     const int n = EXACT ? MT : n_rt;
     // NG == 1: the zero-padded row buffer of row_sums_torch_order_wave
@@ -409,7 +812,7 @@ __device__ __forceinline__ void relax_match_body(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf) {
+    float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf, int *hs) {
     const int b = blockIdx.x;
     const int col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
@@ -461,7 +864,8 @@ __device__ __forceinline__ void relax_match_body(
     }
 
     float X[MT], acc[MT];
-    const int iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr);
+    const int iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
+                                                RelaxTape{nullptr, nullptr}, hs);
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
 
     // ---- R = sum(X_list)/len; logic; Rb; scores ----
@@ -523,7 +927,7 @@ __device__ __forceinline__ void relax_match_body(
 template <int MT, int NG, bool EXACT>
 // (4-wave instantiations up to 20 rows are capped at 256 registers -- 4 spilled -- so that two frames share a CU:
 // 20 x 200 needed 256 VGPRs + 12 AGPRs = one wave per SIMD, i.e. 256 frames filled the chip and 512 took twice as long)
-__global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_match_kernel(
+__global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_match_kernel(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
@@ -533,16 +937,19 @@ __global__ __launch_bounds__(64 * NG, (NG == 4 && MT <= 20) ? 2 : 1) void relax_
     __shared__ float red_buf[2 * NG * (MT + 1)];
     __shared__ float xbuf[MT * 64 * NG];
     __shared__ float rsbuf[MT + 1];
+    __shared__ int hs[4];
+    if (NG == 1 && solver_helper_entry(xbuf, hs)) return;       // 128-thread workgroups: wave 1 is the norm helper
     relax_match_body<MT, NG, EXACT>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                     is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, red_buf,
-                                    xbuf, rsbuf);
+                                    xbuf, rsbuf, hs);
+    if (NG == 1) solver_helper_stop(hs);                        // (paths that never reached the solver)
 }
 
 // Ragged batches of small problems (the product: up to maxseqlen = 5 templates per video, a different count per video):
 // one wave per frame picks the EXACT-row-count body of ITS frame.  The guarded MT = 8 instantiation carried 8 rows and a
 // row guard on every element for every frame (5 templates, eval setting 40 x 5: 183 us per solve; exact: ~120).
 template <int MTMAX>
-__global__ __launch_bounds__(64) void relax_match_ragged_kernel(
+__global__ __launch_bounds__(128) void relax_match_ragged_kernel(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
@@ -552,28 +959,31 @@ __global__ __launch_bounds__(64) void relax_match_ragged_kernel(
     __shared__ float red_buf[2 * (MTMAX + 1)];
     __shared__ float xbuf[MTMAX * 64];
     __shared__ float rsbuf[MTMAX + 1];
+    __shared__ int hs[4];
+    if (solver_helper_entry(xbuf, hs)) return;
     const int Mb = m_valid ? m_valid[blockIdx.x] : M;
 #define DMM_BODY(K)                                                                                                     \
     case K:                                                                                                             \
         if constexpr (K <= MTMAX)                                                                                       \
             relax_match_body<K, 1, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, \
                                          prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,       \
-                                         X_final, red_buf, xbuf, rsbuf);                                                \
+                                         X_final, red_buf, xbuf, rsbuf, hs);                                            \
         break;
     switch (Mb) {
         DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
         default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
             relax_match_body<1, 1, false>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                           is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final,
-                                          red_buf, xbuf, rsbuf);
+                                          red_buf, xbuf, rsbuf, hs);
             break;
     }
 #undef DMM_BODY
+    solver_helper_stop(hs);
 }
 
 // Solver-only kernel on a caller-provided C [B, n, m].
 template <int MT, int NG, bool EXACT>
-__global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__restrict__ Cin, int n_max, int m_max,
+__global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG) void relax_solve_kernel(const float *__restrict__ Cin, int n_max, int m_max,
                                                               const int32_t *__restrict__ rows_valid,
                                                               const int32_t *__restrict__ cols_valid,
                                                               RelaxParams prm, float *__restrict__ X_final,
@@ -582,6 +992,8 @@ __global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__res
     __shared__ float red_buf[2 * NG * (MT + 1)];
     __shared__ float xbuf[MT * 64 * NG];
     __shared__ float rsbuf[MT + 1];
+    __shared__ int hs[4];
+    if (NG == 1 && solver_helper_entry(xbuf, hs)) return;
     const int b = blockIdx.x, col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
     const int n = EXACT ? MT : (rows_valid ? rows_valid[b] : n_max);
@@ -593,12 +1005,14 @@ __global__ __launch_bounds__(64 * NG) void relax_solve_kernel(const float *__res
             if (R_out) R_out[(int64_t)b * n_max * m_max + i] = 0.0f;
         }
         if (iters_out && threadIdx.x == 0) iters_out[b] = 0;
+        if (NG == 1) solver_helper_stop(hs);
         return;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) C[i] = (i < n && col < m) ? Cin[((int64_t)b * n_max + i) * m_max + col] : 0.0f;
     const int iters = relax_core<MT, NG, EXACT>(C, n, m, col, prm, red, xbuf, rsbuf, X, acc,
-                                                cost_out ? cost_out + (int64_t)b * (prm.max_iter + 1) : nullptr);
+                                                cost_out ? cost_out + (int64_t)b * (prm.max_iter + 1) : nullptr,
+                                                RelaxTape{nullptr, nullptr}, hs);
     const float flen = (float)(iters + 1);
     for (int i = 0; i < n_max; ++i) {
         if (col < m_max) {
@@ -772,6 +1186,17 @@ __global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
 
 }  // namespace dmm
 
+namespace dmm {
+// Threads per workgroup: the one-wave solver gets a second wave (the cost-norm helper, norm_helper_wave) while few frames
+// are in flight -- two waves per frame then still sit on different SIMDs; DMM_SOLVER_HELPER_MAX (default 512 frames,
+// 0 = never) moves the switch.
+static int solver_block(int ng, int B) {
+    if (ng != 1) return 64 * ng;
+    static const int helper_max = [] { const char *e = getenv("DMM_SOLVER_HELPER_MAX"); return e ? atoi(e) : 512; }();
+    return B <= helper_max ? 128 : 64;
+}
+}  // namespace dmm
+
 // Kernel selection: exact-row-count instantiations for the common small problems (one wave per
 // frame), guarded generic ones (MT in {8,16,32}) otherwise.
 #define DMM_DISPATCH_SOLVER(M_, W_, EXACT_OK, CALL)                                                          \
@@ -821,13 +1246,13 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
                                           iters_out, X_final, (hipStream_t)stream);
     const bool exact_ok = (m_valid == nullptr);   // every frame has exactly M templates
     if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
-        hipLaunchKernelGGL((dmm::relax_match_ragged_kernel<8>), dim3(B), dim3(64), 0, (hipStream_t)stream, cos_in, inter,
+        hipLaunchKernelGGL((dmm::relax_match_ragged_kernel<8>), dim3(B), dim3(dmm::solver_block(1, B)), 0, (hipStream_t)stream, cos_in, inter,
                            area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out,
                            Rb_out, match_score, det_score, iters_out, X_final);
         return dmm::check_launch();
     }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                    \
-    hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
+    hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream,   \
                        cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, \
                        sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
     DMM_DISPATCH_SOLVER(M, Pp, exact_ok, DMM_CALL);
@@ -848,7 +1273,7 @@ extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const in
         return dmm::launch_relax_solve_rs(C, B, n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out,
                                           (hipStream_t)stream);
 #define DMM_CALL(MT_, NG_, EX_)                                                                                     \
-    hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream, C, \
+    hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream, C, \
                        n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out)
     DMM_DISPATCH_SOLVER(n, m, rows_valid == nullptr, DMM_CALL);
 #undef DMM_CALL

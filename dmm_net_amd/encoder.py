@@ -337,8 +337,8 @@ class FastEncoder(nn.Module):
     * what is left after the 3x3 / 7x7 MIOpen convolutions -- bias, residual, ReLU -- is one in-place HIP launch
       (``dmm_bias_act_bf16``) instead of two or three eager ones.
 
-    ``backbone_feature`` comes back NCHW-contiguous (what the fused ROIAlign kernel reads); ``refine_input_feat`` /
-    ``body_feature`` stay channels-last views.  Wrap in ``GraphedEncoder(FastEncoder(enc))`` to replay from one HIP
+    All outputs stay channels-last views (``backbone_feature`` is read in place by the NHWC form of the fused ROIAlign
+    kernel).  Wrap in ``GraphedEncoder(FastEncoder(enc))`` to replay from one HIP
     graph.  Reference: vision.py:6-38 (body), base.py:35-54 + model_encoder.py:136-146 (heads)."""
 
     def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
@@ -419,5 +419,7 @@ class FastEncoder(nn.Module):
             x2, x3, x4, x5 = feats
             skips = tuple(self._conv(f, getattr(enc, f"sk{k}"), relu=False) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
             p5, p4, p3, p2 = (self._head(f, getattr(enc, f"prop{k}")) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
-            backbone = tuple(p.contiguous() for p in (p2, p3, p4, p5))   # NCHW for the fused ROIAlign kernel
+            # channels-last as they are: the NHWC form of the fused ROIAlign kernel reads them in place (16-byte lane
+            # loads of contiguous channels; four NCHW copies per forward before)
+            backbone = (p2, p3, p4, p5)
         return {"backbone_feature": backbone, "refine_input_feat": skips, "body_feature": (x2, x3, x4, x5)}

@@ -33,6 +33,18 @@ def convert_to_roi_format(boxes: Sequence) -> torch.Tensor:
     return torch.cat([ids.unsqueeze(1), allb], dim=1)
 
 
+def _layout(feats):
+    """'nhwc' when every level is a channels_last tensor (memory [B,H,W,C]) the NHWC kernel accepts, else 'nchw'."""
+    C = int(feats[0].shape[1])
+    vec = 4 if feats[0].dtype == torch.float32 else 8
+    lpc = C // vec
+    ok = C % vec == 0 and ((lpc & (lpc - 1)) == 0 if lpc <= 64 else lpc % 64 == 0)
+    if ok and all(f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous() and f.data_ptr() % 16 == 0
+                  for f in feats):
+        return "nhwc"
+    return "nchw"
+
+
 def _arrays(feats):
     Hs = (ctypes.c_int * 4)(*[int(f.shape[2]) for f in feats])
     Ws = (ctypes.c_int * 4)(*[int(f.shape[3]) for f in feats])
@@ -47,35 +59,34 @@ def roialign4_mean_into(rois: torch.Tensor, feats, out: torch.Tensor) -> torch.T
     if not f0.is_cuda:
         raise _lib.DmmError("roi features need tensors on an MI355X device (no CPU fallback)")
     B, C, R = int(f0.shape[0]), int(f0.shape[1]), int(rois.shape[0])
-    assert all(f.is_contiguous() and f.dtype == f0.dtype and f.shape[:2] == f0.shape[:2] for f in feats)
+    nhwc = _layout(feats) == "nhwc"
+    assert all((nhwc or f.is_contiguous()) and f.dtype == f0.dtype and f.shape[:2] == f0.shape[:2] for f in feats)
     assert rois.is_contiguous() and rois.dtype == torch.float32 and out.is_contiguous() and out.shape == (R, 4 * C)
     Hs, Ws, sc = _arrays(feats)
     ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+    L = _lib.load()
     with _lib.device_guard(rois.device):
-        rc = _lib.load().dmm_roialign4_mean_fwd(ptrs, _DT[f0.dtype], B, C, Hs, Ws, sc, rois.data_ptr(), R, out.data_ptr(),
-                                                torch.cuda.current_stream(rois.device).cuda_stream)
-    _lib.check(rc, "dmm_roialign4_mean_fwd")
+        rc = (L.dmm_roialign4_mean_nhwc_fwd if nhwc else L.dmm_roialign4_mean_fwd)(
+            ptrs, _DT[f0.dtype], B, C, Hs, Ws, sc, rois.data_ptr(), R, out.data_ptr(),
+            torch.cuda.current_stream(rois.device).cuda_stream)
+    _lib.check(rc, "dmm_roialign4_mean_nhwc_fwd" if nhwc else "dmm_roialign4_mean_fwd")
     return out
 
 
 class _RoiAlign4Mean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, f2, f3, f4, f5):
-        feats = [f.contiguous() for f in (f2, f3, f4, f5)]
+        feats = [f2, f3, f4, f5]
         for f in feats:
             if not f.is_cuda:
                 raise _lib.DmmError("roi features need tensors on an MI355X device (no CPU fallback)")
             assert f.dim() == 4 and f.dtype == feats[0].dtype and f.shape[:2] == feats[0].shape[:2]
+        # channels-last levels of an inference encoder are read in place by the NHWC kernel; anything else as NCHW
+        if not (_layout(feats) == "nhwc" and not any(f.requires_grad for f in feats)):
+            feats = [f.contiguous() for f in feats]
         rois = rois.contiguous().float()
-        B, C = feats[0].shape[0], feats[0].shape[1]
-        R = rois.shape[0]
-        out = torch.empty((R, 4 * C), dtype=torch.float32, device=rois.device)
-        Hs, Ws, sc = _arrays(feats)
-        ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        with _lib.device_guard(rois.device):
-            rc = _lib.load().dmm_roialign4_mean_fwd(ptrs, _DT[feats[0].dtype], B, C, Hs, Ws, sc, rois.data_ptr(), R,
-                                                    out.data_ptr(), torch.cuda.current_stream(rois.device).cuda_stream)
-        _lib.check(rc, "dmm_roialign4_mean_fwd")
+        C, R = feats[0].shape[1], rois.shape[0]
+        out = roialign4_mean_into(rois, feats, torch.empty((R, 4 * C), dtype=torch.float32, device=rois.device))
         ctx.save_for_backward(rois)
         ctx.shapes = [tuple(f.shape) for f in feats]
         ctx.dtype = feats[0].dtype

@@ -212,7 +212,10 @@ class StepPlan:
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
         self.clip = ClipProposals.empty(T_cap, B, R, Mm, dev)
         self.slots = ProposalSlots(B, K, H, W, R, dev)
-        self.feats = [torch.zeros((2 * G * B,) + tuple(f.shape[1:]), dtype=f.dtype, device=dev) for f in feat_like]
+        cl = [f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous() for f in feat_like]
+        self.feats = [torch.empty((2 * G * B,) + tuple(f.shape[1:]), dtype=f.dtype, device=dev,
+                                  memory_format=torch.channels_last if c else torch.contiguous_format).zero_()
+                      for f, c in zip(feat_like, cl)]
         C = int(feat_like[0].shape[1])
         self.D = 4 * C
         self.feat_p = torch.zeros((B * K, self.D), **f32)
@@ -236,7 +239,8 @@ class StepPlan:
     def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail):
         return ((self.B, self.O, self.H, self.W, self.R, self.clip.M, self.K, self.G, self.tail) ==
                 (B, O, H, W, R, Mm, K, G, bool(tail)) and T <= self.T_cap and
-                all(tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.dtype == b.dtype for a, b in zip(self.feats, feat_like)))
+                all(tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.dtype == b.dtype and
+                    a.is_contiguous() == b.is_contiguous() for a, b in zip(self.feats, feat_like)))
 
     def body(self):
         """The frame step as launches on the current stream (captured, or run directly)."""

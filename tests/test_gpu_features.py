@@ -77,6 +77,35 @@ def test_roialign4_mean_forward_and_backward_match_g12_fixture():
             assert gerr <= 1e-5 * max(1.0, float(np.abs(ge).max())), (k, l, gerr)
 
 
+@pytest.mark.parametrize("B,C,H,W,n,dtype", [(2, 8, 64, 64, 7, torch.float32), (1, 128, 255, 255, 50, torch.bfloat16),
+                                              (3, 16, 37, 91, 4, torch.float16), (2, 128, 255, 448, 20, torch.float32),
+                                              (1, 1024, 40, 40, 3, torch.bfloat16), (2, 12, 40, 40, 3, torch.float32)])
+def test_roialign4_mean_channels_last_kernel(B, C, H, W, n, dtype):
+    """The NHWC form (channels-last levels, what FastEncoder produces) against the oracle on the same (rounded) values
+    and against the NCHW kernel; dead rois (image index -1) give zero rows; C outside its envelope falls back."""
+    from dmm_net_amd.roi_features import _layout, roialign4_mean_into
+    rng = np.random.default_rng(B * 10 + C)
+    sizes = [((H + s - 1) // s, (W + s - 1) // s) for s in (4, 8, 16, 32)]
+    feats = [torch.from_numpy(rng.standard_normal((B, C, h, w)).astype(np.float32)).to(DEV).to(dtype) for (h, w) in sizes]
+    boxes = [random_boxes(rng, n + b, H, W) for b in range(B)]
+    boxes[0][0] = [0.0, 0.0, W - 1.0, H - 1.0]                  # whole frame: the largest patch
+    rois = np.concatenate([np.concatenate([np.full((len(bb), 1), b, np.float32), bb], 1) for b, bb in enumerate(boxes)])
+    rois[-1, 0] = -1.0                                          # a dead slot
+    exp = oracle.roialign4_mean([f.float().cpu().numpy() for f in feats], rois[:-1])
+    cl = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    expect_nhwc = C % (4 if dtype == torch.float32 else 8) == 0 and C != 12
+    assert (_layout(cl) == "nhwc") == expect_nhwc
+    rt = torch.from_numpy(rois).to(DEV)
+    out = roialign4_mean_into(rt, cl if expect_nhwc else feats, torch.empty((len(rois), 4 * C), device=DEV))
+    ref = roialign4_mean_into(rt, feats, torch.empty((len(rois), 4 * C), device=DEV))
+    scale = max(1.0, float(np.abs(exp).max()))
+    assert float(np.abs(out[:-1].cpu().numpy() - exp).max()) < 2e-5 * scale
+    assert float((out - ref).abs().max()) < 2e-5 * scale
+    assert float(out[-1].abs().sum()) == 0.0 and float(ref[-1].abs().sum()) == 0.0
+    fe_out = FeatureExtractor()(tuple(cl), [Boxes(torch.from_numpy(bb).to(DEV)) for bb in boxes])
+    assert torch.equal(fe_out[:-1], out[:-1])                   # the module takes the same path
+
+
 def test_roialign4_mean_backward_is_the_adjoint():
     rng = np.random.default_rng(5)
     B, C, H, W = 2, 16, 96, 80
@@ -335,7 +364,8 @@ def test_fast_channels_last_encoder_matches_the_folded_encoder(arch, hw):
             assert e_fast <= 2.0 * e_eager + 2e-2, (k, e_fast, e_eager)
             # graph replay == direct launches (MIOpen's split-K convolutions accumulate with atomics: rounding noise only)
             assert float((y.float() - yg.float()).abs().max()) <= 2e-2 * scale
-    assert all(p.is_contiguous() for p in out["backbone_feature"])      # NCHW for the ROIAlign kernel
+    # channels-last, read in place by the NHWC form of the ROIAlign kernel
+    assert all(p.is_contiguous(memory_format=torch.channels_last) for p in out["backbone_feature"])
 
 
 @pytest.mark.parametrize("name,arch", [("r50", "resnet50"), ("r34", "resnet34")])

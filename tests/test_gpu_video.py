@@ -200,11 +200,11 @@ def test_two_phase_slots_equal_paste_nms_gather():
     T, B, H, W, K = 3, 3, 57, 83, 12
     raw = [[_raw_proposals(rng, int(rng.integers(1, 30)), H, W) for _ in range(T)] for _ in range(B)]
     raw[1][2] = _raw_proposals(rng, 1, H, W)
-    clip = prop.ClipProposals.from_boxlists(raw, T, H, W, DEV)
-    slots = prop.ProposalSlots(B, K, H, W, clip.R, DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
     base = torch.tensor([0, 7, 14], dtype=torch.int32, device=DEV)
-    for t in range(T):
+    for t, Rcap in [(0, 0), (1, 0), (2, 0), (0, 80), (2, 80)]:              # R <= 64: one-wave NMS; above: the block kernel
+        clip = prop.ClipProposals.from_boxlists(raw, T, H, W, DEV, R=Rcap)
+        slots = prop.ProposalSlots(B, K, H, W, clip.R, DEV)
         step.fill_(t)
         prop.prepare_slots(clip, slots, 0.4, 0.4, 1, step=step, img_base=base)
         ref = prop.forward_mask_prop([raw[b][t].get_field("mask").to(DEV) for b in range(B)],
