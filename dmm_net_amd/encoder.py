@@ -341,6 +341,8 @@ class FastEncoder(nn.Module):
     kernel).  Wrap in ``GraphedEncoder(FastEncoder(enc))`` to replay from one HIP
     graph.  Reference: vision.py:6-38 (body), base.py:35-54 + model_encoder.py:136-146 (heads)."""
 
+    fused_gemm = True          # 1x1 convolutions through dmm_conv1x1_bf16 (False: torch.mm / addmm + the epilogue kernel)
+
     def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
         super().__init__()
         assert not encoder.training, "FastEncoder is an inference form: eval() first"
@@ -348,29 +350,63 @@ class FastEncoder(nn.Module):
         assert dtype == torch.bfloat16, "the fused epilogue kernel is bf16"
         self.dtype = dtype
         self.src = enc                       # folded fp32 parameters stay the source of truth (state_dict)
-        self._p = {}                         # id(conv) -> prepared (weight, bias)
-
-        def prep(conv: nn.Conv2d):
-            w = conv.weight.detach()
-            b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-            if conv.kernel_size == (1, 1):
-                wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous().to(dtype)          # [Cin, Cout]
-                self._p[id(conv)] = (wt, b, None if b is None else b.to(dtype))
-            else:
-                self._p[id(conv)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, None)
-        for m in enc.modules():
-            if isinstance(m, nn.Conv2d):
-                prep(m)
+        self._p = {}                         # id(conv) -> prepared (weight, fp32 bias, bf16 bias)
+        self._ws = None                      # scratch of the library GEMMs
+        self._prepare()
+        # the prepared tensors are derived state: rebuilt whenever the module moves (.to / .cuda) or loads weights
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._prepare())
         self.eval()
+
+    def _prepare(self):
+        """bf16 weights in the layouts the kernels take + fp32 biases, from ``self.src`` (the folded fp32 parameters)."""
+        dtype = self.dtype
+        self._p = {}
+        for m in self.src.modules():
+            if not isinstance(m, nn.Conv2d):
+                continue
+            w = m.weight.detach()
+            b = (m.bias.detach() if m.bias is not None else w.new_zeros((w.shape[0],))).float().contiguous()
+            if m.kernel_size == (1, 1) and m.groups == 1:
+                assert m.padding == (0, 0), "a padded 1x1 convolution is not a plain matrix product"
+                wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous().to(dtype)          # [Cin, Cout]
+                self._p[id(m)] = (wt, b, b.to(dtype))
+            else:
+                self._p[id(m)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, None)
+        self._ws = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "src"):
+            self._prepare()
+        return out
 
     # -- building blocks --------------------------------------------------------------------------------------
     def _conv1x1(self, x, conv, relu, residual=None):
-        """y = act(x @ W^T + b (+ residual)) on the activation matrix.  stride 2 = a row subsample first."""
+        """y = act(x @ W^T + b (+ residual)) on the activation matrix, ONE library GEMM with the whole tail in its
+        epilogue (``dmm_conv1x1_bf16``: hipBLASLt, residual as the C operand).  stride 2 = a row subsample first."""
+        from . import _lib
         wt, b32, bl = self._p[id(conv)]
         if conv.stride != (1, 1):
-            x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous(memory_format=torch.channels_last)
+            x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
+        x = x.contiguous(memory_format=torch.channels_last)
         B, _, H, W = x.shape
         rows = _as_rows(x)
+        if self.fused_gemm and rows.is_contiguous():
+            if self._ws is None or self._ws.device != x.device:
+                self._ws = torch.empty((32 << 20,), dtype=torch.uint8, device=x.device)
+            res = None
+            if residual is not None:
+                res = _as_rows(residual.contiguous(memory_format=torch.channels_last))
+            y = torch.empty((rows.shape[0], wt.shape[1]), dtype=self.dtype, device=x.device)
+            with _lib.device_guard(x.device):
+                rc = _lib.load().dmm_conv1x1_bf16(rows.data_ptr(), wt.data_ptr(), b32.data_ptr(),
+                                                  None if res is None else res.data_ptr(), rows.shape[0], wt.shape[0],
+                                                  wt.shape[1], int(relu), y.data_ptr(), self._ws.data_ptr(),
+                                                  self._ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+            if rc == 0:
+                return _from_rows(y, B, H, W)
+            if rc != 2:                                                # anything but "no kernel for this shape"
+                _lib.check(rc, "dmm_conv1x1_bf16")
         if residual is not None:
             # (torch.addmm(residual, rows, wt) would first COPY the residual into the output -- a DtoD memcpy per
             # block, 16 per ResNet-50 forward -- so the residual rides in the epilogue launch instead)

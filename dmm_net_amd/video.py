@@ -327,13 +327,17 @@ class FrameLoop:
         # (paste every raw proposal, NMS, gather the kept ones, one host sync per frame).
         self.slots = True
         self.graph = True
+        self.encode_first = 0                                    # frames in the FIRST encoder batch (0 = encode_ahead): a short
+                                                                 # first chunk shortens the pipeline fill before frame 0's step
+        self.encoder_priority = 0                                # HIP stream priority of the encoder's side stream (-1 = high)
         self._side = {}
         self._plan = None
 
     def _side_stream(self, dev, role="proposals"):
-        key = (role, dev.index if dev.index is not None else torch.cuda.current_device())
+        prio = int(self.encoder_priority) if role == "encoder" else 0
+        key = (role, dev.index if dev.index is not None else torch.cuda.current_device(), prio)
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
+            self._side[key] = torch.cuda.Stream(device=dev, priority=prio)
         return self._side[key]
 
 
@@ -365,12 +369,16 @@ class FrameLoop:
         static = getattr(self.encoder, "static_outputs", False)
         plan = None
 
+        # chunks of the clip: (first frame, frames); the first one may be shorter (encode_first)
+        g0 = max(1, min(int(self.encode_first) or G, G, T))
+        chunks = [(0, g0)] + [(t0, min(G, T - t0)) for t0 in range(g0, T, G)]
+        chunk_of = [k for k, (t0, g) in enumerate(chunks) for _ in range(g)]
+
         def encode(k):
-            """chunk k = frames [k*G, k*G + g): encoder batch, time-major; its backbone features go to half k % 2 of the
+            """chunk k = frames [t0, t0 + g): encoder batch, time-major; its backbone features go to half k % 2 of the
             plan's feature batch ON THE STREAM THAT PRODUCED THEM (a static-output encoder overwrites them on its next
             call), after the steps that still read that half (chunk k - 2) have been passed on the main stream."""
-            t0 = k * G
-            g = min(G, T - t0)
+            t0, g = chunks[k]
             ctx = torch.cuda.stream(enc_side) if enc_side is not None else _NULL
             fence = main.record_event() if enc_side is not None else None
             with ctx:
@@ -421,8 +429,8 @@ class FrameLoop:
                 dst[:T].copy_(src[:T], non_blocking=True)
         else:
             ClipProposals.from_boxlists(proposals, T, H, W, dev, out=plan.clip)
-        plan.img_base[:T].copy_(_lib.small_to_device([((t // G) % 2) * G * B + (t % G) * B for t in range(T)],
-                                                     torch.int32, dev))
+        plan.img_base[:T].copy_(_lib.small_to_device([(chunk_of[t] % 2) * G * B + (t - chunks[chunk_of[t]][0]) * B
+                                                      for t in range(T)], torch.int32, dev))
         plan.step.zero_()
         y0 = first_masks.float().view(B, O, H * W)
         plan.hist.copy_(y0.view(B, O, H, W))
@@ -438,16 +446,16 @@ class FrameLoop:
                 y_mask = targets[:, t].float().view(B, O, H * W)
             else:
                 y_mask = None                                            # zeros (only the decoder reads it)
-            j = t % G
+            kc = chunk_of[t]
+            j = t - chunks[kc][0]
             if j == 0:
                 if t > 0:
                     chunk, ready = next_chunk
                 if ready is not None:
                     main.wait_event(ready)
-                if t + G < T:
-                    k = t // G + 1
-                    o, f = encode(k)
-                    next_chunk = (o, land(k, o, f))
+                if kc + 1 < len(chunks):
+                    o, f = encode(kc + 1)
+                    next_chunk = (o, land(kc + 1, o, f))
             if t == 0:                                                   # forward_timestep_init, :215-225
                 boxes, valid = mask_boxes(y0.view(B * O, H, W), 0.0)
                 tplt_valid = valid.view(B, O).long()
@@ -468,8 +476,7 @@ class FrameLoop:
                 plan.tables[:T].copy_(_lib.small_to_device(rows, torch.int32, dev))
             plan.run_step(self.graph)
             if self.refine is not None:
-                gb = min(G, T - (t - j))
-                features = chunk if gb == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
+                features = chunk if chunks[kc][1] == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
                 live = plan.cur[0] > 0
                 out_last = torch.where(live[:, None, None, None], plan.full, plan.hist)
                 zeros = first_masks.new_zeros((B, O, H * W), dtype=torch.float32) if y_mask is None else y_mask

@@ -386,6 +386,16 @@ DMM_API int dmm_ragged_pad(const void *const *src_table, const int32_t *counts, 
 DMM_API int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                               dmm_stream_t stream);
 
+/* (9b) A 1x1 convolution of the channels-last inference encoder with its whole tail as ONE hipBLASLt GEMM:
+ *   y[rows, cout] = relu?( x[rows, cin] . w[cin, cout] + bias[cout] (+ residual[rows, cout]) )
+ * x, w, residual, y bfloat16 row-major and dense, bias fp32, fp32 accumulation, one rounding.  Replaces conv1 / conv3 /
+ * downsample of the torchvision bottlenecks (dmm/modules/vision.py:6-38) and the 1x1 head convolutions (base.py:35-54)
+ * after BatchNorm folding; the residual rides as the GEMM's C operand (beta = 1) instead of a separate pass.
+ * workspace: caller-owned scratch (may be NULL / 0: kernels that need one are then not considered);
+ * DMM_ERR_UNSUPPORTED when the library offers no kernel for the shape (callers fall back to torch.mm + (9)). */
+DMM_API int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias, const void *residual, int64_t rows, int cin,
+                             int cout, int relu, void *y, void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ from dmm_net_amd.proposals import SimpleBoxList
 from dmm_net_amd.roi_features import FeatureExtractor
 
 dev = "cuda:0"
-B, T, O, H, W = int(os.environ.get("B", "4")), 12, 5, 255, 448
+B, T, O, H, W = int(os.environ.get("B", "4")), int(os.environ.get("T", "12")), 5, 255, 448
 rng = np.random.default_rng(0)
 cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
         "score_weight": 0.3}
@@ -52,6 +52,9 @@ for b in range(B):
 first = first.view(B, O, H * W)
 loop = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4, max_proposals=50)
 loop.encode_ahead = int(os.environ.get("AHEAD", "4"))
+loop.encode_first = int(os.environ.get("FIRST", "0"))
+loop.encoder_priority = int(os.environ.get("ENCPRIO", "0"))
+T = int(os.environ.get("T", "12"))
 loop.slots = os.environ.get("SLOTS", "1") != "0"             # fixed-slot frame step (two-phase paste, no host sync)
 loop.graph = os.environ.get("GRAPH", "1") != "0"             # ... replayed from one HIP graph per frame
 labels = []
