@@ -6,11 +6,15 @@ M=10 templates, 255x255 fp32 masks, 20 outer x 5 inner solver iterations.  One "
 (IoU cost tables -> cosine + relaxed assignment -> assignment-weighted mask mix; forward, is_test=1) over a batch of
 ``--frames`` synthetic frames already resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--config 2|3|5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--config 2|3|4|5|loop]
 
 ``--config 5`` = configs[4] (N=200, M=20, fp16 mask planes, fp32 accumulation), ``--config 3`` = configs[2]
-(ResNet-50 + heads in bf16 -> fused 4-level ROIAlign+mean -> the layer, 8 frames); same JSON schema, ``config.workload``
-names the configuration.
+(ResNet-50 + heads in bf16 -> fused 4-level ROIAlign+mean -> the layer, 8 frames), ``--config 4`` = configs[3]'s per-GPU
+share (ResNet-101 training step through DMM_Model, gradient mean over RCCL with the bucketed overlapped all-reduce;
+``--gpus 8`` is the BASELINE configuration), ``--config loop`` = the evaluator's frame loop (video.FrameLoop: encoder +
+two-phase proposal prep + ROI features + matching + label merge, 4 videos of 255x448, eval solver setting 40x5); same
+JSON schema, ``config.workload`` names the configuration.  The default N = 1 line also carries compact results of
+configs 3, 5 and the frame loop under ``other_configs`` (``--no-others`` skips them).
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank owns its own B
 frames (weak scaling; the forward has no exchange step), timing is bracketed by barrier + synchronize on both sides and
@@ -47,7 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5), help="BASELINE configs index + 1")
+    ap.add_argument("--config", default="2", choices=("2", "3", "4", "5", "loop"),
+                    help="BASELINE configs index + 1; loop = the evaluator's frame loop")
+    ap.add_argument("--no-others", action="store_true", help="default run: skip the compact other_configs entries")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 512 for "
                                                           "config 2 / 3 / 5)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream schedule")
@@ -61,7 +67,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank control flow on a single-GPU box)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.config = a.config if a.config == "loop" else int(a.config)
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -350,7 +358,7 @@ def bench_layer(R, ci):
             out["roofline"]["traffic_source"] = f"NOT measured in this run; from {src}" if src else None
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, ci)
-    R.finish(out)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -445,18 +453,248 @@ def bench_config3(R):
                      "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
                      "algorithmic_flops_per_launch": int(flops), "avg_launch_ms": round(enc_ms, 4),
                      "note": "2 x MACs of every convolution of one 8-frame forward / HIP-event time of the graph "
-                             "replay; per-kernel table in profiles/r02_encoder_kernel_table.md"},
+                             "replay; per-layer table in profiles/r02_encoder_layer_table.md"},
     }
-    R.finish(out)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the evaluator's frame loop (video.FrameLoop): what DMM-Net actually runs per frame at inference
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_frame_loop(R, T=12, reps=3, boxlist_path=True):
+    from dmm_net_amd import _lib, video
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd.encoder import FastEncoder, FeatureEncoder, GraphedEncoder, fold_batchnorm
+    from dmm_net_amd.proposals import SimpleBoxList
+    from dmm_net_amd.roi_features import FeatureExtractor
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    _lib.load()
+    B, O, H, W, P = args.frames or 4, 5, 255, 448, 50
+    rng = np.random.default_rng(1000 * rank)
+    torch.manual_seed(0)
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    enc = GraphedEncoder(FastEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(dev).eval())), miopen_find=True)
+
+    def raw(n):
+        x1, y1 = rng.uniform(0, W - 40, n), rng.uniform(0, H - 40, n)
+        bx = np.stack([x1, y1, np.minimum(x1 + rng.uniform(10, 150, n), W - 1), np.minimum(y1 + rng.uniform(10, 100, n), H - 1)], 1)
+        bl = SimpleBoxList(torch.from_numpy(bx.astype(np.float32)), (W, H))
+        bl.add_field("scores", torch.from_numpy(rng.random(n).astype(np.float32)))
+        bl.add_field("mask", torch.from_numpy((rng.random((n, 1, 28, 28)) * 0.6 + 0.4).astype(np.float32)))
+        return bl
+    frames = torch.randn(B, T, 3, H, W, device=dev)
+    props = [[raw(P).to(dev) for _ in range(T)] for _ in range(B)]
+    first = torch.zeros(B, O, H, W, device=dev)
+    for b in range(B):
+        for o in range(3 + b % 3):
+            y0, x0 = int(rng.integers(0, H - 60)), int(rng.integers(0, W - 60))
+            first[b, o, y0:y0 + 50, x0:x0 + 55] = 1.0
+    first = first.view(B, O, H * W)
+
+    def make(slots):
+        lp = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4,
+                             max_proposals=50)
+        lp.slots = lp.graph = slots
+        return lp
+    loop = make(True)
+    seen = []
+
+    def clip(lp):
+        seen.clear()
+        lp.run(frames, first, props, on_labels=lambda b, t, lab: seen.append(t))
+    clip(loop)                                                    # warm-up: graph captures, MIOpen find-db lookups
+    elapsed = R.timed(lambda k: clip(loop), reps, 1)
+    assert len(seen) == B * T
+    ms = elapsed / (reps * T) * 1e3
+    out = {
+        "metric": "frames/sec (evaluator frame loop: ResNet-50 encoder + proposal paste/NMS + ROI features + cost+match "
+                  "layer + label merge), 4 videos of 255x448",
+        "value": round(world * B * T * reps / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": reps * T,
+        "warmup": T, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 encoder, f32 matching layer", "data": "synthetic",
+        "config": {"workload": f"video.FrameLoop: {B} videos x {T} frames of 255x448, {P} raw 28x28 proposals per frame "
+                               "(two-phase paste + NMS(0.4) + top-50 on the device), 5 template slots, eval solver "
+                               "setting 40 outer x 5 inner, label merge; refine decoder out of scope (None); one step = "
+                               "one frame of all videos; fixed-slot step replayed from one HIP graph, encoder chunks of "
+                               f"{loop.encode_ahead} frames on a side stream",
+                   "videos_per_gpu": B, "frames_per_clip": T, "sharding": f"videos x{world}"},
+    }
+    if boxlist_path and rank == 0:
+        old = make(False)
+        clip(old)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        clip(old)
+        torch.cuda.synchronize(dev)
+        out["config"]["boxlist_path_ms_per_step"] = round((time.perf_counter() - t0) / T * 1e3, 4)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[3]: the per-GPU share of the 8-GPU training job -- ResNet-101, clips sharded per GPU, RCCL gradient mean
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_config4(R):
+    from dmm_net_amd import _lib
+    from dmm_net_amd.distributed import GradBucketer
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd.encoder import FeatureEncoder
+    from dmm_net_amd.proposals import SimpleBoxList
+    from dmm_net_amd.roi_features import FeatureExtractor
+    import torch.distributed as dist
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    _lib.load()
+    own_group = False
+    if not dist.is_initialized():                                # N = 1: a one-rank RCCL group, same code path
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl" if args.backend == "nccl" else args.backend, rank=0, world_size=1,
+                                **({"device_id": dev} if args.backend == "nccl" else {}))
+        own_group = True
+    B, F, P, H, W = args.frames or 12, 5, 50, 255, 448           # 4 videos x clip 3 (train_101.sh: batch 4, clip_len 3)
+    torch.manual_seed(rank)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    enc = FeatureEncoder("resnet101").to(dev).train()
+    model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
+                       "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
+    params = list(enc.get_skip_params()) + list(enc.get_backbone_para())
+    opt = torch.optim.Adam(params, lr=1e-4)
+    bucketer = GradBucketer(params, bucket_mb=64.0, overlap=True)
+    img = torch.randn(B, 3, H, W, device=dev)
+
+    def boxes(n):
+        x1 = torch.rand(n, generator=g, device=dev) * (W - 60)
+        y1 = torch.rand(n, generator=g, device=dev) * (H - 60)
+        return torch.stack([x1, y1, x1 + 10 + torch.rand(n, generator=g, device=dev) * 150,
+                            y1 + 10 + torch.rand(n, generator=g, device=dev) * 100], 1).clamp(max=W - 1)
+    props, tboxes = [], []
+    for b in range(B):
+        bl = SimpleBoxList(boxes(P), (W, H))
+        bl.add_field("mask", torch.rand((P, 1, H, W), generator=g, device=dev))
+        bl.add_field("scores", torch.rand(P, generator=g, device=dev))
+        props.append(bl)
+        tboxes.append(SimpleBoxList(boxes(F), (W, H)))
+    mask_last = torch.rand((B, F, H, W), generator=g, device=dev)
+    targets = (torch.rand((B, F, H, W), generator=g, device=dev) > 0.5).float()
+    valid = torch.ones(B, F, device=dev)
+    ev, losses = [], []
+
+    def step(k):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if k is not None else None
+        mark = (lambda i: e[i].record()) if e else (lambda i: None)
+        mark(0)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feats = enc(img)
+        mark(1)
+        tplt = model.fill_template_dict(None, tboxes, feats, None, valid)
+        out, _, match_loss, _ = model(None, props, feats["backbone_feature"], mask_last, tplt, valid, targets)
+        soft = 1.0 - (out * targets).flatten(1).sum(1) / ((out + targets - out * targets).flatten(1).sum(1) + 1e-6)
+        loss = soft.mean() + sum(match_loss) / B
+        mark(2)
+        opt.zero_grad()
+        loss.backward()                                           # buckets are all-reduced under the backward
+        mark(3)
+        bucketer.finish()                                         # what is still in flight / not issued: exposed
+        mark(4)
+        opt.step()
+        mark(5)
+        if e:
+            ev.append(e)
+            losses.append(loss.detach())
+    elapsed = R.timed(step, args.steps, args.warmup)
+    assert bool(torch.isfinite(torch.stack(losses)).all())
+    avg = lambda i, j: float(np.mean([e[i].elapsed_time(e[j]) for e in ev]))
+    grad_bytes = sum(p.numel() * p.element_size() for p in params)
+    # the collective alone (nothing to hide under): bus bandwidth of the bucketed all-reduce
+    torch.cuda.synchronize(dev)
+    plain = GradBucketer(params, bucket_mb=64.0, overlap=False)
+    bucketer.remove_hooks()
+    for _ in range(2):
+        plain.all_reduce_mean()
+    R.fence()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        plain.all_reduce_mean()
+    R.fence()
+    ar_ms = (time.perf_counter() - t0) / 5 * 1e3
+    step_ms = elapsed / args.steps * 1e3
+    algbw = grad_bytes / (ar_ms * 1e-3) / 1e9
+    busbw = algbw * (2.0 * (world - 1) / world if world > 1 else 0.0)
+    out = {
+        "metric": "frames/sec (training step: ResNet-101 encoder + ROI features + matching layer forward/backward + Adam, "
+                  "gradient mean over RCCL), YouTube-VOS-shaped synthetic clips (BASELINE configs[3])",
+        "value": round(world * B / (step_ms * 1e-3), 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16 autocast encoder, f32 matching layer and optimiser", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3], per-GPU share: {B} frames of 255x448 (4 videos x clip 3), ResNet-101 "
+                               "+ heads (torch.nn on MIOpen, random init), 50 proposals, 5 template slots, DMM_Model "
+                               "training forward (10x5 solver, dual IoU with the targets) + soft-IoU + matching loss, "
+                               "backward, Adam; gradient mean = distributed.GradBucketer(overlap=True, 64 MB buckets)",
+                   "frames_per_gpu_per_step": B, "sharding": f"clips x{world}, one RCCL all-reduce per bucket",
+                   "stage_ms": {"encoder_fwd": round(avg(0, 1), 3), "roi_layer_loss_fwd": round(avg(1, 2), 3),
+                                "backward_incl_overlapped_allreduce": round(avg(2, 3), 3),
+                                "allreduce_exposed_after_backward": round(avg(3, 4), 3), "adam": round(avg(4, 5), 3)},
+                   "gradient_mean": {"bytes": grad_bytes, "buckets": bucketer.num_collectives(),
+                                     "allreduce_alone_ms": round(ar_ms, 3),
+                                     "hidden_ms": round(max(ar_ms - avg(3, 4), 0.0), 3),
+                                     "algbw_GBps": round(algbw, 1), "busbw_GBps": round(busbw, 1),
+                                     "xgmi_per_link_GBps": 153.0, "xgmi_links_per_gpu": 7,
+                                     "note": "busbw = algbw x 2(N-1)/N (ring all-reduce); a single ring is bound by one "
+                                             "xGMI link (~153 GB/s), 7 rings by 7 x 153 GB/s; N = 1 moves nothing"}},
+    }
+    if own_group:
+        dist.destroy_process_group()
+    return out
+
+
+def compact(out):
+    """What ``other_configs`` keeps of a workload's line."""
+    c = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"],
+         "steps": out["steps"], "workload": out["config"]["workload"]}
+    if "roofline" in out:
+        c["roofline"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")
+                         if k in out["roofline"]}
+    if "roofline_layer" in out:
+        c["roofline_layer_b_cost_frac"] = out["roofline_layer"]["b_cost_basis"]["frac"]
+    for k in ("stage_ms", "boxlist_path_ms_per_step", "mean_outer_iterations"):
+        if k in out["config"]:
+            c[k] = out["config"][k]
+    return c
 
 
 def main():
     args = parse()
     R = Runner(args)
     if args.config == 3:
-        bench_config3(R)
+        out = bench_config3(R)
+    elif args.config == 4:
+        out = bench_config4(R)
+    elif args.config == "loop":
+        out = bench_frame_loop(R)
     else:
-        bench_layer(R, args.config)
+        out = bench_layer(R, args.config)
+    if args.config == 2 and R.rank == 0 and R.world == 1 and not args.no_extras and not args.no_others:
+        # the other BASELINE configurations and the frame loop, compact, so that the driver's default run sees them
+        import copy
+        others = {}
+        for name, fn, kw in (("config5", lambda r: bench_layer(r, 5), dict(steps=30, warmup=5, frames=0)),
+                             ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
+                             ("frame_loop", bench_frame_loop, dict(frames=0))):
+            a2 = copy.copy(args)
+            a2.no_extras = True
+            for k, v in kw.items():
+                setattr(a2, k, v)
+            R.args = a2
+            try:
+                t0 = time.perf_counter()
+                others[name] = compact(fn(R))
+                others[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+            except Exception as e:                               # a side result must not cost the headline line
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+        R.args = args
+        out["other_configs"] = others
+    R.finish(out)
 
 
 if __name__ == "__main__":

@@ -1,28 +1,39 @@
+def use_shipped_miopen_db(develop: bool = False):
+    """Seed MIOpen's USER find-db / perf-db with the solver choices shipped in ``dmm_net_amd/miopen_db`` (what MIOpen's own
+    search picked on an MI355X for the encoder shapes of BASELINE configs 3 and 4 and the frame loop; plain-text files
+    keyed by problem, entries for other MIOpen builds are simply ignored).
 
-
-def _point_miopen_at_the_repo_db():
-    """MIOpen's user find-db / perf-db for this package: dmm_net_amd/miopen_db holds the solver choices MIOpen's own
-    search made on an MI355X for the encoder shapes of BASELINE configs 3 and 4 (plain-text files keyed by problem;
-    entries for other MIOpen builds are simply ignored).  Must be in the environment before MIOpen initialises, i.e.
-    before the first convolution; an explicit MIOPEN_USER_DB_PATH wins.  A read-only install gets a private copy."""
+    MIOpen WRITES to its user db (every new shape it searches), and the variable is process wide -- so the shipped files
+    are never handed to it directly: they are copied once into a per-user cache directory
+    (``~/.cache/dmm_net_amd/miopen_db-<fingerprint>``, several ranks may race: files are put in place atomically) and
+    MIOPEN_USER_DB_PATH points there.  An explicit MIOPEN_USER_DB_PATH in the environment always wins, and
+    ``DMM_MIOPEN_DB=off`` leaves MIOpen alone altogether.  ``develop=True`` (or ``DMM_MIOPEN_DB=repo``) points MIOpen at
+    the tracked directory itself -- only to refresh what is shipped.  Must run before the first convolution."""
     import os
     import shutil
-    if os.environ.get("MIOPEN_USER_DB_PATH"):
-        return
+    mode = os.environ.get("DMM_MIOPEN_DB", "")
+    if os.environ.get("MIOPEN_USER_DB_PATH") or mode == "off":
+        return os.environ.get("MIOPEN_USER_DB_PATH")
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
     if not os.path.isdir(src):
-        return
-    dst = src
-    if not os.access(src, os.W_OK):
-        dst = os.path.join(os.path.expanduser("~"), ".cache", "dmm_net_amd", "miopen_db")
-        try:
-            os.makedirs(dst, exist_ok=True)
-            for f in os.listdir(src):
-                if not os.path.exists(os.path.join(dst, f)):
-                    shutil.copy(os.path.join(src, f), dst)
-        except OSError:
-            return
+        return None
+    if develop or mode == "repo":
+        os.environ["MIOPEN_USER_DB_PATH"] = src
+        return src
+    files = sorted(f for f in os.listdir(src) if os.path.isfile(os.path.join(src, f)))
+    tag = "%08x" % (sum((i + 1) * os.path.getsize(os.path.join(src, f)) for i, f in enumerate(files)) & 0xFFFFFFFF)
+    dst = os.path.join(os.path.expanduser("~"), ".cache", "dmm_net_amd", "miopen_db-" + tag)
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for f in files:
+            if not os.path.exists(os.path.join(dst, f)):
+                tmp = os.path.join(dst, f".{f}.{os.getpid()}.tmp")
+                shutil.copy(os.path.join(src, f), tmp)
+                os.replace(tmp, os.path.join(dst, f))
+    except OSError:
+        return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
 
 
-_point_miopen_at_the_repo_db()
+use_shipped_miopen_db()

@@ -57,7 +57,9 @@ class GradBucketer:
     ``backward()`` issues the buckets that never completed (parameters without a gradient this step count as zeros,
     like DDP with ``find_unused_parameters=True``, train.py:181), waits, scales by 1/world and scatters back;
     parameters without a gradient on EVERY rank keep ``grad = None`` (``track_unused``: one [n_params] MAX all-reduce)
-    and, being known idle on every rank alike, no longer hold their bucket back in the next step.
+    and, being known idle on every rank alike, no longer hold their bucket back in the next step; should such a
+    parameter produce a gradient after its bucket went out (graphs that change from step to step), ``finish()`` reduces
+    it in one extra collective every rank derives from the used-mask alike -- no rank raises while the others wait.
     A second ``backward()`` before ``finish()`` raises (the in-flight buckets would drop the accumulated part).
     """
 
@@ -124,9 +126,11 @@ class GradBucketer:
     def _on_grad(self, p: torch.nn.Parameter):
         bi, off = self._slot[id(p)]
         if self._launched[bi] and id(p) in self._idle[bi] and id(p) not in self._filled[bi]:
-            raise RuntimeError("GradBucketer(overlap=True): a parameter that was idle on every rank in the previous "
-                               "step produced a gradient after its bucket had been issued; build the bucketer with "
-                               "track_unused=False (or overlap=False) for graphs that change from step to step")
+            # idle on every rank in the previous step, so its bucket went out without waiting for it (carrying zeros in
+            # its slot) -- and now it has a gradient after all.  Raising HERE would stop one rank while the others sit
+            # in the collectives until the RCCL timeout; instead the gradient stays in p.grad and finish() reduces every
+            # such parameter in one extra collective that all ranks derive from the all-reduced used-mask alike.
+            return
         if self._launched[bi]:
             # a second backward() before finish() (gradient accumulation): the bucket already in flight holds only
             # the first backward's gradient and finish() would overwrite p.grad with it -- refuse instead of
@@ -160,6 +164,7 @@ class GradBucketer:
         flat = self._flat[bi]
         flat.div_(world)
         off = 0
+        dsts, srcs = [], []
         for k_i, p in enumerate(self.buckets[bi]):
             k = p.numel()
             if p.grad is None:
@@ -168,8 +173,11 @@ class GradBucketer:
                 if used is None or bool(used[used_off + k_i]):
                     p.grad = flat[off:off + k].view_as(p).clone()
             else:
-                p.grad.copy_(flat[off:off + k].view_as(p))
+                dsts.append(p.grad)
+                srcs.append(flat[off:off + k].view_as(p))
             off += k
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)       # one multi-tensor launch per bucket, not one copy per parameter
 
     @torch.no_grad()
     def _used_mask(self) -> Optional[torch.Tensor]:
@@ -207,10 +215,16 @@ class GradBucketer:
             self._ready[bi] = True
         self._launch_ready_prefix()
         assert self._next == len(self.buckets)
+        idle_before = [set(s) for s in self._idle]
         used = self._used_mask()                   # issued after all bucket collectives on every rank: same order
         uo = 0
+        late = []                                  # went out as "known idle" (zeros) but got a gradient on some rank
         for bi in range(len(self.buckets)):
             self._handles[bi].wait()
+            if used is not None:
+                # (criterion and order are the same on every rank; the LOCAL gradient is taken before the scatter)
+                late += [(p, None if p.grad is None else p.grad.clone()) for k_i, p in enumerate(self.buckets[bi])
+                         if id(p) in idle_before[bi] and bool(used[uo + k_i])]
             self._scatter_back(bi, world, used, uo)
             uo += len(self.buckets[bi])
             self._handles[bi] = None
@@ -218,6 +232,16 @@ class GradBucketer:
             self._ready[bi] = False
             self._launched[bi] = False
         self._next = 0
+        if late:
+            # the same list on every rank (it comes from the MAX-reduced used-mask and the previous step's idle sets,
+            # both identical everywhere): one more flat collective, in parameter order
+            flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in late])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(world)
+            off = 0
+            for p, _ in late:
+                p.grad = flat[off:off + p.numel()].view_as(p).clone()
+                off += p.numel()
 
     @torch.no_grad()
     def all_reduce_mean(self):

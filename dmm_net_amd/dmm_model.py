@@ -148,6 +148,26 @@ class DMM_Model(nn.Module):
         return torch.stack(outs, 0), losses
 
     @staticmethod
+    def _out_mask_last(full, mask_last_occurence, skip):
+        """``out_mask_last`` (dmm_model.py:66-69, :78-80): the matched masks, except that a skipped video keeps its
+        incoming planes.  No video skipped (the usual step): it IS ``full`` -- MatchModel returns the same tensor twice
+        (match_model.py:47) -- not a [B,F,H,W] copy of it."""
+        if not any(skip):
+            return full
+        keep = _lib.small_to_device([bool(s_) for s_ in skip], torch.bool, full.device)
+        return torch.where(keep[:, None, None, None], mask_last_occurence.to(full.dtype), full)
+
+    @staticmethod
+    def _template_features(tplt_dict, B):
+        """The template-feature entry of every video.  The reference passes ``tplt_dict[b]['feat']`` (a list) on
+        (dmm_model.py:151-157) and MatchModel averages the cosines over its entries (match_model.py:71-76); DMM-Net only
+        ever stores ONE entry (templates are fixed from frame 0, dmm_model.py:44) and the batched launch is built for
+        that: a longer list is refused here rather than silently truncated ('hun' / per-video calls take any length)."""
+        for b in range(B):
+            assert len(tplt_dict[b]["feat"]) == 1, "the batched matching path takes one template-feature entry per video"
+        return [tplt_dict[b]["feat"][0] for b in range(B)]
+
+    @staticmethod
     def _proposal_fields(proposals):
         prop_m = [p.get_field("mask").squeeze(1) for p in proposals]
         prop_score = [p.get_field("objectness") if "objectness" in p.fields() else p.get_field("scores")
@@ -167,7 +187,7 @@ class DMM_Model(nn.Module):
         else:
             n_tplt, row_scale = self._valid_layout(tplt_valid_batch)
         skip = [n_tplt[b] == 0 or bool(extra_frame[b]) for b in range(B)]
-        tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
+        tplt_feat = self._template_features(tplt_dict, B)
         tg = None
         if target is not None:
             tg = torch.stack([target[b] for b in range(B)], 0)
@@ -180,11 +200,7 @@ class DMM_Model(nn.Module):
                 packed = [p.get_field("mask_packed") for p in proposals]
             full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
                                         tg, skip, row_scale, packed)
-        out_last = full.clone()
-        for b in range(B):
-            if skip[b]:
-                out_last[b] = mask_last_occurence[b]
-        return full, tplt_dict, [], out_last
+        return full, tplt_dict, [], self._out_mask_last(full, mask_last_occurence, skip)
 
     # ---- dmm_model.py:88-142 -----------------------------------------------------------------------
     def forward(self, args, proposals, backbone_feature, mask_last_occurence, tplt_dict, tplt_valid_batch, targets):
@@ -195,19 +211,12 @@ class DMM_Model(nn.Module):
         prop_m, prop_score = self._proposal_fields(proposals)
         n_tplt, row_scale = self._valid_layout(tplt_valid_batch)            # one host sync for the whole batch
         skip = [n_tplt[b] == 0 for b in range(B)]
-        tplt_feat = [tplt_dict[b]["feat"][0] for b in range(B)]
+        tplt_feat = self._template_features(tplt_dict, B)
         if self.match_algo != "relax":
             full, loss = self._per_video(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                          tplt_valid_batch, n_tplt, targets, skip)
         else:
             full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                            n_tplt, targets, skip, row_scale)
-        out_last = full.clone()
-        match_loss = []
-        for b in range(B):
-            if skip[b]:
-                out_last[b] = mask_last_occurence[b]
-                match_loss.append(prop_feat[b].sum() * 0)            # :121
-            else:
-                match_loss.append(loss[b])
-        return full, tplt_dict, match_loss, out_last
+        match_loss = [prop_feat[b].sum() * 0 if skip[b] else loss[b] for b in range(B)]      # :121
+        return full, tplt_dict, match_loss, self._out_mask_last(full, mask_last_occurence, skip)

@@ -373,6 +373,10 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
         B, N, H, W = fp.B, fp.N, fp.H, fp.W
         M, Pp = Rb.shape[1], Rb.shape[2]
         Rb = Rb.contiguous().float()
+        if n_valid is None:                          # frames are ragged by construction: never read past a short one
+            n_valid = fp.n_valid()
+        if out_dtype not in (None, torch.float32):
+            raise ValueError("mask_mix on per-frame plane tables writes fp32 (dmm_mask_mix_frames)")
         out = torch.empty((B, M, H, W), dtype=torch.float32, device=Rb.device)
         with _lib.device_guard(Rb.device):
             rc = _lib.load().dmm_mask_mix_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], B, N, M, Pp, H * W,
@@ -403,6 +407,8 @@ def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_
         B, N, H, W = fp.B, fp.N, fp.H, fp.W
         M, Pp = Rb.shape[1], Rb.shape[2]
         Rb = Rb.contiguous().float()
+        if n_valid is None:
+            n_valid = fp.n_valid()
         dout = dout.contiguous().float().view(B, M, H * W)
         dRb = torch.empty((B, M, Pp), dtype=torch.float32, device=Rb.device)
         with _lib.device_guard(Rb.device):

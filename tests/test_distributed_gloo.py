@@ -179,3 +179,52 @@ def test_gloo_world2_bucket_order_is_fixed_when_graphs_differ():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _late_grad_worker(rank, world, port, q):
+    """a parameter that was idle on EVERY rank in the previous step lets its bucket go out early; if it then
+    produces a gradient (on one rank only, after the bucket was issued) no rank may raise or hang, and every rank must
+    end up with the plain mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    l1, l2, l3 = torch.nn.Linear(16, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 4)
+    shift = torch.nn.Parameter(torch.zeros(16))               # added to the INPUT: its gradient is the last to arrive
+    params = list(l1.parameters()) + list(l2.parameters()) + list(l3.parameters()) + [shift]
+    gb = GradBucketer(params, bucket_mb=0.004, overlap=True)
+    ok = gb.buckets[0][0] is shift                             # reverse order: it sits in the FIRST bucket to go out
+    for step in range(3):
+        x = torch.randn(8, 16, generator=torch.Generator().manual_seed(50 * step + rank))
+        for p in params:
+            p.grad = None
+        use = step == 1 and rank == 1                          # idle everywhere in step 0; one rank uses it in step 1
+        l3(torch.relu(l2(torch.relu(l1(x + shift if use else x))))).pow(2).sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        if step == 1:
+            ok &= gb._launched[0]                              # bucket 0 left before shift's gradient existed
+        gb.finish()
+        for p, g in zip(params, local):
+            ref = torch.zeros_like(p) if g is None else g.clone()
+            dist.all_reduce(ref)
+            if p is shift and step != 1:
+                ok &= p.grad is None
+            else:
+                ok &= p.grad is not None and bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    gb.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world2_late_gradient_of_a_previously_idle_parameter():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_late_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
