@@ -931,8 +931,137 @@ def g16():
     save("g16_encoder_heads", d)
 
 
+# ------------------------------------------------------------------------------------------ G17
+def g17():
+    """a9 / a11 FIRST HAND: the reference's own ``dmm.modules.dmm_model.DMM_Model`` (with its ``FeatureExtractor``,
+    feature_extractor.py:6-62) imported and run on the CPU.  The one absent symbol is maskrcnn_benchmark's ``Pooler``;
+    its stub holds ``.poolers = [legacy ROIAlign at scale s]`` built from G12's differentiable per-bin formulation, which
+    is all FeatureExtractor touches (:18, :50-51).  Everything else -- convert_to_roi_format, the [R,4,C,14,14] buffer,
+    .mean(4).mean(3), fill_template_dict, prepare_tplt_feature's OF/FO matmuls, the per-video loop with its O == 0 /
+    extra_frame branches, MatchModel -- is the reference's code.  Cases: ragged proposal counts; live templates
+    O in {2, 0, 3 (non-prefix), 5}; an 'extra' frame; inference (is_test = 1) and the training forward with targets
+    (is_test = 0) incl. the gradients that reach the four backbone levels."""
+    BoxList = _install_third_party_stubs()
+    import types
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+
+    class _Level(torch.nn.Module):
+        def __init__(self, s):
+            super().__init__()
+            self.s = s
+
+        def forward(self, feat, rois):
+            return _roialign_legacy(feat, rois, self.s)
+
+    class Pooler(torch.nn.Module):
+        def __init__(self, output_size, scales, sampling_ratio):
+            super().__init__()
+            assert tuple(output_size) == (14, 14) and sampling_ratio == 2
+            self.poolers = torch.nn.ModuleList([_Level(s) for s in scales])
+    m = types.ModuleType("maskrcnn_benchmark.modeling.poolers")
+    m.Pooler = Pooler
+    sys.modules["maskrcnn_benchmark.modeling.poolers"] = m
+    from dmm.modules.dmm_model import DMM_Model          # noqa: E402  (reference)
+
+    B, F, C, H, W = 4, 5, 16, 64, 96
+    counts = [6, 9, 7, 8]
+    valid = np.array([[1, 1, 0, 0, 0], [0, 0, 0, 0, 0], [1, 0, 1, 0, 1], [1, 1, 1, 1, 1]], np.float32)
+    extra = [False, False, False, False]
+    rng = np.random.Generator(np.random.PCG64(1700))
+    feats = [rng.standard_normal((B, C, -(-H // s), -(-W // s)), dtype=np.float32) for s in (4, 8, 16, 32)]
+
+    def boxes(n):
+        x1, y1 = rng.uniform(0, W * 0.6, n), rng.uniform(0, H * 0.6, n)
+        return np.stack([x1, y1, np.minimum(x1 + rng.uniform(4, W * 0.5, n), W - 1),
+                         np.minimum(y1 + rng.uniform(4, H * 0.5, n), H - 1)], 1).astype(np.float32)
+    pbox = [boxes(n) for n in counts]
+    tbox = [boxes(F) for _ in range(B)]
+    pmask, pscore = [], []
+    for b, n in enumerate(counts):
+        fr = synth.make_frame(n, F, H, W, 8, seed=1710 + b, kind="structured", with_targets=True)
+        pmask.append(fr.proposed_mask.astype(np.float32))
+        pscore.append(fr.proposal_score.astype(np.float32))
+    frs = [synth.make_frame(counts[b], F, H, W, 8, seed=1710 + b, kind="structured", with_targets=True) for b in range(B)]
+    mask_last = np.stack([fr.mask_last_occurence for fr in frs]).astype(np.float32)
+    targets = np.stack([fr.targets for fr in frs]).astype(np.float32)
+    d = dict(shape=np.array([B, F, C, H, W], np.int32), counts=np.array(counts, np.int32), valid=valid,
+             mask_last=mask_last, targets=targets)
+    for l in range(4):
+        d[f"feat{l}"] = feats[l]
+    for b in range(B):
+        d[f"pbox{b}"], d[f"tbox{b}"], d[f"pmask{b}"], d[f"pscore{b}"] = pbox[b], tbox[b], pmask[b], pscore[b]
+
+    def boxlists(ft_dev):
+        props, tpl = [], []
+        for b in range(B):
+            p = BoxList(T(pbox[b]), (W, H))
+            p.add_field("mask", T(pmask[b]).unsqueeze(1))
+            p.add_field("scores" if b % 2 == 0 else "objectness", T(pscore[b]))
+            props.append(p)
+            tpl.append(BoxList(T(tbox[b]), (W, H)))
+        return props, tpl
+
+    # ---- inference (is_test = 1), without and with an 'extra' frame ----
+    model = DMM_Model(cfg(10, 5), is_test=1)
+    with torch.no_grad():
+        ft = [T(f) for f in feats]
+        props, tpl = boxlists(ft)
+        features = {"backbone_feature": ft, "refine_input_feat": ft}
+        tplt_dict = model.fill_template_dict(None, tpl, features, None, T(valid))
+        d["tplt_feat"] = torch.stack([tplt_dict[b]["feat"][0] for b in range(B)]).numpy()
+        d["prop_feat"] = model.feature_extractor(ft, props).numpy()
+        for tag, ex in (("plain", [False] * B), ("extra", [False, False, True, False])):
+            infos = {"args": None, "shape": [[H, W]] * B, "extra_frame": ex, "valid": T(valid)}
+            out, _, ml_, last = model.inference(infos, props, ft, T(mask_last), tplt_dict)
+            assert ml_ == []
+            d[f"test/{tag}/output_mask"], d[f"test/{tag}/out_mask_last"] = out.numpy(), last.numpy()
+            d[f"test/{tag}/extra"] = np.array(ex, np.int32)
+    # ---- training forward (is_test = 0) with targets, gradients to the backbone levels ----
+    model = DMM_Model(cfg(10, 5), is_test=0)
+    ft = [T(f).requires_grad_(True) for f in feats]
+    props, tpl = boxlists(ft)
+    tplt_dict = model.fill_template_dict(None, tpl, {"backbone_feature": ft, "refine_input_feat": ft}, None, T(valid))
+    out, _, losses, last = model(None, props, ft, T(mask_last), tplt_dict, T(valid), T(targets))
+    wgt = T(rng.standard_normal(out.shape, dtype=np.float32))
+    total = (out * wgt).sum() + sum(losses)
+    total.backward()
+    d["train/output_mask"], d["train/out_mask_last"] = out.detach().numpy(), last.detach().numpy()
+    d["train/losses"] = np.array([float(x) for x in losses], np.float32)
+    d["train/wgt"] = wgt.numpy()
+    for l in range(4):
+        d[f"train/grad{l}"] = ft[l].grad.numpy()
+    save("g17_dmm_model_first_hand", d)
+
+
+# ------------------------------------------------------------------------------------------ G18
+def g18():
+    """The TOLERANCE contract next to the bit-exact one.  The bit-exact goldens pin ATen's AVX2 reduction order of one
+    torch build; north_star's bar is `assignment within 1e-5, argmax identical`.  This fixture is the reference run with
+    ``ATEN_CPU_CAPABILITY=default`` (scalar kernels: another summation order) on inputs where no data-dependent exit
+    fires early (iters == max_iter under both orders), so that a torch upgrade that changes the vectorised order still
+    leaves a test that states what must hold: |R - R_ref| <= 1e-5, identical row argmax, identical iteration count.
+    Must be generated with:  ATEN_CPU_CAPABILITY=default python tests/golden/gen_golden.py g18"""
+    assert os.environ.get("ATEN_CPU_CAPABILITY") == "default", "run with ATEN_CPU_CAPABILITY=default"
+    d = {}
+    k = 0
+    for (P, O, H, W, D, it, pj, seed) in [(50, 10, 64, 64, 512, 20, 5, 1801), (50, 5, 48, 80, 512, 40, 5, 1802),
+                                          (8, 3, 64, 64, 64, 10, 5, 1803), (200, 20, 32, 32, 512, 20, 5, 1804),
+                                          (33, 7, 40, 56, 256, 20, 5, 1805), (3, 5, 32, 32, 64, 10, 5, 1806)]:
+        fr = synth.make_frame(P, O, H, W, D, seed=seed, kind="uniform")
+        for is_test in (0, 1):
+            r = run_layer(fr, it, pj, is_test, full=False)
+            if int(r["n_xlist"]) - 1 != it:
+                continue                                           # an early exit is order-chaotic: not this fixture's job
+            d.update(flat(f"c{k}", dict(shape=np.array([P, O, H, W, D, it, pj, seed, is_test], np.int32), R=r["R"],
+                                        match_score=r["match_score"], det_score=r["det_score"],
+                                        sim=r["sim"], argmax=r["argmax"], checksum=np.array(fr.checksum()))))
+            k += 1
+    d["n"] = np.int32(k)
+    save("g18_scalar_order_tolerance", d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
-                             "g15", "g16"]
+                             "g15", "g16", "g17"]      # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
     for w in which:
         globals()[w]()

@@ -387,3 +387,60 @@ def test_fast_encoder_heads_match_reference_g16(name, arch):
             exp = torch.from_numpy(g[f"{name}/eval/{k}"]).to(DEV)
             err = float((v.float() - exp).abs().max()) / max(1.0, float(exp.abs().max()))
             assert err <= 3e-2, (k, err)                      # bf16 inputs, weights and outputs; fp32 accumulation
+
+
+def test_config3_bf16_path_is_bounded_against_fp32():
+    """BASELINE config 3 (bf16 encoder) CHECKED, not only exercised: with trained-like BatchNorm statistics (eval mode)
+    the bf16 inference encoder (FastEncoder: channels-last, library GEMMs with fused epilogues) -> NHWC ROI features ->
+    cost + solver must stay close to the same pipeline on the fp32 folded encoder: the similarity table within a stated
+    bound and the same proposal chosen for every template whose fp32 decision is not a near tie."""
+    from conftest import record_achieved
+    from dmm_net_amd import ops
+    from dmm_net_amd.encoder import FastEncoder, fold_batchnorm
+    torch.manual_seed(11)
+    enc = FeatureEncoder("resnet50").to(DEV)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    enc.eval()
+    folded = fold_batchnorm(enc)
+    fast = FastEncoder(folded)
+    fe = FeatureExtractor()
+    B, P, O, H, W = 8, 50, 10, 255, 255
+    img = torch.randn(B, 3, H, W, device=DEV)
+    frames = [synth.make_frame(P, O, H, W, 8, seed=3100 + b, kind="structured") for b in range(B)]
+
+    def tight(masks):
+        out = []
+        for m in masks:
+            ys, xs = np.where(m > 0.5)
+            out.append([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1] if len(xs) else [0, 0, 8, 8])
+        return Boxes(torch.from_numpy(np.asarray(out, np.float32)).to(DEV))
+    pb, tb = [tight(fr.proposed_mask) for fr in frames], [tight(fr.mask_last_occurence) for fr in frames]
+    pm = torch.stack([torch.from_numpy(fr.proposed_mask) for fr in frames]).to(DEV)
+    tm = torch.stack([torch.from_numpy(fr.mask_last_occurence) for fr in frames]).to(DEV)
+    sc = torch.stack([torch.from_numpy(fr.proposal_score) for fr in frames]).to(DEV)
+    inter, ap, at = ops.iou_counts(pm, tm)
+    res = {}
+    with torch.no_grad():
+        for tag, net in (("fp32", folded), ("bf16", fast)):
+            bf = net(img)["backbone_feature"]
+            pf, tf = fe(bf, pb).view(B, P, 512), fe(bf, tb).view(B, O, 512)
+            cos = ops.cosine_features(tf, pf)
+            res[tag] = ops.relax_match(cos, inter, ap, at, sc, score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
+            res[tag]["cos"] = cos
+    assert res["bf16"]["cos"].dtype == torch.float32 and bool(torch.isfinite(res["bf16"]["sim"]).all())
+    d_sim = float((res["bf16"]["sim"] - res["fp32"]["sim"]).abs().max())
+    d_cos = float((res["bf16"]["cos"] - res["fp32"]["cos"]).abs().max())
+    record_achieved("config3_bf16/sim_abs_err", d_sim)
+    record_achieved("config3_bf16/cos_abs_err", d_cos)
+    # sim = 0.7 cos + 0.3 iou, iou identical; achieved on the MI355X: cos 1.8e-3, sim 1.2e-3, every argmax equal
+    assert d_cos <= 0.01 and d_sim <= 0.007 + 1e-6, (d_cos, d_sim)
+    R32, R16 = res["fp32"]["R"][:, :, :P], res["bf16"]["R"][:, :, :P]
+    top2 = R32.topk(2, dim=2).values
+    decided = (top2[..., 0] - top2[..., 1]) > 0.1                             # fp32 decision is not a near tie
+    same = R32.argmax(2) == R16.argmax(2)
+    record_achieved("config3_bf16/argmax_agree_frac", float(same.float().mean()))
+    assert int(decided.sum()) >= B * O // 2
+    assert bool(same[decided].all()), (int((~same & decided).sum()), int(decided.sum()))
