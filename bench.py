@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--parts", type=int, default=0, help="slices of the batch in the 2-lane schedule (default 2)")
     ap.add_argument("--nchw-encoder", action="store_true", help="config 3: the round-1 NCHW / all-MIOpen encoder")
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
+    ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
+                                                              "fp16-state one BASELINE configs[4] names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="no cpu_baseline / batch_sweep / in-run PMC traffic")
     ap.add_argument("--no-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc child passes")
@@ -263,8 +265,10 @@ def bench_layer(R, ci):
     inputs = make_inputs(B)
     # pre-allocated plan: nothing is allocated in the timed region.  pipeline = streaming lane (cost, mix) on the
     # current stream + latency lane (normalise, cosine, solver) on a side stream (ops.ForwardPlan)
+    # config 5 = "fp16 Sinkhorn with fp32 accumulate": the opt-in fp16-state solver (tolerance mode, include/dmm_match.h (3c))
+    sstate = "f16" if (ci == 5 and not getattr(args, "f32_solver", False)) else "f32"
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=mdt, pipeline=False if args.no_pipeline else (True if args.pipeline else None),
-                           time_kernels=True, out_dtype=odt, parts=args.parts or 2)
+                           time_kernels=True, out_dtype=odt, parts=args.parts or 2, solver_state=sstate)
     kw = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
     ev = []
 
@@ -301,13 +305,15 @@ def bench_layer(R, ci):
                                          "fp16 mask planes (BASELINE configs[4])",
         "value": round(world * fps_rank, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if ci == 2 else "f16 planes (in and out), f32 accumulate",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if ci == 2 else ("f16 planes (in and out)" + (", f16 solver state" if sstate == "f16" else "") + ", f32 accumulate"),
         "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[{ci - 1}]: {N} proposals x {M} templates, 255x255 "
                                 f"{'fp32' if ci == 2 else 'fp16'} masks, D=512, 20 outer x 5 inner relax iterations, "
                                 "forward is_test=1, uniform-random masks"),
                    "frames_per_gpu_per_step": B, "mean_outer_iterations": round(it_mean, 3),
-                   "sharding": f"frames x{world} (no collective in the forward)", "schedule": plan.schedule_name()},
+                   "sharding": f"frames x{world} (no collective in the forward)", "schedule": plan.schedule_name(),
+                   "solver_state": sstate},
         "roofline": {"bound": "hbm", "kernel": cost_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": int(fpl),
@@ -331,7 +337,8 @@ def bench_layer(R, ci):
         for b in (1, 4, 8, 64, 512, 1024):
             if b > B:
                 continue
-            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt, graph=b <= 32)
+            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt, graph=b <= 32,
+                                                     solver_state=sstate)
             inp = inputs if b == B else tuple(t[:b] for t in inputs)
             ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
             sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}

@@ -67,6 +67,33 @@ struct BlockRed {
         }
         phase ^= 1;
     }
+    // vals[r] = wave-uniform partial row sums; on return vals[r] = (block total of row r - 1) / fm, wave-uniform.  Lane r
+    // of every wave adds the NG partials of row r and divides ONCE; the results come back through readlane.
+    template <int CNT>
+    __device__ __forceinline__ void row_steps(float (&vals)[CNT], float fm) {
+        const int lane = threadIdx.x & 63;
+        float t;
+        if (NG == 1) {
+            t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i) t = lane == i ? vals[i] : t;
+        } else {
+            float *p = buf + phase * NG * (MT + 1);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) p[wave * (MT + 1) + i] = vals[i];
+            }
+            __syncthreads();
+            const int r = lane < CNT ? lane : 0;
+            t = p[r];
+#pragma unroll
+            for (int w = 1; w < NG; ++w) t = t + p[w * (MT + 1) + r];
+            phase ^= 1;
+        }
+        t = (t - 1.0f) / fm;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) vals[i] = readlane_f32(t, i);
+    }
     template <int CNT, typename OP>
     __device__ __forceinline__ void fold(float (&vals)[CNT], OP op) {
         if (NG == 1) return;
@@ -123,6 +150,19 @@ __device__ __forceinline__ void row_sums_torch_order(const float *xbuf, int n, i
         // it fetches 42 words where 25 are needed and the clamping arithmetic outweighs the saved round trips)
         const float s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });   // m <= 256
         if (l == 0) rsbuf[r] = s;
+    }
+    __syncthreads();                                   // rsbuf complete, xbuf free again
+}
+// The row projection's step (row sum - 1) / m instead of the sum: computed ONCE per row by the lane that holds the sum
+// (every thread recomputed it for every row before: 7 instructions x rows per sweep and thread).
+template <int NG>
+__device__ __forceinline__ void row_steps_torch_order(const float *xbuf, int n, int m, float fm, float rcp_m, float *rsbuf) {
+    __syncthreads();                                   // xbuf complete
+    const int l = threadIdx.x & 7;
+    for (int r = threadIdx.x >> 3; r < n; r += 8 * NG) {
+        const float *x = xbuf + r * m;
+        const float s = torder::inner_sum_group8_small(m, l, [&](int i) { return x[i]; });   // m <= 256
+        if (l == 0) rsbuf[r] = div_by_const(s - 1.0f, fm, rcp_m);
     }
     __syncthreads();                                   // rsbuf complete, xbuf free again
 }
@@ -765,18 +805,20 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
                 for (int i = 0; i < MT; ++i) xbuf[i * m + col] = X[i];
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
-            float rsv[MT];
+            float rsv[MT], trv[MT];
             if (NG == 1) {
                 row_sums_torch_order_wave<MT>(rowbuf, n, m, rsv);
-            } else {
-                row_sums_torch_order<NG>(xbuf, n, m, rsbuf);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) rsv[i] = DMM_ROW(i) ? rsbuf[i] : 0.0f;
+                for (int i = 0; i < MT; ++i) trv[i] = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
+            } else {
+                row_steps_torch_order<NG>(xbuf, n, m, fm, rcp_m, rsbuf);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) trv[i] = DMM_ROW(i) ? rsbuf[i] : 0.0f;
             }
             unsigned moved_bits = 0;                            // OR of the squares' bit patterns: non-zero <=> some square
 #pragma unroll                                                  // is non-zero (a NaN has non-zero bits: "moved")
             for (int i = 0; i < MT; ++i) {
-                float tr = div_by_const(rsv[i] - 1.0f, fm, rcp_m);
+                float tr = trv[i];
                 tr = (live && DMM_ROW(i)) ? tr : 0.0f;          // dead columns / rows keep their zeros (x - 0 = x, P2 = 0)
                 const float x = X[i];
                 const float y = x - tr;
@@ -801,11 +843,159 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
     return len - 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// relax_matching core with the solver STATE IN PACKED FP16 and fp32 sums (BASELINE configs[4]: "fp16 Sinkhorn with fp32
+// accumulate"); opt-in (dmm_relax_match_f16s), NOT bit exact -- a tolerance mode.  Same algorithm and control flow as
+// relax_core (relax_match.py:36-105): projected gradient steps, Dykstra sweeps over {X >= 0}, {column sums <= 1},
+// {row sums = 1}, both data-dependent exits, R = mean of the pre-projection iterates.  What changes:
+//   * X, the three Dykstra increments and the sweep's start copy are half2 PAIRS OF ROWS per thread (5 registers per two
+//     rows instead of 10): the 20 x 200 problem of config 5 needs ~110 VGPRs instead of 256 + spills, so four waves fit a
+//     SIMD and the solver can run BESIDE the streaming count kernel (the fp32 form holds half of a CU's registers for
+//     0.3 ms and the 2-lane schedule lost to the single stream);
+//   * element-wise steps are v_pk_add_f16 / v_pk_max_f16 (two rows per instruction), the column sums v_dot2_f32_f16
+//     against (1, 1) -- fp32 accumulation, two rows per instruction --, row sums / cost norm / sum of iterates are fp32
+//     (DPP tree + LDS fold: no summation order to reproduce here);
+//   * the exits compare the fp16 iterate bit for bit and the fp32 cost for equality: they fire when the fp16 iteration
+//     has reached its fixed point, which need not be the step at which the fp32 reference's does.
+// Tolerance (tests/test_gpu_parity.py): |R - R_fp32| <= 1e-2 where both ran the same number of iterations, identical
+// row argmax wherever the fp32 decision is not a near tie.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+template <int MT, int NG>
+__device__ __forceinline__ int relax_core_h(const float (&C)[MT], int n, int m, int col, const RelaxParams prm,
+                                            BlockRed<MT, NG> &red, float *accbuf /* LDS [MT][64 NG] */, float (&X)[MT],
+                                            float (&acc)[MT]) {
+    constexpr int MP = (MT + 1) / 2;
+    constexpr int LD = 64 * NG;
+    float *acc_t = accbuf + threadIdx.x;               // sum(X_list) of this thread's column: LDS, touched once per
+                                                       // outer iteration (20 registers less in the sweep)
+#define DMM_ROWH(i) ((i) < n)
+    const bool live = col < m;
+    const float fn = (float)n, fm = (float)m;
+    // ---- greedy row-min initialisation in fp32 (relax_match.py:45-55), as relax_core ----
+    float cm[1] = {-__builtin_inff()};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        if (DMM_ROWH(i) && live) cm[0] = C[i] > cm[0] ? C[i] : cm[0];
+    cm[0] = wave_max(cm[0]);
+    red.fold(cm, fmax_op());
+    const float cmax = cm[0];
+    int best_row = 0;
+    {
+        float bv = C[0];
+#pragma unroll
+        for (int i = 1; i < MT; ++i)
+            if (DMM_ROWH(i) && C[i] < bv) { bv = C[i]; best_row = i; }
+    }
+    {
+        float crm[MT], vmin[MT];
+        int cand[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            crm[i] = (live && DMM_ROWH(i)) ? (i == best_row ? C[i] : cmax) : __builtin_inff();
+            vmin[i] = crm[i];
+        }
+        wave_min_rows<MT>(vmin);
+        red.fold(vmin, fmin_op());
+#pragma unroll
+        for (int i = 0; i < MT; ++i) cand[i] = (live && crm[i] == vmin[i]) ? col : 0x7fffffff;
+        wave_min_rows_i32<MT>(cand);
+        red.min_i32(cand);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) X[i] = (DMM_ROWH(i) && col == cand[i]) ? 1.0f : 0.0f;
+    }
+    const h16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, one2 = {(_Float16)1.0f, (_Float16)1.0f};
+    h16x2 Xh[MP], Ch[MP], P0[MP], P1[MP], P2[MP];
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        Xh[k] = h16x2{(_Float16)X[2 * k], (_Float16)(2 * k + 1 < MT ? X[2 * k + 1] : 0.0f)};
+        Ch[k] = h16x2{(_Float16)C[2 * k], (_Float16)(2 * k + 1 < MT ? C[2 * k + 1] : 0.0f)};
+        P0[k] = zero2; P1[k] = zero2; P2[k] = zero2;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc_t[i * LD] = 0.0f + X[i];
+    const h16x2 lr2 = {(_Float16)prm.lr, (_Float16)prm.lr};
+    int len = 1;
+    float cost_prev = 0.0f;
+    for (int it = 0; it < prm.max_iter; ++it) {
+        float cq[1] = {0.0f};
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            Xh[k] = Xh[k] - lr2 * Ch[k];                           // X = X - lr*C (:69)
+            acc_t[(2 * k) * LD] = acc_t[(2 * k) * LD] + (float)Xh[k].x;   // sum(X_list) in fp32
+            if (2 * k + 1 < MT) acc_t[(2 * k + 1) * LD] = acc_t[(2 * k + 1) * LD] + (float)Xh[k].y;
+            const h16x2 pr = Xh[k] * Ch[k];
+            cq[0] = __builtin_amdgcn_fdot2(pr, pr, cq[0], false);  // ||X*C||_F^2, fp32 accumulate
+        }
+        cq[0] = wave_sum(cq[0]);
+        red.sum(cq);
+        const float cost = __builtin_sqrtf(cq[0]);
+        ++len;
+        for (int j = 0; j < prm.proj_iter; ++j) {
+            h16x2 Xs[MP];
+            float cs = 0.0f;
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                Xs[k] = Xh[k];
+                const h16x2 x = Xh[k] + P0[k];
+                const h16x2 y = __builtin_elementwise_max(x, zero2);   // {X >= 0} (:74-76)
+                P0[k] = x - y;
+                Xh[k] = y + P1[k];                                 // (:78)
+                cs = __builtin_amdgcn_fdot2(Xh[k], one2, cs, false);   // X.sum(dim=0), fp32
+            }
+            const bool over = cs > 1.0f;
+            const _Float16 tch = (_Float16)(over ? (cs - 1.0f) / fn : 0.0f);
+            float rs[MT];
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const h16x2 tcp = {DMM_ROWH(2 * k) ? tch : (_Float16)0.0f, DMM_ROWH(2 * k + 1) ? tch : (_Float16)0.0f};
+                const h16x2 x = Xh[k];
+                const h16x2 y = x - tcp;                           // project_col (:21-34)
+                P1[k] = x - y;
+                Xh[k] = y + P2[k];                                 // (:82)
+                rs[2 * k] = (float)Xh[k].x;
+                if (2 * k + 1 < MT) rs[2 * k + 1] = (float)Xh[k].y;
+            }
+            wave_sum_rows<MT>(rs);                                 // X.sum(dim=1), fp32 (dead columns hold zeros)
+            red.row_steps(rs, fm);                                 // fold the waves, (sum - 1) / m once per row
+            bool moved = false;
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const float t0 = (live && DMM_ROWH(2 * k)) ? rs[2 * k] : 0.0f;
+                const float t1 = (live && 2 * k + 1 < MT && DMM_ROWH(2 * k + 1)) ? rs[2 * k + 1 < MT ? 2 * k + 1 : 0] : 0.0f;
+                const h16x2 trp = {(_Float16)t0, (_Float16)t1};
+                const h16x2 x = Xh[k];
+                const h16x2 y = x - trp;                           // project_row (:9-19)
+                P2[k] = x - y;
+                Xh[k] = y;
+                const h16x2 d = y - Xs[k];
+                moved |= (d.x != (_Float16)0.0f) | (d.y != (_Float16)0.0f);
+            }
+            float mv[1] = {__ballot(moved) != 0ull ? 1.0f : 0.0f};
+            red.fold(mv, fmax_op());
+            if (mv[0] == 0.0f) break;                              // (:88-89)
+        }
+        if (cost_prev == cost) break;                              // (:96-98)
+        cost_prev = cost;
+    }
+#undef DMM_ROWH
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        X[2 * k] = (float)Xh[k].x;
+        if (2 * k + 1 < MT) X[2 * k + 1] = (float)Xh[k].y;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc_t[i * LD];
+    return len - 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Layer kernel: iou + mix with the cosine table + pad + solver + scores.  grid = B, block = 64*NG.
 // ---------------------------------------------------------------------------------------------
 // One frame: red_buf [2 * NG * (MT + 1)], xbuf [MT * 64 * NG], rsbuf [MT + 1] floats of LDS.
-template <int MT, int NG, bool EXACT>
+template <int MT, int NG, bool EXACT, bool HALF = false>
 __device__ __forceinline__ void relax_match_body(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
@@ -864,8 +1054,17 @@ __device__ __forceinline__ void relax_match_body(
     }
 
     float X[MT], acc[MT];
-    const int iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
-                                                RelaxTape{nullptr, nullptr}, hs);
+    int iters;
+    if constexpr (HALF) {
+        iters = relax_core_h<MT, NG>(C, Mb, Pp, col, prm, red, xbuf, X, acc);
+        // the fp32 costs are not kept alive across the solver (register budget): sim was stored above, C = -sim_pad
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            C[i] = (DMM_ROW(i) && col < Pp) ? -(has_prop ? sim_b[(int64_t)i * N + col] : 0.0f) : 0.0f;
+    } else {
+        iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
+                                          RelaxTape{nullptr, nullptr}, hs);
+    }
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
 
     // ---- R = sum(X_list)/len; logic; Rb; scores ----
@@ -943,6 +1142,23 @@ __global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 
                                     is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, red_buf,
                                     xbuf, rsbuf, hs);
     if (NG == 1) solver_helper_stop(hs);                        // (paths that never reached the solver)
+}
+
+// fp16-state form (relax_core_h): 4 waves per SIMD (<= 128 VGPRs) so that it runs beside the streaming kernels.
+template <int MT, int NG, bool EXACT>
+__global__ __launch_bounds__(64 * NG, 4) void relax_match_h_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final) {
+    __shared__ float red_buf[2 * NG * (MT + 1)];
+    __shared__ float xbuf[MT * 64 * NG];
+    __shared__ float rsbuf[MT + 1];
+    relax_match_body<MT, NG, EXACT, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou,
+                                          prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
+                                          X_final, red_buf, xbuf, rsbuf, nullptr);
 }
 
 // Ragged batches of small problems (the product: up to maxseqlen = 5 templates per video, a different count per video):
@@ -1308,5 +1524,42 @@ extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, i
                        tape)
     DMM_DISPATCH_SOLVER(M, Pp, exact_ok, DMM_CALL);
 #undef DMM_CALL
+    return dmm::check_launch();
+}
+
+// (3c) dmm_relax_match_f32 with the solver state in packed fp16 and fp32 sums -- the tolerance mode of BASELINE
+// configs[4] ("fp16 Sinkhorn with fp32 accumulate"); see relax_core_h.
+extern "C" int dmm_relax_match_f16s(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                    const int32_t *area_t, const float *score_p, int B, int N, int M,
+                                    const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                    int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
+                                    float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                    dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    if (!cos_in || !inter || !area_p || !area_t || !score_p || !sim_out || !Rb_out || !match_score || !det_score)
+        return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    const dmm::RelaxParams prm{max_iter, proj_iter, lr};
+    const float w_feat = (float)(1.0 - (double)score_weight), w_iou = score_weight;
+    const int ng = (Pp + 63) / 64 <= 1 ? 1 : ((Pp + 63) / 64 == 2 ? 2 : 4);
+#define DMM_CALLH(MT_, NG_, EX_)                                                                                        \
+    hipLaunchKernelGGL((dmm::relax_match_h_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,     \
+                       cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test,     \
+                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
+#define DMM_PICKH(NG_)                                                                  \
+    do {                                                                                \
+        if (M <= 8) DMM_CALLH(8, NG_, false);                                           \
+        else if (M <= 16) DMM_CALLH(16, NG_, false);                                    \
+        else if (M == 20 && !m_valid && NG_ == 4) DMM_CALLH(20, 4, true);               \
+        else DMM_CALLH(32, NG_, false);                                                 \
+    } while (0)
+    if (ng == 1) DMM_PICKH(1);
+    else if (ng == 2) DMM_PICKH(2);
+    else DMM_PICKH(4);
+#undef DMM_PICKH
+#undef DMM_CALLH
     return dmm::check_launch();
 }

@@ -278,9 +278,11 @@ def cosine_features(feat_t: torch.Tensor, feat_p: torch.Tensor) -> torch.Tensor:
 
 
 def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test,
-                n_valid=None, m_valid=None, want_x=False):
+                n_valid=None, m_valid=None, want_x=False, state="f32"):
     """Similarity mix + relaxed assignment + scores for B frames.  cos [B,M,N] = feature_sim.
-    Returns dict(sim, R, Rb, match_score, det_score, iters, X)."""
+    Returns dict(sim, R, Rb, match_score, det_score, iters, X).  ``state="f16"``: the opt-in tolerance mode with the
+    solver state in packed fp16 and fp32 sums (``dmm_relax_match_f16s``, BASELINE configs[4]); the default reproduces
+    the reference bit for bit."""
     _need_gpu(cos, inter)
     B, M, N = cos.shape
     Pp = padded_width(N, M)
@@ -291,13 +293,15 @@ def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, 
                iters=torch.empty((B,), dtype=torch.int32, device=dev),
                X=torch.empty((B, M, Pp), **f32) if want_x else None)
     cos, score_p = cos.contiguous().float(), score_p.contiguous().float()
+    assert state in ("f32", "f16")
+    L = _lib.load()
+    fn = L.dmm_relax_match_f32 if state == "f32" else L.dmm_relax_match_f16s
     with _lib.device_guard(dev):
-        rc = _lib.load().dmm_relax_match_f32(
-            _ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
-            float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
-            _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]), _ptr(out["det_score"]), _ptr(out["iters"]),
-            _ptr(out["X"]), _stream(cos))
-    _lib.check(rc, "dmm_relax_match_f32")
+        rc = fn(_ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
+                float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
+                _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]), _ptr(out["det_score"]), _ptr(out["iters"]),
+                _ptr(out["X"]), _stream(cos))
+    _lib.check(rc, "dmm_relax_match_" + ("f32" if state == "f32" else "f16s"))
     return out
 
 
@@ -532,15 +536,20 @@ class ForwardPlan:
     """
 
     def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None,
-                 split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2, graph_fork=False):
+                 split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2, graph_fork=False,
+                 solver_state="f32"):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
         self.mask_dtype = mask_dtype
+        # "f16": dmm_relax_match_f16s (packed-fp16 solver state, fp32 sums; opt-in tolerance mode of BASELINE configs[4]).
+        # Its <= 128 VGPRs let it share a SIMD with the streaming kernels, so wide tables can take the 2-lane schedule.
+        assert solver_state in ("f32", "f16")
+        self.solver_state = solver_state
         # default: two lanes for large batches whose solver fits beside the streaming kernels (one wave per frame, exact
         # row count: M <= 16, Pp <= 64); the multi-wave solvers of wide tables hold up to 256 VGPRs per wave and only
         # serialise with them (config 5: 2.26 ms single stream vs 2.37 ms two lanes per 256 frames)
-        auto = B >= 64 and M <= 16 and self.Pp <= 64
+        auto = B >= 64 and ((M <= 16 and self.Pp <= 64) or solver_state == "f16")
         self.pipeline = auto if pipeline is None else bool(pipeline)
         # time_kernels: the single-stream form issues the granular C-ABI calls (same kernels as dmm_match_forward) so
         # that HIP events can bracket the cost and mix launches; bench.py sets kernel_events = {} per timed step
@@ -548,7 +557,7 @@ class ForwardPlan:
         # are the next frame's fp16 templates); the fused single C call writes fp32 only -> granular launches otherwise
         self.out_dtype = out_dtype or torch.float32
         assert self.out_dtype in (torch.float32, mask_dtype)
-        self.time_kernels = bool(time_kernels) or self.out_dtype != torch.float32
+        self.time_kernels = bool(time_kernels) or self.out_dtype != torch.float32 or solver_state != "f32"
         self.kernel_events = None
         # opt-in: it only pays for callers that present the SAME tensors again (static buffers: bench loops, serving
         # loops over GraphedEncoder outputs); a frame loop with fresh proposal tensors would capture and never replay
@@ -605,7 +614,8 @@ class ForwardPlan:
 
     def schedule_name(self) -> str:
         if self.pipeline:
-            return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams"
+            return "streaming lane (cost, mix) + latency lane (normalise, cosine, solver) on 2 HIP streams" + \
+                (" [fp16-state solver]" if self.solver_state == "f16" else "")
         if self.graph_mode:
             if not self._graphs:
                 return "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
@@ -639,13 +649,16 @@ class ForwardPlan:
                                _ptr(m_valid), _ptr(inter), _ptr(ap), _ptr(at), ms)
         if self.graph_fork:
             main.wait_stream(side)
-        rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
-                                    _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
-                                    float(lr), int(is_test), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),
-                                    _ptr(self.match_score), _ptr(self.det_score), _ptr(self.iters), None, ms)
+        rc |= self._solver(L)(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
+                               _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
+                               float(lr), int(is_test), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),
+                               _ptr(self.match_score), _ptr(self.det_score), _ptr(self.iters), None, ms)
         rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
                                 _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], M * HW, HW, ms)
         _lib.check(rc, "ForwardPlan.run (forked)")
+
+    def _solver(self, L):
+        return L.dmm_relax_match_f32 if self.solver_state == "f32" else L.dmm_relax_match_f16s
 
     def _mark(self, name, stream, begin):
         """HIP event on ``stream`` before / after a kernel launch when bench.py asked for kernel timing."""
@@ -722,11 +735,11 @@ class ForwardPlan:
                 self._mark("cost", main, False)
                 rc |= self._feature_sim(L, feat_p, feat_t, n_valid, m_valid, ms)
                 self._mark("solver", main, True)
-                rc |= L.dmm_relax_match_f32(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
-                                            _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter),
-                                            int(proj_iter), float(lr), int(is_test), _ptr(self.sim), _ptr(self.R),
-                                            _ptr(self.Rb), _ptr(self.match_score), _ptr(self.det_score),
-                                            _ptr(self.iters), None, ms)
+                rc |= self._solver(L)(_ptr(self.cos), _ptr(inter), _ptr(ap), _ptr(at), _ptr(score_p), B, N, M,
+                                       _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter),
+                                       int(proj_iter), float(lr), int(is_test), _ptr(self.sim), _ptr(self.R),
+                                       _ptr(self.Rb), _ptr(self.match_score), _ptr(self.det_score),
+                                       _ptr(self.iters), None, ms)
                 self._mark("solver", main, False)
                 self._mark("mix", main, True)
                 rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
@@ -768,7 +781,7 @@ class ForwardPlan:
             for h, (b, e) in enumerate(self.halves):
                 inter, ap, at = self._tables(h)
                 side.wait_event(self.ev_cost[h])
-                rc |= L.dmm_relax_match_f32(
+                rc |= self._solver(L)(
                     self.cos.data_ptr() + 4 * b * M * N, _ptr(inter), _ptr(ap), _ptr(at), score_p.data_ptr() + 4 * b * N,
                     e - b, N, M, nv(n_valid, b), nv(m_valid, b), float(score_weight), int(max_iter), int(proj_iter),
                     float(lr), int(is_test), self.sim.data_ptr() + 4 * b * M * N,

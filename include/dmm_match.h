@@ -179,6 +179,21 @@ DMM_API int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const
                                 float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                                 dmm_stream_t stream);
 
+/* (3c) The same with the solver STATE in packed fp16 and every sum in fp32 -- BASELINE configs[4]'s "fp16 Sinkhorn with
+ * fp32 accumulate".  A TOLERANCE mode, opt-in: the default (dmm_relax_match_f32) reproduces the reference bit for bit
+ * including its exact-equality exits (relax_match.py:88-89, :96-98); here the iteration runs on fp16 iterates, so R is
+ * within 1e-2 of the fp32 result (2.5e-3 measured on the config-2 / config-5 shapes) while both execute the same number of iterations, the row argmax is the same wherever
+ * the fp32 decision is not a near tie, and the exits fire at the fp16 iteration's own fixed point.  What it buys: the
+ * 20 x 200 problem needs <= 128 VGPRs (fp32: 256 + spills), four waves per SIMD, so the solver runs beside the streaming
+ * cost / mix kernels instead of serialising with them. */
+DMM_API int dmm_relax_match_f16s(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                 const int32_t *area_t, const float *score_p /*[B,N]*/, int B, int N, int M,
+                                 const int32_t *n_valid, const int32_t *m_valid,
+                                 float score_weight, int max_iter, int proj_iter, float lr, int is_test,
+                                 float *sim_out, float *R_out, float *Rb_out,
+                                 float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                 dmm_stream_t stream);
+
 /* Solver only, on caller-provided cost matrices C [B,n,m] (relax_matching itself,
  * relax_match.py:36-105; with max_iter = 0 it is the greedy initialisation used by
  * compute_matching_loss, match_helper.py:44): X_final, R = mean(X_list), cost list [B,max_iter+1]
