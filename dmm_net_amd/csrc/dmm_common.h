@@ -177,6 +177,11 @@ __device__ __forceinline__ float div_by_const(float a, float b, float rcp) {
 // sustains 7.1-7.2 TB/s where cached loads stop at 6.3 TB/s (tools/hbm_probe.py).
 // ---- mask element loads: 4 consecutive pixels as fp32 (load4), or one full 16-byte lane load (loadv: 4 fp32 or
 // 8 half/bfloat16 pixels) for the streaming kernels -------------------------------------------------------
+// (-DDMM_PLANE_LOADS_CACHED builds the plane loads WITHOUT the non-temporal hint: the experiment of tools/mall_probe.py --
+// do planes the cost pass streamed stay in the Infinity Cache for the mix?  The product keeps the hint.)
+#ifdef DMM_PLANE_LOADS_CACHED
+#define __builtin_nontemporal_load(p) (*(p))
+#endif
 typedef _Float16 half8u __attribute__((ext_vector_type(8), aligned(2)));
 typedef uint32_t uint4u __attribute__((ext_vector_type(4), aligned(2)));
 template <typename T> struct MaskIO;

@@ -3,6 +3,8 @@
 //   dmm_solve_rs.hip  row-split, RG x CG waves per frame            (latency form / wide tables)
 // Both issue the same fp32 operations in the same order (reference relax_match.py:36-105): bit-identical results.
 #pragma once
+#include <stdlib.h>
+
 #include "dmm_torch_order.h"
 
 namespace dmm {

@@ -1,0 +1,63 @@
+// dmm_solve_h.hip -- the fp16-state form of the relaxed-assignment solver (dmm_relax_match_f16s): BASELINE configs[4]'s
+// "fp16 Sinkhorn with fp32 accumulate", an opt-in TOLERANCE mode next to the bit-exact fp32 forms of dmm_solve.hip.
+// Core: relax_core_h in dmm_solve_core.h (reference: relax_matching, dmm/modules/submodules/relax_match.py:36-105).
+// Its own translation unit: the ten instantiations compile beside dmm_solve.hip instead of behind it.
+#include "dmm_solve_core.h"
+
+namespace dmm {
+
+// fp16-state form (relax_core_h): 4 waves per SIMD (<= 128 VGPRs) so that it runs beside the streaming kernels.
+template <int MT, int NG, bool EXACT>
+__global__ __launch_bounds__(64 * NG, 4) void relax_match_h_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final) {
+    __shared__ float red_buf[2 * NG * (MT + 1)];
+    __shared__ float xbuf[MT * 64 * NG];
+    __shared__ float rsbuf[MT + 1];
+    relax_match_body<MT, NG, EXACT, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou,
+                                          prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
+                                          X_final, red_buf, xbuf, rsbuf, nullptr);
+}
+
+}  // namespace dmm
+
+// (3c) dmm_relax_match_f32 with the solver state in packed fp16 and fp32 sums -- the tolerance mode of BASELINE
+// configs[4] ("fp16 Sinkhorn with fp32 accumulate"); see relax_core_h.
+extern "C" int dmm_relax_match_f16s(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                    const int32_t *area_t, const float *score_p, int B, int N, int M,
+                                    const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                    int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
+                                    float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                    dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    if (!cos_in || !inter || !area_p || !area_t || !score_p || !sim_out || !Rb_out || !match_score || !det_score)
+        return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    const dmm::RelaxParams prm{max_iter, proj_iter, lr};
+    const float w_feat = (float)(1.0 - (double)score_weight), w_iou = score_weight;
+    const int ng = (Pp + 63) / 64 <= 1 ? 1 : ((Pp + 63) / 64 == 2 ? 2 : 4);
+#define DMM_CALLH(MT_, NG_, EX_)                                                                                        \
+    hipLaunchKernelGGL((dmm::relax_match_h_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,     \
+                       cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test,     \
+                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
+#define DMM_PICKH(NG_)                                                                  \
+    do {                                                                                \
+        if (M <= 8) DMM_CALLH(8, NG_, false);                                           \
+        else if (M <= 16) DMM_CALLH(16, NG_, false);                                    \
+        else if (M == 20 && !m_valid && NG_ == 4) DMM_CALLH(20, 4, true);               \
+        else DMM_CALLH(32, NG_, false);                                                 \
+    } while (0)
+    if (ng == 1) DMM_PICKH(1);
+    else if (ng == 2) DMM_PICKH(2);
+    else DMM_PICKH(4);
+#undef DMM_PICKH
+#undef DMM_CALLH
+    return dmm::check_launch();
+}
