@@ -195,3 +195,49 @@ extern "C" int dmm_match_forward_packed(const void *masks_p, const uint64_t *pac
     return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
                         (int64_t)M * HW, HW, stream);
 }
+
+// (5c) Cost + assignment of the fixed-slot frame step, BOTH sides of the cost pass on 1-bit planes and no mix: the
+// proposals' words from dmm_paste_kept_f32, the templates' words from the previous frame's dmm_step_finish_f32.
+// cosine (dense, also clears the count tables) -> counts on the words -> solver; Rb / scores / iters out.
+extern "C" int dmm_match_solve_packed(const uint64_t *packed_p, const uint64_t *packed_t, const float *feat_p,
+                                      const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,
+                                      const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                      int proj_iter, float lr, int is_test, float *Rb_out, float *match_score,
+                                      float *det_score, float *sim_out, float *R_out, int32_t *iters_out, void *workspace,
+                                      size_t workspace_bytes, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || HW < 0 || D < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    if (!packed_p || !packed_t || !feat_p || !feat_t || !score_p || !Rb_out || !match_score || !det_score || !workspace)
+        return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
+    dmm::Workspace w = dmm::carve(workspace, B, N, M, D);
+    if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
+    const int64_t wd = dmm_pack_words(HW);
+    float *sim = sim_out ? sim_out : w.sim;
+    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    int rc = force_tile ? DMM_ERR_UNSUPPORTED
+                        : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
+                                                   (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
+    if (rc == DMM_OK) {
+        rc = dmm::iou_counts_prezeroed(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, (int64_t)N * wd, wd, (int64_t)M * wd,
+                                       wd, n_valid, m_valid, w.inter, w.area_p, w.area_t, stream);
+        if (rc != DMM_OK) return rc;
+    } else if (rc != DMM_ERR_UNSUPPORTED) {
+        return rc;
+    } else {
+        rc = dmm_iou_counts(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, (int64_t)N * wd, wd, (int64_t)M * wd, wd, n_valid,
+                            m_valid, w.inter, w.area_p, w.area_t, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_cosine_f32(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, stream);
+        if (rc != DMM_OK) return rc;
+    }
+    return dmm_relax_match_f32(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid, score_weight,
+                               max_iter, proj_iter, lr, is_test, sim, R_out, Rb_out, match_score, det_score, iters_out,
+                               nullptr, stream);
+}

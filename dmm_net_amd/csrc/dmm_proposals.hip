@@ -423,13 +423,33 @@ __global__ __launch_bounds__(256) void paste_kept_kernel(
     }
     if (!live) return;
     const int64_t p = fi * R + r;
-    stage_padded(prob + p * M * M, M, padding, pad_s);
-    __syncthreads();
     const PasteGeom g = paste_geom(boxes + p * 4, M, padding, im_h, im_w);
-    float *plane = planes + (int64_t)slot * plane_stride;
+    float *plane = planes ? planes + (int64_t)slot * plane_stride : nullptr;
     const int HW = im_h * im_w;
     const int lane = threadIdx.x & 63;
+    const int i_beg = blockIdx.x * kPasteIters * 1024;
     const int i_end = min(((HW + 255) / 256) * 256, (int)(blockIdx.x + 1) * kPasteIters * 1024);
+    // a band that lies above or below the (clipped) box is all zeros: no probabilities to stage, nothing to evaluate --
+    // three of four bands of a typical proposal
+    const int row_a = i_beg / im_w, row_b = (min(i_end, HW) - 1) / im_w;
+    if (row_b < g.y_0 || row_a >= g.y_1 || g.x_1 <= g.x_0) {
+        for (int i4 = i_beg + 4 * threadIdx.x; i4 < i_end; i4 += 1024) {
+            if (plane) {
+                if (i4 + 3 < HW) {
+                    float4u t;
+                    t.x = 0.0f; t.y = 0.0f; t.z = 0.0f; t.w = 0.0f;
+                    *reinterpret_cast<float4u *>(plane + i4) = t;
+                } else {
+                    for (int q = 0; q < 4; ++q)
+                        if (i4 + q < HW) plane[i4 + q] = 0.0f;
+                }
+            }
+            if (packed && lane < 4) packed[(int64_t)slot * packed_stride + (i4 - 4 * lane) / 64 + lane] = 0ull;
+        }
+        return;
+    }
+    stage_padded(prob + p * M * M, M, padding, pad_s);
+    __syncthreads();
     for (int i4 = blockIdx.x * kPasteIters * 1024 + 4 * threadIdx.x; i4 < i_end; i4 += 1024) {
         float vv[4];
         int y = i4 / im_w, x = i4 - y * im_w;
@@ -438,14 +458,16 @@ __global__ __launch_bounds__(256) void paste_kept_kernel(
             vv[q] = (i4 + q < HW && g.inside(y, x)) ? paste_value(g, pad_s, y, x) : 0.0f;
             if (++x == im_w) { x = 0; ++y; }
         }
-        if (i4 + 3 < HW) {
-            float4u t;
-            t.x = vv[0]; t.y = vv[1]; t.z = vv[2]; t.w = vv[3];
-            *reinterpret_cast<float4u *>(plane + i4) = t;
-        } else {
+        if (plane) {
+            if (i4 + 3 < HW) {
+                float4u t;
+                t.x = vv[0]; t.y = vv[1]; t.z = vv[2]; t.w = vv[3];
+                *reinterpret_cast<float4u *>(plane + i4) = t;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (i4 + q < HW) plane[i4 + q] = vv[q];
+                for (int q = 0; q < 4; ++q)
+                    if (i4 + q < HW) plane[i4 + q] = vv[q];
+            }
         }
         if (packed) {
             const unsigned long long b0 = __ballot(vv[0] > 0.5f), b1 = __ballot(vv[1] > 0.5f);
@@ -453,6 +475,178 @@ __global__ __launch_bounds__(256) void paste_kept_kernel(
             if (lane < 4)
                 packed[(int64_t)slot * packed_stride + (i4 - 4 * lane) / 64 + lane] =
                     lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+        }
+    }
+}
+
+// ---- frame-step epilogue on fixed slots -----------------------------------------------------------------------------
+// What the evaluator does with the assignment of a frame (match_model.py:134-144 mask mix, dmm_model.py:66-69 / :78-80
+// out_mask_last, evaluator.py:134-139 label map) in ONE pass over the pixels, WITHOUT the proposals' soft planes ever
+// having been written: full_outmask[m, x] = sum_n Rb[m, n] * plane_n[x] needs plane values of the few selected
+// proposals only (test mode: the row maxima), and a plane value is paste_value() of the raw 28 x 28 probabilities -- so
+// the kept proposals are pasted ON THE FLY for the selected (row, proposal) pairs, the result goes to full_outmask,
+// to the template history (unless the video was skipped), to the label map, and -- thresholded -- to the history's
+// 1-bit planes the next frame's cost pass counts on.  Bytes of a frame step: 9 MB out instead of 91 MB of pasted planes
+// + three more passes (pack templates, commit, merge).
+// Accumulation per row = mask_mix_rows_kernel's: fma(w, v, acc) over the non-zero weights in ascending column order
+// from 0 (a single product in test mode), zero weights skipped, the same paste_value -> bit identical to paste + mix.
+// grid = (ceil(HW / (1024 kFinishIters)), B); block = 256; thread = 4 consecutive pixels per 1024-pixel step over all
+// M <= 8 rows (kFinishIters = 1 measured best: 24 us per 4 x 255x448 step against 31 us with 4 steps per workgroup).  Mp = M_mask + 2 pad <= 32.
+constexpr int kFinishRows = 8, kFinishChunk = 16, kFinishPad = 32 * 32, kFinishIters = 1;
+
+__global__ __launch_bounds__(256) void step_finish_kernel(
+    const float *__restrict__ Rb, int Pp, const float *__restrict__ prob, const float *__restrict__ boxes,
+    const int32_t *__restrict__ keep, const int32_t *__restrict__ keep_count, int B, int R, int Mm, int K, int M, int im_h,
+    int im_w, int padding, const int32_t *__restrict__ step, const int32_t *__restrict__ m_valid,
+    const int32_t *__restrict__ commit, const int32_t *__restrict__ o_valid, float *__restrict__ full,
+    float *__restrict__ hist, unsigned long long *__restrict__ packed_hist, int64_t words,
+    uint8_t *__restrict__ labels) {
+    __shared__ float pad_s[kFinishChunk][kFinishPad];
+    __shared__ PasteGeom geom_s[kFinishChunk];
+    __shared__ float w_s[kFinishRows][kFinishChunk];
+    __shared__ int uslot_s[DMM_MAX_PROPOSALS];
+    __shared__ int wcnt_s[4];
+    __shared__ int hit_s[kFinishChunk];
+    const int b = blockIdx.y, HW = im_h * im_w;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int Nb = keep_count[b];
+    Nb = Nb < 0 ? 0 : (Nb > K ? K : Nb);
+    int Mb = m_valid ? m_valid[b] : M;
+    Mb = Mb < 0 ? 0 : (Mb > M ? M : Mb);
+    if (Nb == 0) Mb = 0;
+    const float *Rb_b = Rb + (int64_t)b * M * Pp;
+    // the proposals (columns) that carry a non-zero weight in any live row, ascending
+    {
+        const int n = threadIdx.x;
+        bool used = false;
+        if (n < Nb)
+            for (int m = 0; m < Mb; ++m) used |= Rb_b[(int64_t)m * Pp + n] != 0.0f;
+        const unsigned long long bal = __ballot(used);
+        if (lane == 0) wcnt_s[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) base += k < wave ? wcnt_s[k] : 0;
+        if (used) uslot_s[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = n;
+    }
+    __syncthreads();
+    const int U = wcnt_s[0] + wcnt_s[1] + wcnt_s[2] + wcnt_s[3];
+    const int64_t fi = step_of(step) * B + b;
+    const int Mp = Mm + 2 * padding;
+    const bool do_commit = commit ? commit[b] != 0 : false;
+    int Ob = o_valid ? o_valid[b] : M;
+    Ob = Ob < 0 ? 0 : (Ob > M ? M : Ob);
+    // this workgroup's pixels: kFinishIters steps of 1024; the image rows they touch decide which proposals matter here
+    const int i_beg = blockIdx.x * kFinishIters * 1024;
+    const int i_end = min(((HW + 255) / 256) * 256, i_beg + kFinishIters * 1024);
+    const int row_a = i_beg / im_w, row_b = (min(i_end, HW) - 1) / im_w;
+    int staged = -1;                                            // chunk of used proposals currently in LDS
+    for (int it = 0; it < kFinishIters; ++it) {
+        const int i4 = i_beg + it * 1024 + 4 * threadIdx.x;
+        if (i_beg + it * 1024 >= i_end) break;                  // (uniform)
+        int py[4], px[4];
+        {
+            int y = i4 / im_w, x = i4 - y * im_w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                py[q] = y; px[q] = x;
+                if (++x == im_w) { x = 0; ++y; }
+            }
+        }
+        float acc[kFinishRows][4];
+#pragma unroll
+        for (int m = 0; m < kFinishRows; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][q] = 0.0f;
+        for (int c0 = 0; c0 < U; c0 += kFinishChunk) {
+            const int nu = min(kFinishChunk, U - c0);
+            if (staged != c0) {                                 // (uniform; with <= 16 used proposals: once per workgroup)
+                __syncthreads();                                // the previous chunk is consumed
+                if (threadIdx.x < nu) {
+                    const int64_t p = fi * R + keep[(int64_t)b * K + uslot_s[c0 + threadIdx.x]];
+                    const PasteGeom g = paste_geom(boxes + p * 4, Mm, padding, im_h, im_w);
+                    geom_s[threadIdx.x] = g;
+                    hit_s[threadIdx.x] = (row_b >= g.y_0 && row_a < g.y_1 && g.x_1 > g.x_0) ? 1 : 0;
+                }
+                if (threadIdx.x < kFinishRows * kFinishChunk) {
+                    const int m = threadIdx.x / kFinishChunk, u = threadIdx.x - m * kFinishChunk;
+                    w_s[m][u] = (m < Mb && u < nu) ? Rb_b[(int64_t)m * Pp + uslot_s[c0 + u]] : 0.0f;
+                }
+                __syncthreads();
+                for (int t = threadIdx.x; t < nu * Mp * Mp; t += 256) {
+                    const int u = t / (Mp * Mp), e = t - u * Mp * Mp;
+                    if (!hit_s[u]) continue;                    // its box misses this workgroup's rows: never evaluated
+                    const int yy = e / Mp - padding, xx = e % Mp - padding;
+                    const int64_t p = fi * R + keep[(int64_t)b * K + uslot_s[c0 + u]];
+                    pad_s[u][e] = (yy >= 0 && yy < Mm && xx >= 0 && xx < Mm) ? prob[p * Mm * Mm + yy * Mm + xx] : 0.0f;
+                }
+                __syncthreads();
+                staged = c0;
+            }
+            for (int u = 0; u < nu; ++u) {
+                if (!hit_s[u]) continue;                        // plane is zero here: fma(w, 0, acc) = acc
+                const PasteGeom g = geom_s[u];
+                float v[4];
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = i4 + q < HW && g.inside(py[q], px[q]);
+                    v[q] = in ? paste_value(g, pad_s[u], py[q], px[q]) : 0.0f;
+                    any |= in;
+                }
+                if (__ballot(any) == 0ull) continue;
+#pragma unroll
+                for (int m = 0; m < kFinishRows; ++m) {
+                    const float w = w_s[m][u];
+                    if (w != 0.0f) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[m][q] = __builtin_fmaf(w, v[q], acc[m][q]);
+                    }
+                }
+            }
+        }
+        // ---- outputs of this step ----
+        float best[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int arg[4] = {0, 0, 0, 0};
+        const bool whole = i4 + 3 < HW;
+#pragma unroll
+        for (int m = 0; m < kFinishRows; ++m) {
+            if (m >= M) break;
+            float *fo = full + ((int64_t)b * M + m) * HW + i4;
+            float *ho = hist + ((int64_t)b * M + m) * HW + i4;
+            if (whole) {
+                float4u t;
+                t.x = acc[m][0]; t.y = acc[m][1]; t.z = acc[m][2]; t.w = acc[m][3];
+                *reinterpret_cast<float4u *>(fo) = t;
+                if (do_commit) *reinterpret_cast<float4u *>(ho) = t;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i4 + q < HW) {
+                        fo[q] = acc[m][q];
+                        if (do_commit) ho[q] = acc[m][q];
+                    }
+            }
+            if (m < Ob) {                                       // evaluator.py:134-139: first maximum wins
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (arg[q] == 0 || acc[m][q] > best[q]) { best[q] = acc[m][q]; arg[q] = m + 1; }
+            }
+            if (do_commit && packed_hist) {                     // the history's 1-bit planes (ballot layout, pad bits 0)
+                const unsigned long long b0 = __ballot(acc[m][0] > 0.5f), b1 = __ballot(acc[m][1] > 0.5f);
+                const unsigned long long b2 = __ballot(acc[m][2] > 0.5f), b3 = __ballot(acc[m][3] > 0.5f);
+                if (lane < 4)
+                    packed_hist[((int64_t)b * M + m) * words + (i4 - 4 * lane) / 64 + lane] =
+                        lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+            }
+        }
+        if (labels) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i4 + q < HW) {
+                    const float bg = 1.0f - best[q];
+                    labels[(int64_t)b * HW + i4 + q] = (uint8_t)((Ob > 0 && best[q] > bg) ? arg[q] : 0);
+                }
         }
     }
 }
@@ -533,8 +727,8 @@ extern "C" int dmm_paste_kept_f32(const float *prob, const float *boxes, const f
                                   float *rois, dmm_stream_t stream) {
     if (images < 0 || R < 0 || M <= 0 || K <= 0 || im_h < 0 || im_w < 0 || padding < 0) return DMM_ERR_BAD_ARG;
     if (images == 0) return DMM_OK;
-    if (!prob || !boxes || !scores || !tight || !keep || !keep_count || !planes ||
-        plane_stride < (int64_t)im_h * im_w)
+    if (!prob || !boxes || !scores || !tight || !keep || !keep_count || (!planes && !packed) ||
+        (planes && plane_stride < (int64_t)im_h * im_w))
         return DMM_ERR_BAD_ARG;
     if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
     if ((int64_t)images * K > 65535) return DMM_ERR_UNSUPPORTED;                  // grid.y
@@ -545,5 +739,22 @@ extern "C" int dmm_paste_kept_f32(const float *prob, const float *boxes, const f
                        scores, tight, keep, keep_count, images, R, M, K, im_h, im_w, padding, step, img_base, planes,
                        plane_stride, reinterpret_cast<unsigned long long *>(packed), dmm_pack_words(im_h * im_w),
                        kept_boxes, kept_scores, rois);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_step_finish_f32(const float *Rb, int Pp, const float *prob, const float *boxes, const int32_t *keep,
+                                   const int32_t *keep_count, int B, int R, int Mm, int K, int M, int im_h, int im_w,
+                                   int padding, const int32_t *step, const int32_t *m_valid, const int32_t *commit,
+                                   const int32_t *o_valid, float *full, float *hist, uint64_t *packed_hist,
+                                   uint8_t *labels, dmm_stream_t stream) {
+    if (B < 0 || R < 0 || Mm <= 0 || K <= 0 || M < 0 || im_h < 0 || im_w < 0 || padding < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0 || im_h * im_w == 0) return DMM_OK;
+    if (!Rb || !prob || !boxes || !keep || !keep_count || !full || !hist) return DMM_ERR_BAD_ARG;
+    if (M > dmm::kFinishRows || Mm + 2 * padding > 32 || Pp > DMM_MAX_PROPOSALS || K > Pp || B > 65535)
+        return DMM_ERR_UNSUPPORTED;
+    const int HW = im_h * im_w;
+    hipLaunchKernelGGL(dmm::step_finish_kernel, dim3((HW + 1024 * dmm::kFinishIters - 1) / (1024 * dmm::kFinishIters), B), dim3(256), 0, (hipStream_t)stream, Rb, Pp,
+                       prob, boxes, keep, keep_count, B, R, Mm, K, M, im_h, im_w, padding, step, m_valid, commit, o_valid,
+                       full, hist, reinterpret_cast<unsigned long long *>(packed_hist), dmm_pack_words(HW), labels);
     return dmm::check_launch();
 }

@@ -516,6 +516,29 @@ def match_forward_packed(masks_p, packed_p, masks_t, feat_p, feat_t, score_p, n_
     return out
 
 
+def match_solve_packed(packed_p, packed_t, feat_p, feat_t, score_p, n_valid, m_valid, HW, *, score_weight, max_iter,
+                        proj_iter, lr, is_test, out, workspace):
+    """Cost + assignment on 1-bit planes of BOTH sides, no mix (``dmm_match_solve_packed``): packed_p [B,N,words],
+    packed_t [B,M,words]; ``out`` = (Rb [B,M,Pp], match_score [B,M], det_score [B,M], iters [B]) caller-owned, like the
+    workspace (>= dmm_workspace_bytes): nothing is allocated -- the middle of a captured frame step."""
+    _need_gpu(packed_p, packed_t, feat_p, feat_t, score_p)
+    B, N, wd = packed_p.shape
+    M, D = packed_t.shape[1], feat_p.shape[-1]
+    assert packed_p.is_contiguous() and packed_t.is_contiguous() and packed_t.shape == (B, M, wd) and wd == pack_words(HW)
+    assert feat_p.is_contiguous() and feat_t.is_contiguous() and score_p.is_contiguous()
+    Rb, ms, ds, iters = out
+    assert Rb.is_contiguous() and Rb.shape == (B, M, padded_width(N, M))
+    L = _lib.load()
+    assert workspace.numel() >= int(L.dmm_workspace_bytes(B, N, M, D))
+    with _lib.device_guard(packed_p.device):
+        rc = L.dmm_match_solve_packed(_ptr(packed_p), _ptr(packed_t), _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M,
+                                      int(HW), D, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter),
+                                      int(proj_iter), float(lr), int(is_test), _ptr(Rb), _ptr(ms), _ptr(ds), None, None,
+                                      _ptr(iters), _ptr(workspace), workspace.numel(), _stream(packed_p))
+    _lib.check(rc, "dmm_match_solve_packed")
+    return out
+
+
 class ForwardPlan:
     """Pre-allocated forward of B same-shaped frames: nothing is allocated or synchronised per call.
 

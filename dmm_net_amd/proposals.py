@@ -224,12 +224,14 @@ class ProposalSlots:
     count ``count`` [B] int32 (ON THE DEVICE: it is the ``n_valid`` of the matching kernels) and the ROIAlign rows
     ``rois`` [B*K,5].  Slots past the count are dead (score 0, roi image index -1, stale plane never read)."""
 
-    def __init__(self, B: int, K: int, H: int, W: int, R: int, device):
+    def __init__(self, B: int, K: int, H: int, W: int, R: int, device, soft_planes: bool = True):
         from .ops import pack_words
         f32 = dict(dtype=torch.float32, device=device)
         i32 = dict(dtype=torch.int32, device=device)
         self.B, self.K, self.H, self.W, self.R = B, K, H, W, R
-        self.planes = torch.zeros((B, K, H, W), **f32)
+        # soft_planes=False: only the 1-bit planes are produced (the frame step's epilogue pastes the selected proposals
+        # on the fly, dmm_step_finish_f32) -- the soft planes are 10x the bytes of everything else in a frame step
+        self.planes = torch.zeros((B, K, H, W), **f32) if soft_planes else None
         self.packed = torch.zeros((B, K, pack_words(H * W)), dtype=torch.int64, device=device)
         self.boxes, self.scores = torch.zeros((B, K, 4), **f32), torch.zeros((B, K), **f32)
         self.rois = torch.zeros((B * K, 5), **f32)
@@ -261,7 +263,8 @@ def prepare_slots(clip: ClipProposals, slots: ProposalSlots, nms_thresh: float, 
         rc = L.dmm_paste_kept_f32(clip.prob.data_ptr(), clip.boxes.data_ptr(), clip.scores.data_ptr(),
                                   slots.tight.data_ptr(), slots.keep.data_ptr(), slots.count.data_ptr(), clip.B, clip.R,
                                   clip.M, slots.K, slots.H, slots.W, int(padding), sp,
-                                  None if img_base is None else img_base.data_ptr(), slots.planes.data_ptr(),
+                                  None if img_base is None else img_base.data_ptr(),
+                                  None if slots.planes is None else slots.planes.data_ptr(),
                                   slots.H * slots.W, slots.packed.data_ptr(), slots.boxes.data_ptr(),
                                   slots.scores.data_ptr(), slots.rois.data_ptr(), s)
         _lib.check(rc, "dmm_paste_kept_f32")

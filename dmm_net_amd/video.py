@@ -189,13 +189,17 @@ class StepPlan:
     clip of the same shape with NO host input:
 
         step_select   row *step of the per-clip tables -> m_valid [B] (live templates, 0 = video skipped) / commit [B]
-        proposal_boxes -> nms_slots -> paste_kept     raw proposals of frame *step -> K slots (proposals.prepare_slots)
+        proposal_boxes -> nms_slots -> paste_kept     raw proposals of frame *step -> K slots (proposals.prepare_slots);
+                                                      ONLY the 1-bit planes of the kept proposals are written
         roialign4_mean                                slots' roi rows on the feature batch -> feat_p [B,K,D]
-        match_forward_packed                          counts on 1-bit planes, cosine, solver, mix -> full [B,O,H,W]
-        (x row_scale)                                 only when the live templates are not a prefix (dmm_model.py:151-156)
-        commit_masks                                  hist[b] = full[b] unless skipped          (out_mask_last, :78-80)
-        merge_labels                                  label map of the frame                       (evaluator.py:134-139)
+        match_solve_packed                            cosine, counts on 1-bit planes (proposals AND templates), solver -> Rb
+        (x row_scale on Rb)                           only when the live templates are not a prefix (dmm_model.py:151-156)
+        step_finish                                   mix with the selected proposals pasted on the fly -> full [B,O,H,W];
+                                                      hist[b] = full[b] unless skipped (out_mask_last, :78-80); the
+                                                      history's 1-bit planes; label map (evaluator.py:134-139)
         step_advance                                  *step += 1
+    (more than 8 template slots or raw masks above 30 x 30: the soft planes are pasted and match_forward_packed +
+    commit_masks + merge_labels run instead.)
 
     The clip's raw proposals live in ``clip`` ([T_cap,B,R,..]); the encoder's backbone features of two chunks of G frames
     in ``feats[l]`` [2*G*B, C, H_l, W_l] (chunk k in half k % 2), addressed through the roi rows' image index
@@ -211,7 +215,13 @@ class StepPlan:
         dev = torch.device(device)
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
         self.clip = ClipProposals.empty(T_cap, B, R, Mm, dev)
-        self.slots = ProposalSlots(B, K, H, W, R, dev)
+        # fused epilogue (dmm_step_finish_f32): the selected proposals are pasted on the fly in the mix, the soft planes
+        # are never written, commit / label merge / the history's 1-bit planes come out of the same pass
+        self.fused = O <= 8 and Mm + 2 * padding <= 32
+        self.slots = ProposalSlots(B, K, H, W, R, dev, soft_planes=not self.fused)
+        self.Pp = ops.padded_width(K, O)
+        self.Rb = torch.zeros((B, O, self.Pp), **f32)
+        self.packed_hist = torch.zeros((B, O, ops.pack_words(H * W)), dtype=torch.int64, device=dev)
         cl = [f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous() for f in feat_like]
         self.feats = [torch.empty((2 * G * B,) + tuple(f.shape[1:]), dtype=f.dtype, device=dev,
                                   memory_format=torch.channels_last if c else torch.contiguous_format).zero_()
@@ -254,6 +264,23 @@ class StepPlan:
                       img_base=self.img_base)
         roialign4_mean_into(self.slots.rois, self.feats, self.feat_p)
         score_weight, max_iter, proj_iter, lr, is_test = self.cfg
+        if self.fused:
+            ops.match_solve_packed(self.slots.packed, self.packed_hist, self.feat_p.view(self.B, self.K, self.D),
+                                   self.tplt_feat, self.slots.scores, self.slots.count, self.cur[0], self.H * self.W,
+                                   score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr,
+                                   is_test=is_test, out=(self.Rb, self.out[1], self.out[2], self.out[3]),
+                                   workspace=self.workspace)
+            if self.row_scale is not None:
+                self.Rb.mul_(self.row_scale[:, :, None])         # rows of slots i < O with valid[i] == 0: zero weights
+            c = self.clip
+            _lib.check(L.dmm_step_finish_f32(
+                self.Rb.data_ptr(), self.Pp, c.prob.data_ptr(), c.boxes.data_ptr(), self.slots.keep.data_ptr(),
+                self.slots.count.data_ptr(), self.B, c.R, c.M, self.K, self.O, self.H, self.W, self.padding,
+                self.step.data_ptr(), self.cur[0].data_ptr(), self.cur[1].data_ptr() if self.tail else None,
+                self.n_tplt.data_ptr(), self.full.data_ptr(), self.hist.data_ptr(), self.packed_hist.data_ptr(),
+                self.labels.data_ptr() if self.tail else None, s), "dmm_step_finish_f32")
+            _lib.check(L.dmm_step_advance(self.step.data_ptr(), s), "dmm_step_advance")
+            return
         ops.match_forward_packed(self.slots.planes, self.slots.packed, self.hist, self.feat_p.view(self.B, self.K, self.D),
                                  self.tplt_feat, self.slots.scores, self.slots.count, self.cur[0],
                                  score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test,
@@ -276,10 +303,11 @@ class StepPlan:
         if g is None:
             # warm-up on the real buffers would advance the clip: save / restore the two pieces of state it touches
             from .ops import _CAPTURE_LOCK
-            keep_step, keep_hist = self.step.clone(), self.hist.clone()
+            keep_step, keep_hist, keep_packed = self.step.clone(), self.hist.clone(), self.packed_hist.clone()
             self.body()
             self.step.copy_(keep_step)
             self.hist.copy_(keep_hist)
+            self.packed_hist.copy_(keep_packed)
             with _CAPTURE_LOCK, torch.cuda.device(self.device):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -434,6 +462,9 @@ class FrameLoop:
         plan.step.zero_()
         y0 = first_masks.float().view(B, O, H * W)
         plan.hist.copy_(y0.view(B, O, H, W))
+        if plan.fused:
+            from . import ops
+            plan.packed_hist.copy_(ops.pack_masks(plan.hist))
         history, state, prev_mask, tplt_valid = [], None, y0, None
         hist_all = torch.empty((T, B, O, H * W), dtype=torch.float32, device=dev)
         lab_all = torch.empty((T, B, H, W), dtype=torch.uint8, device=dev) if on_labels is not None else None
@@ -483,6 +514,9 @@ class FrameLoop:
                 outs, hist_new, state = self.refine(features, prev_mask, zeros, plan.full, out_last, tplt_valid, state)
                 if t > 0:
                     plan.hist.copy_(hist_new.view(B, O, H, W))
+                    if plan.fused:
+                        from . import ops
+                        plan.packed_hist.copy_(ops.pack_masks(plan.hist))
                 outs = outs.reshape(B, O, H * W)
             else:
                 outs = plan.full.view(B, O, H * W)

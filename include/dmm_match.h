@@ -286,6 +286,18 @@ DMM_API int dmm_match_forward_packed(const void *masks_p, const uint64_t *packed
                                      float *match_score, float *det_score, float *sim_out, float *R_out, float *Rb_out,
                                      int32_t *iters_out, void *workspace, size_t workspace_bytes, dmm_stream_t stream);
 
+/* (5c) Cost + assignment of a fixed-slot frame step with BOTH sides of the cost pass on 1-bit planes and no mix (the
+ * mix is part of (8c)): packed_p [B,N,words] from dmm_paste_kept_f32, packed_t [B,M,words] from the previous frame's
+ * dmm_step_finish_f32 (or dmm_pack_masks for the first frame), both dense.  cosine -> counts -> solver
+ * (match_model.py:49-130, :146-147); Rb [B,M,Pp], match_score / det_score [B,M], sim (may be NULL), R (may be NULL),
+ * iters (may be NULL).  workspace >= dmm_workspace_bytes(B, N, M, D). */
+DMM_API int dmm_match_solve_packed(const uint64_t *packed_p, const uint64_t *packed_t, const float *feat_p,
+                                   const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,
+                                   const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                   int proj_iter, float lr, int is_test, float *Rb_out, float *match_score,
+                                   float *det_score, float *sim_out, float *R_out, int32_t *iters_out, void *workspace,
+                                   size_t workspace_bytes, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (6) Fused 4-level ROIAlign + spatial mean: the reference's ROI feature extractor
  * (dmm/modules/feature_extractor.py:20-52: maskrcnn_benchmark legacy ROIAlign, 14x14 bins,
@@ -340,7 +352,8 @@ DMM_API int dmm_nms_f32(const float *boxes, const float *scores, const int32_t *
  * dmm_nms_slots_f32: NMS(thresh) + top-K on the tight boxes -> keep [images, K] raw indices in descending score order,
  *   keep_count [images] (stays on the device: it is the n_valid of the matching entry points); R <= 1024;
  * dmm_paste_kept_f32: slot (i, k), k < keep_count[i], receives raw proposal keep[i, k]: its soft plane
- *   planes[(i*K + k) * plane_stride ..], its 1-bit plane packed [images, K, dmm_pack_words] (may be NULL), kept_boxes
+ *   planes[(i*K + k) * plane_stride ..] (NULL = do not write soft planes, see (8c)), its 1-bit plane packed [images, K,
+ *   dmm_pack_words] (may be NULL), kept_boxes
  *   [images, K, 4] (the tight box), kept_scores [images, K] and the ROIAlign row rois [images*K, 5] = (img_base[*step]
  *   + i, tight box) (each may be NULL; img_base NULL = 0).  Dead slots: plane untouched, score 0, box 0, roi image
  *   index -1 (dmm_roialign4_mean_fwd writes a zero feature row for it).
@@ -380,6 +393,22 @@ DMM_API int dmm_merge_labels_f32(const float *masks, int B, int O, int HW, int64
  * dmm_commit_masks_f32: out_mask_last of the per-video driver (dmm/modules/dmm_model.py:66-69 / :78-80): hist[b] =
  *   full[b] ([per_video] floats each) where commit[b] != 0; a skipped video (no live template, 'extra' frame) keeps its
  *   template planes. */
+/* (8c) Frame-step epilogue on fixed slots: the mask mix (match_model.py:134-144), out_mask_last (dmm_model.py:66-69 /
+ * :78-80) and the label map (evaluator.py:134-139) of every video of the step in ONE pass over the pixels, pasting the
+ * few selected proposals ON THE FLY from their raw probabilities (so dmm_paste_kept_f32 may run with planes = NULL: the
+ * soft planes of a frame, 10x the bytes of everything else in the step, are never written):
+ *   full[b,m,:]  = sum_n Rb[b,m,n] * paste(raw proposal keep[b,n])   for m < m_valid[b], zeros otherwise (bit identical
+ *                  to dmm_paste_kept_f32 + dmm_mask_mix: same paste arithmetic, same fma order);
+ *   hist[b]      = full[b] where commit[b] != 0 (a skipped video keeps its template planes);
+ *   packed_hist  = 1-bit planes of the new hist[b] (what the next frame's (5c) counts on; may be NULL);
+ *   labels[b,x]  = as dmm_merge_labels_f32 over the first o_valid[b] rows of full (may be NULL).
+ * Rb [B,M,Pp]; raw prob / boxes as in (7b) (clip resident, frame *step); keep / keep_count from dmm_nms_slots_f32.
+ * M <= 8 rows, mask size + 2 padding <= 32; otherwise DMM_ERR_UNSUPPORTED (callers then paste the planes and use (4)). */
+DMM_API int dmm_step_finish_f32(const float *Rb, int Pp, const float *prob, const float *boxes, const int32_t *keep,
+                                const int32_t *keep_count, int B, int R, int Mm, int K, int M, int im_h, int im_w,
+                                int padding, const int32_t *step, const int32_t *m_valid, const int32_t *commit,
+                                const int32_t *o_valid, float *full, float *hist, uint64_t *packed_hist, uint8_t *labels,
+                                dmm_stream_t stream);
 DMM_API int dmm_step_select_i32(const int32_t *table, const int32_t *step, int n, int32_t *out, dmm_stream_t stream);
 DMM_API int dmm_step_advance(int32_t *step, dmm_stream_t stream);
 DMM_API int dmm_commit_masks_f32(const float *full, float *hist, const int32_t *commit, int B, int64_t per_video,
