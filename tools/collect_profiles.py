@@ -6,6 +6,7 @@
   <tag>_bench.json                  python bench.py                      (all extras: cpu baseline, sweep, in-run traffic)
   <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-extras
   <tag>_bench_config5.json / _config3.json     python bench.py --config 5 / 3
+  <tag>_bench_frame_loop.json / _bench_config4_1gpu.json   python bench.py --config loop / --config 4
   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-extras
   <tag>_kernel_stats_single_stream.csv / _config5.csv / _config3.csv   same with --no-pipeline / --config 5 / --config 3
   <tag>_pmc_traffic.json            two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), per-kernel averages;
@@ -45,15 +46,20 @@ if not only_pmc and os.environ.get("ONLY_STATS") is None:
         last_json(run(bench + ["--config", "5", "--no-cpu-baseline"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_config3.json"), "w").write(
         last_json(run(bench + ["--config", "3"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_frame_loop.json"), "w").write(
+        last_json(run(bench + ["--config", "loop"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_config4_1gpu.json"), "w").write(
+        last_json(run(bench + ["--config", "4", "--steps", "10", "--warmup", "4"]).stdout) + "\n")
 
 only = os.environ.get("ONLY_STATS")                       # e.g. ONLY_STATS=_config3: just that kernel-stats pass
 for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]), ("_config5", ["--config", "5"]),
-                                           ("_config3", ["--config", "3", "--steps", "50"]))):
+                                           ("_config3", ["--config", "3", "--steps", "50"]),
+                                           ("_frame_loop", ["--config", "loop"]))):
     if only is not None and suffix != only:
         continue
     d = f"/tmp/prof_stats{suffix}"
     shutil.rmtree(d, ignore_errors=True)
-    if suffix == "_config3":
+    if suffix in ("_config3", "_frame_loop"):
         # MIOpen's find step (GraphedEncoder(miopen_find=True), first forward of the process) times every applicable
         # solver once, its reference `naive_conv_*` kernels included: 128 calls of 4.8 ms = 83 % of the summary.  For
         # THIS profile only they are taken out of the candidates (the timed encoder is the same with and without:
