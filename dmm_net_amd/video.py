@@ -207,7 +207,7 @@ class StepPlan:
     frame 0, dmm_model.py:44)."""
 
     def __init__(self, B, O, H, W, R, Mm, K, G, T_cap, feat_like, device, cfg, nms_thresh, mask_thresh, padding,
-                 tail: bool):
+                 tail: bool, fuse_epilogue: bool = True):
         from . import ops
         self.B, self.O, self.H, self.W, self.R, self.K, self.G, self.T_cap = B, O, H, W, R, K, G, T_cap
         self.cfg, self.tail = cfg, bool(tail)
@@ -217,7 +217,7 @@ class StepPlan:
         self.clip = ClipProposals.empty(T_cap, B, R, Mm, dev)
         # fused epilogue (dmm_step_finish_f32): the selected proposals are pasted on the fly in the mix, the soft planes
         # are never written, commit / label merge / the history's 1-bit planes come out of the same pass
-        self.fused = O <= 8 and Mm + 2 * padding <= 32
+        self.fused = bool(fuse_epilogue) and O <= 8 and Mm + 2 * padding <= 32
         self.slots = ProposalSlots(B, K, H, W, R, dev, soft_planes=not self.fused)
         self.Pp = ops.padded_width(K, O)
         self.Rb = torch.zeros((B, O, self.Pp), **f32)
@@ -246,9 +246,10 @@ class StepPlan:
         self.graphs = {}                                         # row_scale? -> captured graph
         self.device = dev
 
-    def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail):
+    def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail, fuse_epilogue=True):
         return ((self.B, self.O, self.H, self.W, self.R, self.clip.M, self.K, self.G, self.tail) ==
                 (B, O, H, W, R, Mm, K, G, bool(tail)) and T <= self.T_cap and
+                self.fused == (bool(fuse_epilogue) and O <= 8 and Mm + 2 * self.padding <= 32) and
                 all(tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.dtype == b.dtype and
                     a.is_contiguous() == b.is_contiguous() for a, b in zip(self.feats, feat_like)))
 
@@ -355,6 +356,8 @@ class FrameLoop:
         # (paste every raw proposal, NMS, gather the kept ones, one host sync per frame).
         self.slots = True
         self.graph = True
+        self.fuse_epilogue = True                                # dmm_step_finish_f32: mix with on-the-fly paste + commit +
+                                                                 # label map in one pass, no soft proposal planes (StepPlan)
         self.encode_first = 0                                    # frames in the FIRST encoder batch (0 = encode_ahead): a short
                                                                  # first chunk shortens the pipeline fill before frame 0's step
         self.encoder_priority = 0                                # HIP stream priority of the encoder's side stream (-1 = high)
@@ -462,12 +465,12 @@ class FrameLoop:
         cfg = self.dmm.match_layer
         tail = self.refine is None
         plan = self._plan
-        if plan is None or not plan.key_fits(B, O, H, W, R, Mm, K, G, T, out0["backbone_feature"], tail) \
-                or plan.device != dev:
+        if plan is None or not plan.key_fits(B, O, H, W, R, Mm, K, G, T, out0["backbone_feature"], tail,
+                                             self.fuse_epilogue) or plan.device != dev:
             plan = self._plan = StepPlan(B, O, H, W, R, Mm, K, G, max(T, 32), out0["backbone_feature"], dev,
                                          (float(cfg.cfgs["score_weight"]), int(cfg.max_iter), int(cfg.proj_iter),
                                           float(cfg.relax_lr), int(bool(cfg.is_test))),
-                                         self.nms_thresh, self.mask_thresh, self.padding, tail)
+                                         self.nms_thresh, self.mask_thresh, self.padding, tail, self.fuse_epilogue)
         ready = land(0, out0, fence0)
         chunk = out0
         # ---- the clip's raw proposals and per-frame tables: one upload, before the loop ----------------------------

@@ -255,7 +255,8 @@ def test_frame_loop_fixed_slots_and_graph_equal_boxlist_path_without_host_syncs(
 
     ref_h, ref_l = run(make(False, False))
     for (slots, graph, kn) in [(True, False, {}), (True, True, {}), (True, True, dict(encode_ahead=1, encode_overlap=False)),
-                               (True, True, dict(encode_ahead=3))]:
+                               (True, True, dict(encode_ahead=3)), (True, True, dict(fuse_epilogue=False)),
+                               (True, False, dict(fuse_epilogue=False, encode_ahead=2))]:
         lp = make(slots, graph, **kn)
         for rep in range(3):                                             # replays of the captured step; races
             h, l = run(lp)
@@ -279,8 +280,9 @@ def test_frame_loop_fixed_slots_and_graph_equal_boxlist_path_without_host_syncs(
         state = outs.mean() if state is None else state + outs.mean()
         return outs, hist_new * 0.5 + 0.5 * outs.view_as(hist_new), state
     rh, rl = run(make(False, False, refine=refine))
-    gh, gl = run(make(True, True, refine=refine))
-    assert all(torch.equal(a, c) for a, c in zip(rh, gh)) and all(torch.equal(rl[k], gl[k]) for k in rl)
+    for fe_ in (True, False):
+        gh, gl = run(make(True, True, refine=refine, fuse_epilogue=fe_))
+        assert all(torch.equal(a, c) for a, c in zip(rh, gh)) and all(torch.equal(rl[k], gl[k]) for k in rl), fe_
     # no host round trip per frame: the count does not grow with the clip length
     lp = make(True, True)
     run(lp)                                                              # capture

@@ -90,3 +90,35 @@ def test_video_ops_refuse_cpu_tensors():
         video.mask_boxes(torch.zeros(2, 4, 4))
     with pytest.raises(DmmError):
         video.merge_labels(torch.zeros(1, 2, 16))
+
+
+def test_clip_proposals_packs_ragged_boxlists_on_the_host():
+    """ClipProposals.from_boxlists (host logic of the fixed-slot frame step): frame-major [T,B,R,..] layout, zero padding
+    past a list's count, the last entry of a short video reused (evaluator.py:101-106), boxes rescaled like
+    BoxList.resize when a list was made for another image size, 'objectness' accepted for 'scores'."""
+    from dmm_net_amd.proposals import ClipProposals
+    rng = np.random.default_rng(4)
+    H, W, T = 40, 60, 3
+
+    def bl(n, size=(W, H), field="scores"):
+        b = SimpleBoxList(torch.from_numpy(rng.uniform(0, 30, (n, 4)).astype(np.float32)), size)
+        b.add_field(field, torch.from_numpy(rng.random(n).astype(np.float32)))
+        b.add_field("mask", torch.from_numpy(rng.random((n, 1, 28, 28)).astype(np.float32)))
+        return b
+    props = [[bl(5), bl(2), bl(7)], [bl(3, size=(2 * W, 2 * H))]]            # video 1: one list, made at twice the size
+    clip = ClipProposals.from_boxlists(props, T, H, W, "cpu")
+    assert (clip.T, clip.B, clip.R, clip.M) == (T, 2, 7, 28)
+    assert clip.counts.tolist() == [[5, 3], [2, 3], [7, 3]]
+    for t in range(T):
+        p = props[0][t]
+        n = len(p)
+        assert torch.equal(clip.boxes[t, 0, :n], p.bbox) and float(clip.boxes[t, 0, n:].abs().sum()) == 0.0
+        assert torch.equal(clip.prob[t, 0, :n], p.get_field("mask")[:, 0]) and torch.equal(clip.scores[t, 0, :n], p.get_field("scores"))
+        q = props[1][0]
+        assert torch.equal(clip.boxes[t, 1, :3], q.bbox * 0.5)                 # resized to (W, H); reused for every frame
+        assert torch.equal(clip.prob[t, 1, :3], q.get_field("mask")[:, 0])
+    big = ClipProposals.empty(8, 2, 10, 28, "cpu")
+    out = ClipProposals.from_boxlists(props, T, H, W, "cpu", out=big)
+    assert out is big and torch.equal(big.prob[:T, :, :7], clip.prob) and big.counts[:T].tolist() == clip.counts.tolist()
+    obj = [[bl(4, field="objectness")] for _ in range(2)]
+    assert ClipProposals.from_boxlists(obj, 1, H, W, "cpu").scores.shape == (1, 2, 4)
