@@ -51,14 +51,14 @@ for b in range(B):
         first[b, o, y0:y0 + 50, x0:x0 + 55] = 1.0
 first = first.view(B, O, H * W)
 loop = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4, max_proposals=50)
-loop.encode_ahead = int(os.environ.get("AHEAD", "4"))
+loop.encode_ahead = int(os.environ.get("AHEAD", "0"))            # 0 = by clip length
 loop.encode_first = int(os.environ.get("FIRST", "0"))
 loop.encoder_priority = int(os.environ.get("ENCPRIO", "0"))
 T = int(os.environ.get("T", "12"))
 loop.slots = os.environ.get("SLOTS", "1") != "0"             # fixed-slot frame step (two-phase paste, no host sync)
 loop.graph = os.environ.get("GRAPH", "1") != "0"             # ... replayed from one HIP graph per frame
 labels = []
-loop.run(frames[:, :3] if loop.encode_ahead == 1 else frames, first, props, on_labels=lambda b, t, lab: None)   # warm-up (graph capture, MIOpen find for every chunk shape)
+loop.run(frames, first, props, on_labels=lambda b, t, lab: None)   # warm-up (graph capture, MIOpen find for every chunk shape)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 loop.run(frames, first, props, on_labels=lambda b, t, lab: labels.append(lab))
