@@ -479,6 +479,66 @@ __global__ __launch_bounds__(256) void paste_kept_kernel(
     }
 }
 
+
+// Phase 3 when only the 1-bit planes are wanted (dmm_paste_kept_f32 with planes = NULL: the frame step's epilogue pastes
+// the selected proposals on the fly).  grid = (4, images * K); block = 1024 (16 waves): the workgroups of a slot clear
+// the slot's words and evaluate only the 256-pixel blocks its (clipped) box touches -- a wave per block, four ballots
+// per block, exactly the words paste_kept_kernel would write (the evaluation is the cost: ~14 of 20 us with one
+// workgroup per slot, the rest is the chain of dependent index loads).  (The band decomposition above launched 28 workgroups per slot,
+// three quarters of them to write zeros: 17.6 us for 4 x 50 slots of 255 x 448; this form: see DESIGN.md.)
+__global__ __launch_bounds__(1024) void pack_kept_kernel(
+    const float *__restrict__ prob, const float *__restrict__ boxes, const float *__restrict__ scores,
+    const float *__restrict__ tight, const int32_t *__restrict__ keep, const int32_t *__restrict__ keep_count, int images,
+    int R, int M, int K, int im_h, int im_w, int padding, const int32_t *__restrict__ step,
+    const int32_t *__restrict__ img_base, unsigned long long *__restrict__ packed, int64_t packed_stride,
+    float *__restrict__ kept_boxes, float *__restrict__ kept_scores, float *__restrict__ rois) {
+    __shared__ float pad_s[64 * 64];
+    const int slot = blockIdx.y, img = slot / K, k = slot - img * K;
+    const int part = blockIdx.x, parts = gridDim.x;             // a slot's blocks are dealt out to `parts` workgroups
+    const int64_t st = step_of(step), fi = st * images + img;
+    const bool live = k < keep_count[img];
+    const int r = live ? keep[(int64_t)img * K + k] : 0;
+    if (part == 0 && threadIdx.x < 4) {
+        const float tb = live ? tight[((int64_t)img * R + r) * 4 + threadIdx.x] : 0.0f;
+        if (kept_boxes) kept_boxes[(int64_t)slot * 4 + threadIdx.x] = tb;
+        if (rois) rois[(int64_t)slot * 5 + 1 + threadIdx.x] = tb;
+        if (threadIdx.x == 0) {
+            if (kept_scores) kept_scores[slot] = live ? scores[fi * R + r] : 0.0f;
+            if (rois) rois[(int64_t)slot * 5] = live ? (float)((img_base ? img_base[st] : 0) + img) : -1.0f;
+        }
+    }
+    if (!live) return;
+    const int64_t p = fi * R + r;
+    const PasteGeom g = paste_geom(boxes + p * 4, M, padding, im_h, im_w);
+    const int HW = im_h * im_w, nblk = (HW + 255) / 256;
+    unsigned long long *words = packed + (int64_t)slot * packed_stride;
+    // blocks of 256 pixels the box's rows touch: [b_lo, b_hi]
+    int b_lo = nblk, b_hi = -1;
+    if (g.y_1 > g.y_0 && g.x_1 > g.x_0) {
+        b_lo = (g.y_0 * im_w + g.x_0) / 256;
+        b_hi = ((g.y_1 - 1) * im_w + g.x_1 - 1) / 256;
+    }
+    for (int w = part * 1024 + threadIdx.x; w < 4 * nblk; w += 1024 * parts)     // everything outside: zero words
+        if ((w >> 2) < b_lo || (w >> 2) > b_hi) words[w] = 0ull;
+    if (b_hi < b_lo) return;
+    stage_padded(prob + p * M * M, M, padding, pad_s);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = b_lo + part * 16 + wave; q <= b_hi; q += 16 * parts) {
+        const int i4 = 256 * q + 4 * lane;
+        int y = i4 / im_w, x = i4 - y * im_w;
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vv[e] = (i4 + e < HW && g.inside(y, x)) ? paste_value(g, pad_s, y, x) : 0.0f;
+            if (++x == im_w) { x = 0; ++y; }
+        }
+        const unsigned long long b0 = __ballot(vv[0] > 0.5f), b1 = __ballot(vv[1] > 0.5f);
+        const unsigned long long b2 = __ballot(vv[2] > 0.5f), b3 = __ballot(vv[3] > 0.5f);
+        if (lane < 4) words[4 * q + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+    }
+}
+
 // ---- frame-step epilogue on fixed slots -----------------------------------------------------------------------------
 // What the evaluator does with the assignment of a frame (match_model.py:134-144 mask mix, dmm_model.py:66-69 / :78-80
 // out_mask_last, evaluator.py:134-139 label map) in ONE pass over the pixels, WITHOUT the proposals' soft planes ever
@@ -732,6 +792,13 @@ extern "C" int dmm_paste_kept_f32(const float *prob, const float *boxes, const f
         return DMM_ERR_BAD_ARG;
     if (M + 2 * padding > 64) return DMM_ERR_UNSUPPORTED;
     if ((int64_t)images * K > 65535) return DMM_ERR_UNSUPPORTED;                  // grid.y
+    if (!planes) {                                              // 1-bit planes only: one workgroup per slot
+        hipLaunchKernelGGL(dmm::pack_kept_kernel, dim3(4, images * K), dim3(1024), 0, (hipStream_t)stream, prob, boxes, scores,
+                           tight, keep, keep_count, images, R, M, K, im_h, im_w, padding, step, img_base,
+                           reinterpret_cast<unsigned long long *>(packed), dmm_pack_words(im_h * im_w), kept_boxes,
+                           kept_scores, rois);
+        return dmm::check_launch();
+    }
     const int nsteps = (im_h * im_w + 1023) / 1024;
     int bands = (nsteps + dmm::kPasteIters - 1) / dmm::kPasteIters;
     bands = bands < 1 ? 1 : bands;

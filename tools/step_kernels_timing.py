@@ -52,6 +52,11 @@ out = (full, torch.zeros(B, O, device=dev), torch.zeros(B, O, device=dev), torch
 mval = torch.tensor([3 + b % 3 for b in range(B)], dtype=torch.int32, device=dev)
 commit = torch.ones(B, dtype=torch.int32, device=dev)
 labels = torch.zeros(B, H * W, dtype=torch.uint8, device=dev)
+Pp = ops.padded_width(K, O)
+Rb = torch.zeros(B, O, Pp, device=dev)
+packed_hist = ops.pack_masks(hist)
+hist2 = hist.clone()
+ws = torch.empty(int(L.dmm_workspace_bytes_packed(B, K, O, 4 * C, H * W)), dtype=torch.uint8, device=dev)
 prop.prepare_slots(clip, slots, 0.4, 0.4, 1, step=step)
 print("kept per video:", slots.count.tolist())
 rows = {
@@ -61,6 +66,9 @@ rows = {
     "roialign4_mean (nhwc bf16)": lambda: roialign4_mean_into(slots.rois, feats, feat_p),
     "match_forward_packed 40x5": lambda: ops.match_forward_packed(slots.planes, slots.packed, hist, feat_p.view(B, K, -1), tplt, slots.scores, slots.count, mval, score_weight=0.3, max_iter=40, proj_iter=5, lr=0.1, is_test=1, out=out),
     "match_forward_packed 0x0": lambda: ops.match_forward_packed(slots.planes, slots.packed, hist, feat_p.view(B, K, -1), tplt, slots.scores, slots.count, mval, score_weight=0.3, max_iter=0, proj_iter=0, lr=0.1, is_test=1, out=out),
+    "paste_kept (1-bit planes only)": lambda: L.dmm_paste_kept_f32(clip.prob.data_ptr(), clip.boxes.data_ptr(), clip.scores.data_ptr(), slots.tight.data_ptr(), slots.keep.data_ptr(), slots.count.data_ptr(), B, R, 28, K, H, W, 1, sp, None, None, H * W, slots.packed.data_ptr(), slots.boxes.data_ptr(), slots.scores.data_ptr(), slots.rois.data_ptr(), s),
+    "match_solve_packed 40x5": lambda: ops.match_solve_packed(slots.packed, packed_hist, feat_p.view(B, K, -1), tplt, slots.scores, slots.count, mval, H * W, score_weight=0.3, max_iter=40, proj_iter=5, lr=0.1, is_test=1, out=(Rb, out[1], out[2], out[3]), workspace=ws),
+    "step_finish": lambda: L.dmm_step_finish_f32(Rb.data_ptr(), Pp, clip.prob.data_ptr(), clip.boxes.data_ptr(), slots.keep.data_ptr(), slots.count.data_ptr(), B, R, 28, K, O, H, W, 1, sp, mval.data_ptr(), commit.data_ptr(), mval.data_ptr(), full.data_ptr(), hist2.data_ptr(), packed_hist.data_ptr(), labels.data_ptr(), s),
     "commit_masks": lambda: L.dmm_commit_masks_f32(full.data_ptr(), hist.data_ptr(), commit.data_ptr(), B, O * H * W, s),
     "merge_labels": lambda: L.dmm_merge_labels_f32(full.data_ptr(), B, O, H * W, O * H * W, H * W, mval.data_ptr(), labels.data_ptr(), s),
     "step_advance": lambda: L.dmm_step_advance(step.data_ptr(), s) or step.zero_(),
