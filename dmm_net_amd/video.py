@@ -341,6 +341,17 @@ class FrameLoop:
     NEXT batch is encoded on its own stream while this one's steps run (outputs of a static-buffer encoder are cloned).
     An encoder whose output for an image depends on the rest of the batch (BatchNorm in train mode) needs
     ``encode_ahead = 1``.
+
+    Two execution forms, bit-identical results (tests/test_gpu_video.py):
+    ``slots = True`` (default; raw proposal masks, ``algo: 'relax'``): the FIXED-SLOT frame step of ``StepPlan`` -- the
+    clip's raw proposals are uploaded once (``proposals.ClipProposals``; ``run`` also accepts one directly), the proposals
+    that survive NMS + top-k live in ``max_proposals`` slots per video with the live count on the device, the whole step is
+    nine launches and, with ``graph = True``, ONE HIP-graph replay per frame: no host sync, upload or allocation per
+    frame.  ``fuse_epilogue`` (<= 8 template slots, raw masks <= 30 x 30): no soft proposal plane is ever written, the mix
+    pastes its selected proposals on the fly and emits ``out_mask_last``, the label map and the template history's 1-bit
+    planes in the same pass.  ``on_labels(b, t, labels)`` receives a view of a per-clip buffer, valid in stream order.
+    ``slots = False``: the BoxList path -- paste every raw proposal, NMS, index the kept ones (one host sync per frame),
+    ``DMM_Model.inference`` -- the reference's per-frame steps one to one (also taken for ``pasted = True`` / ``algo: 'hun'``).
     """
 
     def __init__(self, encoder: Callable, dmm, refine: Optional[Callable] = None, nms_thresh: float = 0.4,
