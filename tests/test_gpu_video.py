@@ -292,3 +292,52 @@ def test_frame_loop_fixed_slots_and_graph_equal_boxlist_path_without_host_syncs(
     assert len(c6) == len(c3) <= 2, (c6, c3)
     _, old = _count_host_syncs(lambda: make(False, False).run(frames, first, props, n_frames, on_labels=quiet))
     assert len(old) >= T
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_frame_step_fuzz_fixed_slots_equal_boxlist_path(seed):
+    """Random clips -- image sizes with H*W not a multiple of 4 / 256, 1..8 template slots with random empty objects
+    (non-prefix layouts, videos without templates), 1..70 raw proposals per frame (above 64 the general NMS kernel), top-k
+    below / at / above the kept count, random NMS thresholds and clip lengths per video -- through the fixed-slot step
+    (graph replay, fused and unfused epilogue) and the BoxList path: histories and label maps bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    B, T, O = int(rng.integers(1, 5)), int(rng.integers(2, 7)), int(rng.integers(1, 9))
+    H, W = [(37, 53), (64, 96), (51, 50), (96, 128), (33, 47), (80, 45)][seed % 6]
+    Rmax = int(rng.integers(1, 71))
+    K = int(rng.choice([3, 10, 20, Rmax]))
+    nms_t = float(rng.choice([0.2, 0.4, 0.7]))
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": int(rng.integers(1, 30)), "relax_proj_iter": int(rng.integers(1, 6)),
+            "relax_learning_rate": 0.1, "score_weight": 0.3}
+    n_frames = [int(rng.integers(1, T + 1)) for _ in range(B)]
+    n_frames[0] = T
+
+    def rawp(n):
+        x1, y1 = rng.uniform(0, W - 12, n), rng.uniform(0, H - 12, n)
+        bx = np.stack([x1, y1, np.minimum(x1 + rng.uniform(4, W * 0.6, n), W - 1), np.minimum(y1 + rng.uniform(4, H * 0.6, n), H - 1)], 1)
+        bl = prop.SimpleBoxList(torch.from_numpy(bx.astype(np.float32)), (W, H))
+        bl.add_field("scores", torch.from_numpy(np.round(rng.random(n), 2).astype(np.float32)))    # ties on purpose
+        bl.add_field("mask", torch.from_numpy((rng.random((n, 1, 28, 28)) * 0.8 + 0.2).astype(np.float32)))
+        return bl
+    props = [[rawp(int(rng.integers(1, Rmax + 1))) for _ in range(n_frames[b])] for b in range(B)]
+    frames = torch.randn(B, T, 3, H, W, device=DEV)
+    first = torch.zeros(B, O, H, W, device=DEV)
+    for b in range(B):
+        for o in range(O):
+            if rng.random() < 0.65:
+                y0, x0 = int(rng.integers(0, H - 10)), int(rng.integers(0, W - 10))
+                first[b, o, y0:y0 + int(rng.integers(4, 12)), x0:x0 + int(rng.integers(4, 12))] = 1.0
+    first = first.view(B, O, H * W)
+
+    def run(slots, graph, fe_=True):
+        lp = video.FrameLoop(_PoolEncoder(), DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()),
+                             nms_thresh=nms_t, max_proposals=K)
+        lp.slots, lp.graph, lp.fuse_epilogue = slots, graph, fe_
+        labs = {}
+        h = lp.run(frames, first, props, n_frames, on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()))
+        return [x.clone() for x in h], labs
+    ref_h, ref_l = run(False, False)
+    for (graph, fe_) in [(True, True), (True, False), (False, True)]:
+        h, l = run(True, graph, fe_)
+        assert sorted(l) == sorted(ref_l)
+        assert all(torch.equal(a, c) for a, c in zip(ref_h, h)), (seed, graph, fe_)
+        assert all(torch.equal(ref_l[k], l[k]) for k in ref_l), (seed, graph, fe_)
