@@ -210,3 +210,23 @@ def test_bench_multi_rank_control_flow_is_launched_like_the_driver():
     assert out["config"]["frames_per_gpu_per_step"] == 128
     assert abs(out["value"] - 2 * 128 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-3 * out["value"]
     assert 0 < out["roofline"]["frac"] < 1.0
+
+
+def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean():
+    """``bench.py --config 4 --gpus 2`` launched like the driver would for the 8-GPU line (BASELINE configs[3]): every
+    rank trains its own frames through DMM_Model, gradients are averaged by the overlapped bucketer, rank 0 prints one
+    JSON line with the all-reduce accounting.  gloo, because two RCCL ranks cannot share this box's one GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", "2",
+           "--steps", "2", "--warmup", "1", "--frames", "2", "--backend", "gloo"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    gm = out["config"]["gradient_mean"]
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["frames_per_gpu_per_step"] == 2
+    assert gm["buckets"] >= 3 and gm["bytes"] > 150e6 and gm["allreduce_alone_ms"] > 0
+    assert abs(gm["busbw_GBps"] - gm["algbw_GBps"]) <= 0.06 * gm["algbw_GBps"] + 0.1        # 2 (N-1) / N = 1 at N = 2
+    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"]
