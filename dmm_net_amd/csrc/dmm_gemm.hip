@@ -12,12 +12,17 @@
 // MFMA work goes to the library (north_star: matrix cores for the backbone only, through rocm libraries); this file is
 // the descriptor plumbing: row-major operands are handed over as the transposed column-major problem
 //     Y^T [Cout, rows] = W^T [Cout, Cin] . X^T [Cin, rows]   (no data movement: a row-major [r, c] IS a column-major [c, r]).
-// Heuristic picks are cached per shape; the call is stream-ordered and graph-capturable.
+// The algorithm is picked per shape ONCE: the library's heuristic returns up to kTuneCandidates kernels, the first call
+// of a shape (outside a stream capture) times each of them on the call's own operands and keeps the fastest -- at the
+// encoder's sizes (rows x Cin x Cout around 2048 x 1024 x 256, 8-12 us per product, 64 tiles on 256 CUs) the first
+// heuristic pick is often not the fastest.  DMM_GEMM_TUNE=1 keeps the first pick.  Picks are cached; the call is
+// stream-ordered and graph-capturable (a shape first seen DURING a capture takes the first pick, untimed).
 #include <hipblaslt/hipblaslt.h>
 
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "dmm_common.h"
 
@@ -30,7 +35,11 @@ struct GemmPlan {
     hipblasLtMatmulAlgo_t algo;
     size_t workspace = 0;
     bool ok = false;
+    // the heuristic's other candidates until the first un-captured call has timed them
+    std::vector<hipblasLtMatmulHeuristicResult_t> candidates;
 };
+
+constexpr int kTuneCandidates = 24, kTuneRuns = 8;
 
 std::mutex g_mu;
 hipblasLtHandle_t g_handle = nullptr;
@@ -64,16 +73,61 @@ bool build_plan(GemmPlan &p, int64_t rows, int cin, int cout, bool relu, bool re
     // non-null value is enough for the query, the real pointer is set per call
     const void *dummy = (const void *)0x1000;
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
-    hipblasLtMatmulHeuristicResult_t res[1];
+    static const int want = [] {
+        const char *e = getenv("DMM_GEMM_TUNE");
+        const int v = e ? atoi(e) : kTuneCandidates;
+        return v < 1 ? 1 : (v > kTuneCandidates ? kTuneCandidates : v);
+    }();
+    hipblasLtMatmulHeuristicResult_t res[kTuneCandidates];
     int found = 0;
     const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, residual ? p.c : p.d, p.d, pref,
-                                                               1, res, &found);
+                                                               want, res, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return false;
     p.algo = res[0].algo;
     p.workspace = res[0].workspaceSize;
     p.ok = true;
+    for (int i = 0; i < found; ++i)
+        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= ws_limit) p.candidates.push_back(res[i]);
+    if (p.candidates.size() < 2) p.candidates.clear();
     return true;
+}
+
+// Time the heuristic's candidates on the operands of this call and keep the fastest (first un-captured call of a shape).
+// Every candidate writes the same product into y, so the caller's result is unaffected; a candidate the library
+// rejects at launch is skipped.  Caller holds g_mu.
+void tune_plan(GemmPlan &p, const void *x, const void *w, const void *residual, void *y, void *workspace,
+               size_t workspace_bytes, hipStream_t stream) {
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+    cand.swap(p.candidates);                                     // one attempt per plan, whatever happens
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+    const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
+    float best = 0.0f;
+    int best_i = -1;
+    for (size_t i = 0; i < cand.size(); ++i) {
+        bool ok = true;
+        for (int r = 0; r < kTuneRuns + 1 && ok; ++r) {          // run 0 warms the kernel up (code load), then timed
+            if (r == 1 && hipEventRecord(e0, stream) != hipSuccess) ok = false;
+            ok = ok && hipblasLtMatmul(g_handle, p.desc, &alpha, w, p.a, x, p.b, &beta, residual ? residual : y,
+                                       residual ? p.c : p.d, y, p.d, &cand[i].algo, workspace, workspace_bytes,
+                                       stream) == HIPBLAS_STATUS_SUCCESS;
+        }
+        float ms = 0.0f;
+        if (!ok || hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        if (best_i < 0 || ms < best) { best = ms; best_i = (int)i; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best_i >= 0) {
+        p.algo = cand[best_i].algo;
+        p.workspace = cand[best_i].workspaceSize;
+    }
 }
 
 }  // namespace
@@ -110,6 +164,13 @@ extern "C" int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias,
     if (hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) !=
         HIPBLAS_STATUS_SUCCESS)
         return DMM_ERR_LAUNCH;
+    if (!plan->candidates.empty()) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
+            dmm::tune_plan(*plan, x, w, residual, y, workspace, workspace_bytes, (hipStream_t)stream);
+        else
+            (void)hipGetLastError();
+    }
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
     const hipblasStatus_t st =
         hipblasLtMatmul(dmm::g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta, residual ? residual : y,

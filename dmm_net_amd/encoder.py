@@ -23,8 +23,13 @@ from __future__ import annotations
 
 from typing import Dict, Tuple
 
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
+
+_NO_CTX = contextlib.nullcontext()
 
 
 def get_skip_dims(model_name: str):
@@ -287,14 +292,56 @@ class GraphedEncoder:
                 finally:
                     torch.backends.cudnn.benchmark = old
             torch.cuda.current_stream(img.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = self._forward(static_in)
-            entry = self._graphs[key] = (graph, static_in, static_out)
+            if isinstance(self.encoder, FastEncoder) and self.encoder.heads_overlap:
+                entry = self._graphs[key] = self._capture_levels(static_in)
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._forward(static_in)
+                entry = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = entry
         static_in.copy_(img)
-        graph.replay()
+        if isinstance(graph, tuple):
+            main, side = torch.cuda.current_stream(img.device), self.encoder._heads_stream(img.device)
+            for body, heads in zip(*graph):
+                body.replay()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    heads.replay()
+            for tail in graph[0][len(graph[1]):]:
+                tail.replay()
+            main.wait_stream(side)
+        else:
+            graph.replay()
         return static_out
+
+    def _capture_levels(self, static_in):
+        """``FastEncoder`` as 4 body graphs (stem + layer1, layer2, layer3, layer4; replayed on the caller's stream) and 4
+        head graphs (``prop_k`` + ``sk_k`` of one level; replayed on the encoder's side stream as soon as the level is
+        done; ``sk_5`` is a fifth graph on the caller's stream beside ``prop_5``).  At the product's batch sizes every convolution is a 5-30 us launch that fills a fraction of the 256 CUs and
+        the 12 head convolutions were a serial ~0.28 ms tail behind layer4; a single graph does not run its branches side
+        by side, two streams do.  Each chain has its own memory pool (graphs that share a pool must never overlap)."""
+        fast = self.encoder
+        pools = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        body, heads, feats, props, skips = [], [], [], [], []
+        x = static_in
+        for i, k in enumerate(fast.LEVELS):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pools[0]), torch.no_grad():
+                x = fast._level(i, fast._stem(static_in) if i == 0 else x)
+            h = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(h, pool=pools[1]), torch.no_grad():
+                p = fast._prop(k, x, on_side=True)
+                if k != fast.LEVELS[-1]:
+                    sk = fast._skip(k, x, on_side=True)
+            body.append(g), heads.append(h), feats.append(x), props.append(p)
+            if k == fast.LEVELS[-1]:                     # nothing left to hide under: the last pair is split over both
+                g = torch.cuda.CUDAGraph()               # streams (this graph follows the fork on the caller's stream)
+                with torch.cuda.graph(g, pool=pools[0]), torch.no_grad():
+                    sk = fast._skip(k, x)
+                body.append(g)
+            skips.append(sk)
+        return (tuple(body), tuple(heads)), static_in, fast._pack(feats, props, skips)
 
 
 # ---- channels-last inference encoder: 1x1 convolutions as hipBLASLt GEMMs, fused epilogues ----------------------
@@ -342,6 +389,11 @@ class FastEncoder(nn.Module):
     graph.  Reference: vision.py:6-38 (body), base.py:35-54 + model_encoder.py:136-146 (heads)."""
 
     fused_gemm = True          # 1x1 convolutions through dmm_conv1x1_bf16 (False: torch.mm / addmm + the epilogue kernel)
+    # The `sk` / `prop` heads of a level only need that level's body output: they are issued on a SIDE stream as soon as
+    # the level is done and run under the deeper levels of the body (at the product's batch sizes every convolution is a
+    # 5-30 us launch that fills a fraction of the 256 CUs; the 12 head convolutions are ~30 % of the forward's kernel time
+    # and were a serial tail after layer4).  Captured in a HIP graph the fork / join become graph edges.
+    heads_overlap = os.environ.get("DMM_ENCODER_HEADS_OVERLAP", "1") != "0"
 
     def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
         super().__init__()
@@ -351,7 +403,9 @@ class FastEncoder(nn.Module):
         self.dtype = dtype
         self.src = enc                       # folded fp32 parameters stay the source of truth (state_dict)
         self._p = {}                         # id(conv) -> prepared (weight, fp32 bias, bf16 bias)
-        self._ws = None                      # scratch of the library GEMMs
+        self._ws = {}                        # scratch of the library GEMMs, one per stream that runs them
+        self._side = {}                      # device index -> the heads' side stream
+        self._on_side = False                # the call being issued belongs to the heads' stream
         self._prepare()
         # the prepared tensors are derived state: rebuilt whenever the module moves (.to / .cuda) or loads weights
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._prepare())
@@ -372,7 +426,7 @@ class FastEncoder(nn.Module):
                 self._p[id(m)] = (wt, b, b.to(dtype))
             else:
                 self._p[id(m)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, None)
-        self._ws = None
+        self._ws = {}
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -392,8 +446,11 @@ class FastEncoder(nn.Module):
         B, _, H, W = x.shape
         rows = _as_rows(x)
         if self.fused_gemm and rows.is_contiguous():
-            if self._ws is None or self._ws.device != x.device:
-                self._ws = torch.empty((32 << 20,), dtype=torch.uint8, device=x.device)
+            stream = torch.cuda.current_stream(x.device)
+            ws = self._ws.get((x.device.index, self._on_side))
+            if ws is None:                     # the heads' GEMMs run beside the body's: no shared scratch
+                ws = self._ws[(x.device.index, self._on_side)] = torch.empty((32 << 20,), dtype=torch.uint8,
+                                                                             device=x.device)
             res = None
             if residual is not None:
                 res = _as_rows(residual.contiguous(memory_format=torch.channels_last))
@@ -401,8 +458,8 @@ class FastEncoder(nn.Module):
             with _lib.device_guard(x.device):
                 rc = _lib.load().dmm_conv1x1_bf16(rows.data_ptr(), wt.data_ptr(), b32.data_ptr(),
                                                   None if res is None else res.data_ptr(), rows.shape[0], wt.shape[0],
-                                                  wt.shape[1], int(relu), y.data_ptr(), self._ws.data_ptr(),
-                                                  self._ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+                                                  wt.shape[1], int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream.cuda_stream)
             if rc == 0:
                 return _from_rows(y, B, H, W)
             if rc != 2:                                                # anything but "no kernel for this shape"
@@ -440,22 +497,69 @@ class FastEncoder(nn.Module):
         out = self._conv(x, head[0], relu=True)                        # conv -> (folded BN) -> ReLU
         return self._conv(out, head[3], relu=False)                    # conv -> (folded BN)
 
+    def _heads_stream(self, dev):
+        side = self._side.get(dev.index)
+        if side is None:
+            side = self._side[dev.index] = torch.cuda.Stream(device=dev)
+        return side
+
+    # -- the forward in pieces (GraphedEncoder captures them as separate graphs) -----------------------------------
+    LEVELS = (2, 3, 4, 5)
+
+    def _stem(self, img):
+        x = img.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        return self.src.base.maxpool(self._conv(x, self.src.base.conv1, relu=True))
+
+    def _level(self, i, x):
+        for blk in getattr(self.src.base, f"layer{i + 1}"):
+            x = self._block(x, blk)
+        return x
+
+    def _prop(self, k, x, on_side=False):
+        self._on_side = bool(on_side)
+        try:
+            return self._head(x, getattr(self.src, f"prop{k}"))
+        finally:
+            self._on_side = False
+
+    def _skip(self, k, x, on_side=False):
+        self._on_side = bool(on_side)
+        try:
+            return self._conv(x, getattr(self.src, f"sk{k}"), relu=False)
+        finally:
+            self._on_side = False
+
+    @staticmethod
+    def _pack(feats, props, skips):
+        # channels-last as they are: the NHWC form of the fused ROIAlign kernel reads them in place (16-byte lane loads of
+        # contiguous channels; four NCHW copies per forward before)
+        return {"backbone_feature": tuple(props), "refine_input_feat": tuple(reversed(skips)), "body_feature": tuple(feats)}
+
     def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
         assert img.dim() == 4 and img.shape[1] == 3, img.shape
-        enc, body = self.src, self.src.base
         with torch.no_grad():
-            x = img.to(self.dtype).contiguous(memory_format=torch.channels_last)
-            x1 = self._conv(x, body.conv1, relu=True)
-            x = body.maxpool(x1)
-            feats = []
-            for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
-                for blk in layer:
-                    x = self._block(x, blk)
+            # fork / join only outside a capture: one HIP graph replays its branches no faster than in sequence (measured:
+            # config-3 encoder 1.05 ms with the fork captured, 1.02 without); GraphedEncoder overlaps the heads with
+            # separate graphs on two streams instead
+            fork = self.heads_overlap and img.is_cuda and not torch.cuda.is_current_stream_capturing()
+            main = torch.cuda.current_stream(img.device) if fork else None
+            side = self._heads_stream(img.device) if fork else None
+            x = self._stem(img)
+            feats, skips, props = [], [], []
+            for i, k in enumerate(self.LEVELS):
+                x = self._level(i, x)
                 feats.append(x)
-            x2, x3, x4, x5 = feats
-            skips = tuple(self._conv(f, getattr(enc, f"sk{k}"), relu=False) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
-            p5, p4, p3, p2 = (self._head(f, getattr(enc, f"prop{k}")) for f, k in ((x5, 5), (x4, 4), (x3, 3), (x2, 2)))
-            # channels-last as they are: the NHWC form of the fused ROIAlign kernel reads them in place (16-byte lane
-            # loads of contiguous channels; four NCHW copies per forward before)
-            backbone = (p2, p3, p4, p5)
-        return {"backbone_feature": backbone, "refine_input_feat": skips, "body_feature": (x2, x3, x4, x5)}
+                last = k == self.LEVELS[-1]                             # nothing left to hide under: split the pair
+                if fork:
+                    side.wait_stream(main)                              # this level's heads under the deeper levels
+                with (torch.cuda.stream(side) if fork else _NO_CTX):
+                    props.append(self._prop(k, x, on_side=fork))
+                    if not last:
+                        skips.append(self._skip(k, x, on_side=fork))
+                if last:
+                    skips.append(self._skip(k, x))
+            if fork:
+                main.wait_stream(side)
+                for t in props + skips:                                 # side-stream allocations consumed on `main`
+                    t.record_stream(main)
+        return self._pack(feats, props, skips)
