@@ -65,7 +65,42 @@ __global__ __launch_bounds__(256) void bias_act_bf16_scalar_kernel(uint16_t *__r
     x[i] = (uint16_t)bf16_rne(v);
 }
 
+// Patch matrix of a 3x3 / pad 1 convolution on a channels-last activation: cols[(b, ho, wo), (kh, kw, c)] =
+// x[b, s*ho + kh - 1, s*wo + kw - 1, c] (zero outside the image).  One thread = 8 consecutive channels of one tap (16-byte
+// load, 16-byte store); the nine taps of an output pixel are neighbouring threads, so the input stays in L2 (each element
+// is read 9 / s^2 times) and the stores of a row of the matrix are contiguous.
+__global__ __launch_bounds__(256) void im2col3x3_bf16_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ cols,
+                                                             int H, int W, int c8, int Ho, int Wo, int stride, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // over rows * 9 * c8
+    if (i >= n) return;
+    const int c = (int)(i % c8);
+    int64_t t = i / c8;
+    const int tap = (int)(t % 9);
+    t /= 9;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int64_t b = t / Ho;
+    const int hi = ho * stride + tap / 3 - 1, wi = wo * stride + tap % 3 - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = reinterpret_cast<const u32x4 *>(x)[((b * H + hi) * W + wi) * c8 + c];
+    reinterpret_cast<u32x4 *>(cols)[i] = v;
+}
+
 }  // namespace dmm
+
+extern "C" int dmm_im2col3x3_bf16(const void *x, int B, int H, int W, int C, int stride, void *cols, dmm_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2)) return DMM_ERR_BAD_ARG;
+    if (B == 0) return DMM_OK;
+    if (!x || !cols) return DMM_ERR_BAD_ARG;
+    if (C & 7) return DMM_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;     // (H + 2 - 3) / s + 1
+    const int64_t n = (int64_t)B * Ho * Wo * 9 * (C / 8), blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dmm::im2col3x3_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)x, (uint16_t *)cols, H, W, C / 8, Ho, Wo, stride, n);
+    return dmm::check_launch();
+}
 
 extern "C" int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                                  dmm_stream_t stream) {

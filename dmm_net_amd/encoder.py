@@ -425,8 +425,12 @@ class FastEncoder(nn.Module):
                 wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous().to(dtype)          # [Cin, Cout]
                 self._p[id(m)] = (wt, b, b.to(dtype))
             else:
-                self._p[id(m)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, None)
+                col = None
+                if self._patch_ok(m):                                  # [(kh, kw, cin), Cout]: rows of the patch matrix
+                    col = w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous().to(dtype)
+                self._p[id(m)] = (w.to(dtype).contiguous(memory_format=torch.channels_last), b, col)
         self._ws = {}
+        self._patch_choice = {}              # (conv id, input shape) -> True: patch matrix + GEMM, False: MIOpen
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -474,10 +478,85 @@ class FastEncoder(nn.Module):
             y = torch.addmm(bl, rows, wt)
         return _from_rows(y, B, H, W)
 
-    def _convkxk(self, x, conv, relu, residual=None):
+    # Opt-in (DMM_CONV3X3=auto): 3x3 convolutions on SMALL feature maps as patch matrix + library GEMM.  layer3 / layer4
+    # and the heads work on 16x16 ... 8x8 maps: the patch matrix is a few MB (one 3-4 us copy kernel) and the product runs
+    # with bias (+ residual) + ReLU in its epilogue, against MIOpen's convolution + the separate bias / ReLU pass; both
+    # are timed ONCE per (convolution, input shape) on the first call outside a capture and the faster one is kept.
+    # Measured on the config-3 encoder with MIOpen's find-db picks: 0.931 -> 0.922 ms per forward -- MIOpen's CK kernels are
+    # hard to beat with an explicit patch matrix, so the default stays "miopen" (= MIOpen for every k x k convolution).
+    patch_mode = os.environ.get("DMM_CONV3X3", "miopen")
+    PATCH_MAX_BYTES = 16 << 20
+
+    @staticmethod
+    def _patch_ok(conv):
+        return (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.stride in ((1, 1), (2, 2)) and conv.in_channels % 8 == 0)
+
+    def _conv3x3_patches(self, x, conv, relu, residual=None):
+        from . import _lib
+        _, b32, wcol = self._p[id(conv)]
+        B, C, H, W = x.shape
+        s = conv.stride[0]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        x = x.contiguous(memory_format=torch.channels_last)
+        stream = torch.cuda.current_stream(x.device)
+        cols = torch.empty((B * Ho * Wo, 9 * C), dtype=self.dtype, device=x.device)
+        y = torch.empty((B * Ho * Wo, wcol.shape[1]), dtype=self.dtype, device=x.device)
+        ws = self._ws.get((x.device.index, self._on_side))
+        if ws is None:
+            ws = self._ws[(x.device.index, self._on_side)] = torch.empty((32 << 20,), dtype=torch.uint8, device=x.device)
+        res = None if residual is None else _as_rows(residual.contiguous(memory_format=torch.channels_last))
+        with _lib.device_guard(x.device):
+            L = _lib.load()
+            _lib.check(L.dmm_im2col3x3_bf16(x.data_ptr(), B, H, W, C, s, cols.data_ptr(), stream.cuda_stream),
+                       "dmm_im2col3x3_bf16")
+            rc = L.dmm_conv1x1_bf16(cols.data_ptr(), wcol.data_ptr(), b32.data_ptr(), None if res is None else res.data_ptr(),
+                                    cols.shape[0], cols.shape[1], wcol.shape[1], int(relu), y.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), stream.cuda_stream)
+        if rc == 2:
+            return None                                                # no library kernel for this shape
+        _lib.check(rc, "dmm_conv1x1_bf16")
+        return _from_rows(y, B, Ho, Wo)
+
+    def _use_patches(self, x, conv, relu, residual):
+        if self._p[id(conv)][2] is None or self.patch_mode == "miopen" or not x.is_cuda:
+            return False
+        B, C, H, W = x.shape
+        s = conv.stride[0]
+        if B * ((H - 1) // s + 1) * ((W - 1) // s + 1) * 9 * C * 2 > self.PATCH_MAX_BYTES:
+            return False
+        key = (id(conv), tuple(x.shape))
+        pick = self._patch_choice.get(key)
+        if pick is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False                                           # not decided yet and no way to time here
+            def timed(fn):
+                for _ in range(3):
+                    if fn() is None:
+                        return float("inf")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(8):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+            t_gemm = timed(lambda: self._conv3x3_patches(x, conv, relu, residual))
+            t_lib = timed(lambda: self._conv_miopen(x, conv, relu, residual))
+            pick = self._patch_choice[key] = bool(t_gemm < t_lib)
+        return pick
+
+    def _conv_miopen(self, x, conv, relu, residual=None):
         w, b32, _ = self._p[id(conv)]
         y = torch.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return _bias_act_(y, b32, residual, relu)
+
+    def _convkxk(self, x, conv, relu, residual=None):
+        if self._use_patches(x, conv, relu, residual):
+            y = self._conv3x3_patches(x, conv, relu, residual)
+            if y is not None:
+                return y
+        return self._conv_miopen(x, conv, relu, residual)
 
     def _conv(self, x, conv, relu, residual=None):
         if conv.kernel_size == (1, 1) and conv.groups == 1:

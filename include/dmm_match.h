@@ -430,6 +430,14 @@ DMM_API int dmm_ragged_pad(const void *const *src_table, const int32_t *counts, 
 DMM_API int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                               dmm_stream_t stream);
 
+/* (9c) Patch matrix of a 3x3 / padding 1 / stride 1|2 convolution on a channels-last bf16 activation x [B, H, W, C]
+ * (C % 8 == 0): cols [B * Ho * Wo, 9 * C] with cols[(b, ho, wo), (kh, kw, c)] = x[b, s ho + kh - 1, s wo + kw - 1, c], zero
+ * outside the image; Ho = (H - 1) / s + 1.  With it the small-spatial 3x3 convolutions of the encoder (layer3 / layer4 of
+ * the torchvision bodies, dmm/modules/vision.py:6-38, and the 3x3 heads, base.py:35-54) run as dmm_conv1x1_bf16 on the
+ * patch matrix -- one GEMM with bias (+ residual) + ReLU in its epilogue -- where that beats MIOpen's convolution + a
+ * separate bias / ReLU pass (encoder.FastEncoder times both once per shape). */
+DMM_API int dmm_im2col3x3_bf16(const void *x, int B, int H, int W, int C, int stride, void *cols, dmm_stream_t stream);
+
 /* (9b) A 1x1 convolution of the channels-last inference encoder with its whole tail as ONE hipBLASLt GEMM:
  *   y[rows, cout] = relu?( x[rows, cin] . w[cin, cout] + bias[cout] (+ residual[rows, cout]) )
  * x, w, residual, y bfloat16 row-major and dense, bias fp32, fp32 accumulation, one rounding.  Replaces conv1 / conv3 /

@@ -444,3 +444,39 @@ def test_config3_bf16_path_is_bounded_against_fp32():
     record_achieved("config3_bf16/argmax_agree_frac", float(same.float().mean()))
     assert int(decided.sum()) >= B * O // 2
     assert bool(same[decided].all()), (int((~same & decided).sum()), int(decided.sum()))
+
+
+@pytest.mark.parametrize("stride,residual", [(1, False), (2, False), (1, True)])
+def test_conv3x3_as_patch_matrix_gemm_matches_the_library_convolution(stride, residual):
+    """FastEncoder's second form of a 3x3 convolution (dmm_im2col3x3_bf16 + dmm_conv1x1_bf16: patch matrix, ONE GEMM with
+    bias (+ residual) + ReLU in the epilogue) against MIOpen's convolution + the bias / ReLU pass, and the patch matrix
+    itself against torch's unfold, element for element."""
+    import torch.nn as nn
+    from dmm_net_amd import _lib
+    from dmm_net_amd.encoder import FastEncoder, FeatureEncoder
+    torch.manual_seed(5)
+    B, C, H, W, Co = 3, 64, 13, 18, 96
+    x = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    cols = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.load().dmm_im2col3x3_bf16(x.data_ptr(), B, H, W, C, stride, cols.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "im2col")
+    ref = torch.nn.functional.unfold(x.float(), 3, padding=1, stride=stride)            # [B, C * 9, L], (c, kh, kw) order
+    ref = ref.view(B, C, 9, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, 9 * C)
+    assert torch.equal(cols.float(), ref)
+    fast = FastEncoder(FeatureEncoder("resnet34", hidden_size=16).to(DEV).eval())
+    conv = nn.Conv2d(C, Co, 3, stride, 1).to(DEV)
+    fast.src.add_module("extra", conv)
+    fast._prepare()
+    res = torch.randn(B, Co, Ho, Wo, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) \
+        if residual else None
+    a = fast._conv3x3_patches(x, conv, True, res)
+    b = fast._conv_miopen(x, conv, True, res)
+    assert a is not None and a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
+    want = torch.relu(torch.nn.functional.conv2d(x.float(), conv.weight.to(torch.bfloat16).float(), conv.bias, stride, 1)
+                      + (res.float() if residual else 0.0))
+    err_a, err_b = float((a.float() - want).abs().max()), float((b.float() - want).abs().max())
+    scale = float(want.abs().max())
+    assert err_a <= 1e-2 * scale and err_b <= 2e-2 * scale, (err_a, err_b, scale)     # bf16 output rounding: 2^-8 relative
+    from conftest import record_achieved
+    record_achieved(f"conv3x3_patch_gemm_vs_fp32/s{stride}r{int(residual)}", err_a / scale)
