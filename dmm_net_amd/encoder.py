@@ -302,7 +302,8 @@ class GraphedEncoder:
         graph, static_in, static_out = entry
         static_in.copy_(img)
         if isinstance(graph, tuple):
-            main, side = torch.cuda.current_stream(img.device), self.encoder._heads_stream(img.device)
+            main = torch.cuda.current_stream(img.device)
+            side = self.encoder._heads_stream(img.device, main)
             for body, heads in zip(*graph):
                 body.replay()
                 side.wait_stream(main)
@@ -342,6 +343,43 @@ class GraphedEncoder:
                 body.append(g)
             skips.append(sk)
         return (tuple(body), tuple(heads)), static_in, fast._pack(feats, props, skips)
+
+
+def _streams_overlap(main, cand, cycles: int = 400_000) -> bool:
+    """True when a kernel on ``cand`` runs BESIDE a kernel on ``main`` (the two streams sit on different hardware queues):
+    a spin kernel on each, forked and joined by events, against one spin kernel alone."""
+    def timed(both):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        if both:
+            cand.wait_event(e0)
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(cycles)
+        with torch.cuda.stream(main):
+            torch.cuda._sleep(cycles)
+        if both:
+            main.wait_stream(cand)
+        e1.record(main)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    timed(True)
+    alone = min(timed(False), timed(False))
+    return min(timed(True), timed(True)) < 1.5 * alone
+
+
+def pick_parallel_stream(dev, others, priority: int = 0, tries: int = 8):
+    """A stream whose kernels run BESIDE those of every stream in ``others``.  HIP maps streams onto a few hardware
+    queues (4 per priority level by default) as they are created, and two streams that share a queue run one after the
+    other: whether a "side stream" overlaps anything depends on what else the process has created.  torch hands out
+    streams from a pool per priority in turn, so successive candidates sit on successive queues; each is probed
+    (``_streams_overlap``).  A HIGH-priority stream (-1) comes from a queue set of its own and never shares with the
+    default-priority streams of the process."""
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=dev, priority=priority)
+        if all(_streams_overlap(o, cand) for o in others):
+            return cand
+    return cand
 
 
 # ---- channels-last inference encoder: 1x1 convolutions as hipBLASLt GEMMs, fused epilogues ----------------------
@@ -406,6 +444,7 @@ class FastEncoder(nn.Module):
         self._ws = {}                        # scratch of the library GEMMs, one per stream that runs them
         self._side = {}                      # device index -> the heads' side stream
         self._on_side = False                # the call being issued belongs to the heads' stream
+        self.avoid_streams = []              # streams of the caller the heads should not share a hardware queue with
         self._prepare()
         # the prepared tensors are derived state: rebuilt whenever the module moves (.to / .cuda) or loads weights
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._prepare())
@@ -576,10 +615,19 @@ class FastEncoder(nn.Module):
         out = self._conv(x, head[0], relu=True)                        # conv -> (folded BN) -> ReLU
         return self._conv(out, head[3], relu=False)                    # conv -> (folded BN)
 
-    def _heads_stream(self, dev):
-        side = self._side.get(dev.index)
+    def _heads_stream(self, dev, main=None):
+        """The side stream of the heads for work whose body runs on ``main``.  HIP maps streams onto a few hardware queues
+        in creation order and two streams that share a queue run one after the other -- then the fork only costs (measured
+        inside a process that had created other streams before: config-3 encoder 1.13 ms against 0.95).  So a candidate is
+        PROBED once per ``main``: a spin kernel on both streams must take the time of one, not of two."""
+        key = (dev.index, main.cuda_stream if main is not None else 0)
+        side = self._side.get(key)
         if side is None:
-            side = self._side[dev.index] = torch.cuda.Stream(device=dev)
+            if main is None or torch.cuda.is_current_stream_capturing():
+                side = self._side.get((dev.index, 0)) or torch.cuda.Stream(device=dev, priority=-1)
+            else:
+                side = pick_parallel_stream(dev, [main] + [o for o in self.avoid_streams if o.device == main.device], priority=-1)
+            self._side[key] = side
         return side
 
     # -- the forward in pieces (GraphedEncoder captures them as separate graphs) -----------------------------------
@@ -622,7 +670,7 @@ class FastEncoder(nn.Module):
             # separate graphs on two streams instead
             fork = self.heads_overlap and img.is_cuda and not torch.cuda.is_current_stream_capturing()
             main = torch.cuda.current_stream(img.device) if fork else None
-            side = self._heads_stream(img.device) if fork else None
+            side = self._heads_stream(img.device, main) if fork else None
             x = self._stem(img)
             feats, skips, props = [], [], []
             for i, k in enumerate(self.LEVELS):

@@ -372,7 +372,7 @@ class FrameLoop:
                                                                  # label map in one pass, no soft proposal planes (StepPlan)
         self.encode_first = 0                                    # frames in the FIRST encoder batch (0 = encode_ahead): a short
                                                                  # first chunk shortens the pipeline fill before frame 0's step
-        self.encoder_priority = 0                                # HIP stream priority of the encoder's side stream (-1 = high)
+        self.encoder_priority = -1                               # HIP stream priority of the encoder's side stream (-1 = high: its own hardware-queue set)
         self._side = {}
         self._plan = None
 
@@ -385,11 +385,15 @@ class FrameLoop:
             return int(self.encode_ahead)
         return max(4, min(9, -(-int(T) // 3)))
 
-    def _side_stream(self, dev, role="proposals"):
+    def _side_stream(self, dev, role="proposals", beside=()):
         prio = int(self.encoder_priority) if role == "encoder" else 0
         key = (role, dev.index if dev.index is not None else torch.cuda.current_device(), prio)
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev, priority=prio)
+            if beside and not torch.cuda.is_current_stream_capturing():
+                from .encoder import pick_parallel_stream
+                self._side[key] = pick_parallel_stream(dev, list(beside), priority=prio)
+            else:
+                self._side[key] = torch.cuda.Stream(device=dev, priority=prio)
         return self._side[key]
 
 
@@ -412,16 +416,19 @@ class FrameLoop:
     def _run_slots(self, frames, first_masks, proposals, n_frames, targets, on_labels):
         """``run`` on the fixed-slot step: zero host syncs per frame, and with ``graph`` one graph replay per frame.
 
-        The steps run on the loop's OWN stream, created back to back with the encoder's: HIP maps streams onto a handful
-        of hardware queues in creation order, and two streams that share a queue serialise -- with the caller's stream
-        for the steps it depended on what else the process had created whether the encoder really overlapped them
-        (the same loop: 0.61 ms per step alone, 0.74 ms behind other workloads in one process = encoder + steps in series).
+        The steps run on the loop's OWN stream and the encoder's stream is PROBED against it: HIP maps streams onto a
+        handful of hardware queues as they are created, and two streams that share a queue serialise -- it depended on
+        what else the process had created whether the encoder really overlapped the steps (the same loop: 0.61 ms per
+        step alone, 0.74 ms behind other workloads in one process = encoder + steps in series).
         The caller's stream is joined on both sides; ``on_labels`` callbacks run under the step stream."""
         dev = frames.device
         caller = torch.cuda.current_stream(dev)
-        work = self._side_stream(dev, "steps")                   # (created first, then "encoder": consecutive queues)
+        work = self._side_stream(dev, "steps")
         if self.encode_overlap:
-            self._side_stream(dev, "encoder")
+            self._side_stream(dev, "encoder", beside=[work])     # probed: a queue of its own
+            fast = getattr(self.encoder, "encoder", self.encoder)
+            if hasattr(fast, "avoid_streams") and work not in fast.avoid_streams:
+                fast.avoid_streams.append(work)                  # ... and the encoder's own side stream a third one
         work.wait_stream(caller)
         with torch.cuda.stream(work):
             history = self._run_slots_on_stream(frames, first_masks, proposals, n_frames, targets, on_labels)
@@ -492,7 +499,9 @@ class FrameLoop:
                                          (float(cfg.cfgs["score_weight"]), int(cfg.max_iter), int(cfg.proj_iter),
                                           float(cfg.relax_lr), int(bool(cfg.is_test))),
                                          self.nms_thresh, self.mask_thresh, self.padding, tail, self.fuse_epilogue)
-        ready = land(0, out0, fence0)
+        # (the plan's buffers may have just been created -- zero-filled -- on THIS stream: chunk 0 lands behind that, not
+        # behind the fence taken before the plan existed; a high-priority encoder stream overtook the fill otherwise)
+        ready = land(0, out0, main.record_event() if enc_side is not None else None)
         chunk = out0
         # ---- the clip's raw proposals and per-frame tables: one upload, before the loop ----------------------------
         if isinstance(proposals, ClipProposals):

@@ -475,8 +475,8 @@ def test_conv3x3_as_patch_matrix_gemm_matches_the_library_convolution(stride, re
     assert a is not None and a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
     want = torch.relu(torch.nn.functional.conv2d(x.float(), conv.weight.to(torch.bfloat16).float(), conv.bias, stride, 1)
                       + (res.float() if residual else 0.0))
-    err_a, err_b = float((a.float() - want).abs().max()), float((b.float() - want).abs().max())
-    scale = float(want.abs().max())
+    err_a, err_b = float((a.float() - want).abs().max().detach()), float((b.float() - want).abs().max().detach())
+    scale = float(want.abs().max().detach())
     assert err_a <= 1e-2 * scale and err_b <= 2e-2 * scale, (err_a, err_b, scale)     # bf16 output rounding: 2^-8 relative
     from conftest import record_achieved
     record_achieved(f"conv3x3_patch_gemm_vs_fp32/s{stride}r{int(residual)}", err_a / scale)
