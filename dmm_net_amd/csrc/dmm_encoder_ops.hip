@@ -87,7 +87,70 @@ __global__ __launch_bounds__(256) void im2col3x3_bf16_kernel(const uint16_t *__r
     reinterpret_cast<u32x4 *>(cols)[i] = v;
 }
 
+// Stem tail: relu(x + bias) followed by the 3x3 / stride 2 / padding 1 max-pool, in one pass over the convolution's output.
+// x + bias, relu and the bf16 rounding are non-decreasing, so they commute with the maximum: the window maximum of the RAW
+// values is taken first (exact in bf16), then bias, relu and ONE rounding -- bit identical to rounding every element
+// first and pooling after, without writing and re-reading the 4x larger pre-pool activation.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_bf16_kernel(const uint16_t *__restrict__ x,
+                                                                     const float *__restrict__ bias,
+                                                                     uint16_t *__restrict__ y, int H, int W, int c8, int Ho,
+                                                                     int Wo, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // over B * Ho * Wo * c8
+    if (i >= n) return;
+    const int c = (int)(i % c8);
+    int64_t t = i / c8;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int64_t b = t / Ho;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -__builtin_inff();
+#pragma unroll
+    for (int dh = -1; dh <= 1; ++dh) {
+        const int hi = 2 * ho + dh;
+        if (hi < 0 || hi >= H) continue;
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+            const int wi = 2 * wo + dw;
+            if (wi < 0 || wi >= W) continue;
+            const u32x4 v = reinterpret_cast<const u32x4 *>(x)[((b * H + hi) * W + wi) * c8 + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(v[k] << 16), hi_ = __uint_as_float(v[k] & 0xFFFF0000u);
+                m[2 * k] = lo > m[2 * k] ? lo : m[2 * k];
+                m[2 * k + 1] = hi_ > m[2 * k + 1] ? hi_ : m[2 * k + 1];
+            }
+        }
+    }
+    const float4 b0 = *reinterpret_cast<const float4 *>(bias + 8 * c), b1 = *reinterpret_cast<const float4 *>(bias + 8 * c + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float lo = m[2 * k] + bb[2 * k], hi_ = m[2 * k + 1] + bb[2 * k + 1];
+        lo = lo > 0.0f ? lo : 0.0f;
+        hi_ = hi_ > 0.0f ? hi_ : 0.0f;
+        o[k] = bf16_rne(lo) | (bf16_rne(hi_) << 16);
+    }
+    reinterpret_cast<u32x4 *>(y)[i] = o;
+}
+
 }  // namespace dmm
+
+extern "C" int dmm_bias_relu_maxpool_bf16(const void *x, const float *bias, int B, int H, int W, int C, void *y,
+                                          dmm_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (B == 0) return DMM_OK;
+    if (!x || !bias || !y) return DMM_ERR_BAD_ARG;
+    if (C & 7) return DMM_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t n = (int64_t)B * Ho * Wo * (C / 8), blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dmm::bias_relu_maxpool_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)x, bias, (uint16_t *)y, H, W, C / 8, Ho, Wo, n);
+    return dmm::check_launch();
+}
 
 extern "C" int dmm_im2col3x3_bf16(const void *x, int B, int H, int W, int C, int stride, void *cols, dmm_stream_t stream) {
     if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2)) return DMM_ERR_BAD_ARG;

@@ -372,8 +372,9 @@ def pick_parallel_stream(dev, others, priority: int = 0, tries: int = 8):
     queues (4 per priority level by default) as they are created, and two streams that share a queue run one after the
     other: whether a "side stream" overlaps anything depends on what else the process has created.  torch hands out
     streams from a pool per priority in turn, so successive candidates sit on successive queues; each is probed
-    (``_streams_overlap``).  A HIGH-priority stream (-1) comes from a queue set of its own and never shares with the
-    default-priority streams of the process."""
+    (``_streams_overlap``).  (High-priority streams are NOT the way out: with the heads or the loop's encoder on a
+    priority -1 stream a stand-alone process ran the config-3 forward in 4.1 ms instead of 0.95 -- measured on three
+    boxes -- although the same code inside a process with more streams ran at full speed.)"""
     cand = None
     for _ in range(tries):
         cand = torch.cuda.Stream(device=dev, priority=priority)
@@ -624,9 +625,9 @@ class FastEncoder(nn.Module):
         side = self._side.get(key)
         if side is None:
             if main is None or torch.cuda.is_current_stream_capturing():
-                side = self._side.get((dev.index, 0)) or torch.cuda.Stream(device=dev, priority=-1)
+                side = self._side.get((dev.index, 0)) or torch.cuda.Stream(device=dev)
             else:
-                side = pick_parallel_stream(dev, [main] + [o for o in self.avoid_streams if o.device == main.device], priority=-1)
+                side = pick_parallel_stream(dev, [main] + [o for o in self.avoid_streams if o.device == main.device])
             self._side[key] = side
         return side
 
@@ -634,8 +635,29 @@ class FastEncoder(nn.Module):
     LEVELS = (2, 3, 4, 5)
 
     def _stem(self, img):
+        """conv1 -> (folded bn1) -> relu -> maxpool: the bias, the relu and the 3x3 / stride 2 pool are ONE pass over the
+        convolution's output (``dmm_bias_relu_maxpool_bf16``, bit identical to the two separate passes)."""
+        from . import _lib
+        body = self.src.base
         x = img.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        return self.src.base.maxpool(self._conv(x, self.src.base.conv1, relu=True))
+        mp = body.maxpool
+        as_int = lambda v: v if isinstance(v, int) else v[0]
+        fusable = (os.environ.get("DMM_STEM_FUSED", "1") != "0" and x.is_cuda and isinstance(mp, nn.MaxPool2d) and as_int(mp.kernel_size) == 3 and as_int(mp.stride) == 2
+                   and as_int(mp.padding) == 1 and as_int(mp.dilation) == 1 and not mp.ceil_mode
+                   and body.conv1.out_channels % 8 == 0)
+        if not fusable:
+            return mp(self._conv(x, body.conv1, relu=True))
+        w, b32, _ = self._p[id(body.conv1)]
+        c1 = body.conv1
+        y = torch.nn.functional.conv2d(x, w, None, c1.stride, c1.padding, c1.dilation, c1.groups)
+        B, C, H, W = y.shape
+        out = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=self.dtype, device=y.device,
+                          memory_format=torch.channels_last)
+        with _lib.device_guard(y.device):
+            _lib.check(_lib.load().dmm_bias_relu_maxpool_bf16(y.data_ptr(), b32.data_ptr(), B, H, W, C, out.data_ptr(),
+                                                              torch.cuda.current_stream(y.device).cuda_stream),
+                       "dmm_bias_relu_maxpool_bf16")
+        return out
 
     def _level(self, i, x):
         for blk in getattr(self.src.base, f"layer{i + 1}"):

@@ -372,7 +372,7 @@ class FrameLoop:
                                                                  # label map in one pass, no soft proposal planes (StepPlan)
         self.encode_first = 0                                    # frames in the FIRST encoder batch (0 = encode_ahead): a short
                                                                  # first chunk shortens the pipeline fill before frame 0's step
-        self.encoder_priority = -1                               # HIP stream priority of the encoder's side stream (-1 = high: its own hardware-queue set)
+        self.encoder_priority = 0                                # HIP stream priority of the encoder's side stream (-1 = high; measured harmful, see encoder.pick_parallel_stream)
         self._side = {}
         self._plan = None
 

@@ -430,6 +430,13 @@ DMM_API int dmm_ragged_pad(const void *const *src_table, const int32_t *counts, 
 DMM_API int dmm_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
                               dmm_stream_t stream);
 
+/* (9d) Stem tail of the channels-last inference encoder: y = maxpool3x3/s2/p1( relu(x + bias[c]) ) in ONE pass over the stem
+ * convolution's output x [B, H, W, C] bf16 (C % 8 == 0) -> y [B, (H-1)/2+1, (W-1)/2+1, C]; bit identical to
+ * dmm_bias_act_bf16 followed by the pool (bias, relu and rounding are monotone, so the window maximum is taken first).
+ * Replaces bn1 -> relu -> maxpool of the torchvision bodies (dmm/modules/vision.py:11-21 forward) after BatchNorm folding. */
+DMM_API int dmm_bias_relu_maxpool_bf16(const void *x, const float *bias, int B, int H, int W, int C, void *y,
+                                       dmm_stream_t stream);
+
 /* (9c) Patch matrix of a 3x3 / padding 1 / stride 1|2 convolution on a channels-last bf16 activation x [B, H, W, C]
  * (C % 8 == 0): cols [B * Ho * Wo, 9 * C] with cols[(b, ho, wo), (kh, kw, c)] = x[b, s ho + kh - 1, s wo + kw - 1, c], zero
  * outside the image; Ho = (H - 1) / s + 1.  With it the small-spatial 3x3 convolutions of the encoder (layer3 / layer4 of

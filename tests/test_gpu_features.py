@@ -480,3 +480,21 @@ def test_conv3x3_as_patch_matrix_gemm_matches_the_library_convolution(stride, re
     assert err_a <= 1e-2 * scale and err_b <= 2e-2 * scale, (err_a, err_b, scale)     # bf16 output rounding: 2^-8 relative
     from conftest import record_achieved
     record_achieved(f"conv3x3_patch_gemm_vs_fp32/s{stride}r{int(residual)}", err_a / scale)
+
+
+def test_stem_tail_bias_relu_maxpool_is_bit_identical_to_the_two_passes():
+    """dmm_bias_relu_maxpool_bf16 (one pass over the stem convolution's output) == dmm_bias_act_bf16 then torch's
+    3x3 / stride 2 / padding 1 max-pool, bit for bit (monotone operations commute with the maximum) -- odd sizes, negative
+    and huge values included."""
+    from dmm_net_amd import _lib
+    from dmm_net_amd.encoder import _bias_act_
+    torch.manual_seed(9)
+    for (B, C, H, W) in [(2, 64, 13, 17), (1, 8, 1, 1), (3, 16, 128, 96)]:
+        x = (torch.randn(B, C, H, W, device=DEV) * 3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x[0, :, 0, 0] = 1e30
+        bias = torch.randn(C, device=DEV)
+        want = torch.nn.functional.max_pool2d(_bias_act_(x.clone(memory_format=torch.channels_last), bias, None, True), 3, 2, 1)
+        out = torch.empty_like(want, memory_format=torch.channels_last)
+        _lib.check(_lib.load().dmm_bias_relu_maxpool_bf16(x.data_ptr(), bias.data_ptr(), B, H, W, C, out.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "stem tail")
+        assert out.shape == want.shape and torch.equal(out, want)

@@ -53,7 +53,7 @@ first = first.view(B, O, H * W)
 loop = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4, max_proposals=50)
 loop.encode_ahead = int(os.environ.get("AHEAD", "0"))            # 0 = by clip length
 loop.encode_first = int(os.environ.get("FIRST", "0"))
-loop.encoder_priority = int(os.environ.get("ENCPRIO", "-1"))
+loop.encoder_priority = int(os.environ.get("ENCPRIO", "0"))
 T = int(os.environ.get("T", "12"))
 loop.slots = os.environ.get("SLOTS", "1") != "0"             # fixed-slot frame step (two-phase paste, no host sync)
 loop.graph = os.environ.get("GRAPH", "1") != "0"             # ... replayed from one HIP graph per frame
