@@ -375,14 +375,20 @@ class FrameLoop:
         self.encoder_priority = 0                                # HIP stream priority of the encoder's side stream (-1 = high; measured harmful, see encoder.pick_parallel_stream)
         self._side = {}
         self._plan = None
+        self._prefetched = None              # (key, encoder output) of the next clip's first chunk (run(next_frames=...))
 
-    def _frames_per_chunk(self, T: int) -> int:
+    def _frames_per_chunk(self, T: int, pipelined: bool = False) -> int:
         """``encode_ahead``, or by clip length when it is 0.  The ResNet gets more efficient with the batch (4 videos of
         255x448: 0.64 / 0.60 ms per frame step at 4 frames per chunk for clips of 12 / 24 frames, 0.50 at 8 of 24, 0.46 at
         9 of 36) while the first chunk is pipeline fill nothing overlaps -- about a third of the clip per chunk, between
-        4 and 9 frames, was the best or within 2 % of it for clips of 12 to 48 frames."""
+        4 and 9 frames, was the best or within 2 % of it for clips of 12 to 48 frames.  ``pipelined`` (clips back to back,
+        ``run(next_frames=...)``): the first chunk is issued under the previous clip, no fill to pay, so only the encoder's
+        efficiency counts: up to 12 frames per chunk (12-frame clips: 0.50 / 0.48 / 0.42 ms per step at 4 / 6 / 12 frames
+        per chunk; 36-frame clips: 0.39 / 0.38 / 0.39 / 0.43 at 9 / 12 / 18 / 36)."""
         if int(self.encode_ahead) > 0:
             return int(self.encode_ahead)
+        if pipelined:
+            return max(4, min(12, int(T)))
         return max(4, min(9, -(-int(T) // 3)))
 
     def _side_stream(self, dev, role="proposals", beside=()):
@@ -413,7 +419,7 @@ class FrameLoop:
         K = self.max_proposals if self.max_proposals > 0 else R
         return 0 < R <= 1024 and Mm + 2 * self.padding <= 64 and frames.shape[0] * K <= 65535 and O <= 32 and K <= 256
 
-    def _run_slots(self, frames, first_masks, proposals, n_frames, targets, on_labels):
+    def _run_slots(self, frames, first_masks, proposals, n_frames, targets, on_labels, next_frames=None):
         """``run`` on the fixed-slot step: zero host syncs per frame, and with ``graph`` one graph replay per frame.
 
         The steps run on the loop's OWN stream and the encoder's stream is PROBED against it: HIP maps streams onto a
@@ -431,37 +437,47 @@ class FrameLoop:
                 fast.avoid_streams.append(work)                  # ... and the encoder's own side stream a third one
         work.wait_stream(caller)
         with torch.cuda.stream(work):
-            history = self._run_slots_on_stream(frames, first_masks, proposals, n_frames, targets, on_labels)
+            history = self._run_slots_on_stream(frames, first_masks, proposals, n_frames, targets, on_labels, next_frames)
         caller.wait_stream(work)
         for h in history[:1]:
             h.record_stream(caller)                              # (the entries are views of one buffer)
         return history
 
-    def _run_slots_on_stream(self, frames, first_masks, proposals, n_frames, targets, on_labels):
+    def _first_chunk(self, T: int, pipelined: bool = False) -> int:
+        G = max(1, min(self._frames_per_chunk(T, pipelined), T))
+        return max(1, min(int(self.encode_first) or G, G, T))
+
+    def _run_slots_on_stream(self, frames, first_masks, proposals, n_frames, targets, on_labels, next_frames=None):
         B, T, C, H, W = frames.shape
         O = first_masks.shape[1]
         dev = frames.device
         main = torch.cuda.current_stream(dev)
-        G = max(1, min(self._frames_per_chunk(T), T))
         enc_side = self._side_stream(dev, "encoder") if self.encode_overlap else None
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0][:3] != (frames.data_ptr(), tuple(frames.shape), frames._version):
+            pre = None                                           # a prefetch for other frames: ignored
+        pipelined = enc_side is not None and (pre is not None or next_frames is not None)
+        G = max(1, min(self._frames_per_chunk(T, pipelined), T))
         need_features = self.refine is not None                  # the decoder reads refine_input_feat of every frame
         static = getattr(self.encoder, "static_outputs", False)
         plan = None
 
         # chunks of the clip: (first frame, frames); the first one may be shorter (encode_first)
-        g0 = max(1, min(int(self.encode_first) or G, G, T))
+        g0 = self._first_chunk(T, pipelined)
         chunks = [(0, g0)] + [(t0, min(G, T - t0)) for t0 in range(g0, T, G)]
         chunk_of = [k for k, (t0, g) in enumerate(chunks) for _ in range(g)]
 
-        def encode(k):
+        def encode(k, clip=None):
             """chunk k = frames [t0, t0 + g): encoder batch, time-major; its backbone features go to half k % 2 of the
             plan's feature batch ON THE STREAM THAT PRODUCED THEM (a static-output encoder overwrites them on its next
-            call), after the steps that still read that half (chunk k - 2) have been passed on the main stream."""
-            t0, g = chunks[k]
+            call), after the steps that still read that half (chunk k - 2) have been passed on the main stream.
+            ``clip``: the NEXT clip's frames -- its first chunk, prefetched."""
+            t0, g = chunks[k] if clip is None else (0, self._first_chunk(clip.shape[1], True))
+            src = frames if clip is None else clip
             ctx = torch.cuda.stream(enc_side) if enc_side is not None else _NULL
             fence = main.record_event() if enc_side is not None else None
             with ctx:
-                xs = frames[:, t0] if g == 1 else frames[:, t0:t0 + g].transpose(0, 1).reshape(g * B, C, H, W)
+                xs = src[:, t0] if g == 1 else src[:, t0:t0 + g].transpose(0, 1).reshape(g * src.shape[0], C, H, W)
                 out = self.encoder(xs)
                 if need_features and static:
                     out = _map_tensors(out, lambda v: v.clone())
@@ -482,7 +498,10 @@ class FrameLoop:
 
         if enc_side is not None:
             enc_side.wait_stream(main)
-        out0, fence0 = encode(0)
+        if pre is not None and pre[0] == (frames.data_ptr(), tuple(frames.shape), frames._version, g0, enc_side):
+            out0 = pre[1]                                        # issued under the previous clip's last steps
+        else:
+            out0, _ = encode(0)
         # ---- the plan (buffers + captured graph) for this shape --------------------------------------------------------
         if isinstance(proposals, ClipProposals):
             R, Mm = proposals.R, proposals.M
@@ -540,6 +559,12 @@ class FrameLoop:
                 if kc + 1 < len(chunks):
                     o, f = encode(kc + 1)
                     next_chunk = (o, land(kc + 1, o, f))
+                elif (next_frames is not None and enc_side is not None and next_frames.is_cuda
+                      and tuple(next_frames.shape[2:]) == (C, H, W)):
+                    # the encoder's stream has nothing left to do for this clip: the next clip's first chunk
+                    self._prefetched = ((next_frames.data_ptr(), tuple(next_frames.shape), next_frames._version,
+                                         self._first_chunk(next_frames.shape[1], True), enc_side),
+                                        encode(0, clip=next_frames)[0])
             if t == 0:                                                   # forward_timestep_init, :215-225
                 boxes, valid = mask_boxes(y0.view(B * O, H, W), 0.0)
                 tplt_valid = valid.view(B, O).long()
@@ -604,17 +629,23 @@ class FrameLoop:
     @torch.no_grad()
     def run(self, frames: torch.Tensor, first_masks: torch.Tensor, proposals: Sequence[Sequence],
             n_frames: Optional[Sequence[int]] = None, targets: Optional[torch.Tensor] = None,
-            on_labels: Optional[Callable] = None):
+            on_labels: Optional[Callable] = None, next_frames: Optional[torch.Tensor] = None):
         """frames [B,T,3,H,W]; first_masks [B,O,H*W] (frame-0 annotation); proposals[b][t] (the last entry is reused
         for missing frames, evaluator.py:101-106); n_frames[b] = real length of video b (later frames are 'extra',
         :86); targets [B,T,O,HW] optional per-frame annotation (zeros otherwise).  Calls ``on_labels(b, t, uint8 [H,W])``
-        for every real frame and returns the list over t of ``outs`` [B,O,HW]."""
+        for every real frame and returns the list over t of ``outs`` [B,O,HW].
+
+        ``next_frames``: the frames of the clip the NEXT ``run`` call will be given (the evaluator walks a list of clips,
+        evaluator.py:63-70).  Its first encoder chunk is then issued on the encoder's stream under this clip's last
+        steps, when that stream has nothing left to do -- the next clip starts without the pipeline fill (one chunk of the
+        encoder that nothing overlaps: a quarter of a 12-frame clip's time).  Results are unchanged; a later ``run`` on
+        other frames simply ignores the prefetch."""
         B, T, C, H, W = frames.shape
         O = first_masks.shape[1]
         dev = frames.device
         n_frames = list(n_frames) if n_frames is not None else [T] * B
         if self._slots_ok(frames, proposals, O):
-            return self._run_slots(frames, first_masks, proposals, n_frames, targets, on_labels)
+            return self._run_slots(frames, first_masks, proposals, n_frames, targets, on_labels, next_frames)
         history, state, mask_hist = [], None, None
         tplt_dict = tplt_valid = prev_mask = n_tplt = row_scale = None
         # Proposal look-ahead.  A frame's proposals (paste, tight boxes, NMS, top-k) depend on nothing the loop computes,

@@ -294,6 +294,69 @@ def test_frame_loop_fixed_slots_and_graph_equal_boxlist_path_without_host_syncs(
     assert len(old) >= T
 
 
+def test_frame_loop_prefetch_of_the_next_clip_changes_no_result():
+    """``run(next_frames=...)`` issues the next clip's first encoder chunk under this clip's last steps.  A walk over three
+    clips (different lengths, one with a decoder-free static-output encoder = a captured graph) gives the same histories
+    and labels with and without it; a prefetch for frames that are then NOT the next clip is ignored."""
+    from dmm_net_amd.encoder import GraphedEncoder
+    rng = np.random.default_rng(21)
+    B, O, H, W = 2, 4, 96, 128
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    first = torch.zeros(B, O, H, W, device=DEV)
+    for b in range(B):
+        for o in range(2 + b):
+            y0, x0 = int(rng.integers(0, H - 30)), int(rng.integers(0, W - 30))
+            first[b, o, y0:y0 + 25, x0:x0 + 28] = 1.0
+    first = first.view(B, O, H * W)
+    clips = []
+    for T in (5, 9, 3):
+        clips.append((torch.randn(B, T, 3, H, W, device=DEV),
+                      [[_raw_proposals(rng, 20 + t + 3 * b, H, W) for t in range(T)] for b in range(B)]))
+
+    class _StaticPool(_PoolEncoder):                                     # outputs alias fixed buffers, like a replayed graph
+        static_outputs = True
+
+        def __call__(self, x):
+            out = super().__call__(x)
+            key = tuple(x.shape)
+            buf = self.__dict__.setdefault("buf", {})
+            if key not in buf:
+                buf[key] = {k: tuple(torch.empty_like(v) for v in vs) for k, vs in out.items()}
+            for k, vs in out.items():
+                for d, v in zip(buf[key][k], vs):
+                    d.copy_(v)
+            return buf[key]
+
+    for enc_cls in (_PoolEncoder, _StaticPool):
+        def make():
+            return video.FrameLoop(enc_cls(), DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()),
+                                   nms_thresh=0.4, max_proposals=20)
+
+        def walk(lp, prefetch, wrong=False):
+            res = []
+            for i, (fr, pr) in enumerate(clips):
+                nxt = None
+                if prefetch and i + 1 < len(clips):
+                    nxt = clips[i + 1][0] if not wrong else clips[0][0]
+                labs = {}
+                h = lp.run(fr, first, pr, on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()), next_frames=nxt)
+                res.append(([x.clone() for x in h], labs))
+            return res
+        ref = walk(make(), False)
+        for rep in range(3):
+            for wrong in (False, True):
+                got = walk(make(), True, wrong)
+                for (rh, rl), (gh, gl) in zip(ref, got):
+                    assert len(rh) == len(gh) and all(torch.equal(a, c) for a, c in zip(rh, gh)), (enc_cls.__name__, rep, wrong)
+                    assert sorted(rl) == sorted(gl) and all(torch.equal(rl[k], gl[k]) for k in rl)
+    lp = make()
+    lp.run(clips[0][0], first, clips[0][1], next_frames=clips[1][0])
+    assert lp._prefetched is not None                                    # ... and it is really taken by the next run
+    lp.run(clips[1][0], first, clips[1][1])
+    assert lp._prefetched is None
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_frame_step_fuzz_fixed_slots_equal_boxlist_path(seed):
     """Random clips -- image sizes with H*W not a multiple of 4 / 256, 1..8 template slots with random empty objects

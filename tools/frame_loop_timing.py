@@ -65,6 +65,15 @@ loop.run(frames, first, props, on_labels=lambda b, t, lab: labels.append(lab))
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"FrameLoop B={B} videos x {T} frames: {dt / T * 1e3:.2f} ms per frame step = {B * T / dt:.0f} frames/s")
+# clips back to back, the next clip's first encoder chunk issued under this clip's last steps (run(next_frames=...))
+loop.run(frames, first, props, on_labels=lambda b, t, lab: None, next_frames=frames)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    loop.run(frames, first, props, on_labels=lambda b, t, lab: None, next_frames=frames)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print(f"  back to back with the next clip prefetched: {dt / T * 1e3:.2f} ms per frame step = {B * T / dt:.0f} frames/s")
 if os.environ.get("PROFILE"):
     import cProfile
     import pstats
