@@ -583,7 +583,7 @@ def bench_config4(R):
     model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
                        "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
     params = list(enc.get_skip_params()) + list(enc.get_backbone_para())
-    opt = torch.optim.Adam(params, lr=1e-4)
+    opt = torch.optim.Adam(params, lr=1e-4, fused=True)          # one multi-tensor kernel (foreach form: 2.3 ms per step)
     bucketer = GradBucketer(params, bucket_mb=64.0, overlap=True)
     img = torch.randn(B, 3, H, W, device=dev)
 

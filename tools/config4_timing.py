@@ -25,7 +25,7 @@ fe = FeatureExtractor()
 cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
         "score_weight": 0.3}
 model = DMM_Model(cfgs, is_test=0, feature_extractor=fe)
-opt = torch.optim.Adam(list(enc.get_skip_params()) + list(enc.get_backbone_para()), lr=1e-4)
+opt = torch.optim.Adam(list(enc.get_skip_params()) + list(enc.get_backbone_para()), lr=1e-4, fused=True)
 img = torch.randn(B, 3, H, W, device=dev)
 if CL:
     img = img.contiguous(memory_format=torch.channels_last)
