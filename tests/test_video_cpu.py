@@ -122,3 +122,20 @@ def test_clip_proposals_packs_ragged_boxlists_on_the_host():
     assert out is big and torch.equal(big.prob[:T, :, :7], clip.prob) and big.counts[:T].tolist() == clip.counts.tolist()
     obj = [[bl(4, field="objectness")] for _ in range(2)]
     assert ClipProposals.from_boxlists(obj, 1, H, W, "cpu").scores.shape == (1, 2, 4)
+
+
+def test_frame_loop_chunk_sizes_by_clip_length_and_mode():
+    """Host logic of the encoder chunking: a third of the clip within [4, 9] frames when every clip pays its own pipeline
+    fill, up to 12 frames when clips follow each other back to back (``run(next_frames=...)``); ``encode_ahead`` /
+    ``encode_first`` override; chunks never exceed the clip."""
+    from dmm_net_amd import video
+    lp = video.FrameLoop(encoder=lambda x: None, dmm=None)
+    assert [lp._frames_per_chunk(T) for T in (1, 4, 12, 18, 24, 27, 36, 100)] == [4, 4, 4, 6, 8, 9, 9, 9]
+    assert [lp._frames_per_chunk(T, True) for T in (1, 4, 12, 18, 36)] == [4, 4, 12, 12, 12]
+    assert [lp._first_chunk(T) for T in (1, 3, 12, 36)] == [1, 3, 4, 9]
+    assert [lp._first_chunk(T, True) for T in (1, 3, 12, 36)] == [1, 3, 12, 12]
+    lp.encode_ahead = 5
+    assert lp._frames_per_chunk(36) == lp._frames_per_chunk(36, True) == 5 and lp._first_chunk(3, True) == 3
+    lp.encode_first = 2
+    assert lp._first_chunk(36) == lp._first_chunk(36, True) == 2
+    assert lp._prefetched is None
