@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "dmm_common.h"
+#include "dmm_solve.h"
 
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
@@ -18,8 +19,16 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct Workspace {
     int32_t *inter, *area_p, *area_t;
     float *featn_p, *featn_t, *cosv, *sim, *Rb;
+    float *wide;                       // solver state of the general kernel (tables outside the compiled envelope)
     size_t bytes;
 };
+
+// tables the fast solver kernels are not compiled for: the general forms of dmm_wide.hip take them
+static bool wide_shape(int N, int M) {
+    const int Pp = N > M ? N : M + 1;
+    const char *e = getenv("DMM_WIDE");                          // read per call: tests force the general kernels
+    return M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || (e && e[0] == '1');
+}
 
 static Workspace carve(void *base, int B, int N, int M, int D) {
     const int Pp = N > M ? N : M + 1;
@@ -39,6 +48,9 @@ static Workspace carve(void *base, int B, int N, int M, int D) {
     w.cosv = (float *)take(sizeof(float) * (size_t)B * M * N);
     w.sim = (float *)take(sizeof(float) * (size_t)B * M * N);
     w.Rb = (float *)take(sizeof(float) * (size_t)B * M * Pp);
+    w.wide = nullptr;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || getenv("DMM_WIDE"))
+        w.wide = (float *)take(sizeof(float) * (size_t)B * wide_scratch_floats(M, Pp));
     w.bytes = off;
     return w;
 }
@@ -80,13 +92,34 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
         !workspace)
         return DMM_ERR_BAD_ARG;
     const int Pp = N > M ? N : M + 1;
-    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
     // the mix needs the pixel values: 1-bit planes are an input format of dmm_iou_counts only (reject before any launch)
     if (mask_dtype != DMM_F32 && mask_dtype != DMM_F16 && mask_dtype != DMM_BF16) return DMM_ERR_BAD_ARG;
     dmm::Workspace w = dmm::carve(workspace, B, N, M, D);
     if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
     float *sim = sim_out ? sim_out : w.sim;
     float *Rb = Rb_out ? Rb_out : w.Rb;
+    if (dmm::wide_shape(N, M)) {
+        // Outside the envelope of the fast kernels (M <= 32, Pp <= 256): counts (they tile any N x M), the features
+        // normalised, then the general kernels -- same operations, same order, any size (dmm_wide.hip).
+        if (!w.wide || B > 65535) return DMM_ERR_UNSUPPORTED;
+        int rc = dmm_iou_counts(masks_p, masks_t, mask_dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, w.inter,
+                                w.area_p, w.area_t, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_p, (int64_t)B * N, D, w.featn_p, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm_feature_normalize_f32(feat_t, (int64_t)B * M, D, w.featn_t, nullptr, stream);
+        if (rc != DMM_OK) return rc;
+        rc = dmm::launch_cosine_wide(w.featn_t, w.featn_p, B, N, M, D, n_valid, m_valid, w.cosv, (hipStream_t)stream);
+        if (rc != DMM_OK) return rc;
+        if (max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
+        const float w_feat = (float)(1.0 - (double)score_weight);
+        rc = dmm::launch_relax_match_wide(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid, w_feat,
+                                          score_weight, dmm::RelaxParams{max_iter, proj_iter, lr}, is_test, sim, R_out, Rb,
+                                          match_score, det_score, iters_out, nullptr, w.wide, (hipStream_t)stream);
+        if (rc != DMM_OK) return rc;
+        return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                            (int64_t)M * HW, HW, stream);
+    }
     // Feature similarity FIRST when the batch is dense and D is one the lanes kernel takes: that launch also clears the
     // three count tables (contiguous in the workspace), so the counts start without a memset node -- 4.6 us of a
     // one-frame call's 135.  Otherwise counts (with their memset), then the tile kernel or normalise x 2 + cosine.

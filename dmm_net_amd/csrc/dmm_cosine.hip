@@ -8,6 +8,7 @@
 // the table is bit exact against the reference -- it feeds the solver, whose exit tests are sensitive to
 // the last ulp.  Work is tiny (M*N*D = 256 kFLOP per frame at the BASELINE config); the kernels are laid
 // out for exactness first, parallelism across frames second.
+#include "dmm_solve.h"
 #include "dmm_torch_order.h"
 
 namespace dmm {
@@ -470,8 +471,11 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (B < 0 || N < 0 || M < 0 || D < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || N == 0 || M == 0) return DMM_OK;
     if (!featn_t || !featn_p || !cos_out) return DMM_ERR_BAD_ARG;
-    if (N > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
-    if (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) return DMM_ERR_UNSUPPORTED;
+    // outside what the tiled kernels stage in LDS (N <= 256 columns, a whole row when one proposal is live): the general
+    // kernel of dmm_wide.hip -- same sums, one thread per output.  DMM_WIDE=1 (tests) sends every call there.
+    const char *wide_env = getenv("DMM_WIDE");
+    if (N > DMM_MAX_PROPOSALS || (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) || (wide_env && wide_env[0] == '1'))
+        return dmm::launch_cosine_wide(featn_t, featn_p, B, N, M, D, n_valid, m_valid, cos_out, (hipStream_t)stream);
     const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
     const int slots = 256 / tpm;
     static const int rows_min_n = [] { const char *e = getenv("DMM_COS_ROWS_MIN_N"); return e ? atoi(e) : 65; }();
@@ -492,7 +496,8 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
         const size_t l1 = sizeof(float) * (size_t)D * slots;
         lds = l1 > lds ? l1 : lds;
     }
-    if (lds > 160 * 1024) return DMM_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024)
+        return dmm::launch_cosine_wide(featn_t, featn_p, B, N, M, D, n_valid, m_valid, cos_out, (hipStream_t)stream);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)dmm::cosine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);

@@ -368,6 +368,45 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The mix for ANY N, M (tables outside the fast kernel's envelope: it compacts a row's weights into a 256-entry LDS list
+// with one thread per proposal column).  Same arithmetic -- the non-zero weights of the row in ascending column order,
+// acc = fma(w, v, acc) from zero -- with the row walked in place (wave-uniform loads); one thread per pixel.
+// Correctness path, not a streaming kernel.  grid = (pixel blocks, M, B).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void mask_mix_wide_kernel(const float *__restrict__ Rb, const T *__restrict__ masks_p,
+                                                            int N, int M, int Pp, int HW, int64_t sp_b, int64_t sp_n,
+                                                            const int32_t *__restrict__ n_valid,
+                                                            const int32_t *__restrict__ m_valid, TO *__restrict__ out,
+                                                            int64_t so_b, int64_t so_m) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= HW) return;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    float acc = 0.0f;
+    if (m < Mb) {
+        const float *Rrow = Rb + ((int64_t)b * M + m) * Pp;
+        const T *Pb = frame_base(masks_p, b, sp_b);
+        for (int n = 0; n < Nb; ++n) {
+            const float w = Rrow[n];
+            if (w != 0.0f) acc = __builtin_fmaf(w, MaskIO<T>::load1(Pb + (int64_t)n * sp_n + x), acc);
+        }
+    }
+    MixOut<TO>::store1(out + (int64_t)b * so_b + (int64_t)m * so_m + x, acc);
+}
+
+template <typename T, typename TO>
+static int mask_mix_wide_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
+                               int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
+                               int64_t so_m, hipStream_t stream) {
+    hipLaunchKernelGGL((mask_mix_wide_kernel<T, TO>), dim3((HW + 255) / 256, M, B), dim3(256), 0, stream, Rb, masks_p, N, M,
+                       Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m);                 // (M, B <= 65535: caller)
+    return check_launch();
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
@@ -376,10 +415,34 @@ extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, 
     if (B < 0 || N < 0 || M < 0 || HW < 0 || Pp < N) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0 || HW == 0) return DMM_OK;
     if (!Rb || !masks_p || !out) return DMM_ERR_BAD_ARG;
-    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
+    if (M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW || so_m < HW) return DMM_ERR_BAD_ARG;
     if (out_dtype != DMM_F32 && out_dtype != dtype) return DMM_ERR_BAD_ARG;      // fp32, or the planes' own 16-bit type
     hipStream_t s = (hipStream_t)stream;
+    const char *wide_env = getenv("DMM_WIDE");                                    // tests: the general kernel everywhere
+    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || (wide_env && wide_env[0] == '1')) {
+        switch (dtype) {
+            case DMM_F32:
+                return dmm::mask_mix_wide_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
+                                                              n_valid, m_valid, (float *)out, so_b, so_m, s);
+            case DMM_F16:
+                if (out_dtype == DMM_F16)
+                    return dmm::mask_mix_wide_typed<dmm::f16_t, dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp,
+                                                                            HW, sp_b, sp_n, n_valid, m_valid,
+                                                                            (dmm::f16_t *)out, so_b, so_m, s);
+                return dmm::mask_mix_wide_typed<dmm::f16_t, float>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp, HW, sp_b,
+                                                                   sp_n, n_valid, m_valid, (float *)out, so_b, so_m, s);
+            case DMM_BF16:
+                if (out_dtype == DMM_BF16)
+                    return dmm::mask_mix_wide_typed<dmm::bf16_t, dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, B, N, M,
+                                                                              Pp, HW, sp_b, sp_n, n_valid, m_valid,
+                                                                              (dmm::bf16_t *)out, so_b, so_m, s);
+                return dmm::mask_mix_wide_typed<dmm::bf16_t, float>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW,
+                                                                    sp_b, sp_n, n_valid, m_valid, (float *)out, so_b, so_m, s);
+            default:
+                return DMM_ERR_BAD_ARG;
+        }
+    }
     switch (dtype) {
         case DMM_F32:
             return dmm::mask_mix_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n, n_valid,

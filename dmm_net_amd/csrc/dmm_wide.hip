@@ -1,0 +1,314 @@
+// dmm_wide.hip -- the layer's GENERAL forms, for tables outside the envelope the fast kernels are compiled for
+// (M <= 32 template rows, solver width Pp = max(N, M + 1) <= 256): feature similarity and the relaxed-assignment solver with
+// its prologue / epilogue for ANY N and M (the general mask mix sits next to the fast one in dmm_mix.hip).
+//
+// The reference is unbounded (relax_matching, dmm/modules/submodules/relax_match.py:36-105, takes any [n, m] cost matrix;
+// get_cosine_score, dmm/utils/match_helper.py:51-64; match_with_first_frame, dmm/modules/match_model.py:98-148); DMM-Net's
+// own configurations (<= 100 proposals, a handful of objects) never leave the envelope, so these kernels are written for
+// CORRECTNESS, not speed: the solver state lives in a global-memory scratch (L2 resident), one workgroup per frame walks
+// the reference's steps with a barrier between them.  They issue the same fp32 operations in the same order as the fast
+// kernels -- ATen's reduction orders from dmm_torch_order.h, which are written for any length -- so results are bit
+// identical to the reference's CPU path here too (tests/test_gpu_wide.py: against the oracle at wide shapes, and against
+// every layer golden with DMM_WIDE=1 forcing these kernels inside the envelope).
+//
+// Roofline: none of it is bound by HBM or MFMA -- dependent chains through L2; the IoU counts (dmm_cost.hip tiles any
+// N x M) remain the streaming part.
+#include "dmm_solve.h"
+
+namespace dmm {
+
+constexpr int kWideThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// cos[b, m, n] = sum_d RN(tn[m, d] * pn[n, d]) over the [D, Nb] slab of products in ATen's outer-sum order (columns below
+// outer_class_bound(Nb): one cascade chain; the rest: ILP-4 row_sum), or -- one live proposal -- the inner sum over D.
+// grid = (ceil(M * N / 256) | ceil(M * 8 / 256), B).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWideThreads) void cosine_wide_kernel(const float *__restrict__ tn,
+                                                                   const float *__restrict__ pn, int N, int M, int D,
+                                                                   const int32_t *__restrict__ n_valid,
+                                                                   const int32_t *__restrict__ m_valid,
+                                                                   float *__restrict__ cos_out) {
+    const int b = blockIdx.y;
+    const int Nb = n_valid ? n_valid[b] : N, Mb = m_valid ? m_valid[b] : M;
+    float *out = cos_out + (int64_t)b * M * N;
+    const int64_t gid = (int64_t)blockIdx.x * kWideThreads + threadIdx.x;
+    if (Nb == 1) {                                        // [O, D, 1]: the reduced dimension is the fastest one
+        const int m = (int)(gid >> 3), l = threadIdx.x & 7;
+        const bool live = m < Mb;
+        const float *q = tn + ((int64_t)b * M + (live ? m : 0)) * D, *k = pn + (int64_t)b * N * D;
+        const float s = torder::inner_sum_group8(D, l, [&](long d) { return q[d] * k[d]; });
+        if (l == 0 && m < M) out[(int64_t)m * N] = live ? s : 0.0f;
+        if (m < M)
+            for (int n = 1 + l; n < N; n += 8) out[(int64_t)m * N + n] = 0.0f;
+        return;
+    }
+    if (gid >= (int64_t)M * N) return;
+    const int m = (int)(gid / N), n = (int)(gid - (int64_t)m * N);
+    if (m >= Mb || n >= Nb) { out[gid] = 0.0f; return; }
+    const float *q = tn + ((int64_t)b * M + m) * D, *k = pn + ((int64_t)b * N + n) * D;
+    out[gid] = torder::outer_sum_col(D, n < torder::outer_class_bound(Nb), [&](long d) { return q[d] * k[d]; });
+}
+
+int launch_cosine_wide(const float *featn_t, const float *featn_p, int B, int N, int M, int D, const int32_t *n_valid,
+                       const int32_t *m_valid, float *cos_out, hipStream_t stream) {
+    const int64_t per = (int64_t)M * (N > 8 ? N : 8);     // 8 lanes per output when a frame has ONE live proposal
+    const int64_t gx = (per + kWideThreads - 1) / kWideThreads;
+    if (gx > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        hipLaunchKernelGGL(cosine_wide_kernel, dim3((unsigned)gx, nb), dim3(kWideThreads), 0, stream,
+                           featn_t + (int64_t)b0 * M * D, featn_p + (int64_t)b0 * N * D, N, M, D,
+                           n_valid ? n_valid + b0 : nullptr, m_valid ? m_valid + b0 : nullptr,
+                           cos_out + (int64_t)b0 * M * N);
+    }
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Solver + prologue + epilogue, one workgroup per frame, state in `scratch` (wide_scratch_floats(M, Pp) floats per frame).
+// Same contract as relax_match_kernel (dmm_solve.hip): sim, R, Rb, match_score, det_score, iters, X_final.
+// ---------------------------------------------------------------------------------------------
+size_t wide_scratch_floats(int M, int PpS) { return (size_t)9 * M * PpS + (size_t)PpS + 2 * (size_t)M + 64; }
+
+__device__ __forceinline__ float wide_block_max(float v, float *sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int k = 1; k < kWideThreads / 64; ++k) r = sh[k] > r ? sh[k] : r;
+    return r;
+}
+// max over the aligned 8-lane group (every lane gets it)
+__device__ __forceinline__ float group8_max(float v) {
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const float o = __shfl_xor(v, d, 8);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kWideThreads) void relax_match_wide_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou, RelaxParams prm,
+    int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final, float *__restrict__ scratch, int64_t scratch_stride) {
+    __shared__ float sh[8];
+    const int b = blockIdx.x, tid = threadIdx.x, l = tid & 7, grp = tid >> 3;
+    constexpr int NT = kWideThreads, NGRP = kWideThreads / 8;
+    const int Nb = n_valid ? n_valid[b] : N;
+    const int Mb = m_valid ? m_valid[b] : M;
+    const int PpS = N > M ? N : M + 1;                                 // table stride
+    float *Rb_b = Rb_out + (int64_t)b * M * PpS;
+    float *R_b = R_out ? R_out + (int64_t)b * M * PpS : nullptr;
+    float *X_b = X_final ? X_final + (int64_t)b * M * PpS : nullptr;
+    float *sim_b = sim_out + (int64_t)b * M * N;
+    // everything the live block below does not write: zeros (dead frame: all of it, dmm_model.py:118-122)
+    const bool dead = Mb <= 0 || Nb <= 0;
+    const int n = dead ? 0 : Mb;                                      // live rows
+    const int m = dead ? 0 : (Nb > Mb ? Nb : Mb + 1);                 // live solver width (match_model.py:109-113)
+    for (int e = tid; e < M * PpS; e += NT) {
+        const int i = e / PpS, c = e - i * PpS;
+        if (i >= n || c >= m) {
+            Rb_b[e] = 0.0f;
+            if (R_b) R_b[e] = 0.0f;
+            if (X_b) X_b[e] = 0.0f;
+        }
+    }
+    for (int e = tid; e < M * N; e += NT) {
+        const int i = e / N, c = e - i * N;
+        if (i >= n || c >= Nb) sim_b[e] = 0.0f;
+    }
+    for (int i = n + tid; i < M; i += NT) {
+        match_score[(int64_t)b * M + i] = 0.0f;
+        det_score[(int64_t)b * M + i] = 0.0f;
+    }
+    if (dead) {
+        if (iters_out && tid == 0) iters_out[b] = 0;
+        return;
+    }
+    const int cnt = n * m;
+    float *C = scratch + (int64_t)b * scratch_stride;
+    const size_t cap = (size_t)M * PpS;
+    float *X = C + cap, *Y = X + cap, *P0 = Y + cap, *P1 = P0 + cap, *P2 = P1 + cap, *Xs = P2 + cap, *acc = Xs + cap,
+          *tmp = acc + cap, *tc = tmp + cap, *rt = tc + PpS;
+    int *idx = reinterpret_cast<int *>(rt + M);
+
+    // ---- sim = (1-w)*cos + w*iou (match_model.py:90, match_helper.py:24-27); pad; C = -sim ----
+    {
+        const float *cos_b = cos_in + (int64_t)b * M * N;
+        const int32_t *inter_b = inter + (int64_t)b * M * N;
+        for (int e = tid; e < cnt; e += NT) {
+            const int i = e / m, c = e - i * m;
+            float simv = 0.0f;
+            if (c < Nb) {
+                const int in = inter_b[(int64_t)i * N + c];
+                const int un = area_p[(int64_t)b * N + c] + area_t[(int64_t)b * M + i] - in;
+                const float iou = (float)in / ((float)un + 1e-6f);
+                const float a = cos_b[(int64_t)i * N + c] * w_feat, cc = iou * w_iou;
+                simv = a + cc;
+                sim_b[(int64_t)i * N + c] = simv;
+            }
+            C[e] = -simv;                                              // padded columns: -0.0
+        }
+    }
+    __syncthreads();
+
+    // ---- greedy row-min initialisation (relax_match.py:45-55); max / first-argmin are order free ----
+    {
+        float cm = -__builtin_inff();
+        for (int e = tid; e < cnt; e += NT) cm = C[e] > cm ? C[e] : cm;
+        const float cmax = wide_block_max(cm, sh);
+        for (int c = tid; c < m; c += NT) {
+            int best = 0;
+            float bv = C[c];
+            for (int i = 1; i < n; ++i)
+                if (C[i * m + c] < bv) { bv = C[i * m + c]; best = i; }   // first argmin over rows
+            for (int i = 0; i < n; ++i) Y[i * m + c] = i == best ? C[i * m + c] : cmax;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            int best = 0;
+            float bv = Y[i * m];
+            for (int c = 1; c < m; ++c)
+                if (Y[i * m + c] < bv) { bv = Y[i * m + c]; best = c; }   // first argmin over columns
+            idx[i] = best;
+        }
+        __syncthreads();
+        for (int e = tid; e < cnt; e += NT) {
+            const int i = e / m, c = e - i * m;
+            const float x0 = c == idx[i] ? 1.0f : 0.0f;
+            X[e] = x0;
+            acc[e] = 0.0f + x0;                                        // sum(X_list) starts at 0 + X0
+            P0[e] = 0.0f; P1[e] = 0.0f; P2[e] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const float fn = (float)n, fm = (float)m;
+    const int cbound = torder::outer_class_bound(m);
+    int len = 1;
+    float cost_prev = 0.0f;
+    for (int it = 0; it < prm.max_iter; ++it) {
+        // gradient step X = X - lr*C (:69); cost = ||X*C||_F (:70); X_list.append(X) (:71)
+        for (int e = tid; e < cnt; e += NT) {
+            const float g = prm.lr * C[e];
+            const float x = X[e] - g;
+            X[e] = x;
+            tmp[e] = x * C[e];
+            acc[e] = acc[e] + x;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float c = torder::norm2_group8(cnt, tid, [&](long i) { return tmp[i]; });
+            if (tid == 0) sh[4] = c;
+        }
+        __syncthreads();
+        const float cost = sh[4];
+        ++len;
+        for (int j = 0; j < prm.proj_iter; ++j) {
+            // {X >= 0} (:74-76), then X = Y + P1 (:78)
+            for (int e = tid; e < cnt; e += NT) {
+                const float xs = X[e];
+                Xs[e] = xs;
+                const float x = xs + P0[e];
+                const float y = x > 0.0f ? x : 0.0f;
+                P0[e] = x - y;
+                X[e] = y + P1[e];
+            }
+            __syncthreads();
+            // project_col (:21-34): column sums in ATen's outer-sum order
+            for (int c = tid; c < m; c += NT) {
+                const float cs = torder::outer_sum_col(n, c < cbound, [&](long i) { return X[i * m + c]; });
+                tc[c] = cs <= 1.0f ? 0.0f : (cs - 1.0f) / fn;          // (x - 0 = x exactly; a NaN sum gives a NaN step)
+            }
+            __syncthreads();
+            for (int e = tid; e < cnt; e += NT) {
+                const int c = e % m;
+                const float x = X[e];
+                const float y = x - tc[c];
+                P1[e] = x - y;
+                X[e] = y + P2[e];                                      // (:82)
+            }
+            __syncthreads();
+            // project_row (:9-19): row sums in ATen's inner-sum order, one 8-lane group per row
+            for (int i = grp; i < n; i += NGRP) {
+                const float s = torder::inner_sum_group8(m, l, [&](long k) { return X[i * m + k]; });
+                if (l == 0) rt[i] = (s - 1.0f) / fm;
+            }
+            __syncthreads();
+            int moved = 0;
+            for (int e = tid; e < cnt; e += NT) {
+                const int i = e / m;
+                const float x = X[e];
+                const float y = x - rt[i];
+                P2[e] = x - y;
+                X[e] = y;                                              // (:86)
+                const float d = y - Xs[e];
+                const float sq = d * d;
+                moved |= !(sq == 0.0f);                                // ||X - X_start|| == 0 (:88): every square is zero
+            }
+            if (!__syncthreads_or(moved)) break;
+        }
+        if (cost_prev == cost) break;                                  // (:96-98)
+        cost_prev = cost;
+    }
+    const int iters = len - 1;
+    if (iters_out && tid == 0) iters_out[b] = iters;
+
+    // ---- R = sum(X_list)/len; logic; Rb; scores (match_model.py:121-147), one 8-lane group per row ----
+    const float flen = (float)len;
+    for (int i = grp; i < n; i += NGRP) {
+        float mx = -__builtin_inff();
+        for (int c = l; c < m; c += 8) {
+            const float r = acc[i * m + c] / flen;
+            mx = r > mx ? r : mx;
+        }
+        mx = group8_max(mx);
+        auto rb_of = [&](int c) {
+            const float r = acc[i * m + c] / flen;
+            const float lg = is_test ? (r == mx ? 1.0f : 0.0f) : (r > 0.01f ? 1.0f : 0.0f);
+            return r * lg;                                             // (:130)
+        };
+        float ms = -__builtin_inff();
+        for (int c = l; c < m; c += 8) {
+            const float r = acc[i * m + c] / flen;
+            const float rb = rb_of(c);
+            const float rc = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            const float v = rc * (-C[i * m + c]);                      // (:146)
+            ms = v > ms ? v : ms;
+            Rb_b[(int64_t)i * PpS + c] = rb;
+            if (R_b) R_b[(int64_t)i * PpS + c] = r;
+            if (X_b) X_b[(int64_t)i * PpS + c] = X[i * m + c];
+        }
+        ms = group8_max(ms);
+        const float ds = torder::inner_sum_group8(m, l, [&](long k) {     // (score * Rb).sum(1) (:147)
+            const float sc = k < Nb ? score_p[(int64_t)b * N + k] : 0.0f;
+            return sc * rb_of((int)k);
+        });
+        if (l == 0) {
+            match_score[(int64_t)b * M + i] = ms;
+            det_score[(int64_t)b * M + i] = ds;
+        }
+    }
+}
+
+int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
+                            const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
+                            float w_feat, float w_iou, RelaxParams prm, int is_test, float *sim_out, float *R_out,
+                            float *Rb_out, float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                            float *scratch, hipStream_t stream) {
+    const int PpS = N > M ? N : M + 1;
+    const int64_t stride = (int64_t)wide_scratch_floats(M, PpS);
+    hipLaunchKernelGGL(relax_match_wide_kernel, dim3(B), dim3(kWideThreads), 0, stream, cos_in, inter, area_p, area_t,
+                       score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score,
+                       det_score, iters_out, X_final, scratch, stride);
+    return check_launch();
+}
+
+}  // namespace dmm

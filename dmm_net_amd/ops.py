@@ -442,11 +442,13 @@ _CAPTURE_LOCK = threading.Lock()
 
 
 def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test,
-                  n_valid=None, m_valid=None):
+                  n_valid=None, m_valid=None, return_tables=False):
     """The whole forward of B frames as ONE C-ABI call (``dmm_match_forward``: counts -> normalise -> cosine -> solver
     -> mix on the current stream): fresh output tensors, intermediates in a workspace cached per (device, stream).
     The inference path of ``MatchModel`` (no autograd bookkeeping, 1 ctypes call instead of 7, no per-call
-    intermediate allocations).  Returns (full_outmask [B,M,H,W], match_score [B,M], det_score [B,M], iters [B])."""
+    intermediate allocations).  Returns (full_outmask [B,M,H,W], match_score [B,M], det_score [B,M], iters [B]) and, with
+    ``return_tables``, a dict of sim [B,M,N], R and Rb [B,M,Pp].  ANY N and M: tables outside the envelope of the fast
+    kernels (M <= 32, Pp = max(N, M + 1) <= 256) take the general kernels of ``dmm_wide.hip`` inside the same call."""
     _need_gpu(masks_p, masks_t, feat_p, feat_t, score_p)
     assert masks_p.dtype == masks_t.dtype and masks_p.dtype in _DT
     masks_p, sp_b, sp_n = _planes(masks_p)
@@ -466,12 +468,20 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
     full = torch.empty((B, M, H, W), **f32)
     ms, ds = torch.empty((B, M), **f32), torch.empty((B, M), **f32)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    tables = None
+    if return_tables:
+        Pp = padded_width(N, M)
+        tables = {"sim": torch.empty((B, M, N), **f32), "R": torch.empty((B, M, Pp), **f32),
+                  "Rb": torch.empty((B, M, Pp), **f32)}
+    tp = (lambda k: _ptr(tables[k])) if tables else (lambda k: None)
     with _lib.device_guard(dev):
         rc = L.dmm_match_forward(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p), _ptr(feat_t),
                                  _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
                                  float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(full),
-                                 _ptr(ms), _ptr(ds), None, None, None, _ptr(iters), _ptr(ws), ws.numel(), stream)
+                                 _ptr(ms), _ptr(ds), tp("sim"), tp("R"), tp("Rb"), _ptr(iters), _ptr(ws), ws.numel(), stream)
     _lib.check(rc, "dmm_match_forward")
+    if return_tables:
+        return full, ms, ds, iters, tables
     return full, ms, ds, iters
 
 

@@ -54,8 +54,14 @@ typedef void *dmm_stream_t; /* hipStream_t */
 
 #define DMM_API __attribute__((visibility("default")))
 
-/* Limits of the compiled kernels (dmm_relax_* / dmm_mask_mix_*).  dmm_iou_counts_* tiles
- * internally and accepts any N, M. */
+/* Envelope of the FAST kernels: the solver keeps a frame's table in registers (M rows, Pp = max(N, M+1) columns).
+ * DMM-Net's configurations sit well inside it (<= 100 proposals, a handful of objects).  The reference itself is
+ * unbounded (relax_match.py:36-105), and so is the layer here: dmm_match_forward (5), dmm_cosine_f32 (2) and dmm_mask_mix*
+ * (4) take ANY N and M -- beyond the envelope through general kernels (same operations in the same order, bit identical
+ * to the reference's CPU path there too; written for correctness, not speed), dmm_iou_counts_* tiles any N x M.  The
+ * granular solver entries dmm_relax_match_* / dmm_relax_solve_* (no workspace argument to hold the general solver's
+ * state), the backward entries, the 1-bit forms (5b) / (5c) and the frame-step entries keep the envelope and answer
+ * DMM_ERR_UNSUPPORTED outside it. */
 #define DMM_MAX_TEMPLATES 32  /* M  */
 #define DMM_MAX_PROPOSALS 256 /* Pp */
 
@@ -254,7 +260,9 @@ DMM_API int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype, co
 /* ---------------------------------------------------------------------------------------------
  * (5) The whole forward of MatchModel for B frames (match_model.py:24-47, targets=None):
  * (1) -> (2) -> (3) -> (4) on `stream`, intermediates in `workspace`.
- * Outputs as in (3)/(4).  workspace >= dmm_workspace_bytes(B, N, M, D).
+ * Outputs as in (3)/(4).  workspace >= dmm_workspace_bytes(B, N, M, D).  Any N, M: outside the fast kernels' envelope
+ * (M > 32 or max(N, M+1) > 256) the workspace also holds the general solver's state (9 tables of M x Pp floats per
+ * frame; dmm_workspace_bytes accounts for it) and the general kernels run inside this call.
  * ------------------------------------------------------------------------------------------- */
 DMM_API size_t dmm_workspace_bytes(int B, int N, int M, int D);
 

@@ -1060,8 +1060,27 @@ def g18():
     save("g18_scalar_order_tolerance", d)
 
 
+# ------------------------------------------------------------------------------------------ G19
+WIDE_CASES = [(300, 40, 1), (20, 50, 1), (20, 50, 0), (257, 33, 0), (400, 1, 1)]     # (P, O, is_test)
+
+
+def g19():
+    """Tables OUTSIDE the envelope the fast kernels are compiled for (O > 32 template rows or solver width > 256): the
+    reference is unbounded (relax_match.py:36-105 takes any [n, m]), the general kernels (dmm_wide.hip) and the oracle have
+    to follow it there too.  The reference's own MatchModel on 24 x 24 masks, D = 64, 12 outer x 4 inner iterations."""
+    d = {}
+    for k, (P, O, is_test) in enumerate(WIDE_CASES):
+        fr = synth.make_frame(P, O, 24, 24, 64, seed=1900 + k, kind="uniform")
+        r = run_layer(fr, 12, 4, is_test, full=False)
+        keep = {key: r[key] for key in ("inter", "area_p", "area_t", "iou", "cos", "sim", "n_xlist", "R", "argmax", "logic",
+                                        "Rb", "match_score", "det_score", "outmask_sum", "outmask_sample")}
+        keep["checksum"] = np.array(fr.checksum())
+        d.update(flat(f"c{k}", keep))
+    save("g19_wide_tables", d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
-                             "g15", "g16", "g17"]      # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
+                             "g15", "g16", "g17", "g19"]     # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
     for w in which:
         globals()[w]()

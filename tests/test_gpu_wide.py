@@ -1,0 +1,149 @@
+"""GPU parity of the GENERAL kernels (dmm_wide.hip, the general mask mix): tables outside the envelope the fast kernels are
+compiled for -- more than 32 template rows, solver width max(N, M + 1) above 256.  The reference is unbounded
+(relax_match.py:36-105); bars as everywhere: integer and fp32 tables, scores and executed iterations BIT exact against the
+oracle and against the reference's own output (G19), test-mode masks bit exact, train-mode masks within 1e-5.
+With DMM_WIDE=1 the same kernels run INSIDE the envelope, where every shape also has a fast kernel to agree with."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden
+from dmm_net_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+WIDE_CASES = [(300, 40, 1), (20, 50, 1), (20, 50, 0), (257, 33, 0), (400, 1, 1)]     # gen_golden.WIDE_CASES
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def forward(frames, max_iter, proj_iter, is_test, n_valid=None, m_valid=None):
+    """frames: list of synth frames of one shape -> batched ops.match_forward with tables, as numpy."""
+    st = lambda key: dev(np.stack([getattr(f, key) for f in frames]))
+    full, ms, ds, it, tab = ops.match_forward(st("proposed_mask"), st("mask_last_occurence"), st("proposed_feature"),
+                                              st("template_feature"), st("proposal_score"), score_weight=0.3,
+                                              max_iter=max_iter, proj_iter=proj_iter, lr=0.1, is_test=is_test,
+                                              n_valid=n_valid, m_valid=m_valid, return_tables=True)
+    torch.cuda.synchronize()
+    out = dict(full_outmask=full, match_score=ms, det_score=ds, iters=it, **tab)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def check_frame(g, b, o, is_test, N, M):
+    """frame b of the batched result g against the oracle's dict o for its live [M', N'] block."""
+    Mo, No = o["sim"].shape
+    Ppo = o["R"].shape[1]
+    assert int(g["iters"][b]) == o["iters"]
+    assert np.array_equal(g["sim"][b, :Mo, :No], o["sim"]), float(np.abs(g["sim"][b, :Mo, :No] - o["sim"]).max())
+    assert np.array_equal(g["R"][b, :Mo, :Ppo], o["R"]), float(np.abs(g["R"][b, :Mo, :Ppo] - o["R"]).max())
+    assert np.array_equal(g["Rb"][b, :Mo, :Ppo], o["Rb"])
+    assert np.array_equal(g["match_score"][b, :Mo], o["match_score"])
+    assert np.array_equal(g["det_score"][b, :Mo], o["det_score"])
+    full = g["full_outmask"][b, :Mo].reshape(Mo, -1)
+    ref = o["full_outmask"].reshape(Mo, -1)
+    if is_test:
+        assert np.array_equal(full, ref)
+    else:
+        assert float(np.abs(full.astype(np.float64) - ref).max()) <= 1e-5
+    # everything outside the live block is zero
+    for key, lim in (("sim", (Mo, No)), ("R", (Mo, Ppo)), ("Rb", (Mo, Ppo))):
+        t = g[key][b].copy()
+        t[:lim[0], :lim[1]] = 0
+        assert not t.any(), key
+    assert not g["match_score"][b, Mo:].any() and not g["det_score"][b, Mo:].any() and not g["full_outmask"][b, Mo:].any()
+
+
+@pytest.mark.parametrize("P,O", [(300, 40), (257, 33), (64, 64), (400, 1), (20, 50), (130, 129), (513, 70), (1, 40)])
+@pytest.mark.parametrize("is_test", [1, 0])
+def test_wide_tables_bit_exact_vs_oracle(P, O, is_test):
+    fr = synth.make_frame(P, O, 24, 24, 64, seed=9000 + P + 7 * O, kind="uniform")
+    o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                             fr.proposal_score, max_iter=12, proj_iter=4, is_test=is_test)
+    g = forward([fr], 12, 4, is_test)
+    check_frame(g, 0, o, is_test, P, O)
+
+
+@pytest.mark.parametrize("k", range(len(WIDE_CASES)))
+def test_g19_reference_output_at_wide_shapes(k):
+    """First hand: the reference's own MatchModel output (tests/golden/g19_wide_tables.npz)."""
+    gold = golden("g19_wide_tables").group(f"c{k}")
+    P, O, is_test = WIDE_CASES[k]
+    fr = synth.make_frame(P, O, 24, 24, 64, seed=1900 + k, kind="uniform")
+    g = forward([fr], 12, 4, is_test)
+    assert int(g["iters"][0]) + 1 == int(gold["n_xlist"])
+    for key in ("sim", "R", "Rb", "match_score", "det_score"):
+        assert np.array_equal(g[key][0], gold[key]), key
+    assert np.array_equal(g["R"][0].argmax(1), gold["argmax"])
+    s = g["full_outmask"][0].astype(np.float64).reshape(O, -1).sum(1)
+    assert np.allclose(s, gold["outmask_sum"], rtol=1e-6, atol=1e-3)
+
+
+def test_wide_ragged_batch_dead_frames_and_single_proposal():
+    """One launch over frames with different live counts inside a wide table: a full frame, ONE live proposal (the inner-sum
+    form of the similarity), a frame without proposals, one without templates, a narrow live block inside the wide table."""
+    P, O, H, W, D = 300, 40, 16, 16, 64
+    frames = [synth.make_frame(P, O, H, W, D, seed=7700 + b, kind="uniform") for b in range(5)]
+    nv, mv = [300, 1, 0, 257, 9], [40, 35, 40, 0, 3]
+    for is_test in (1, 0):
+        g = forward(frames, 10, 3, is_test, n_valid=torch.tensor(nv, dtype=torch.int32, device=DEV),
+                    m_valid=torch.tensor(mv, dtype=torch.int32, device=DEV))
+        for b, fr in enumerate(frames):
+            if nv[b] == 0 or mv[b] == 0:
+                assert int(g["iters"][b]) == 0
+                for key in ("sim", "R", "Rb", "match_score", "det_score", "full_outmask"):
+                    assert not g[key][b].any(), (b, key)
+                continue
+            o = oracle.match_forward(fr.proposed_mask[:nv[b]], fr.mask_last_occurence[:mv[b]], fr.proposed_feature[:nv[b]],
+                                     fr.template_feature[:mv[b]], fr.proposal_score[:nv[b]], max_iter=10, proj_iter=3,
+                                     is_test=is_test)
+            check_frame(g, b, o, is_test, P, O)
+
+
+def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones(monkeypatch):
+    """DMM_WIDE=1 sends dmm_match_forward through the general kernels at shapes the fast kernels cover: same tables, scores,
+    iteration counts (data-dependent exits included: structured frames converge early) and -- same arithmetic in the mix --
+    the same masks bit for bit in both modes; and both equal the oracle."""
+    cases = [(1, 1, 5, 7, 16, "uniform", 6, 3), (9, 8, 17, 13, 100, "uniform", 6, 3), (33, 5, 20, 20, 64, "uniform", 6, 3),
+             (50, 10, 32, 32, 512, "structured", 80, 5), (7, 32, 8, 8, 8, "uniform", 6, 3), (255, 31, 6, 6, 48, "uniform", 6, 3),
+             (12, 6, 24, 24, 64, "structured", 100, 5), (200, 20, 16, 16, 512, "uniform", 20, 5)]
+    exits = 0
+    for k, (P, O, H, W, D, kind, it, pj) in enumerate(cases):
+        fr = synth.make_frame(P, O, H, W, D, seed=9300 + k, kind=kind)
+        for is_test in (1, 0):
+            monkeypatch.delenv("DMM_WIDE", raising=False)
+            fast = forward([fr], it, pj, is_test)
+            monkeypatch.setenv("DMM_WIDE", "1")
+            wide = forward([fr], it, pj, is_test)
+            for key in fast:
+                assert np.array_equal(fast[key], wide[key]), (P, O, is_test, key)
+            o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                                     fr.proposal_score, max_iter=it, proj_iter=pj, is_test=is_test)
+            check_frame(wide, 0, o, is_test, P, O)
+            exits += int(wide["iters"][0]) < it
+    assert exits >= 2, "no case exercised the data-dependent exits"
+    # 16-bit planes through the general mix: same result as the fast mix
+    fr = synth.make_frame(40, 6, 20, 20, 64, seed=9400, kind="uniform")
+    for dt in (torch.float16, torch.bfloat16):
+        res = []
+        for wide in (False, True):
+            monkeypatch.setenv("DMM_WIDE", "1") if wide else monkeypatch.delenv("DMM_WIDE", raising=False)
+            out = ops.match_forward(dev(fr.proposed_mask)[None].to(dt), dev(fr.mask_last_occurence)[None].to(dt),
+                                    dev(fr.proposed_feature)[None], dev(fr.template_feature)[None],
+                                    dev(fr.proposal_score)[None], score_weight=0.3, max_iter=8, proj_iter=3, lr=0.1, is_test=0)
+            res.append([t.clone() for t in out])
+        assert all(torch.equal(a, c) for a, c in zip(*res)), dt
+
+
+def test_granular_solver_entry_still_refuses_wide_tables():
+    """Only the fused forward carries the scratch the general solver needs (its workspace): dmm_relax_match_f32 on its own
+    keeps the envelope and says so."""
+    from dmm_net_amd import _lib
+    z = torch.zeros((1, 40, 300), device=DEV)
+    zi = torch.zeros((1, 40, 300), dtype=torch.int32, device=DEV)
+    with pytest.raises(_lib.DmmError, match="envelope"):
+        ops.relax_match(z, zi, torch.zeros((1, 300), dtype=torch.int32, device=DEV),
+                        torch.zeros((1, 40), dtype=torch.int32, device=DEV), torch.zeros((1, 300), device=DEV),
+                        score_weight=0.3, max_iter=2, proj_iter=2, lr=0.1, is_test=1)

@@ -298,3 +298,19 @@ def test_g18_tolerance_contract_against_the_scalar_order_reference():
         close(o["match_score"], c["match_score"], 1e-5)
         close(o["det_score"], c["det_score"], 1e-5)
     assert worst > 0.0 or int(g["n"]) == 0      # the two orders DO differ somewhere: this is not the bit-exact test again
+
+
+# ------------------------------------------------------------------------------------------ G19
+WIDE_CASES = [(300, 40, 1), (20, 50, 1), (20, 50, 0), (257, 33, 0), (400, 1, 1)]     # gen_golden.WIDE_CASES
+
+
+@pytest.mark.parametrize("k", range(len(WIDE_CASES)))
+def test_g19_tables_outside_the_fast_kernels_envelope(k):
+    """The reference's own MatchModel beyond 32 template rows / 256 solver columns (it is unbounded): the oracle's sums are
+    written for any length and stay bit exact there -- which makes it the checker of the general HIP kernels."""
+    g = golden("g19_wide_tables")
+    P, O, is_test = WIDE_CASES[k]
+    fr = synth.make_frame(P, O, 24, 24, 64, seed=1900 + k, kind="uniform")
+    assert fr.checksum() == str(g[f"c{k}/checksum"])
+    o = check_layer(fr, g.group(f"c{k}"), 12, 4, is_test, big=True)
+    assert o["R"].shape == (O, max(P, O + 1))
