@@ -147,3 +147,21 @@ def test_granular_solver_entry_still_refuses_wide_tables():
         ops.relax_match(z, zi, torch.zeros((1, 300), dtype=torch.int32, device=DEV),
                         torch.zeros((1, 40), dtype=torch.int32, device=DEV), torch.zeros((1, 300), device=DEV),
                         score_weight=0.3, max_iter=2, proj_iter=2, lr=0.1, is_test=1)
+
+
+def test_matchmodel_dropin_takes_wide_tables_at_inference():
+    """The reference's call -- MatchModel(cfgs, is_test=1)(features, masks, [template features], template masks, scores) --
+    with 300 proposals x 40 templates: the fused forward's general kernels behind the same nn.Module signature."""
+    from dmm_net_amd.match_model import MatchModel
+    P, O = 300, 40
+    fr = synth.make_frame(P, O, 24, 24, 64, seed=9500, kind="uniform")
+    model = MatchModel({"matching": {"algo": "relax"}, "relax_max_iter": 12, "relax_proj_iter": 4,
+                        "relax_learning_rate": 0.1, "score_weight": 0.3}, 1)
+    with torch.no_grad():
+        fo, ms, ds, fo2, loss = model(dev(fr.proposed_feature), dev(fr.proposed_mask), [dev(fr.template_feature)],
+                                      dev(fr.mask_last_occurence), dev(fr.proposal_score))
+    o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                             fr.proposal_score, max_iter=12, proj_iter=4, is_test=1)
+    assert fo2 is fo and loss == {}
+    assert np.array_equal(fo.cpu().numpy(), o["full_outmask"].reshape(O, 24, 24))
+    assert np.array_equal(ms.cpu().numpy(), o["match_score"]) and np.array_equal(ds.cpu().numpy(), o["det_score"])
