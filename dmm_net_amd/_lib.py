@@ -29,7 +29,7 @@ SYMBOLS = (
     "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad",
     "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
     "dmm_paste_kept_f32", "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32", "dmm_roialign4_mean_nhwc_fwd",
-    "dmm_conv1x1_bf16", "dmm_im2col3x3_bf16", "dmm_bias_relu_maxpool_bf16", "dmm_relax_match_f16s", "dmm_match_solve_packed", "dmm_step_finish_f32",
+    "dmm_conv1x1_bf16", "dmm_im2col3x3_bf16", "dmm_bias_relu_maxpool_bf16", "dmm_relax_any_scratch_bytes", "dmm_relax_match_any_f32", "dmm_relax_match_f16s", "dmm_match_solve_packed", "dmm_step_finish_f32",
 )
 
 _lib = None
@@ -89,6 +89,10 @@ def load():
     L.dmm_relax_match_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_float, c_int, c_int, c_float,
                                       c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dmm_relax_match_f16s.argtypes = L.dmm_relax_match_f32.argtypes
+    L.dmm_relax_match_any_f32.argtypes = L.dmm_relax_match_f32.argtypes[:-1] + [vp, sz, vp]
+    L.dmm_relax_match_any_f32.restype = c_int
+    L.dmm_relax_any_scratch_bytes.argtypes = [c_int, c_int, c_int]
+    L.dmm_relax_any_scratch_bytes.restype = sz
     L.dmm_relax_match_f16s.restype = c_int
     L.dmm_relax_solve_f32.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, vp]
     L.dmm_relax_bwd_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]

@@ -373,6 +373,38 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
     return dmm::check_launch();
 }
 
+// (3) for ANY N, M: the general solver (dmm_wide.hip) keeps its state in caller-provided scratch.  Inside the fast kernels'
+// envelope this IS dmm_relax_match_f32 (the scratch is not touched); DMM_WIDE=1 (tests) forces the general kernel.
+extern "C" size_t dmm_relax_any_scratch_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return sizeof(float) * (size_t)B * dmm::wide_scratch_floats(M, N > M ? N : M + 1);
+}
+
+extern "C" int dmm_relax_match_any_f32(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                       const int32_t *area_t, const float *score_p, int B, int N, int M,
+                                       const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                       int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
+                                       float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                       void *scratch, size_t scratch_bytes, dmm_stream_t stream) {
+    if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
+    if (B == 0 || M == 0) return DMM_OK;
+    if (N == 0) return DMM_ERR_BAD_ARG;
+    const int Pp = N > M ? N : M + 1;
+    const char *e = getenv("DMM_WIDE");
+    if (M <= DMM_MAX_TEMPLATES && Pp <= DMM_MAX_PROPOSALS && !(e && e[0] == '1'))
+        return dmm_relax_match_f32(cos_in, inter, area_p, area_t, score_p, B, N, M, n_valid, m_valid, score_weight, max_iter,
+                                   proj_iter, lr, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
+                                   X_final, stream);
+    if (!cos_in || !inter || !area_p || !area_t || !score_p || !sim_out || !Rb_out || !match_score || !det_score || !scratch)
+        return DMM_ERR_BAD_ARG;
+    if (scratch_bytes < dmm_relax_any_scratch_bytes(B, N, M)) return DMM_ERR_WORKSPACE;
+    const float w_feat = (float)(1.0 - (double)score_weight);
+    return dmm::launch_relax_match_wide(cos_in, inter, area_p, area_t, score_p, B, N, M, n_valid, m_valid, w_feat,
+                                        score_weight, dmm::RelaxParams{max_iter, proj_iter, lr}, is_test, sim_out, R_out,
+                                        Rb_out, match_score, det_score, iters_out, X_final, (float *)scratch,
+                                        (hipStream_t)stream);
+}
+
 extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const int32_t *rows_valid,
                                    const int32_t *cols_valid, int max_iter, int proj_iter, float lr,
                                    float *X_final, float *R_out, float *cost_out, int32_t *iters_out,

@@ -282,7 +282,8 @@ def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, 
     """Similarity mix + relaxed assignment + scores for B frames.  cos [B,M,N] = feature_sim.
     Returns dict(sim, R, Rb, match_score, det_score, iters, X).  ``state="f16"``: the opt-in tolerance mode with the
     solver state in packed fp16 and fp32 sums (``dmm_relax_match_f16s``, BASELINE configs[4]); the default reproduces
-    the reference bit for bit."""
+    the reference bit for bit.  Tables outside the fast kernels' envelope (M > 32 or Pp > 256) go through
+    ``dmm_relax_match_any_f32`` (general solver, state in a scratch tensor allocated here) -- fp32 state only."""
     _need_gpu(cos, inter)
     B, M, N = cos.shape
     Pp = padded_width(N, M)
@@ -296,11 +297,17 @@ def relax_match(cos, inter, area_p, area_t, score_p, *, score_weight, max_iter, 
     assert state in ("f32", "f16")
     L = _lib.load()
     fn = L.dmm_relax_match_f32 if state == "f32" else L.dmm_relax_match_f16s
+    args = (_ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
+            float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
+            _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]), _ptr(out["det_score"]), _ptr(out["iters"]),
+            _ptr(out["X"]))
     with _lib.device_guard(dev):
-        rc = fn(_ptr(cos), _ptr(inter), _ptr(area_p), _ptr(area_t), _ptr(score_p), B, N, M, _ptr(n_valid), _ptr(m_valid),
-                float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(out["sim"]),
-                _ptr(out["R"]), _ptr(out["Rb"]), _ptr(out["match_score"]), _ptr(out["det_score"]), _ptr(out["iters"]),
-                _ptr(out["X"]), _stream(cos))
+        if state == "f32" and (M > _lib.MAX_TEMPLATES or Pp > _lib.MAX_PROPOSALS):
+            scratch = torch.empty((int(L.dmm_relax_any_scratch_bytes(B, N, M)),), dtype=torch.uint8, device=dev)
+            rc = L.dmm_relax_match_any_f32(*args, _ptr(scratch), scratch.numel(), _stream(cos))
+            scratch.record_stream(torch.cuda.current_stream(dev))
+        else:
+            rc = fn(*args, _stream(cos))
     _lib.check(rc, "dmm_relax_match_" + ("f32" if state == "f32" else "f16s"))
     return out
 

@@ -59,8 +59,8 @@ typedef void *dmm_stream_t; /* hipStream_t */
  * unbounded (relax_match.py:36-105), and so is the layer here: dmm_match_forward (5), dmm_cosine_f32 (2) and dmm_mask_mix*
  * (4) take ANY N and M -- beyond the envelope through general kernels (same operations in the same order, bit identical
  * to the reference's CPU path there too; written for correctness, not speed), dmm_iou_counts_* tiles any N x M.  The
- * granular solver entries dmm_relax_match_* / dmm_relax_solve_* (no workspace argument to hold the general solver's
- * state), the backward entries, the 1-bit forms (5b) / (5c) and the frame-step entries keep the envelope and answer
+ * granular solver entries dmm_relax_match_f32 / _f16s / dmm_relax_solve_* (no argument to hold the general solver's state:
+ * use dmm_relax_match_any_f32 (3d)), the backward entries, the 1-bit forms (5b) / (5c) and the frame-step entries keep the envelope and answer
  * DMM_ERR_UNSUPPORTED outside it. */
 #define DMM_MAX_TEMPLATES 32  /* M  */
 #define DMM_MAX_PROPOSALS 256 /* Pp */
@@ -184,6 +184,18 @@ DMM_API int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const
                                 float *sim_out, float *R_out, float *Rb_out,
                                 float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                                 dmm_stream_t stream);
+
+/* (3d) The same for ANY N and M (the reference's relax_matching is unbounded, relax_match.py:36-105): outside the fast
+ * kernels' envelope the general solver keeps its state -- 9 tables of M x Pp floats per frame -- in `scratch`
+ * (>= dmm_relax_any_scratch_bytes(B, N, M)); inside the envelope this is (3) and the scratch is not touched.  Same
+ * outputs, bit identical to the reference's CPU path at every size. */
+DMM_API size_t dmm_relax_any_scratch_bytes(int B, int N, int M);
+DMM_API int dmm_relax_match_any_f32(const float *cos_in, const int32_t *inter, const int32_t *area_p,
+                                    const int32_t *area_t, const float *score_p, int B, int N, int M,
+                                    const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
+                                    int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
+                                    float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                                    void *scratch, size_t scratch_bytes, dmm_stream_t stream);
 
 /* (3c) The same with the solver STATE in packed fp16 and every sum in fp32 -- BASELINE configs[4]'s "fp16 Sinkhorn with
  * fp32 accumulate".  A TOLERANCE mode, opt-in: the default (dmm_relax_match_f32) reproduces the reference bit for bit

@@ -750,7 +750,8 @@ def test_layer_many_shapes_bit_exact_vs_oracle(solver_kernel):
 
 
 def test_envelope_errors_are_loud():
-    """Shapes outside the compiled solver envelope raise (status 2), never fall back: M <= 32, Pp <= 256."""
+    """Entries without a general form answer status 2 outside the fast kernels' envelope (M <= 32, Pp <= 256) -- they never
+    fall back to anything (the fused forward and ops.relax_match's fp32 path DO take any size: tests/test_gpu_wide.py)."""
     from dmm_net_amd import _lib
     rng = np.random.Generator(np.random.PCG64(3))
     pm = torch.from_numpy(rng.random((1, 300, 8, 8), dtype=np.float32)).to(DEV)
@@ -759,9 +760,15 @@ def test_envelope_errors_are_loud():
     ri, rp, rt = oracle.iou_counts(pm[0].cpu().numpy(), tm[0].cpu().numpy())
     assert np.array_equal(inter[0].cpu().numpy(), ri) and np.array_equal(ap[0].cpu().numpy(), rp)
     cos = torch.zeros((1, 4, 300), device=DEV)
-    with pytest.raises(_lib.DmmError, match="envelope"):
+    with pytest.raises(_lib.DmmError, match="envelope"):           # the fp16-state tolerance mode has no general form
         ops.relax_match(cos, inter, ap, at, torch.zeros((1, 300), device=DEV), score_weight=0.3, max_iter=2, proj_iter=2,
-                        lr=0.1, is_test=1)
+                        lr=0.1, is_test=1, state="f16")
+    L = _lib.load()                                                # ... nor does the plain granular entry (no scratch argument)
+    outs = [torch.zeros(4 * 300, device=DEV) for _ in range(5)]
+    rc = L.dmm_relax_match_f32(cos.data_ptr(), inter.data_ptr(), ap.data_ptr(), at.data_ptr(), outs[0].data_ptr(), 1, 300, 4,
+                               None, None, 0.3, 2, 2, 0.1, 1, outs[1].data_ptr(), None, outs[2].data_ptr(),
+                               outs[3].data_ptr(), outs[4].data_ptr(), None, None, None)
+    assert rc == 2 and "envelope" in L.dmm_status_string(rc).decode()
     with pytest.raises(_lib.DmmError):
         ops.relax_solve(torch.zeros((1, 33, 40), device=DEV), 1, 1, 0.1)
     with pytest.raises(_lib.DmmError, match="MI355X"):

@@ -137,16 +137,49 @@ def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones(monkeypatc
         assert all(torch.equal(a, c) for a, c in zip(*res)), dt
 
 
-def test_granular_solver_entry_still_refuses_wide_tables():
-    """Only the fused forward carries the scratch the general solver needs (its workspace): dmm_relax_match_f32 on its own
-    keeps the envelope and says so."""
-    from dmm_net_amd import _lib
-    z = torch.zeros((1, 40, 300), device=DEV)
-    zi = torch.zeros((1, 40, 300), dtype=torch.int32, device=DEV)
-    with pytest.raises(_lib.DmmError, match="envelope"):
-        ops.relax_match(z, zi, torch.zeros((1, 300), dtype=torch.int32, device=DEV),
-                        torch.zeros((1, 40), dtype=torch.int32, device=DEV), torch.zeros((1, 300), device=DEV),
-                        score_weight=0.3, max_iter=2, proj_iter=2, lr=0.1, is_test=1)
+def test_granular_calls_compose_to_the_same_result_at_wide_tables():
+    """counts -> normalise -> cosine -> relax_match (dmm_relax_match_any_f32, scratch allocated by the wrapper) -> mix, the
+    way the per-video driver chains them: the same tables as the fused forward and the oracle."""
+    for (P, O) in [(300, 40), (20, 50), (1, 40)]:
+        fr = synth.make_frame(P, O, 24, 24, 64, seed=9600 + P, kind="uniform")
+        for is_test in (1, 0):
+            pm, tm = dev(fr.proposed_mask)[None], dev(fr.mask_last_occurence)[None]
+            inter, ap, at = ops.iou_counts(pm, tm)
+            cos = ops.cosine(ops.feature_normalize(dev(fr.template_feature)[None]),
+                             ops.feature_normalize(dev(fr.proposed_feature)[None]))
+            r = ops.relax_match(cos, inter, ap, at, dev(fr.proposal_score)[None], score_weight=0.3, max_iter=12, proj_iter=4,
+                                lr=0.1, is_test=is_test, want_x=True)
+            full = ops.mask_mix(r["Rb"], pm)
+            g = forward([fr], 12, 4, is_test)
+            for key in ("sim", "R", "Rb", "match_score", "det_score", "iters"):
+                assert np.array_equal(r[key].cpu().numpy(), g[key]), (P, O, key)
+            assert np.array_equal(full.cpu().numpy(), g["full_outmask"])
+            o = oracle.relax(-np.pad(g["sim"][0], ((0, 0), (0, max(P, O + 1) - P))), 12, 4, 0.1)
+            assert np.array_equal(r["X"][0].cpu().numpy(), o["X"]) and int(r["iters"][0]) == o["iters"]
+
+
+def test_dmm_model_inference_with_wide_tables():
+    """The per-video driver (dmm_model.py:48-158 counterpart) on 2 videos with 300 / 270 proposals and 40 template slots:
+    every video against the oracle's single-frame forward."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    from test_gpu_parity import _Props
+    O, H, W, D = 40, 20, 20, 64
+    counts = [300, 270]
+    frames = [synth.make_frame(P, O, H, W, D, seed=9700 + b, kind="uniform") for b, P in enumerate(counts)]
+    feats = torch.cat([dev(fr.proposed_feature) for fr in frames], 0)
+    model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 8, "relax_proj_iter": 3, "relax_learning_rate": 0.1,
+                       "score_weight": 0.3}, is_test=1, feature_extractor=lambda bf, props: feats)
+    props = [_Props(dev(fr.proposed_mask).unsqueeze(1), dev(fr.proposal_score)) for fr in frames]
+    tplt = {b: {"feat": [dev(fr.template_feature)]} for b, fr in enumerate(frames)}
+    valid = torch.ones((2, O), device=DEV)
+    ml = dev(np.stack([fr.mask_last_occurence for fr in frames]))
+    with torch.no_grad():
+        out, _, losses, last = model.inference({"args": None, "shape": None, "extra_frame": [0, 0], "valid": valid}, props,
+                                               None, ml, tplt)
+    for b, fr in enumerate(frames):
+        o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                                 fr.proposal_score, max_iter=8, proj_iter=3, is_test=1)
+        assert np.array_equal(out[b].cpu().numpy().reshape(O, -1), o["full_outmask"].reshape(O, -1)), b
 
 
 def test_matchmodel_dropin_takes_wide_tables_at_inference():
