@@ -17,7 +17,8 @@
 
 namespace dmm {
 
-constexpr int kWideThreads = 256;
+constexpr int kWideThreads = 256;          // similarity kernel
+constexpr int kWideSolverThreads = 1024;   // solver: one workgroup per frame, 16 waves share its element-wise passes
 
 // ---------------------------------------------------------------------------------------------
 // cos[b, m, n] = sum_d RN(tn[m, d] * pn[n, d]) over the [D, Nb] slab of products in ATen's outer-sum order (columns below
@@ -78,7 +79,7 @@ __device__ __forceinline__ float wide_block_max(float v, float *sh) {
     __syncthreads();
     float r = sh[0];
 #pragma unroll
-    for (int k = 1; k < kWideThreads / 64; ++k) r = sh[k] > r ? sh[k] : r;
+    for (int k = 1; k < kWideSolverThreads / 64; ++k) r = sh[k] > r ? sh[k] : r;
     return r;
 }
 // max over the aligned 8-lane group (every lane gets it)
@@ -91,16 +92,17 @@ __device__ __forceinline__ float group8_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(kWideThreads) void relax_match_wide_kernel(
+__global__ __launch_bounds__(kWideSolverThreads) void relax_match_wide_kernel(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou, RelaxParams prm,
     int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final, float *__restrict__ scratch, int64_t scratch_stride) {
-    __shared__ float sh[8];
+    float *__restrict__ X_final, float *__restrict__ scratch, int64_t scratch_stride, int x_in_lds) {
+    __shared__ float sh[kWideSolverThreads / 64 + 1];
+    extern __shared__ __attribute__((aligned(16))) float x_lds[];     // the iterate X when the table fits (the sums read it)
     const int b = blockIdx.x, tid = threadIdx.x, l = tid & 7, grp = tid >> 3;
-    constexpr int NT = kWideThreads, NGRP = kWideThreads / 8;
+    constexpr int NT = kWideSolverThreads, NGRP = kWideSolverThreads / 8;
     const int Nb = n_valid ? n_valid[b] : N;
     const int Mb = m_valid ? m_valid[b] : M;
     const int PpS = N > M ? N : M + 1;                                 // table stride
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kWideThreads) void relax_match_wide_kernel(
     const int cnt = n * m;
     float *C = scratch + (int64_t)b * scratch_stride;
     const size_t cap = (size_t)M * PpS;
-    float *X = C + cap, *Y = X + cap, *P0 = Y + cap, *P1 = P0 + cap, *P2 = P1 + cap, *Xs = P2 + cap, *acc = Xs + cap,
+    float *X = x_in_lds ? x_lds : C + cap, *Y = C + 2 * cap, *P0 = Y + cap, *P1 = P0 + cap, *P2 = P1 + cap, *Xs = P2 + cap, *acc = Xs + cap,
           *tmp = acc + cap, *tc = tmp + cap, *rt = tc + PpS;
     int *idx = reinterpret_cast<int *>(rt + M);
 
@@ -206,10 +208,10 @@ __global__ __launch_bounds__(kWideThreads) void relax_match_wide_kernel(
         __syncthreads();
         if (tid < 8) {
             const float c = torder::norm2_group8(cnt, tid, [&](long i) { return tmp[i]; });
-            if (tid == 0) sh[4] = c;
+            if (tid == 0) sh[kWideSolverThreads / 64] = c;
         }
         __syncthreads();
-        const float cost = sh[4];
+        const float cost = sh[kWideSolverThreads / 64];
         ++len;
         for (int j = 0; j < prm.proj_iter; ++j) {
             // {X >= 0} (:74-76), then X = Y + P1 (:78)
@@ -305,9 +307,19 @@ int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int
                             float *scratch, hipStream_t stream) {
     const int PpS = N > M ? N : M + 1;
     const int64_t stride = (int64_t)wide_scratch_floats(M, PpS);
-    hipLaunchKernelGGL(relax_match_wide_kernel, dim3(B), dim3(kWideThreads), 0, stream, cos_in, inter, area_p, area_t,
-                       score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score,
-                       det_score, iters_out, X_final, scratch, stride);
+    // the iterate X is what the column / row sums read element by element: in LDS while M x Pp floats fit (152 KB), else
+    // with the rest of the state in the L2-resident scratch (300 x 40 at 20 x 5: 3.6 ms from L2, see tools/wide_timing.py)
+    size_t lds = sizeof(float) * (size_t)M * PpS;
+    const int x_in_lds = lds <= 152 * 1024;
+    if (!x_in_lds) lds = 0;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)relax_match_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(relax_match_wide_kernel, dim3(B), dim3(kWideSolverThreads), lds, stream, cos_in, inter, area_p,
+                       area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out, Rb_out,
+                       match_score, det_score, iters_out, X_final, scratch, stride, x_in_lds);
     return check_launch();
 }
 
