@@ -80,3 +80,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
                     "relax_learning_rate": 0.1, "score_weight": 0.3}, 1)
     with pytest.raises(_lib.DmmError):
         m(torch.zeros(2, 8), torch.zeros(2, 4, 4), [torch.zeros(1, 8)], torch.zeros(1, 4, 4), torch.zeros(2))
+
+
+def test_workspace_sizes_cover_the_general_solver_outside_the_envelope():
+    """Host-side size functions (no GPU): beyond 32 templates / 256 solver columns the fused forward's workspace also holds
+    the general solver's state -- 9 tables of M x Pp floats per frame -- and dmm_relax_any_scratch_bytes says what the
+    granular any-size entry needs."""
+    L = _lib.load()
+    B, D = 3, 64
+    inside, wide_n, wide_m = L.dmm_workspace_bytes(B, 200, 20, D), L.dmm_workspace_bytes(B, 300, 20, D), \
+        L.dmm_workspace_bytes(B, 20, 40, D)
+    assert wide_n - inside > 9 * B * 20 * 300 * 4 and wide_m > 9 * B * 40 * 41 * 4
+    for (N, M) in [(300, 40), (20, 50), (50, 10)]:
+        Pp = max(N, M + 1)
+        need = L.dmm_relax_any_scratch_bytes(B, N, M)
+        assert 9 * B * M * Pp * 4 <= need <= 10 * B * M * Pp * 4 + B * 4096
+    assert L.dmm_relax_any_scratch_bytes(0, 300, 40) == 0
+    # argument validation of the any-size entry happens before any launch
+    assert L.dmm_relax_match_any_f32(None, None, None, None, None, -1, 300, 40, None, None, 0.3, 2, 2, 0.1, 1, None, None, None,
+                                     None, None, None, None, None, 0, None) == 1
