@@ -292,7 +292,11 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
                        const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
                        int32_t *area_t2, int n0, int m0, int wap, int wat, hipStream_t stream) {
     static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
-    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 1024; }();
+    // workgroups below which a launch is split further (one chunk per workgroup, sub-tiles of proposals).  Every sub-tile
+    // re-reads the frame's template planes, so the target must not be higher than it takes to fill the chip: measured per
+    // call (cosine + counts + solver + mix) at B = 1 / 4 / 8 / 64 frames of 50 x 10, 255 x 255: 1024 -> 0.109 / 0.124 / 0.137
+    // / 0.473 ms, 512 -> 0.109 / 0.117 / 0.134 / 0.345, 256 -> 0.106 / 0.121 / 0.135 / 0.346, 2048 -> 0.109 / 0.133 / 0.142 / 0.474
+    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 512; }();
     const char *tiny_env = getenv("DMM_COST_TINY_FRAMES");       // read per call: tests flip it
     const int tiny_frames = tiny_env ? atoi(tiny_env) : 8;      // B = 8: 0.162 ms per sequence with it, 0.191 without
     static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
@@ -333,7 +337,7 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
-    // ... and sub-tiles of >= 8 proposals until ~1024 workgroups exist (B = 1, N = 50: 16 workgroups took 33 us,
+    // ... and sub-tiles of >= 8 proposals until ~small_wgs workgroups exist (B = 1, N = 50: 16 workgroups took 33 us,
     // 448 take 17; B = 4: 53 us with 64)
     const int ntile = (N - n0) < NG * kWave ? (N - n0) : NG * kWave;
     int sub_count = 1, n_sub = NG * kWave;
