@@ -16,7 +16,9 @@ two-phase proposal prep + ROI features + matching + label merge, 4 videos of 255
 JSON schema, ``config.workload`` names the configuration.  The default N = 1 line also carries compact results of
 configs 3, 5 and the frame loop under ``other_configs`` (``--no-others`` skips them).
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank owns its own B
+N > 1 runs one rank per GPU over RCCL: launched by the driver through torch.distributed.run, or -- when ``--gpus N`` is
+given WITHOUT a launcher around it (WORLD_SIZE unset) -- by this script re-executing itself under torch.distributed.run;
+a world size other than N is an error, never a number.  Every rank owns its own B
 frames (weak scaling; the forward has no exchange step), timing is bracketed by barrier + synchronize on both sides and
 the MAX over ranks is used.  Rank 0 prints ONE JSON line.
 
@@ -63,6 +65,8 @@ def parse():
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
                                                               "fp16-state one BASELINE configs[4] names")
+    ap.add_argument("--settle", type=int, default=8, help="config 4: untimed steps before the W warm-ups (MIOpen solver "
+                                                          "picks, allocator working set, bucketer steady mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="no cpu_baseline / batch_sweep / in-run PMC traffic")
     ap.add_argument("--no-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc child passes")
@@ -175,6 +179,30 @@ def profile_traffic(tag_file, key):
         return None, None
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` (N > 1) without a launcher around it: become ``python -m torch.distributed.run
+    --nproc-per-node N ... bench.py <same arguments>`` (one rank per GPU, rendezvous on 127.0.0.1), so that a plain
+    invocation can never print a 1-GPU number for an N-GPU request.  Under a launcher (WORLD_SIZE set) nothing happens
+    here; ``Runner`` then insists on WORLD_SIZE == N."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, this box has {ndev} "
+                         "(RCCL refuses two ranks on one device; --backend gloo only exercises the control flow)")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)                        # does not return
+
+
 class Runner:
     """dist init, fences and the timed loop shared by the three workloads."""
 
@@ -183,8 +211,9 @@ class Runner:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus and self.world > 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if self.world != args.gpus:
+            # never a number for another rank count than the one asked for
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
         local = local % max(torch.cuda.device_count(), 1)   # identity on a full node; lets 2 test ranks share 1 GPU
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
@@ -219,7 +248,31 @@ class Runner:
             elapsed = float(t.item())
         return elapsed
 
+    def gather(self, obj):
+        """One python object per rank, on every rank (the per-rank lines of an N-GPU run)."""
+        if self.dist is None:
+            return [obj]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, obj)
+        return got
+
+    def rank_spread(self, out, fps_rank, frac=None):
+        """n_gpus comes from the process group actually formed; per-rank min / max so that a slow rank is visible."""
+        per = self.gather({"fps": float(fps_rank), "frac": None if frac is None else float(frac),
+                           "dev": torch.cuda.current_device()})
+        assert len(per) == self.world == out["n_gpus"]
+        out["rccl_ranks"] = self.world if (self.dist is not None and self.args.backend == "nccl") else \
+            (1 if self.dist is None else 0)
+        out["per_rank"] = {"frames_per_s_min": round(min(p["fps"] for p in per), 1),
+                           "frames_per_s_max": round(max(p["fps"] for p in per), 1),
+                           "devices": sorted({p["dev"] for p in per}), "backend": self.args.backend if self.dist else None}
+        if frac is not None:
+            out["per_rank"]["roofline_frac_min"] = round(min(p["frac"] for p in per), 4)
+            out["per_rank"]["roofline_frac_max"] = round(max(p["frac"] for p in per), 4)
+
     def finish(self, out):
+        if self.dist is not None:
+            assert self.dist.get_world_size() == self.args.gpus == out["n_gpus"]
         if self.rank == 0:
             print(json.dumps(out), flush=True)
         if self.dist is not None:
@@ -326,6 +379,7 @@ def bench_layer(R, ci):
                                              "achieved": round((b_cost + b_mix) * fps_rank / 1e9, 1),
                                              "frac": round((b_cost + b_mix) * fps_rank / 1e9 / HBM_PEAK_GBS, 4)}},
     }
+    R.rank_spread(out, fps_rank, achieved / HBM_PEAK_GBS)
     if mix_ms:
         out["roofline_mix"] = {"bound": "hbm", "kernel": "dmm::mask_mix_rows_kernel", "achieved": round(mix_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mix_gbs / HBM_PEAK_GBS, 4),
@@ -626,6 +680,13 @@ def bench_config4(R):
         if e:
             ev.append(e)
             losses.append(loss.detach())
+    # settle first (not part of W or K): MIOpen picks / tunes its backward solvers on the first calls, the caching allocator
+    # reaches its working set, and the bucketer leaves its per-step used-mask exchange after two identical masks -- the
+    # timed steps are the steady state a long training job runs in
+    settle = max(int(args.settle), 0)                            # the same count on every rank (collectives inside)
+    for _ in range(settle):
+        step(None)
+    syncs0 = bucketer.host_syncs
     elapsed = R.timed(step, args.steps, args.warmup)
     assert bool(torch.isfinite(torch.stack(losses)).all())
     avg = lambda i, j: float(np.mean([e[i].elapsed_time(e[j]) for e in ev]))
@@ -659,7 +720,12 @@ def bench_config4(R):
                    "stage_ms": {"encoder_fwd": round(avg(0, 1), 3), "roi_layer_loss_fwd": round(avg(1, 2), 3),
                                 "backward_incl_overlapped_allreduce": round(avg(2, 3), 3),
                                 "allreduce_exposed_after_backward": round(avg(3, 4), 3), "adam": round(avg(4, 5), 3)},
+                   "settle_steps_before_warmup": settle,
                    "gradient_mean": {"bytes": grad_bytes, "buckets": bucketer.num_collectives(),
+                                     "gradients_are_bucket_views": True, "divide": "in the collective (ReduceOp.AVG)"
+                                     if args.backend == "nccl" else "SUM + one divide (backend has no AVG)",
+                                     "used_mask_mode": bucketer.mode,
+                                     "host_reads_in_timed_steps": bucketer.host_syncs - syncs0,
                                      "allreduce_alone_ms": round(ar_ms, 3),
                                      "hidden_ms": round(max(ar_ms - avg(3, 4), 0.0), 3),
                                      "algbw_GBps": round(algbw, 1), "busbw_GBps": round(busbw, 1),
@@ -690,6 +756,7 @@ def compact(out):
 
 def main():
     args = parse()
+    self_launch(args)
     R = Runner(args)
     if args.config == 3:
         out = bench_config3(R)
@@ -699,6 +766,8 @@ def main():
         out = bench_frame_loop(R)
     else:
         out = bench_layer(R, args.config)
+    if "per_rank" not in out:
+        R.rank_spread(out, out["value"] / R.world)
     if args.config == 2 and R.rank == 0 and R.world == 1 and not args.no_extras and not args.no_others:
         # the other BASELINE configurations and the frame loop, compact, so that the driver's default run sees them
         import copy

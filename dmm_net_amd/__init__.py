@@ -21,7 +21,13 @@ def use_shipped_miopen_db(develop: bool = False):
         os.environ["MIOPEN_USER_DB_PATH"] = src
         return src
     files = sorted(f for f in os.listdir(src) if os.path.isfile(os.path.join(src, f)))
-    tag = "%08x" % (sum((i + 1) * os.path.getsize(os.path.join(src, f)) for i, f in enumerate(files)) & 0xFFFFFFFF)
+    import hashlib
+    h = hashlib.sha256()                     # names + CONTENT: an update of the same size must not keep a stale copy
+    for f in files:
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(fh.read())
+    tag = h.hexdigest()[:12]
     dst = os.path.join(os.path.expanduser("~"), ".cache", "dmm_net_amd", "miopen_db-" + tag)
     try:
         os.makedirs(dst, exist_ok=True)

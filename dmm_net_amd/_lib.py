@@ -22,6 +22,7 @@ MAX_PROPOSALS = 256
 # every symbol include/dmm_match.h declares
 SYMBOLS = (
     "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
+    "dmm_set_option", "dmm_get_option", "dmm_reset_options",
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_feature_sim_bwd_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
     "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
@@ -68,6 +69,11 @@ def load():
     L.dmm_status_string.argtypes = [c_int]
     L.dmm_last_hip_error.restype = c_int
     L.dmm_build_info.restype = ctypes.c_char_p
+    L.dmm_set_option.argtypes = [c_int, c_int]
+    L.dmm_set_option.restype = c_int
+    L.dmm_get_option.argtypes = [c_int]
+    L.dmm_get_option.restype = c_int
+    L.dmm_reset_options.restype = c_int
     L.dmm_iou_counts.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, vp, vp,
                                  vp, vp, vp, vp]
     L.dmm_iou_counts_dual.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64,
@@ -159,6 +165,16 @@ def load():
         getattr(L, f).restype = c_int
     if L.dmm_abi_version() != 1:
         raise DmmError("libdmm_match.so ABI version mismatch")
+    # libdmm_match.so needs libhipblaslt.so.1 / libamdhip64.so.7 by SONAME; torch (imported above) has already mapped its
+    # bundled copies under the same sonames, so the loader binds to those -- ONE HIP runtime and ONE hipBLASLt per process.
+    try:
+        with open("/proc/self/maps") as f:
+            lt = {ln.split()[-1] for ln in f if "libhipblaslt.so" in ln}
+        if len(lt) > 1:
+            import warnings
+            warnings.warn(f"two hipBLASLt copies are mapped ({sorted(lt)}): import torch before loading {LIB_PATH}")
+    except OSError:
+        pass
     _lib = L
     return L
 
@@ -169,6 +185,40 @@ def check(rc: int, what: str):
         msg = L.dmm_status_string(rc).decode()
         extra = f" (hipError {L.dmm_last_hip_error()})" if rc == 3 else ""
         raise DmmError(f"{what}: {msg}{extra}")
+
+
+# include/dmm_match.h (0): dispatch options, set through the ABI (the library reads no environment variable)
+OPTIONS = {name: k for k, name in enumerate((
+    "COST_KERNEL", "COST_TINY_FRAMES", "SOLVER_KERNEL", "FORCE_WIDE", "COSINE_KERNEL", "COST_WGS", "COST_SMALL_WGS",
+    "COST_TL_WGS", "COST_XCD", "MIX_XCD", "MIX_WGS", "MIX_STEPQ", "MIX_ALIGN", "MIX_NT", "SOLVER_HELPER_MAX", "NMS_WAVE",
+    "COS_ROWS_MIN_N", "GEMM_TUNE", "PACK_VARIANT", "SMALL_FUSED"))}
+
+
+def set_option(name: str, value: int):
+    check(load().dmm_set_option(OPTIONS[name], int(value)), f"dmm_set_option({name}, {value})")
+
+
+def get_option(name: str) -> int:
+    return int(load().dmm_get_option(OPTIONS[name]))
+
+
+class options:
+    """``with _lib.options(COST_KERNEL=1, COST_TINY_FRAMES=0): ...`` -- pin dispatch options for a block (tests, A/B
+    timing) and put the previous values back."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def small_to_device(values, dtype, device):

@@ -1,6 +1,9 @@
 // dmm_api.hip -- C-ABI glue of libdmm_match.so: status/reporting and the fused forward entry point
 // that chains the four kernels of MatchModel.forward (dmm/modules/match_model.py:24-47) on one stream.
+#include <limits.h>
 #include <stdlib.h>
+
+#include <atomic>
 
 #include "dmm_common.h"
 #include "dmm_solve.h"
@@ -14,6 +17,23 @@ int iou_counts_prezeroed(const void *masks_p, const void *masks_t, int dtype, in
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
 
+// ---- dispatch options -------------------------------------------------------------------------------------------------
+static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
+    /* COST_KERNEL */ -1,      /* COST_TINY_FRAMES */ 8,   /* SOLVER_KERNEL */ -1,  /* FORCE_WIDE */ 0,
+    /* COSINE_KERNEL */ 0,     /* COST_WGS */ 8192,        /* COST_SMALL_WGS */ 512, /* COST_TL_WGS */ 512,
+    /* COST_XCD */ 1,          /* MIX_XCD */ 1,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
+    /* MIX_ALIGN */ 128,       /* MIX_NT */ 3,             /* SOLVER_HELPER_MAX */ 512, /* NMS_WAVE */ 1,
+    /* COS_ROWS_MIN_N */ 65,   /* GEMM_TUNE */ 1,          /* PACK_VARIANT */ 4,    /* SMALL_FUSED */ 1,
+};
+static std::atomic<int> g_opts[DMM_OPT_COUNT] = {
+    {kOptDefaults[0]},  {kOptDefaults[1]},  {kOptDefaults[2]},  {kOptDefaults[3]},  {kOptDefaults[4]},
+    {kOptDefaults[5]},  {kOptDefaults[6]},  {kOptDefaults[7]},  {kOptDefaults[8]},  {kOptDefaults[9]},
+    {kOptDefaults[10]}, {kOptDefaults[11]}, {kOptDefaults[12]}, {kOptDefaults[13]}, {kOptDefaults[14]},
+    {kOptDefaults[15]}, {kOptDefaults[16]}, {kOptDefaults[17]}, {kOptDefaults[18]}, {kOptDefaults[19]},
+};
+static_assert(DMM_OPT_COUNT == 20, "kOptDefaults / g_opts list every option");
+int opt(int key) { return g_opts[key].load(std::memory_order_relaxed); }
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -24,10 +44,10 @@ struct Workspace {
 };
 
 // tables the fast solver kernels are not compiled for: the general forms of dmm_wide.hip take them
+// (DMM_OPT_FORCE_WIDE: tests send tables inside the envelope there too)
 static bool wide_shape(int N, int M) {
     const int Pp = N > M ? N : M + 1;
-    const char *e = getenv("DMM_WIDE");                          // read per call: tests force the general kernels
-    return M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || (e && e[0] == '1');
+    return M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || opt(DMM_OPT_FORCE_WIDE) == 1;
 }
 
 static Workspace carve(void *base, int B, int N, int M, int D) {
@@ -49,7 +69,7 @@ static Workspace carve(void *base, int B, int N, int M, int D) {
     w.sim = (float *)take(sizeof(float) * (size_t)B * M * N);
     w.Rb = (float *)take(sizeof(float) * (size_t)B * M * Pp);
     w.wide = nullptr;
-    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || getenv("DMM_WIDE"))
+    if (wide_shape(N, M))                                        // the one test both the sizes and the dispatch use
         w.wide = (float *)take(sizeof(float) * (size_t)B * wide_scratch_floats(M, Pp));
     w.bytes = off;
     return w;
@@ -57,6 +77,32 @@ static Workspace carve(void *base, int B, int N, int M, int D) {
 }  // namespace dmm
 
 extern "C" int dmm_abi_version(void) { return DMM_ABI_VERSION; }
+
+extern "C" int dmm_set_option(int option, int value) {
+    if (option < 0 || option >= DMM_OPT_COUNT) return DMM_ERR_BAD_ARG;
+    switch (option) {                                            // ranges: a bad value must not reach a launch computation
+        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD: case DMM_OPT_MIX_XCD:
+        case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: if (value < 0 || value > 1) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_MIX_ALIGN: if (value != 16 && value != 32 && value != 64 && value != 128) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_MIX_NT: if (value < 0 || value > 3) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_COST_WGS: case DMM_OPT_COST_SMALL_WGS: case DMM_OPT_COST_TL_WGS: case DMM_OPT_MIX_WGS:
+        case DMM_OPT_MIX_STEPQ: case DMM_OPT_GEMM_TUNE: case DMM_OPT_COS_ROWS_MIN_N:
+            if (value < 1) return DMM_ERR_BAD_ARG; break;
+        default: if (value < 0) return DMM_ERR_BAD_ARG; break;
+    }
+    dmm::g_opts[option].store(value, std::memory_order_relaxed);
+    return DMM_OK;
+}
+
+extern "C" int dmm_get_option(int option) {
+    return (option < 0 || option >= DMM_OPT_COUNT) ? INT_MIN : dmm::opt(option);
+}
+
+extern "C" int dmm_reset_options(void) {
+    for (int k = 0; k < DMM_OPT_COUNT; ++k) dmm::g_opts[k].store(dmm::kOptDefaults[k], std::memory_order_relaxed);
+    return DMM_OK;
+}
 
 extern "C" const char *dmm_status_string(int status) {
     switch (status) {
@@ -123,7 +169,7 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
     // Feature similarity FIRST when the batch is dense and D is one the lanes kernel takes: that launch also clears the
     // three count tables (contiguous in the workspace), so the counts start without a memset node -- 4.6 us of a
     // one-frame call's 135.  Otherwise counts (with their memset), then the tile kernel or normalise x 2 + cosine.
-    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     int rc = DMM_ERR_UNSUPPORTED;
     if (!n_valid && !m_valid && !force_tile)
         rc = dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
@@ -200,7 +246,7 @@ extern "C" int dmm_match_forward_packed(const void *masks_p, const uint64_t *pac
     // Feature similarity of ALL slots as a dense batch (rows past a frame's n_valid / m_valid are computed and never
     // read: the solver masks them) -- the one-launch kernel, which also clears the count tables; bit identical to the
     // ragged three-launch form on every live entry.
-    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     rc = force_tile ? DMM_ERR_UNSUPPORTED
                     : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
                                                (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
@@ -249,7 +295,7 @@ extern "C" int dmm_match_solve_packed(const uint64_t *packed_p, const uint64_t *
     if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
     const int64_t wd = dmm_pack_words(HW);
     float *sim = sim_out ? sim_out : w.sim;
-    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     int rc = force_tile ? DMM_ERR_UNSUPPORTED
                         : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
                                                    (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);

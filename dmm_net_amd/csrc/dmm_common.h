@@ -7,6 +7,10 @@
 #include "../../include/dmm_match.h"
 
 namespace dmm {
+// Dispatch options (include/dmm_match.h (0), dmm_set_option): process-wide integers set THROUGH THE ABI -- the library
+// never reads the environment.  One relaxed atomic load per use.
+int opt(int key);
+
 
 constexpr int kWave = 64;
 

@@ -472,13 +472,12 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
     if (B == 0 || N == 0 || M == 0) return DMM_OK;
     if (!featn_t || !featn_p || !cos_out) return DMM_ERR_BAD_ARG;
     // outside what the tiled kernels stage in LDS (N <= 256 columns, a whole row when one proposal is live): the general
-    // kernel of dmm_wide.hip -- same sums, one thread per output.  DMM_WIDE=1 (tests) sends every call there.
-    const char *wide_env = getenv("DMM_WIDE");
-    if (N > DMM_MAX_PROPOSALS || (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) || (wide_env && wide_env[0] == '1'))
+    // kernel of dmm_wide.hip -- same sums, one thread per output.  DMM_OPT_FORCE_WIDE (tests) sends every call there.
+    if (N > DMM_MAX_PROPOSALS || (D > dmm::kCosMaxD1 && (N == 1 || n_valid)) || dmm::opt(DMM_OPT_FORCE_WIDE) == 1)
         return dmm::launch_cosine_wide(featn_t, featn_p, B, N, M, D, n_valid, m_valid, cos_out, (hipStream_t)stream);
     const int tpm = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
     const int slots = 256 / tpm;
-    static const int rows_min_n = [] { const char *e = getenv("DMM_COS_ROWS_MIN_N"); return e ? atoi(e) : 65; }();
+    const int rows_min_n = dmm::opt(DMM_OPT_COS_ROWS_MIN_N);
     if (N >= rows_min_n && N > 1 && !n_valid && !m_valid && D % dmm::kCosDC == 0 && D <= (1 << 19)) {
         constexpr int RPT = 4;                               // template rows per thread
         const size_t lds4 = sizeof(float) * ((size_t)slots * RPT * dmm::kCosDC + (size_t)N * dmm::kCosLD);
@@ -521,9 +520,9 @@ extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p,
     // envelope of the one-launch form; callers fall back to normalise + normalise + cosine outside it
     if (N < 2 || N > DMM_MAX_PROPOSALS || M > DMM_MAX_TEMPLATES || D <= 0 || (D % 64) != 0 || D > (1 << 19) || B > 65535)
         return DMM_ERR_UNSUPPORTED;
-    // D spread over the lanes (dmm_cosine_lanes.hip) where its envelope holds; DMM_COSINE_KERNEL=tile keeps the
+    // D spread over the lanes (dmm_cosine_lanes.hip) where its envelope holds; DMM_OPT_COSINE_KERNEL = 1 keeps the
     // one-thread-per-output tile kernel below (A/B timing, and every other D)
-    static const bool force_tile = [] { const char *e = getenv("DMM_COSINE_KERNEL"); return e && e[0] == 't'; }();
+    const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     if (!force_tile) {
         const int rc = dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, cos_out, (hipStream_t)stream);
         if (rc != DMM_ERR_UNSUPPORTED) return rc;

@@ -291,15 +291,14 @@ static int launch_tile(const T *masks_p, const T *masks_t, const T *masks_t2, in
                        int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m, const int32_t *n_valid,
                        const int32_t *m_valid, int32_t *inter, int32_t *area_p, int32_t *area_t, int32_t *inter2,
                        int32_t *area_t2, int n0, int m0, int wap, int wat, hipStream_t stream) {
-    static const int target_wgs = [] { const char *e = getenv("DMM_COST_WGS"); return e ? atoi(e) : 8192; }();
+    const int target_wgs = opt(DMM_OPT_COST_WGS);
     // workgroups below which a launch is split further (one chunk per workgroup, sub-tiles of proposals).  Every sub-tile
     // re-reads the frame's template planes, so the target must not be higher than it takes to fill the chip: measured per
     // call (cosine + counts + solver + mix) at B = 1 / 4 / 8 / 64 frames of 50 x 10, 255 x 255: 1024 -> 0.109 / 0.124 / 0.137
     // / 0.473 ms, 512 -> 0.109 / 0.117 / 0.134 / 0.345, 256 -> 0.106 / 0.121 / 0.135 / 0.346, 2048 -> 0.109 / 0.133 / 0.142 / 0.474
-    static const int small_wgs = [] { const char *e = getenv("DMM_COST_SMALL_WGS"); return e ? atoi(e) : 512; }();
-    const char *tiny_env = getenv("DMM_COST_TINY_FRAMES");       // read per call: tests flip it
-    const int tiny_frames = tiny_env ? atoi(tiny_env) : 8;      // B = 8: 0.162 ms per sequence with it, 0.191 without
-    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
+    const int small_wgs = opt(DMM_OPT_COST_SMALL_WGS);
+    const int tiny_frames = opt(DMM_OPT_COST_TINY_FRAMES);       // default 8: B = 8 0.162 ms per sequence with it, 0.191 without
+    const int xcd_remap = opt(DMM_OPT_COST_XCD);
     // A handful of frames (the product's B = 1 / B = 4 calls) is a LATENCY problem: with 1024-pixel chunks one frame
     // has 64 of them, one per workgroup, so three waves of every workgroup idled and the working one went through 9
     // dependent load batches (10 template planes + 8 proposals, 2 planes in flight): 19 us at B = 1.  The same kernel
@@ -491,14 +490,14 @@ static int launch_tl(const T *masks_p, const T *masks_t, const T *masks_t2, int 
     // FEW, long-lived workgroups: every one zeroes and flushes its own [proposal][row] table (4200 entries at config 5),
     // and this kernel's rate does not follow its occupancy (2 waves per SIMD stream as fast as 4).  Measured at config 5,
     // ms per launch at 512 / 2048 / 8192 workgroups: 512 frames 2.42 / 2.48 / 2.53, 128 frames 0.68 / 0.71 / 0.71.
-    static const int target_wgs = [] { const char *e = getenv("DMM_COST_TL_WGS"); return e ? atoi(e) : 512; }();
+    const int target_wgs = opt(DMM_OPT_COST_TL_WGS);
     int splits = (target_wgs + B - 1) / B;
     const int max_splits = (nchunks + kCostThreads / kWave - 1) / (kCostThreads / kWave);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int chunks_per_wg = (nchunks + splits - 1) / splits;
     splits = (nchunks + chunks_per_wg - 1) / chunks_per_wg;
-    static const int xcd_remap = [] { const char *e = getenv("DMM_COST_XCD"); return e ? atoi(e) : 1; }();
+    const int xcd_remap = opt(DMM_OPT_COST_XCD);
     const int RS = (masks_t2 ? 2 * mt : mt) + 1;
     const size_t lds = sizeof(unsigned) * ((size_t)nt * RS + kWave);
     hipLaunchKernelGGL((iou_counts_tl_kernel<T>), dim3(splits, B), dim3(kCostThreads), lds, stream, masks_p, masks_t,
@@ -535,9 +534,8 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
     // proposal tile: accumulators are MT x NG per lane, and at MT > 16 a 4-group tile drops to 1 wave/SIMD
     // (measured 2.6 TB/s on config 5), so those shapes run as 128-proposal tiles (templates re-read once
     // per tile: +9 % bytes at N=200, M=20).
-    // kernel choice: DMM_COST_KERNEL = 0 (register tiles) / 1 (template lanes) / unset = by shape
-    const char *kernel_env = getenv("DMM_COST_KERNEL");          // read per call: tests flip it
-    const int kernel_mode = kernel_env ? atoi(kernel_env) : -1;
+    // kernel choice: DMM_OPT_COST_KERNEL = 0 (register tiles) / 1 (template lanes) / -1 = by shape (the IoU tests pin both)
+    const int kernel_mode = opt(DMM_OPT_COST_KERNEL);
     if constexpr (!std::is_same<T, packed_t>::value) {
         const int rows = masks_t2 ? 2 * M : M;
         const bool use_tl = kernel_mode == 1 || (kernel_mode < 0 && (rows > 16 || N > 128));

@@ -12,7 +12,7 @@
 // MFMA work goes to the library (north_star: matrix cores for the backbone only, through rocm libraries); this file is
 // the descriptor plumbing: row-major operands are handed over as the transposed column-major problem
 //     Y^T [Cout, rows] = W^T [Cout, Cin] . X^T [Cin, rows]   (no data movement: a row-major [r, c] IS a column-major [c, r]).
-// The algorithm is picked per shape ONCE and cached: the library heuristic's first pick.  Opt-in (DMM_GEMM_TUNE=n, n <= 24):
+// The algorithm is picked per shape ONCE and cached: the library heuristic's first pick.  Opt-in (option DMM_OPT_GEMM_TUNE = n, n <= 24):
 // the first call of a shape outside a stream capture times the heuristic's first n candidates on the call's own operands
 // and keeps the fastest.  Measured on the config-3 encoder: 0.945 -> 0.937 ms per forward, i.e. the first pick is already
 // good at these sizes (rows x Cin x Cout around 2048 x 1024 x 256, 8-12 us per product), so it is off by default.  The
@@ -42,7 +42,15 @@ struct GemmPlan {
 constexpr int kTuneCandidates = 24, kTuneRuns = 8;
 
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_handles;                               // one handle per device (created on it)
+hipblasLtHandle_t handle_of(int dev) {                                    // under g_mu
+    auto it = g_handles.find(dev);
+    if (it != g_handles.end()) return it->second;
+    hipblasLtHandle_t h = nullptr;
+    if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+    g_handles[dev] = h;
+    return h;
+}
 std::map<std::tuple<int, int64_t, int, int, int, int>, GemmPlan> g_plans;   // (device, rows, Cin, Cout, relu, residual)
 
 #define DMM_LT_TRY(expr)                                    \
@@ -50,7 +58,7 @@ std::map<std::tuple<int, int64_t, int, int, int, int>, GemmPlan> g_plans;   // (
         if ((expr) != HIPBLAS_STATUS_SUCCESS) return false; \
     } while (0)
 
-bool build_plan(GemmPlan &p, int64_t rows, int cin, int cout, bool relu, bool residual, size_t ws_limit) {
+bool build_plan(hipblasLtHandle_t g_handle, GemmPlan &p, int64_t rows, int cin, int cout, bool relu, bool residual, size_t ws_limit) {
     const hipDataType bf16 = HIP_R_16BF;
     DMM_LT_TRY(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     const hipblasOperation_t op_n = HIPBLAS_OP_N;
@@ -73,9 +81,8 @@ bool build_plan(GemmPlan &p, int64_t rows, int cin, int cout, bool relu, bool re
     // non-null value is enough for the query, the real pointer is set per call
     const void *dummy = (const void *)0x1000;
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
-    static const int want = [] {
-        const char *e = getenv("DMM_GEMM_TUNE");
-        const int v = e ? atoi(e) : 1;
+    const int want = [] {
+        const int v = dmm::opt(DMM_OPT_GEMM_TUNE);
         return v < 1 ? 1 : (v > kTuneCandidates ? kTuneCandidates : v);
     }();
     hipblasLtMatmulHeuristicResult_t res[kTuneCandidates];
@@ -96,7 +103,7 @@ bool build_plan(GemmPlan &p, int64_t rows, int cin, int cout, bool relu, bool re
 // Time the heuristic's candidates on the operands of this call and keep the fastest (first un-captured call of a shape).
 // Every candidate writes the same product into y, so the caller's result is unaffected; a candidate the library
 // rejects at launch is skipped.  Caller holds g_mu.
-void tune_plan(GemmPlan &p, const void *x, const void *w, const void *residual, void *y, void *workspace,
+void tune_plan(hipblasLtHandle_t g_handle, GemmPlan &p, const void *x, const void *w, const void *residual, void *y, void *workspace,
                size_t workspace_bytes, hipStream_t stream) {
     std::vector<hipblasLtMatmulHeuristicResult_t> cand;
     cand.swap(p.candidates);                                     // one attempt per plan, whatever happens
@@ -142,14 +149,16 @@ extern "C" int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias,
     int dev = 0;
     DMM_HIP_TRY(hipGetDevice(&dev));
     dmm::GemmPlan *plan = nullptr;
+    hipblasLtHandle_t handle = nullptr;
     {
         std::lock_guard<std::mutex> lk(dmm::g_mu);
-        if (!dmm::g_handle && hipblasLtCreate(&dmm::g_handle) != HIPBLAS_STATUS_SUCCESS) return DMM_ERR_LAUNCH;
+        handle = dmm::handle_of(dev);
+        if (!handle) return DMM_ERR_LAUNCH;
         auto key = std::make_tuple(dev, rows, cin, cout, relu ? 1 : 0, residual ? 1 : 0);
         auto it = dmm::g_plans.find(key);
         if (it == dmm::g_plans.end()) {
             dmm::GemmPlan p;
-            if (!dmm::build_plan(p, rows, cin, cout, relu != 0, residual != nullptr, workspace ? workspace_bytes : 0))
+            if (!dmm::build_plan(handle, p, rows, cin, cout, relu != 0, residual != nullptr, workspace ? workspace_bytes : 0))
                 p.ok = false;
             it = dmm::g_plans.emplace(key, p).first;
         }
@@ -167,13 +176,13 @@ extern "C" int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias,
     if (!plan->candidates.empty()) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
-            dmm::tune_plan(*plan, x, w, residual, y, workspace, workspace_bytes, (hipStream_t)stream);
+            dmm::tune_plan(handle, *plan, x, w, residual, y, workspace, workspace_bytes, (hipStream_t)stream);
         else
             (void)hipGetLastError();
     }
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
     const hipblasStatus_t st =
-        hipblasLtMatmul(dmm::g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta, residual ? residual : y,
+        hipblasLtMatmul(handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta, residual ? residual : y,
                         residual ? plan->c : plan->d, y, plan->d, &plan->algo, workspace, workspace_bytes,
                         (hipStream_t)stream);
     if (st != HIPBLAS_STATUS_SUCCESS) {

@@ -338,23 +338,23 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
                           int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
                           int64_t so_m, hipStream_t stream) {
     constexpr int E = 16 / (int)sizeof(T);
-    static const int align_bytes = [] { const char *e = getenv("DMM_MIX_ALIGN"); return e ? atoi(e) : 128; }();
+    const int align_bytes = opt(DMM_OPT_MIX_ALIGN);
     const int align_mask = align_bytes / (int)sizeof(TO) - 1;
     const int nsteps = (HW + align_mask + kMixThreads * E - 1) / (kMixThreads * E);    // worst-case row misalignment
     // MANY TINY workgroups: 2 steps = 8 KiB of the row each, up to ~320k of them.  Measured at B = 1024 (test mode,
     // one plane per row): 4.2 / 4.9 / 5.1 / 5.2 / 5.75-6.1 TB/s at 10k / 40k / 80k / 160k / 320k workgroups; 1-step
     // workgroups fall back to 5.5-5.8.  In dispatch order the resident workgroups then cover a compact, advancing
-    // window of the output instead of ~2000 independent 64 KiB streams.  DMM_MIX_WGS / DMM_MIX_STEPQ override.
-    static const int target_wgs = [] { const char *e = getenv("DMM_MIX_WGS"); return e ? atoi(e) : 320000; }();
+    // window of the output instead of ~2000 independent 64 KiB streams.  DMM_OPT_MIX_WGS / DMM_OPT_MIX_STEPQ override.
+    const int target_wgs = opt(DMM_OPT_MIX_WGS);
     int splits = (target_wgs + B * M - 1) / (B * M);
-    static const int step_q = [] { const char *e = getenv("DMM_MIX_STEPQ"); return e ? atoi(e) : 2; }();
+    const int step_q = opt(DMM_OPT_MIX_STEPQ);
     const int max_splits = (nsteps + step_q - 1) / step_q;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int steps_per_wg = ((nsteps + splits - 1) / splits + step_q - 1) / step_q * step_q;
     splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
-    static const int nt_mode = [] { const char *e = getenv("DMM_MIX_NT"); return e ? atoi(e) : 3; }();
-    static const int xcd_remap = [] { const char *e = getenv("DMM_MIX_XCD"); return e ? atoi(e) : 1; }();
+    const int nt_mode = opt(DMM_OPT_MIX_NT);
+    const int xcd_remap = opt(DMM_OPT_MIX_XCD);
 #define DMM_MIX_LAUNCH(NT)                                                                                              \
     hipLaunchKernelGGL((mask_mix_rows_kernel<T, TO, NT>), dim3(splits, M, B), dim3(kMixThreads), 0, stream, Rb, masks_p, \
                        N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg, align_mask, xcd_remap)
@@ -419,8 +419,7 @@ extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, 
     if (sp_n < HW || so_m < HW) return DMM_ERR_BAD_ARG;
     if (out_dtype != DMM_F32 && out_dtype != dtype) return DMM_ERR_BAD_ARG;      // fp32, or the planes' own 16-bit type
     hipStream_t s = (hipStream_t)stream;
-    const char *wide_env = getenv("DMM_WIDE");                                    // tests: the general kernel everywhere
-    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || (wide_env && wide_env[0] == '1')) {
+    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || dmm::opt(DMM_OPT_FORCE_WIDE) == 1) {   // tests: the general kernel everywhere
         switch (dtype) {
             case DMM_F32:
                 return dmm::mask_mix_wide_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,

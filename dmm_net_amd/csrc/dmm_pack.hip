@@ -79,9 +79,8 @@ static int pack_typed(const T *masks, int64_t planes, int HW, int64_t plane_stri
                       int64_t packed_stride, hipStream_t stream) {
     const int nblocks = (HW + 255) / 256;
     // segment length x blocks in flight per wave, measured at 51 200 planes of 255 x 255 fp32 (TB/s read): 256x4 5.11 (round
-    // 2's form), 256x8 5.49, 64x4 5.40, 64x8 5.20, 128x8 5.54, 32x8 4.74 -- DMM_PACK_VARIANT=0 is round 2's form
-    const char *ev = getenv("DMM_PACK_VARIANT");
-    const int variant = ev ? atoi(ev) : 4;
+    // 2's form), 256x8 5.49, 64x4 5.40, 64x8 5.20, 128x8 5.54, 32x8 4.74 -- DMM_OPT_PACK_VARIANT = 0 is round 2's form
+    const int variant = opt(DMM_OPT_PACK_VARIANT);
     for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
         const int64_t np = planes - p0 < 65535 ? planes - p0 : 65535;
 #define DMM_PACK_LAUNCH(SEG_, U_)                                                                                       \

@@ -770,7 +770,7 @@ extern "C" int dmm_nms_slots_f32(const float *tight, const float *scores, const 
     if (images == 0) return DMM_OK;
     if (!tight || !scores || !keep || !keep_count) return DMM_ERR_BAD_ARG;
     if (R > dmm::kNmsMax) return DMM_ERR_UNSUPPORTED;
-    static const bool no_wave = [] { const char *e = getenv("DMM_NMS_WAVE"); return e && e[0] == '0'; }();
+    const bool no_wave = dmm::opt(DMM_OPT_NMS_WAVE) == 0;
     if (R <= 64 && !no_wave)
         hipLaunchKernelGGL(dmm::nms_slots_small_kernel, dim3(images), dim3(256), 0, (hipStream_t)stream, tight, scores,
                            counts, images, R, thresh, K, step, keep, keep_count);

@@ -17,7 +17,7 @@ struct RelaxParams {
 // Which mapping serves a launch of B frames with M template rows and solver width Pp.  The row-split form was built
 // to cut the latency of a single frame's dependent chain; measured, the two tie at 10 x 50 and
 // row-split wins ~10 % from ~12 rows up while few frames are in flight, so that is where it is used.
-// DMM_SOLVER_KERNEL=0 forces thread-per-column, =1 row-split wherever it is compiled (Pp <= 64); the tests run every
+// DMM_OPT_SOLVER_KERNEL = 0 forces thread-per-column, 1 row-split wherever it is compiled (Pp <= 64); the tests run every
 // solver golden through both.
 bool use_row_split(int B, int M, int Pp);
 

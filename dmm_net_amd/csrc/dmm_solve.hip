@@ -26,10 +26,10 @@
 namespace dmm {
 
 bool use_row_split(int B, int M, int Pp) {
-    const char *e = getenv("DMM_SOLVER_KERNEL");
+    const int e = opt(DMM_OPT_SOLVER_KERNEL);  // -1 by shape; the solver goldens pin 0 and 1
     if (Pp > 64) return false;                  // the row-split form is compiled for one column group (Pp <= 64)
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
+    if (e == 0) return false;
+    if (e == 1) return true;
     // Round 3: the one-wave latency form (relax_core_w1 + the cost-norm helper wave) overtook it everywhere it is compiled
     // (tools/solver_timing.py, us per solve at 20 x 5, one-wave vs row-split: 5 x 50: 51 vs 82, 10 x 50: 70 vs 99,
     // 16 x 64: 93 vs 112); it stays as the alternative mapping every solver golden is also run through.
@@ -301,11 +301,11 @@ __global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
 
 namespace dmm {
 // Threads per workgroup: the one-wave solver gets a second wave (the cost-norm helper, norm_helper_wave) while few frames
-// are in flight -- two waves per frame then still sit on different SIMDs; DMM_SOLVER_HELPER_MAX (default 512 frames,
+// are in flight -- two waves per frame then still sit on different SIMDs; DMM_OPT_SOLVER_HELPER_MAX (default 512 frames,
 // 0 = never) moves the switch.
 static int solver_block(int ng, int B) {
     if (ng != 1) return 64 * ng;
-    static const int helper_max = [] { const char *e = getenv("DMM_SOLVER_HELPER_MAX"); return e ? atoi(e) : 512; }();
+    const int helper_max = opt(DMM_OPT_SOLVER_HELPER_MAX);
     return B <= helper_max ? 128 : 64;
 }
 }  // namespace dmm
@@ -374,7 +374,7 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
 }
 
 // (3) for ANY N, M: the general solver (dmm_wide.hip) keeps its state in caller-provided scratch.  Inside the fast kernels'
-// envelope this IS dmm_relax_match_f32 (the scratch is not touched); DMM_WIDE=1 (tests) forces the general kernel.
+// envelope this IS dmm_relax_match_f32 (the scratch is not touched); DMM_OPT_FORCE_WIDE (tests) forces the general kernel.
 extern "C" size_t dmm_relax_any_scratch_bytes(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     return sizeof(float) * (size_t)B * dmm::wide_scratch_floats(M, N > M ? N : M + 1);
@@ -390,8 +390,7 @@ extern "C" int dmm_relax_match_any_f32(const float *cos_in, const int32_t *inter
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0) return DMM_ERR_BAD_ARG;
     const int Pp = N > M ? N : M + 1;
-    const char *e = getenv("DMM_WIDE");
-    if (M <= DMM_MAX_TEMPLATES && Pp <= DMM_MAX_PROPOSALS && !(e && e[0] == '1'))
+    if (M <= DMM_MAX_TEMPLATES && Pp <= DMM_MAX_PROPOSALS && dmm::opt(DMM_OPT_FORCE_WIDE) != 1)
         return dmm_relax_match_f32(cos_in, inter, area_p, area_t, score_p, B, N, M, n_valid, m_valid, score_weight, max_iter,
                                    proj_iter, lr, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
                                    X_final, stream);

@@ -357,7 +357,6 @@ __device__ __forceinline__ void row_steps_wave_vs(const float *rowbuf, int n, in
         // acc + vec[0] + vec[1] + ... + vec[7] in that order (torder::add_group8_seq), the passes in lockstep
 #pragma unroll
         for (int p = 0; p < NP; ++p) s[p] = a[p] + p0[p];
-#if !(defined(DMM_DBG) && (DMM_DBG & 4))
 #pragma unroll
         for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<1>(p0[p]);
 #pragma unroll
@@ -372,7 +371,6 @@ __device__ __forceinline__ void row_steps_wave_vs(const float *rowbuf, int n, in
         for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<6>(p0[p]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<7>(p0[p]);
-#endif
     }
     // (row sum - 1) / m once per row, where the sum lives (div_by_const, the passes in lockstep)
     float q0[NP], rr[NP], step[NP];
@@ -543,17 +541,12 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
                 p0 = p0 + p2;
                 p0 = p0 + p3;
                 cs = col_class_a ? a0 + a1 : p0;
-#if defined(DMM_DBG) && (DMM_DBG & 2)
-                cs = Xp[0].x + Xp[MP - 1].y;                    // timing experiment: no column-sum chains
-#endif
             }
-#if !(defined(DMM_DBG) && (DMM_DBG & 8))
             if (moved_prev == 0ull) {                          // sweep j - 1 was the last one (:88-89)
 #pragma unroll
                 for (int k = 0; k < MP; ++k) { Xp[k] = Xs[k]; P0[k] = P0s[k]; }
                 break;
             }
-#endif
             // {column sums <= 1}: project_col (:21-34, :79-80); then X = Y + P2 (:82)
             const bool over = cs > 1.0f;                       // mask = (X_col_sum <= 1)
             float tc = div_by_const(cs - 1.0f, fn, rcp_n);
@@ -568,17 +561,12 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             }
             // {row sums = 1}: project_row (:9-19, :83-84); X.sum(dim=1) in ATen's inner-sum order
             float tr[MT];
-#if defined(DMM_DBG) && (DMM_DBG & 1)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) tr[i] = readlane_f32(tc, i);       // timing experiment: no row sums
-#else
 #pragma unroll
             for (int k = 0; k < MP; ++k) {                     // every lane: dead columns hold exact zeros
                 rowbuf[(2 * k) * kRowStride + col] = Xp[k].x;
                 if (2 * k + 1 < MT) rowbuf[(2 * k + 1) * kRowStride + col] = Xp[k].y;
             }
             row_steps_wave<MT>(rowbuf, n, m, fm, rcp_m, tr);
-#endif
             bool moved = false;
             if (live) {                                        // dead columns keep their zeros
 #pragma unroll
@@ -602,9 +590,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             cost = __int_as_float(hs[2]);
         }
         if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
-#if !(defined(DMM_DBG) && (DMM_DBG & 16))
         if (cost_prev == cost) break;                           // :96-98
-#endif
         cost_prev = cost;
     }
     solver_helper_stop(hs);

@@ -27,7 +27,7 @@
 // BIT EXACTNESS: every fp32 operation and every summation order is the one of dmm_solve.hip / dmm_torch_order.h
 // (ATen outer-sum order for the column sums, vectorized inner-sum order for the row sums, the 2-norm fast path for
 // the cost); only the placement of the operands differs.  tests/test_gpu_parity.py runs all solver goldens through
-// both kernels (DMM_SOLVER_KERNEL=0|1).
+// both kernels (option DMM_OPT_SOLVER_KERNEL = 0 | 1).
 #include "dmm_solve.h"
 
 namespace dmm {

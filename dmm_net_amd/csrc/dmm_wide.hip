@@ -9,7 +9,7 @@
 // the reference's steps with a barrier between them.  They issue the same fp32 operations in the same order as the fast
 // kernels -- ATen's reduction orders from dmm_torch_order.h, which are written for any length -- so results are bit
 // identical to the reference's CPU path here too (tests/test_gpu_wide.py: against the oracle at wide shapes, and against
-// every layer golden with DMM_WIDE=1 forcing these kernels inside the envelope).
+// every layer golden with DMM_OPT_FORCE_WIDE forcing these kernels inside the envelope).
 //
 // Roofline: none of it is bound by HBM or MFMA -- dependent chains through L2; the IoU counts (dmm_cost.hip tiles any
 // N x M) remain the streaming part.

@@ -45,27 +45,43 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
 
 
 class GradBucketer:
-    """Bucketed mean all-reduce of ``param.grad`` over the default process group.
+    """Bucketed mean all-reduce of ``param.grad`` over the default process group, gradients kept as VIEWS of the flat
+    buckets (DDP's ``gradient_as_bucket_view``; the reference gets the mean from DDP, train.py:178-184, and repeats it
+    per tensor, train.py:62-68).
+
+    Data path per step: ONE pack launch per bucket (``torch.cat(out=flat)``; skipped for gradients that already live in
+    the bucket), one collective per bucket that also divides (``ReduceOp.AVG`` on RCCL; SUM + one in-place divide on
+    backends without AVG, e.g. gloo), then ``p.grad`` is re-pointed at its slice of the reduced bucket -- no scatter
+    copy.  The flat buffers are allocated once.  Until the next ``zero_grad`` the gradients alias the buckets: do not
+    hold on to them across steps (same contract as DDP's bucket views).
 
     ``overlap=False``: call ``all_reduce_mean()`` after ``backward()``.
-    ``overlap=True``: buckets are laid out in REVERSE parameter order (gradients arrive last layer first) and
-    post-accumulate-grad hooks copy each gradient into its bucket as autograd produces it; the moment a bucket is
-    complete its all-reduce is issued asynchronously, so the collectives of the late layers run under the backward of
-    the early ones (what DDP does for the reference, train.py:178-184).  Collectives are ALWAYS issued in bucket-index
-    order (a complete bucket waits for its predecessors), because RCCL pairs collectives across ranks by issue order
-    and per-rank autograd graphs may differ (unused parameters, videos without live templates).  ``finish()`` after
-    ``backward()`` issues the buckets that never completed (parameters without a gradient this step count as zeros,
-    like DDP with ``find_unused_parameters=True``, train.py:181), waits, scales by 1/world and scatters back;
-    parameters without a gradient on EVERY rank keep ``grad = None`` (``track_unused``: one [n_params] MAX all-reduce)
-    and, being known idle on every rank alike, no longer hold their bucket back in the next step; should such a
-    parameter produce a gradient after its bucket went out (graphs that change from step to step), ``finish()`` reduces
-    it in one extra collective every rank derives from the used-mask alike -- no rank raises while the others wait.
-    A second ``backward()`` before ``finish()`` raises (the in-flight buckets would drop the accumulated part).
+    ``overlap=True``: buckets are laid out in REVERSE parameter order (gradients arrive last layer first);
+    post-accumulate-grad hooks mark a bucket complete the moment its last gradient exists and its all-reduce is issued
+    asynchronously, under the rest of the backward.  Collectives are ALWAYS issued in bucket-index order (a complete
+    bucket waits for its predecessors), because RCCL pairs collectives across ranks by issue order and per-rank
+    autograd graphs may differ (unused parameters, videos without live templates).  ``finish()`` after ``backward()``
+    issues the buckets that never completed (parameters without a gradient count as zeros, like DDP with
+    ``find_unused_parameters=True``, train.py:181) and waits.  A second ``backward()`` before ``finish()`` raises.
+
+    Which parameters are used (``track_unused``).  Parameters without a gradient on EVERY rank keep ``grad = None`` (no
+    zero gradients for Adam's weight decay) and do not hold their bucket back.  That is a cross-rank fact:
+      * VERIFY mode (the first steps, and whenever the set changes): one [n_params] MAX all-reduce per step, read back
+        on the host -- exact in the same step, but the read drains the stream (what DDP pays every step with
+        ``find_unused_parameters``).  A parameter that was idle everywhere and produces a gradient after its bucket
+        went out is reduced in one extra collective every rank derives from the mask alike.
+      * STEADY mode (after ``steady_after`` consecutive identical masks): the same reduction is issued asynchronously
+        into pinned memory and looked at ONE STEP LATER, so nothing on the step waits for the host.  The used set is
+        assumed unchanged (DDP's ``static_graph``); if the delayed mask disagrees, every rank falls back to VERIFY
+        mode at the same step.  In the one step in between a parameter that was idle everywhere keeps ``grad = None``
+        on every rank even if a rank produced a gradient for it (dropped consistently, never applied on one rank
+        only), and a parameter that went idle everywhere receives a zero gradient instead of ``None``.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, overlap: bool = False,
-                 track_unused: bool = True):
+                 track_unused: bool = True, steady_after: Optional[int] = 2):
         self.track_unused = bool(track_unused)
+        self.steady_after = steady_after if (steady_after and track_unused) else None
         self.launch_log: List[int] = []           # bucket indices in the order their collectives were issued
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
@@ -84,24 +100,37 @@ class GradBucketer:
             key = k
         if cur:
             self.buckets.append(cur)
-        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        # flat buckets, allocated ONCE, and every parameter's slice of its bucket in the parameter's shape
+        self._flat: List[torch.Tensor] = []
+        self._views: List[List[torch.Tensor]] = []
         self._slot = {}
         for bi, bucket in enumerate(self.buckets):
-            off = 0
-            for p in bucket:
-                self._slot[id(p)] = (bi, off)
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
+            views, off = [], 0
+            for k_i, p in enumerate(bucket):
+                self._slot[id(p)] = (bi, k_i)
+                views.append(flat[off:off + p.numel()].view(p.shape))
                 off += p.numel()
+            self._flat.append(flat)
+            self._views.append(views)
+        self._n = sum(len(b) for b in self.buckets)
         self._handles: List[Optional[object]] = [None] * len(self.buckets)
         self._filled = [set() for _ in self.buckets]
         self._ready = [False] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._next = 0                            # lowest bucket index not launched yet (fixed issue order)
-        # parameters that received no gradient on ANY rank in the previous step (from the all-reduced used-mask, hence
-        # identical on every rank -- e.g. the ResNet's unused fc): a bucket does not wait for them, so one idle
-        # parameter in bucket 0 does not hold back every collective until finish()
+        # parameters that received no gradient on ANY rank (from the all-reduced used-mask, hence identical on every
+        # rank -- e.g. the ResNet's unused fc): a bucket does not wait for them
         self._idle = [set() for _ in self.buckets]
         self._hooks = []
-        self._zero_cache = {}
+        self._avg: Optional[bool] = None          # does the backend divide inside the collective?
+        # used-mask protocol state
+        self.mode = "verify"
+        self.host_syncs = 0                       # blocking mask read-backs so far (tests / bench look at it)
+        self._stable = 0
+        self._last_mask: Optional[torch.Tensor] = None
+        self._pending = None                      # steady mode: (pinned host mask, event) of the previous step
+        self._pin_in = self._pin_out = None
         if self.overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -114,48 +143,53 @@ class GradBucketer:
             h.remove()
         self._hooks = []
 
-    def _zeros_like_flat(self, p: torch.nn.Parameter) -> torch.Tensor:
-        z = self._zero_cache.get(id(p))
-        if z is None or z.device != p.device:
-            z = self._zero_cache[id(p)] = torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
-        return z
+    # ------------------------------------------------------------------------------------------------ data path
+    def _aliases(self, g: Optional[torch.Tensor], v: torch.Tensor) -> bool:
+        return g is not None and g.data_ptr() == v.data_ptr() and g.is_contiguous() and g.shape == v.shape
 
-    def _flat_of(self, bi: int) -> torch.Tensor:
-        bucket = self.buckets[bi]
-        n = sum(p.numel() for p in bucket)
-        flat = self._flat[bi]
-        if flat is None or flat.numel() != n:
-            flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
-            self._flat[bi] = flat
-        return flat
+    @torch.no_grad()
+    def _pack(self, bi: int):
+        """Bring bucket ``bi``'s gradients into its flat buffer: one ``cat`` when every gradient exists and lives
+        elsewhere (the usual case after ``zero_grad(set_to_none=True)``: autograd hands fresh tensors), otherwise one
+        multi-tensor copy for those that live elsewhere and one multi-tensor zero for the missing ones; gradients that
+        already ARE their bucket slice (``zero_grad(set_to_none=False)``: autograd accumulated in place) cost nothing."""
+        bucket, views = self.buckets[bi], self._views[bi]
+        grads = [p.grad for p in bucket]
+        alias = [self._aliases(g, v) for g, v in zip(grads, views)]
+        if not any(alias) and all(g is not None for g in grads):
+            torch.cat([g.reshape(-1) for g in grads], out=self._flat[bi])
+            return
+        src = [g for g, a in zip(grads, alias) if g is not None and not a]
+        dst = [v for g, a, v in zip(grads, alias, views) if g is not None and not a]
+        zero = [v for g, v in zip(grads, views) if g is None]
+        if src:
+            torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
+
+    def _collective(self, flat: torch.Tensor):
+        if self._avg is None:
+            self._avg = dist.get_backend() == "nccl"            # RCCL divides in the collective; gloo has no AVG
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
 
     @torch.no_grad()
     def _on_grad(self, p: torch.nn.Parameter):
-        bi, off = self._slot[id(p)]
+        bi, _ = self._slot[id(p)]
         if self._launched[bi] and id(p) in self._idle[bi] and id(p) not in self._filled[bi]:
-            # idle on every rank in the previous step, so its bucket went out without waiting for it (carrying zeros in
-            # its slot) -- and now it has a gradient after all.  Raising HERE would stop one rank while the others sit
-            # in the collectives until the RCCL timeout; instead the gradient stays in p.grad and finish() reduces every
-            # such parameter in one extra collective that all ranks derive from the all-reduced used-mask alike.
+            # idle on every rank so far, so its bucket went out without waiting for it -- and now it has a gradient after
+            # all.  Raising HERE would stop one rank while the others sit in the collectives until the RCCL timeout; the
+            # gradient stays in p.grad and finish() deals with it (verify mode: one extra collective every rank derives
+            # from the all-reduced used-mask alike; steady mode: dropped on every rank, then back to verify mode).
+            self._filled[bi].add(id(p))
             return
         if self._launched[bi]:
             # a second backward() before finish() (gradient accumulation): the bucket already in flight holds only
-            # the first backward's gradient and finish() would overwrite p.grad with it -- refuse instead of
-            # silently dropping the accumulated part
+            # the first backward's gradient -- refuse instead of silently dropping the accumulated part
             raise RuntimeError("GradBucketer(overlap=True): backward() ran again before finish(); call finish() "
                                "after every backward, or use overlap=False for gradient accumulation")
         self._filled[bi].add(id(p))
         if len(self._filled[bi] | self._idle[bi]) == len(self.buckets[bi]):
-            # the bucket is complete: pack its gradients with ONE launch (a copy per parameter from the hook was ~340
-            # small launches per ResNet-101 step on the autograd thread); known-idle parameters contribute zeros
-            flat = self._flat_of(bi)
-            parts = []
-            for q in self.buckets[bi]:
-                if id(q) in self._filled[bi]:
-                    parts.append(q.grad.reshape(-1))
-                else:
-                    parts.append(self._zeros_like_flat(q))
-            torch.cat(parts, out=flat)
+            self._pack(bi)
             self._ready[bi] = True
             self._launch_ready_prefix()
 
@@ -166,71 +200,139 @@ class GradBucketer:
         whose autograd graphs differ (unused parameters, skipped videos) then still pair bucket k with bucket k."""
         while self._next < len(self.buckets) and self._ready[self._next]:
             bi = self._next
-            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+            self._handles[bi] = self._collective(self._flat[bi])
             self._launched[bi] = True
             self.launch_log.append(bi)
             self._next += 1
 
     @torch.no_grad()
-    def _scatter_back(self, bi: int, world: int, used: Optional[torch.Tensor] = None, used_off: int = 0):
-        flat = self._flat[bi]
-        flat.div_(world)
-        off = 0
-        dsts, srcs = [], []
-        for k_i, p in enumerate(self.buckets[bi]):
-            k = p.numel()
-            if p.grad is None:
-                # unused on THIS rank: materialise the mean only if some rank produced a gradient (a parameter
-                # unused everywhere keeps grad None, so optimisers with weight decay leave it alone like under DDP)
-                if used is None or bool(used[used_off + k_i]):
-                    p.grad = flat[off:off + k].view_as(p).clone()
-            else:
-                dsts.append(p.grad)
-                srcs.append(flat[off:off + k].view_as(p))
-            off += k
-        if dsts:
-            torch._foreach_copy_(dsts, srcs)       # one multi-tensor launch per bucket, not one copy per parameter
+    def _adopt(self, bi: int, world: int, used: Optional[List[bool]], used_off: int, keep_none=()):
+        """After bucket ``bi``'s collective: divide where the backend did not, then point every gradient at its slice of
+        the reduced bucket (no copy).  A parameter without a local gradient gets the mean only if some rank produced
+        one (``used``); one that is unused everywhere keeps ``grad = None``."""
+        if not self._avg and world > 1:
+            self._flat[bi].div_(world)
+        for k_i, (p, v) in enumerate(zip(self.buckets[bi], self._views[bi])):
+            if id(p) in keep_none:
+                p.grad = None
+            elif p.grad is None:
+                if used is None or used[used_off + k_i]:
+                    p.grad = v
+            elif p.grad is not v:
+                p.grad = v
+
+    # ------------------------------------------------------------------------------------------------ used-mask
+    def _local_mask(self) -> List[int]:
+        return [0 if p.grad is None else 1 for bucket in self.buckets for p in bucket]
+
+    def _set_idle(self, m: List[bool]):
+        k = 0
+        for bi, bucket in enumerate(self.buckets):
+            self._idle[bi] = {id(p) for j, p in enumerate(bucket) if not m[k + j]}
+            k += len(bucket)
 
     @torch.no_grad()
-    def _used_mask(self) -> Optional[torch.Tensor]:
-        """One tiny MAX all-reduce telling which parameters received a gradient on ANY rank.  Only issued when
-        this rank has parameters without a gradient... which the other ranks cannot know, so it is issued whenever
-        ``track_unused`` is set (default) -- [n_params] uint8, issued FIRST in the fixed collective order."""
+    def _used_mask_sync(self) -> Optional[List[bool]]:
+        """VERIFY mode: one tiny MAX all-reduce telling which parameters received a gradient on ANY rank, read back on
+        the host (drains the stream).  Issued after all bucket collectives on every rank: same order everywhere."""
         if not self.track_unused:
             return None
         dev = self.params[0].device if self.params else torch.device("cpu")
-        m = torch.tensor([0 if p.grad is None else 1 for bucket in self.buckets for p in bucket], dtype=torch.int32,
-                         device=dev)
+        m = torch.tensor(self._local_mask(), dtype=torch.int32, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         m = m.cpu()
-        k = 0
-        for bi, bucket in enumerate(self.buckets):
-            self._idle[bi] = {id(p) for j, p in enumerate(bucket) if not bool(m[k + j])}
-            k += len(bucket)
-        return m
+        self.host_syncs += 1
+        used = [bool(x) for x in m.tolist()]
+        self._set_idle(used)
+        if self._last_mask is not None and used == self._last_mask:
+            self._stable += 1
+        else:
+            self._stable = 1
+        self._last_mask = used
+        if self.steady_after is not None and self._stable >= self.steady_after:
+            self.mode = "steady"                   # the same decision on every rank: it follows the reduced mask
+            self._pending = None
+        return used
 
     @torch.no_grad()
-    def finish(self):
-        """After ``backward()`` with ``overlap=True``: complete (in bucket order), wait, average, scatter back."""
-        world = dist.get_world_size()
-        for bi in range(self._next, len(self.buckets)):
-            bucket = self.buckets[bi]
-            flat = self._flat_of(bi)               # (re)fill in one launch: missing gradients are zeros
-            torch.cat([self._zeros_like_flat(p) if p.grad is None else p.grad.reshape(-1) for p in bucket], out=flat)
-            self._ready[bi] = True
-        self._launch_ready_prefix()
-        assert self._next == len(self.buckets)
+    def _used_mask_async(self):
+        """STEADY mode: the same reduction, issued without a host wait (pinned staging both ways, an event marks the
+        read-back); ``_check_pending`` looks at it one step later."""
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            m = torch.tensor(self._local_mask(), dtype=torch.int32)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            self._pending = (m, None)
+            return
+        if self._pin_in is None:
+            self._pin_in = torch.empty(self._n, dtype=torch.int32).pin_memory()
+            self._pin_out = [torch.empty(self._n, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pin_k = 0
+            self._pin_free = torch.cuda.Event()
+        else:
+            self._pin_free.synchronize()           # the previous step's upload has left the staging buffer (long ago)
+        self._pin_in.copy_(torch.tensor(self._local_mask(), dtype=torch.int32))
+        m = self._pin_in.to(dev, non_blocking=True)
+        self._pin_free.record()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        out = self._pin_out[self._pin_k]
+        self._pin_k ^= 1
+        out.copy_(m, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (out, ev)
+
+    def _check_pending(self):
+        """STEADY mode, at the start of ``finish()``: the PREVIOUS step's reduced mask (complete long ago -- the wait does
+        not drain this step's work).  A change sends every rank back to VERIFY mode at the same step."""
+        if self._pending is None:
+            return
+        m, ev = self._pending
+        self._pending = None
+        if ev is not None:
+            ev.synchronize()
+        used = [bool(x) for x in m.tolist()]
+        if used != self._last_mask:
+            import warnings
+            warnings.warn("GradBucketer: the set of parameters that receive gradients changed; back to the per-step "
+                          "used-mask exchange (one host read per step) until it is stable again")
+            self.mode, self._stable, self._last_mask = "verify", 0, None
+
+    # ------------------------------------------------------------------------------------------------ entry points
+    @torch.no_grad()
+    def _reduce_late(self, late, world):
+        # the same list on every rank (it comes from the MAX-reduced used-mask and the previous idle sets, both
+        # identical everywhere): one more flat collective, in parameter order
+        flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in late])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for p, _ in late:
+            p.grad = flat[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+
+    @torch.no_grad()
+    def _complete(self, world: int):
+        """Shared tail of ``finish()`` / ``all_reduce_mean()``: every bucket collective has been issued."""
         idle_before = [set(s) for s in self._idle]
-        used = self._used_mask()                   # issued after all bucket collectives on every rank: same order
-        uo = 0
-        late = []                                  # went out as "known idle" (zeros) but got a gradient on some rank
+        steady = self.mode == "steady"
+        if steady:
+            self._used_mask_async()
+            used = None
+        else:
+            used = self._used_mask_sync()          # after all bucket collectives on every rank: same order
+        uo, late = 0, []
         for bi in range(len(self.buckets)):
             self._handles[bi].wait()
-            if used is not None:
-                # (criterion and order are the same on every rank; the LOCAL gradient is taken before the scatter)
-                late += [(p, None if p.grad is None else p.grad.clone()) for k_i, p in enumerate(self.buckets[bi])
-                         if id(p) in idle_before[bi] and bool(used[uo + k_i])]
-            self._scatter_back(bi, world, used, uo)
+            keep_none = ()
+            if steady:
+                keep_none = idle_before[bi]        # assumed idle everywhere: None on every rank, whatever happened here
+            elif used is not None:
+                # went out as "known idle" (zeros) but got a gradient on some rank; criterion and order are the same
+                # on every rank; the LOCAL gradient is taken before the views are adopted
+                late += [(p, p.grad) for k_i, p in enumerate(self.buckets[bi])
+                         if id(p) in idle_before[bi] and used[uo + k_i]]
+            self._adopt(bi, world, used, uo, keep_none)
             uo += len(self.buckets[bi])
             self._handles[bi] = None
             self._filled[bi] = set()
@@ -238,15 +340,20 @@ class GradBucketer:
             self._launched[bi] = False
         self._next = 0
         if late:
-            # the same list on every rank (it comes from the MAX-reduced used-mask and the previous step's idle sets,
-            # both identical everywhere): one more flat collective, in parameter order
-            flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in late])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(world)
-            off = 0
-            for p, _ in late:
-                p.grad = flat[off:off + p.numel()].view_as(p).clone()
-                off += p.numel()
+            self._reduce_late(late, world)
+
+    @torch.no_grad()
+    def finish(self):
+        """After ``backward()`` with ``overlap=True``: complete (in bucket order), wait, adopt the bucket views."""
+        world = dist.get_world_size()
+        if self.mode == "steady":
+            self._check_pending()
+        for bi in range(self._next, len(self.buckets)):
+            self._pack(bi)                         # missing gradients are zeros
+            self._ready[bi] = True
+        self._launch_ready_prefix()
+        assert self._next == len(self.buckets)
+        self._complete(world)
 
     @torch.no_grad()
     def all_reduce_mean(self):
@@ -255,18 +362,13 @@ class GradBucketer:
         if self.overlap:
             return self.finish()
         world = dist.get_world_size()
-        handles = []
-        for i, bucket in enumerate(self.buckets):
-            flat = self._flat_of(i)
-            torch.cat([self._zeros_like_flat(p) if p.grad is None else p.grad.reshape(-1) for p in bucket], out=flat)
-            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-            self.launch_log.append(i)
-        used = self._used_mask()
-        uo = 0
+        if self.mode == "steady":
+            self._check_pending()
         for i in range(len(self.buckets)):
-            handles[i].wait()
-            self._scatter_back(i, world, used, uo)
-            uo += len(self.buckets[i])
+            self._pack(i)
+            self._handles[i] = self._collective(self._flat[i])
+            self.launch_log.append(i)
+        self._complete(world)
 
 
 @torch.no_grad()

@@ -148,12 +148,15 @@ class DMM_Model(nn.Module):
         return torch.stack(outs, 0), losses
 
     @staticmethod
-    def _out_mask_last(full, mask_last_occurence, skip):
+    def _out_mask_last(full, mask_last_occurence, skip, alias_ok=False):
         """``out_mask_last`` (dmm_model.py:66-69, :78-80): the matched masks, except that a skipped video keeps its
-        incoming planes.  No video skipped (the usual step): it IS ``full`` -- MatchModel returns the same tensor twice
-        (match_model.py:47) -- not a [B,F,H,W] copy of it."""
+        incoming planes.  The reference returns it as a tensor of its own, and its decoder step then writes the refined
+        masks INTO it (evaluator.py:205) -- so by default this is a separate tensor too.  ``alias_ok`` (the caller
+        promises not to edit either result in place; ``video.FrameLoop`` without a decoder does): with no video
+        skipped it IS ``full`` -- MatchModel returns the same tensor twice (match_model.py:47) -- and the
+        [B,F,H,W] copy is saved."""
         if not any(skip):
-            return full
+            return full if alias_ok else full.clone()
         keep = _lib.small_to_device([bool(s_) for s_ in skip], torch.bool, full.device)
         return torch.where(keep[:, None, None, None], mask_last_occurence.to(full.dtype), full)
 
@@ -200,7 +203,7 @@ class DMM_Model(nn.Module):
                 packed = [p.get_field("mask_packed") for p in proposals]
             full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
                                         tg, skip, row_scale, packed)
-        return full, tplt_dict, [], self._out_mask_last(full, mask_last_occurence, skip)
+        return full, tplt_dict, [], self._out_mask_last(full, mask_last_occurence, skip, bool(infos.get("alias_ok")))
 
     # ---- dmm_model.py:88-142 -----------------------------------------------------------------------
     def forward(self, args, proposals, backbone_feature, mask_last_occurence, tplt_dict, tplt_valid_batch, targets):

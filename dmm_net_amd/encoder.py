@@ -479,6 +479,17 @@ class FastEncoder(nn.Module):
         return out
 
     # -- building blocks --------------------------------------------------------------------------------------
+    def _gemm_scratch(self, device, stream):
+        """32 MB of split-K scratch for the library GEMMs, one buffer per (device, body / heads role, stream that issues
+        the call): the heads' GEMMs run beside the body's, and two callers on two streams must not share one either
+        (ADVICE r3).  Under graph capture the stream is the capture stream; the role keeps the body's and the heads'
+        graphs apart, which replay side by side."""
+        key = (device.index, self._on_side, int(stream.cuda_stream))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.empty((32 << 20,), dtype=torch.uint8, device=device)
+        return ws
+
     def _conv1x1(self, x, conv, relu, residual=None):
         """y = act(x @ W^T + b (+ residual)) on the activation matrix, ONE library GEMM with the whole tail in its
         epilogue (``dmm_conv1x1_bf16``: hipBLASLt, residual as the C operand).  stride 2 = a row subsample first."""
@@ -491,10 +502,7 @@ class FastEncoder(nn.Module):
         rows = _as_rows(x)
         if self.fused_gemm and rows.is_contiguous():
             stream = torch.cuda.current_stream(x.device)
-            ws = self._ws.get((x.device.index, self._on_side))
-            if ws is None:                     # the heads' GEMMs run beside the body's: no shared scratch
-                ws = self._ws[(x.device.index, self._on_side)] = torch.empty((32 << 20,), dtype=torch.uint8,
-                                                                             device=x.device)
+            ws = self._gemm_scratch(x.device, stream)
             res = None
             if residual is not None:
                 res = _as_rows(residual.contiguous(memory_format=torch.channels_last))
@@ -542,9 +550,7 @@ class FastEncoder(nn.Module):
         stream = torch.cuda.current_stream(x.device)
         cols = torch.empty((B * Ho * Wo, 9 * C), dtype=self.dtype, device=x.device)
         y = torch.empty((B * Ho * Wo, wcol.shape[1]), dtype=self.dtype, device=x.device)
-        ws = self._ws.get((x.device.index, self._on_side))
-        if ws is None:
-            ws = self._ws[(x.device.index, self._on_side)] = torch.empty((32 << 20,), dtype=torch.uint8, device=x.device)
+        ws = self._gemm_scratch(x.device, stream)
         res = None if residual is None else _as_rows(residual.contiguous(memory_format=torch.channels_last))
         with _lib.device_guard(x.device):
             L = _lib.load()

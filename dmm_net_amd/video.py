@@ -246,7 +246,18 @@ class StepPlan:
         self.graphs = {}                                         # row_scale? -> captured graph
         self.device = dev
 
-    def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail, fuse_epilogue=True):
+    def key_fits(self, B, O, H, W, R, Mm, K, G, T, feat_like, tail, fuse_epilogue=True, cfg=None, nms_thresh=None,
+                 mask_thresh=None, padding=None):
+        """Can this plan (buffers + captured graphs) serve the clip?  Shapes AND every value the captured launches carry
+        as an immediate: the solver configuration, the NMS / paste thresholds and the padding are baked into the graph,
+        so a change of any of them (``loop.nms_thresh = ...``, another match layer) must rebuild and recapture --
+        the BoxList path reads them live on every frame."""
+        if cfg is not None and tuple(cfg) != tuple(self.cfg):
+            return False
+        if (nms_thresh is not None and float(nms_thresh) != self.nms_thresh) or \
+                (mask_thresh is not None and float(mask_thresh) != self.mask_thresh) or \
+                (padding is not None and int(padding) != self.padding):
+            return False
         return ((self.B, self.O, self.H, self.W, self.R, self.clip.M, self.K, self.G, self.tail) ==
                 (B, O, H, W, R, Mm, K, G, bool(tail)) and T <= self.T_cap and
                 self.fused == (bool(fuse_epilogue) and O <= 8 and Mm + 2 * self.padding <= 32) and
@@ -453,8 +464,10 @@ class FrameLoop:
         dev = frames.device
         main = torch.cuda.current_stream(dev)
         enc_side = self._side_stream(dev, "encoder") if self.encode_overlap else None
+        # a prefetch is identified by the frames TENSOR it was issued for (held in the record, so the allocator cannot hand
+        # its address to another clip) and that tensor's version counter; anything else is dropped
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0][:3] != (frames.data_ptr(), tuple(frames.shape), frames._version):
+        if pre is not None and not (pre[0][0] is frames and pre[0][1] == frames._version):
             pre = None                                           # a prefetch for other frames: ignored
         pipelined = enc_side is not None and (pre is not None or next_frames is not None)
         G = max(1, min(self._frames_per_chunk(T, pipelined), T))
@@ -498,7 +511,7 @@ class FrameLoop:
 
         if enc_side is not None:
             enc_side.wait_stream(main)
-        if pre is not None and pre[0] == (frames.data_ptr(), tuple(frames.shape), frames._version, g0, enc_side):
+        if pre is not None and pre[0][2:] == (g0, enc_side):
             out0 = pre[1]                                        # issued under the previous clip's last steps
         else:
             out0, _ = encode(0)
@@ -510,13 +523,14 @@ class FrameLoop:
             Mm = int(proposals[0][0].get_field("mask").shape[-1])
         K = self.max_proposals if self.max_proposals > 0 else R
         cfg = self.dmm.match_layer
+        cfg = (float(cfg.cfgs["score_weight"]), int(cfg.max_iter), int(cfg.proj_iter), float(cfg.relax_lr),
+               int(bool(cfg.is_test)))
         tail = self.refine is None
         plan = self._plan
-        if plan is None or not plan.key_fits(B, O, H, W, R, Mm, K, G, T, out0["backbone_feature"], tail,
-                                             self.fuse_epilogue) or plan.device != dev:
-            plan = self._plan = StepPlan(B, O, H, W, R, Mm, K, G, max(T, 32), out0["backbone_feature"], dev,
-                                         (float(cfg.cfgs["score_weight"]), int(cfg.max_iter), int(cfg.proj_iter),
-                                          float(cfg.relax_lr), int(bool(cfg.is_test))),
+        if plan is None or plan.device != dev or not plan.key_fits(
+                B, O, H, W, R, Mm, K, G, T, out0["backbone_feature"], tail, self.fuse_epilogue, cfg=cfg,
+                nms_thresh=self.nms_thresh, mask_thresh=self.mask_thresh, padding=self.padding):
+            plan = self._plan = StepPlan(B, O, H, W, R, Mm, K, G, max(T, 32), out0["backbone_feature"], dev, cfg,
                                          self.nms_thresh, self.mask_thresh, self.padding, tail, self.fuse_epilogue)
         # (the plan's buffers may have just been created -- zero-filled -- on THIS stream: chunk 0 lands behind that, not
         # behind the fence taken before the plan existed; a high-priority encoder stream overtook the fill otherwise)
@@ -562,7 +576,8 @@ class FrameLoop:
                 elif (next_frames is not None and enc_side is not None and next_frames.is_cuda
                       and tuple(next_frames.shape[2:]) == (C, H, W)):
                     # the encoder's stream has nothing left to do for this clip: the next clip's first chunk
-                    self._prefetched = ((next_frames.data_ptr(), tuple(next_frames.shape), next_frames._version,
+                    next_frames.record_stream(enc_side)          # read there after this run has returned
+                    self._prefetched = ((next_frames, next_frames._version,
                                          self._first_chunk(next_frames.shape[1], True), enc_side),
                                         encode(0, clip=next_frames)[0])
             if t == 0:                                                   # forward_timestep_init, :215-225
@@ -743,7 +758,9 @@ class FrameLoop:
                                                              for tup in tplt_dict[b]["refine_input_feat"]]
                 prev_mask = y_mask
             infos = {"extra_frame": extra, "valid": tplt_valid, "shape": [[H, W]] * B, "n_tplt": n_tplt,
-                     "row_scale": row_scale}
+                     "row_scale": row_scale,
+                     "alias_ok": self.refine is None}             # nothing here edits init_pred / hist_new in place; a
+                                                                  # decoder may (evaluator.py:205): it gets its own tensor
             hist_in = prev_mask.view(B, O, H, W) if mask_hist is None else mask_hist       # :168-169
             init_pred, tplt_dict, _, hist_new = self.dmm.inference(infos, props, features["backbone_feature"], hist_in,
                                                                    tplt_dict)

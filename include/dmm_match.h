@@ -65,6 +65,42 @@ typedef void *dmm_stream_t; /* hipStream_t */
 #define DMM_MAX_TEMPLATES 32  /* M  */
 #define DMM_MAX_PROPOSALS 256 /* Pp */
 
+/* ---------------------------------------------------------------------------------------------
+ * (0) Dispatch options.  Where an entry point has two kernels (or a tuning value worth A/B-ing) the choice is a
+ * process-wide integer set THROUGH THIS ABI.  The library never reads the environment: a stray variable cannot change what
+ * production dispatches.  Defaults are the measured best; NO option changes a result (the parity tests pin each
+ * alternative and compare bit for bit).  dmm_set_option answers DMM_ERR_BAD_ARG for an unknown option or a value outside
+ * its range; dmm_get_option returns INT_MIN for an unknown option; dmm_reset_options restores every default.
+ * Options are read at launch time: set them before the calls they should affect (they are not captured by value in
+ * a HIP graph -- a captured launch keeps the choice it was captured with).
+ * ------------------------------------------------------------------------------------------- */
+typedef enum dmm_option {
+    DMM_OPT_COST_KERNEL = 0,        /* dmm_iou_counts*: -1 by shape (default), 0 register tiles, 1 template lanes          */
+    DMM_OPT_COST_TINY_FRAMES = 1,   /* largest B that takes the short-chunk instantiation of the register-tile kernel (8) */
+    DMM_OPT_SOLVER_KERNEL = 2,      /* dmm_relax_*: -1 by shape (default), 0 thread per column, 1 row split               */
+    DMM_OPT_FORCE_WIDE = 3,         /* 1: the any-size kernels also inside the fast envelope (0)                          */
+    DMM_OPT_COSINE_KERNEL = 4,      /* fused feature similarity: 0 D over the lanes (default), 1 one thread per output    */
+    DMM_OPT_COST_WGS = 5,           /* workgroup targets of the count kernels: register tiles (8192),                     */
+    DMM_OPT_COST_SMALL_WGS = 6,     /*   sub-tiling threshold of small launches (512),                                     */
+    DMM_OPT_COST_TL_WGS = 7,        /*   template lanes (512)                                                              */
+    DMM_OPT_COST_XCD = 8,           /* XCD-aware workgroup -> (frame, range) mapping of the count kernels (1)              */
+    DMM_OPT_MIX_XCD = 9,            /*   ... of the mix kernel (1)                                                         */
+    DMM_OPT_MIX_WGS = 10,           /* mix kernel: workgroup target (320000),                                              */
+    DMM_OPT_MIX_STEPQ = 11,         /*   steps per workgroup quantum (2),                                                  */
+    DMM_OPT_MIX_ALIGN = 12,         /*   store alignment in bytes: 16 / 32 / 64 / 128 (128),                               */
+    DMM_OPT_MIX_NT = 13,            /*   non-temporal loads (bit 0) / stores (bit 1) (3)                                   */
+    DMM_OPT_SOLVER_HELPER_MAX = 14, /* largest B whose one-wave solver launches carry the cost-norm helper wave (512)      */
+    DMM_OPT_NMS_WAVE = 15,          /* dmm_nms_slots_f32: 1 the one-workgroup kernel for <= 64 boxes (default), 0 general  */
+    DMM_OPT_COS_ROWS_MIN_N = 16,    /* dmm_cosine_f32: from which N the row-blocked form is used (65)                      */
+    DMM_OPT_GEMM_TUNE = 17,         /* dmm_conv1x1_bf16: hipBLASLt heuristic candidates timed per new shape (1 = none)     */
+    DMM_OPT_PACK_VARIANT = 18,      /* dmm_pack_masks: 4 = 128-block segments x 8 loads (default), 0 = 256 x 4             */
+    DMM_OPT_SMALL_FUSED = 19,       /* dmm_match_forward at B <= 8: 1 = feature similarity inside the count launch (default) */
+    DMM_OPT_COUNT = 20
+} dmm_option;
+DMM_API int dmm_set_option(int option, int value);
+DMM_API int dmm_get_option(int option);
+DMM_API int dmm_reset_options(void);
+
 DMM_API int dmm_abi_version(void);
 DMM_API const char *dmm_status_string(int status);
 DMM_API int dmm_last_hip_error(void);         /* hipError_t of the last DMM_ERR_LAUNCH on this thread */

@@ -99,3 +99,32 @@ def test_workspace_sizes_cover_the_general_solver_outside_the_envelope():
     # argument validation of the any-size entry happens before any launch
     assert L.dmm_relax_match_any_f32(None, None, None, None, None, -1, 300, 40, None, None, 0.3, 2, 2, 0.1, 1, None, None, None,
                                      None, None, None, None, None, 0, None) == 1
+
+
+def test_dispatch_options_go_through_the_abi_and_not_through_the_environment(monkeypatch):
+    """VERDICT r3 hygiene: kernel choices / tuning values are integers set with dmm_set_option (include/dmm_match.h (0));
+    the library contains no getenv call, so a stray variable cannot change what production dispatches."""
+    L = _lib.load()
+    names = re.findall(r"\b(DMM_OPT_[A-Z_]+)\s*=\s*(\d+)", open(os.path.join(ROOT, "include", "dmm_match.h")).read())
+    count = dict(names).pop("DMM_OPT_COUNT")
+    assert int(count) == len(_lib.OPTIONS) == len(names) - 1
+    for name, k in names:
+        if name != "DMM_OPT_COUNT":
+            assert _lib.OPTIONS[name[len("DMM_OPT_"):]] == int(k), name
+    defaults = {k: _lib.get_option(k) for k in _lib.OPTIONS}
+    assert defaults["COST_KERNEL"] == -1 and defaults["COST_TINY_FRAMES"] == 8 and defaults["FORCE_WIDE"] == 0
+    monkeypatch.setenv("DMM_WIDE", "1")                           # what used to flip the dispatch
+    monkeypatch.setenv("DMM_COST_KERNEL", "1")
+    assert {k: _lib.get_option(k) for k in _lib.OPTIONS} == defaults
+    inside = L.dmm_workspace_bytes(3, 200, 20, 64)
+    with _lib.options(FORCE_WIDE=1, COST_KERNEL=1):
+        assert _lib.get_option("FORCE_WIDE") == 1 and _lib.get_option("COST_KERNEL") == 1
+        assert L.dmm_workspace_bytes(3, 200, 20, 64) > inside     # sizes and dispatch use ONE test (ADVICE r3)
+    assert {k: _lib.get_option(k) for k in _lib.OPTIONS} == defaults
+    assert L.dmm_set_option(99, 1) == 1 and L.dmm_set_option(_lib.OPTIONS["COST_KERNEL"], 7) == 1
+    assert L.dmm_set_option(_lib.OPTIONS["MIX_ALIGN"], 48) == 1 and L.dmm_get_option(99) == -2 ** 31
+    _lib.set_option("MIX_WGS", 1000)
+    assert L.dmm_reset_options() == 0 and _lib.get_option("MIX_WGS") == defaults["MIX_WGS"]
+    for fn in os.listdir(_lib.CSRC):
+        if fn.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(_lib.CSRC, fn)).read(), fn

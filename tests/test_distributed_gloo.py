@@ -228,3 +228,70 @@ def test_gloo_world2_late_gradient_of_a_previously_idle_parameter():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _steady_worker(rank, world, port, q):
+    """once the set of used parameters has been the same for ``steady_after`` steps the per-step
+    host read of the used-mask stops (STEADY mode: the mask is reduced asynchronously and looked at one step later);
+    gradients are views of the flat buckets; a change of the set is noticed one step late by EVERY rank alike, the
+    parameter that woke up is dropped on every rank in that one step (never applied on one rank only), and the
+    bucketer is back in the exact per-step exchange from the next step on."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    l1, l2, l3 = torch.nn.Linear(16, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 4)
+    shift = torch.nn.Parameter(torch.zeros(16))
+    params = list(l1.parameters()) + list(l2.parameters()) + list(l3.parameters()) + [shift]
+    gb = GradBucketer(params, bucket_mb=0.004, overlap=True, steady_after=2)
+    ok, modes, syncs = True, [], []
+    for step in range(8):
+        x = torch.randn(8, 16, generator=torch.Generator().manual_seed(50 * step + rank))
+        if step % 2:                                           # both zero_grad flavours
+            for p in params:
+                p.grad = None
+        else:
+            for p in params:
+                if p.grad is not None:
+                    p.grad.zero_()
+        use = step == 4 and rank == 1                          # the idle parameter wakes up on ONE rank in step 4
+        fwd = lambda: l3(torch.relu(l2(torch.relu(l1(x + shift if use else x))))).pow(2).sum()
+        # this rank's own gradients, taken WITHOUT the hooks: once gradients are bucket views, a bucket whose collective
+        # is already in flight when backward() returns no longer holds the local values
+        local = list(torch.autograd.grad(fwd(), params[:-1])) + [None]
+        fwd().backward()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            gb.finish()
+        modes.append(gb.mode)
+        syncs.append(gb.host_syncs)
+        ok &= (len(w) == 1) == (step == 5)                     # the change is noticed one step late, once
+        for p, g, v in zip(params, local, [gb._views[gb._slot[id(p)][0]][gb._slot[id(p)][1]] for p in params]):
+            if p is shift:
+                ok &= p.grad is None                           # also in step 4, on BOTH ranks
+                continue
+            ref = g.clone()
+            dist.all_reduce(ref)
+            ok &= p.grad is v                                  # the gradient IS the bucket slice: no scatter copy
+            ok &= bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    # steps 0, 1 verify (2 identical masks) -> steady from step 2; step 5 sees step 4's mask -> verify again for 5, 6
+    ok &= modes == ["verify", "steady", "steady", "steady", "steady", "verify", "steady", "steady"]
+    ok &= syncs == [1, 2, 2, 2, 2, 3, 4, 4]
+    gb.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok), modes, syncs))
+
+
+def test_gloo_world2_steady_mode_takes_the_host_read_off_the_step_and_heals():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_steady_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res

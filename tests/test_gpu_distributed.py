@@ -218,7 +218,7 @@ def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean():
     JSON line with the all-reduce accounting.  gloo, because two RCCL ranks cannot share this box's one GPU."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", "2",
-           "--steps", "2", "--warmup", "1", "--frames", "2", "--backend", "gloo"]
+           "--steps", "2", "--warmup", "1", "--frames", "2", "--backend", "gloo", "--settle", "3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -228,5 +228,33 @@ def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean():
     gm = out["config"]["gradient_mean"]
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["frames_per_gpu_per_step"] == 2
     assert gm["buckets"] >= 3 and gm["bytes"] > 150e6 and gm["allreduce_alone_ms"] > 0
+    assert gm["used_mask_mode"] == "steady" and gm["host_reads_in_timed_steps"] == 0 and gm["gradients_are_bucket_views"]
+    assert out["per_rank"]["backend"] == "gloo" and out["rccl_ranks"] == 0
     assert abs(gm["busbw_GBps"] - gm["algbw_GBps"]) <= 0.06 * gm["algbw_GBps"] + 0.1        # 2 (N-1) / N = 1 at N = 2
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"]
+
+
+def test_bench_plain_invocation_with_gpus_2_launches_two_ranks_itself():
+    """``python bench.py --gpus 2`` with NO launcher around it (WORLD_SIZE unset) used to run on one
+    GPU and print ``"n_gpus": 1``.  It now re-executes itself under torch.distributed.run; the line says 2 ranks, and a
+    world size other than --gpus is an error instead of a number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                             "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames",
+           "128", "--backend", "gloo", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["frames_per_gpu_per_step"] == 128
+    assert out["per_rank"]["frames_per_s_min"] <= out["per_rank"]["frames_per_s_max"]
+    assert 0 < out["per_rank"]["roofline_frac_min"] <= out["per_rank"]["roofline_frac_max"] < 1
+    # over RCCL two ranks cannot share this box's one GPU: refused loudly, no 1-GPU number
+    r = subprocess.run(cmd[:-3] + ["--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "visible GPUs" in r.stderr
+    # a launcher that formed another world size than --gpus: an error too
+    r = subprocess.run(cmd[:2] + ["--gpus", "1", "--no-extras"], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -12,7 +12,7 @@ import torch
 
 import oracle
 from conftest import golden, record_achieved
-from dmm_net_amd import ops, synth
+from dmm_net_amd import _lib, ops, synth
 from dmm_net_amd.match_model import MatchModel
 
 pytestmark = pytest.mark.gpu
@@ -89,18 +89,18 @@ def check_against_golden(o, g, is_test, big=False):
 
 # ------------------------------------------------------------------------------------ cost kernel
 @pytest.fixture(params=["auto", "register-tiles", "register-tiles-small-chunks", "template-lanes"])
-def cost_kernel(request, monkeypatch):
-    """The IoU-count entry point has two kernels (dmm_cost.hip); DMM_COST_KERNEL pins one (read per call).  The register-
-    tile kernel has a second instantiation for a handful of frames (one 16-byte lane load per plane and chunk, 16 planes
-    in flight; B <= DMM_COST_TINY_FRAMES, default 8): pinned off (0) and on for every batch size (64) here."""
+def cost_kernel(request):
+    """The IoU-count entry point has two kernels (dmm_cost.hip); option COST_KERNEL pins one (include/dmm_match.h (0), set
+    through the ABI).  The register-tile kernel has a second instantiation for a handful of frames (one 16-byte lane load per
+    plane and chunk, 16 planes in flight; B <= COST_TINY_FRAMES, default 8): pinned off (0) and on for every batch size (64)
+    here."""
+    kw = {}
     if request.param != "auto":
-        monkeypatch.setenv("DMM_COST_KERNEL", "1" if request.param == "template-lanes" else "0")
+        kw["COST_KERNEL"] = 1 if request.param == "template-lanes" else 0
         if request.param != "template-lanes":
-            monkeypatch.setenv("DMM_COST_TINY_FRAMES", "0" if request.param == "register-tiles" else "64")
-    else:
-        monkeypatch.delenv("DMM_COST_KERNEL", raising=False)
-        monkeypatch.delenv("DMM_COST_TINY_FRAMES", raising=False)
-    return request.param
+            kw["COST_TINY_FRAMES"] = 0 if request.param == "register-tiles" else 64
+    with _lib.options(**kw):
+        yield request.param
 
 
 @pytest.mark.parametrize("N,M,H,W", [(8, 3, 64, 64), (50, 10, 255, 255), (1, 1, 1, 7), (5, 2, 1, 7), (3, 5, 17, 31),
@@ -148,15 +148,13 @@ def test_iou_counts_batched_strided_ragged(cost_kernel):
 
 # ------------------------------------------------------------------------------------ solver
 @pytest.fixture(params=["auto", "thread-per-column", "row-split"])
-def solver_kernel(request, monkeypatch):
+def solver_kernel(request):
     """The solver has two mappings with identical arithmetic (dmm_solve.hip: thread = column, one wave(-group) per
-    frame; dmm_solve_rs.hip: row-split over RG x CG waves).  DMM_SOLVER_KERNEL pins one (read per call); every solver
-    golden must be bit exact through both."""
-    if request.param != "auto":
-        monkeypatch.setenv("DMM_SOLVER_KERNEL", "0" if request.param == "thread-per-column" else "1")
-    else:
-        monkeypatch.delenv("DMM_SOLVER_KERNEL", raising=False)
-    return request.param
+    frame; dmm_solve_rs.hip: row-split over RG x CG waves).  Option SOLVER_KERNEL pins one; every solver golden must be
+    bit exact through both."""
+    kw = {} if request.param == "auto" else {"SOLVER_KERNEL": 0 if request.param == "thread-per-column" else 1}
+    with _lib.options(**kw):
+        yield request.param
 
 
 def test_g1_kat_solver(solver_kernel):

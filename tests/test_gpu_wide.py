@@ -2,14 +2,14 @@
 compiled for -- more than 32 template rows, solver width max(N, M + 1) above 256.  The reference is unbounded
 (relax_match.py:36-105); bars as everywhere: integer and fp32 tables, scores and executed iterations BIT exact against the
 oracle and against the reference's own output (G19), test-mode masks bit exact, train-mode masks within 1e-5.
-With DMM_WIDE=1 the same kernels run INSIDE the envelope, where every shape also has a fast kernel to agree with."""
+With option FORCE_WIDE (dmm_set_option) the same kernels run INSIDE the envelope, where every shape also has a fast kernel to agree with."""
 import numpy as np
 import pytest
 import torch
 
 import oracle
 from conftest import golden
-from dmm_net_amd import ops, synth
+from dmm_net_amd import _lib, ops, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -102,8 +102,8 @@ def test_wide_ragged_batch_dead_frames_and_single_proposal():
             check_frame(g, b, o, is_test, P, O)
 
 
-def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones(monkeypatch):
-    """DMM_WIDE=1 sends dmm_match_forward through the general kernels at shapes the fast kernels cover: same tables, scores,
+def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones():
+    """Option FORCE_WIDE sends dmm_match_forward through the general kernels at shapes the fast kernels cover: same tables, scores,
     iteration counts (data-dependent exits included: structured frames converge early) and -- same arithmetic in the mix --
     the same masks bit for bit in both modes; and both equal the oracle."""
     cases = [(1, 1, 5, 7, 16, "uniform", 6, 3), (9, 8, 17, 13, 100, "uniform", 6, 3), (33, 5, 20, 20, 64, "uniform", 6, 3),
@@ -113,10 +113,9 @@ def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones(monkeypatc
     for k, (P, O, H, W, D, kind, it, pj) in enumerate(cases):
         fr = synth.make_frame(P, O, H, W, D, seed=9300 + k, kind=kind)
         for is_test in (1, 0):
-            monkeypatch.delenv("DMM_WIDE", raising=False)
             fast = forward([fr], it, pj, is_test)
-            monkeypatch.setenv("DMM_WIDE", "1")
-            wide = forward([fr], it, pj, is_test)
+            with _lib.options(FORCE_WIDE=1):
+                wide = forward([fr], it, pj, is_test)
             for key in fast:
                 assert np.array_equal(fast[key], wide[key]), (P, O, is_test, key)
             o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
@@ -129,10 +128,11 @@ def test_general_kernels_inside_the_envelope_agree_with_the_fast_ones(monkeypatc
     for dt in (torch.float16, torch.bfloat16):
         res = []
         for wide in (False, True):
-            monkeypatch.setenv("DMM_WIDE", "1") if wide else monkeypatch.delenv("DMM_WIDE", raising=False)
-            out = ops.match_forward(dev(fr.proposed_mask)[None].to(dt), dev(fr.mask_last_occurence)[None].to(dt),
-                                    dev(fr.proposed_feature)[None], dev(fr.template_feature)[None],
-                                    dev(fr.proposal_score)[None], score_weight=0.3, max_iter=8, proj_iter=3, lr=0.1, is_test=0)
+            with _lib.options(FORCE_WIDE=int(wide)):
+                out = ops.match_forward(dev(fr.proposed_mask)[None].to(dt), dev(fr.mask_last_occurence)[None].to(dt),
+                                        dev(fr.proposed_feature)[None], dev(fr.template_feature)[None],
+                                        dev(fr.proposal_score)[None], score_weight=0.3, max_iter=8, proj_iter=3, lr=0.1,
+                                        is_test=0)
             res.append([t.clone() for t in out])
         assert all(torch.equal(a, c) for a, c in zip(*res)), dt
 

@@ -1,5 +1,5 @@
 """Feature-similarity kernel timing: D-over-lanes kernel (dmm_cosine_lanes.hip) vs the tile kernel
-(DMM_COSINE_KERNEL=tile), device time per launch over back-to-back launches, plus a bit-equality check against the
+(option COSINE_KERNEL = 1), device time per launch over back-to-back launches, plus a bit-equality check against the
 three-launch path.  Usage: python tools/cosine_timing.py [lanes|tile]   (no argument: runs both as child processes)."""
 import os
 import subprocess
@@ -12,7 +12,8 @@ SHAPES = [(1, 50, 10, 512), (4, 50, 10, 512), (64, 50, 10, 512), (512, 50, 10, 5
 
 def child():
     import torch
-    from dmm_net_amd import ops
+    from dmm_net_amd import _lib, ops
+    _lib.set_option("COSINE_KERNEL", 1 if sys.argv[1] == "tile" else 0)
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(5)
     for (B, N, M, D) in SHAPES:
@@ -41,5 +42,4 @@ if __name__ == "__main__":
     else:
         for kind in ("lanes", "tile"):
             print(kind, flush=True)
-            env = dict(os.environ, DMM_COSINE_KERNEL=kind)
-            subprocess.run([sys.executable, os.path.abspath(__file__), kind], env=env, check=False)
+            subprocess.run([sys.executable, os.path.abspath(__file__), kind], check=False)

@@ -6,7 +6,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dmm_net_amd import ops
+from dmm_net_amd import _lib, ops
 
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -30,11 +30,10 @@ for (n, m) in [(10, 50), (5, 50), (20, 200), (32, 256), (16, 64)]:
         C = -torch.rand((B, n, m), generator=g, device=dev)
         row = []
         res = []
-        for k in ("0", "1"):
-            os.environ["DMM_SOLVER_KERNEL"] = k
-            row.append(t_us(lambda: ops.relax_solve(C, 20, 5, 0.1)))
-            res.append(ops.relax_solve(C, 20, 5, 0.1))
+        for k in (0, 1):
+            with _lib.options(SOLVER_KERNEL=k):
+                row.append(t_us(lambda: ops.relax_solve(C, 20, 5, 0.1)))
+                res.append(ops.relax_solve(C, 20, 5, 0.1))
         same = all(torch.equal(res[0][key], res[1][key]) for key in ("X", "R", "iters", "cost"))
         print(f"solver {n:2d} x {m:3d}  B={B:5d}:  thread-per-column {row[0]:8.1f} us   row-split {row[1]:8.1f} us   "
               f"identical={same}", flush=True)
-os.environ.pop("DMM_SOLVER_KERNEL", None)
