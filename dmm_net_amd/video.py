@@ -387,6 +387,8 @@ class FrameLoop:
         self._side = {}
         self._plan = None
         self._prefetched = None              # (key, encoder output) of the next clip's first chunk (run(next_frames=...))
+        self.record_iters = False            # fixed-slot path: keep every step's solver iteration counts in
+        self.last_iters = None               # ``last_iters`` [T,B] int32 (one small device copy per step; tests)
 
     def _frames_per_chunk(self, T: int, pipelined: bool = False) -> int:
         """``encode_ahead``, or by clip length when it is 0.  The ResNet gets more efficient with the batch (4 videos of
@@ -554,6 +556,7 @@ class FrameLoop:
         history, state, prev_mask, tplt_valid = [], None, y0, None
         hist_all = torch.empty((T, B, O, H * W), dtype=torch.float32, device=dev)
         lab_all = torch.empty((T, B, H, W), dtype=torch.uint8, device=dev) if on_labels is not None else None
+        it_all = torch.full((T, B), -1, dtype=torch.int32, device=dev) if self.record_iters else None
         next_chunk = None
         for t in range(T):
             extra = [n <= t for n in n_frames]
@@ -599,6 +602,8 @@ class FrameLoop:
                         for tt in range(T)]
                 plan.tables[:T].copy_(_lib.small_to_device(rows, torch.int32, dev))
             plan.run_step(self.graph)
+            if it_all is not None:
+                it_all[t].copy_(plan.out[3])
             if self.refine is not None:
                 features = chunk if chunks[kc][1] == 1 else _slice_batch(chunk, j * B, (j + 1) * B)
                 live = plan.cur[0] > 0
@@ -626,6 +631,7 @@ class FrameLoop:
                     if not extra[b]:
                         on_labels(b, t, lab_all[t, b])
             history.append(hist_all[t])
+        self.last_iters = it_all
         return history
 
     # model_encoder.py:115-134

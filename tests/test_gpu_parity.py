@@ -1276,7 +1276,7 @@ def test_fp16_state_solver_is_within_its_stated_tolerance(P, O, it, pj):
         r32 = ops.relax_match(cos, inter, ap, at, sc, **kw)
         r16 = ops.relax_match(cos, inter, ap, at, sc, state="f16", **kw)
         assert torch.equal(r16["sim"], r32["sim"])                          # the cost table is the fp32 one
-        worst = 0.0
+        worst, compared, exited, rows, rows_decided = 0.0, 0, 0, 0, 0
         for b in range(B):
             Ob = O if mv is None else int(mv[b])
             Nb = P if nv is None else int(nv[b])
@@ -1284,7 +1284,9 @@ def test_fp16_state_solver_is_within_its_stated_tolerance(P, O, it, pj):
                 assert float(r16["Rb"][b].abs().sum()) == 0.0 and int(r16["iters"][b]) == 0
                 continue
             if int(r32["iters"][b]) != it or int(r16["iters"][b]) != it:
-                continue                                                    # an exit fired: its step is order / precision chaotic
+                exited += 1                                                 # an exit fired: its step is order / precision chaotic
+                continue
+            compared += 1
             R32, R16 = r32["R"][b, :Ob], r16["R"][b, :Ob]
             err = float((R32 - R16).abs().max())
             worst = max(worst, err)
@@ -1292,10 +1294,25 @@ def test_fp16_state_solver_is_within_its_stated_tolerance(P, O, it, pj):
             assert float((r32["match_score"][b, :Ob] - r16["match_score"][b, :Ob]).abs().max()) <= 2e-2
             assert float((r32["det_score"][b, :Ob] - r16["det_score"][b, :Ob]).abs().max()) <= 2e-2
             if Nb >= 2:
-                top2 = R32[:, :max(Nb, 2)].topk(2, dim=1).values
-                decided = (top2[:, 0] - top2[:, 1]) > 0.02
-                assert bool((R32.argmax(1) == R16.argmax(1))[decided].all()), b
-        record_achieved(f"f16_solver/{P}x{O}_{it}x{pj}_{'ragged' if ragged else 'dense'}/R_abs_err", worst)
+                top = R32[:, :max(Nb, 2)].topk(2, dim=1)
+                decided = (top.values[:, 0] - top.values[:, 1]) > 0.02
+                same = R32.argmax(1) == R16.argmax(1)
+                assert bool(same[decided].all()), b
+                # a near tie of the fp32 result: the fp16 pick must at least be one of its two candidates
+                a16 = R16[:, :max(Nb, 2)].argmax(1)
+                assert bool(((a16 == top.indices[:, 0]) | (a16 == top.indices[:, 1]))[~decided].all()), b
+                rows += int(decided.numel())
+                rows_decided += int(decided.sum())
+        tag = f"f16_solver/{P}x{O}_{it}x{pj}_{'ragged' if ragged else 'dense'}"
+        # what the assertions above actually covered: frames compared / skipped because an exit fired, and the share of
+        # rows whose fp32 decision is not a near tie (argmax identity is asserted on exactly those)
+        record_achieved(tag + "/R_abs_err", worst)
+        record_achieved(tag + "/frames_compared", float(compared))
+        record_achieved(tag + "/frames_skipped_exit_fired", float(exited))
+        record_achieved(tag + "/rows_decided_fraction", rows_decided / rows if rows else 1.0)
+        assert compared >= (B if not ragged else 1), (compared, exited)     # uniform inputs, <= 40 iterations: no exit
+        if rows:
+            assert rows_decided / rows >= 0.5, (rows_decided, rows)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "structured"])
@@ -1312,12 +1329,14 @@ def test_fp16_state_solver_on_config5_golden(kind):
     r = ops.relax_match(cos, inter, ap, at, dev(fr.proposal_score)[None], score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1,
                         is_test=1, state="f16")
     R = r["R"][0].cpu().numpy()
-    if int(c["n_xlist"]) - 1 == 20 and int(r["iters"][0]) == 20:
-        err = float(np.abs(R - c["R"]).max())
-        record_achieved(f"f16_solver/g4_c5_{kind}/R_abs_err", err)
-        assert err <= 5e-3, err
-        top2 = np.sort(c["R"], axis=1)[:, -2:]
-        decided = (top2[:, 1] - top2[:, 0]) > 0.02
-        assert np.array_equal(R.argmax(1)[decided], c["argmax"][decided])
-    else:
-        record_achieved(f"f16_solver/g4_c5_{kind}/iters_ref_vs_f16", float(int(c["n_xlist"]) - 1 - int(r["iters"][0])))
+    # the reference ran all 20 iterations on both frames (recorded in the golden); so must the fp16-state solver -- a
+    # different count would be a different fixed point, not a rounding difference
+    assert int(c["n_xlist"]) - 1 == 20 and int(r["iters"][0]) == 20, (int(c["n_xlist"]) - 1, int(r["iters"][0]))
+    err = float(np.abs(R - c["R"]).max())
+    record_achieved(f"f16_solver/g4_c5_{kind}/R_abs_err", err)
+    assert err <= 5e-3, err
+    top2 = np.sort(c["R"], axis=1)[:, -2:]
+    record_achieved(f"f16_solver/g4_c5_{kind}/min_top2_gap_of_the_reference", float((top2[:, 1] - top2[:, 0]).min()))
+    # FULL argmax identity, every row (no near-tie filter): the reference's top-2 gap on these frames is ~1
+    assert np.array_equal(R.argmax(1), c["argmax"])
+    assert np.array_equal(r["Rb"][0].cpu().numpy().argmax(1), c["argmax"])

