@@ -53,8 +53,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="2", choices=("2", "3", "4", "5", "loop"),
-                    help="BASELINE configs index + 1; loop = the evaluator's frame loop")
+    ap.add_argument("--config", default="2", choices=("2", "3", "4", "5", "loop", "train"),
+                    help="BASELINE configs index + 1; loop = the evaluator's frame loop; train = the layer's training "
+                         "form (forward + backward) with per-kernel rooflines")
     ap.add_argument("--no-others", action="store_true", help="default run: skip the compact other_configs entries")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 512 for "
                                                           "config 2 / 3 / 5)")
@@ -62,6 +63,8 @@ def parse():
     ap.add_argument("--pipeline", action="store_true", help="force the 2-lane schedule")
     ap.add_argument("--parts", type=int, default=0, help="slices of the batch in the 2-lane schedule (default 2)")
     ap.add_argument("--nchw-encoder", action="store_true", help="config 3: the round-1 NCHW / all-MIOpen encoder")
+    ap.add_argument("--contiguous-planes", action="store_true", help="config 5: packed [B,K,H,W] planes (round 3's layout) "
+                                                                     "instead of the 128-byte-aligned plane stride")
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
                                                               "fp16-state one BASELINE configs[4] names")
@@ -74,7 +77,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank control flow on a single-GPU box)")
     a = ap.parse_args()
-    a.config = a.config if a.config == "loop" else int(a.config)
+    a.config = a.config if a.config in ("loop", "train") else int(a.config)
     return a
 
 
@@ -308,11 +311,22 @@ def bench_layer(R, ci):
     odt = mdt if (ci == 5 and not args.f32_out) else torch.float32   # config 5: matched masks stay in the storage type
     g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + ci + 1000 * rank)
 
+    # config 5: the 16-bit planes sit at a 128-byte-aligned plane stride (ops.alloc_planes; the C ABI takes the stride) --
+    # what a producer that owns its buffers hands over; --contiguous-planes = the packed [B,K,H,W] layout of round 3,
+    # where every other 255 x 255 fp16 plane starts 2 bytes off a dword
+    aligned = ci == 5 and not args.contiguous_planes
+
+    def planes(b, k):
+        if not aligned:
+            t = torch.rand((b, k, H, W), generator=g, device=dev)
+            return t if mdt == torch.float32 else t.to(mdt)
+        t = ops.alloc_planes(b, k, H, W, mdt, dev, 128, fill=0)
+        for b0 in range(0, b, 64):
+            t[b0:b0 + 64].copy_(torch.rand((min(64, b - b0), k, H, W), generator=g, device=dev))
+        return t
+
     def make_inputs(b):
-        pm = torch.rand((b, N, H, W), generator=g, device=dev)
-        tm = torch.rand((b, M, H, W), generator=g, device=dev)
-        if mdt != torch.float32:
-            pm, tm = pm.to(mdt), tm.to(mdt)
+        pm, tm = planes(b, N), planes(b, M)
         return (pm, tm, torch.randn((b, N, D), generator=g, device=dev), torch.randn((b, M, D), generator=g, device=dev),
                 torch.rand((b, N), generator=g, device=dev))
     inputs = make_inputs(B)
@@ -321,7 +335,8 @@ def bench_layer(R, ci):
     # config 5 = "fp16 Sinkhorn with fp32 accumulate": the opt-in fp16-state solver (tolerance mode, include/dmm_match.h (3c))
     sstate = "f16" if (ci == 5 and not getattr(args, "f32_solver", False)) else "f32"
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=mdt, pipeline=False if args.no_pipeline else (True if args.pipeline else None),
-                           time_kernels=True, out_dtype=odt, parts=args.parts or 2, solver_state=sstate)
+                           time_kernels=True, out_dtype=odt, parts=args.parts or 2, solver_state=sstate,
+                           out_plane_align=128 if aligned else 0)
     kw = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=1)
     ev = []
 
@@ -363,7 +378,8 @@ def bench_layer(R, ci):
         "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[{ci - 1}]: {N} proposals x {M} templates, 255x255 "
                                 f"{'fp32' if ci == 2 else 'fp16'} masks, D=512, 20 outer x 5 inner relax iterations, "
-                                "forward is_test=1, uniform-random masks"),
+                                "forward is_test=1, uniform-random masks"
+                                + ("; planes at a 128-byte-aligned plane stride (65088 elements), in and out" if aligned else "")),
                    "frames_per_gpu_per_step": B, "mean_outer_iterations": round(it_mean, 3),
                    "sharding": f"frames x{world} (no collective in the forward)", "schedule": plan.schedule_name(),
                    "solver_state": sstate},
@@ -392,7 +408,7 @@ def bench_layer(R, ci):
             if b > B:
                 continue
             p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt, graph=b <= 32,
-                                                     solver_state=sstate)
+                                                     solver_state=sstate, out_plane_align=128 if aligned else 0)
             inp = inputs if b == B else tuple(t[:b] for t in inputs)
             ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
             sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}
@@ -404,7 +420,8 @@ def bench_layer(R, ci):
         torch.cuda.empty_cache()
         if not args.no_traffic:
             pref = "dmm::iou_counts_kernel" if ci == 2 else "dmm::iou_counts_tl_kernel"
-            extra = ["--config", str(ci), "--frames", str(B)] + (["--no-pipeline"] if args.no_pipeline else [])
+            extra = ["--config", str(ci), "--frames", str(B)] + (["--no-pipeline"] if args.no_pipeline else []) + \
+                (["--contiguous-planes"] if args.contiguous_planes else [])
             t = pmc_traffic(extra, [pref, "dmm::mask_mix_rows_kernel"])
             if t is not None:
                 out["roofline"]["traffic"] = t[pref]
@@ -738,6 +755,110 @@ def bench_config4(R):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the TRAINING form of the layer (is_test = 0, targets): forward + backward, per-kernel roofline
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_train(R, Bs=(64, 512)):
+    """configs[1]'s shape through the layer as the trainer calls it (dmm_model.py:130-132: is_test=0 with targets):
+    dual IoU counts (templates AND targets in one pass over the proposals, match_helper.py:30-49 + match_model.py:83-89),
+    cosine, solver, the train-mode mix (every plane with R > 0.01, match_model.py:126-129,144), matching loss; backward
+    through mix, taped solver and feature similarity.  ``value`` = frames/s of forward + backward through autograd
+    (``autograd.match_layer_batched``) at the larger batch; every HBM-bound kernel gets HIP-event time / algorithmic bytes."""
+    from dmm_net_amd import _lib, autograd, ops, synth
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    _lib.load()
+    c = synth.CONFIGS[2]
+    N, M, H, W, D = c["P"], c["O"], c["H"], c["W"], c["D"]
+    HW = H * W
+    cfg = dict(score_weight=0.3, max_iter=20, proj_iter=5, lr=0.1, is_test=0)
+    g = torch.Generator(device=dev).manual_seed(synth.BASE_SEED + 7 + 1000 * rank)
+    per_B = {}
+    for B in ((args.frames,) if args.frames else Bs):
+        pm = torch.rand((B, N, H, W), generator=g, device=dev)
+        tm = torch.rand((B, M, H, W), generator=g, device=dev)
+        tg = (torch.rand((B, M, H, W), generator=g, device=dev) > 0.5).float()
+        pf = torch.randn((B, N, D), generator=g, device=dev, requires_grad=True)
+        tf = torch.randn((B, M, D), generator=g, device=dev, requires_grad=True)
+        sc = torch.rand((B, N), generator=g, device=dev)
+        dfull = torch.rand((B, M, H, W), generator=g, device=dev)          # upstream gradient of full_outmask (a loss map)
+
+        def step(k):
+            pf.grad = tf.grad = None
+            full, ms, ds, loss, _ = autograd.match_layer_batched(pf, pm, tf, tm, sc, tg, **cfg)
+            torch.autograd.backward([full, loss], [dfull, torch.ones_like(loss)])
+        steps = max(5, args.steps // (4 if B >= 256 else 1))
+        elapsed = R.timed(step, steps, max(2, args.warmup // 2))
+        assert bool(torch.isfinite(pf.grad).all()) and float(pf.grad.abs().sum()) > 0 and bool(torch.isfinite(tf.grad).all())
+        # ---- the same kernels one by one, HIP events on the stream they run on --------------------------------------
+        with torch.no_grad():
+            (inter, ap, at), (gi, gat) = ops.iou_counts_dual(pm, tm, tg)
+            pn, pnorm = ops.feature_normalize(pf, want_norms=True)
+            tn, tnorm = ops.feature_normalize(tf, want_norms=True)
+            cos = ops.cosine(tn, pn)
+            r = ops.relax_match(cos, inter, ap, at, sc, **cfg)
+            Rb, sim = r["Rb"], r["sim"]
+            nnz = int((Rb[:, :, :N] != 0).sum())                           # planes the train-mode mix streams (R > 0.01)
+            loss, gt, _ = autograd.matching_loss(pm, tg, cos, counts=(gi, ap, gat))
+            dRb = ops.mask_mix_bwd(Rb, pm, dfull)
+            dsim = ops.relax_match_bwd(sim, sc, dRb, None, None, max_iter=20, proj_iter=5, lr=0.1, is_test=0)
+            reps = 20 if B <= 64 else 8
+            t = {
+                "iou_counts_dual": quick_ms(lambda: ops.iou_counts_dual(pm, tm, tg), reps, dev=dev),
+                "feature_sim_fwd (normalise x2 + cosine)": quick_ms(lambda: ops.cosine(
+                    ops.feature_normalize(tf, want_norms=True)[0], ops.feature_normalize(pf, want_norms=True)[0]), reps, dev=dev),
+                "relax_match (train mode)": quick_ms(lambda: ops.relax_match(cos, inter, ap, at, sc, **cfg), reps, dev=dev),
+                "mask_mix (train mode)": quick_ms(lambda: ops.mask_mix(Rb, pm), reps, dev=dev),
+                "matching_loss (greedy one-hot + mse)": quick_ms(lambda: autograd.matching_loss(pm, tg, cos, counts=(gi, ap, gat)),
+                                                                 reps, dev=dev),
+                "mask_mix_bwd": quick_ms(lambda: ops.mask_mix_bwd(Rb, pm, dfull), reps, dev=dev),
+                "relax_match_bwd": quick_ms(lambda: ops.relax_match_bwd(sim, sc, dRb, None, None, max_iter=20, proj_iter=5,
+                                                                        lr=0.1, is_test=0), reps, dev=dev),
+                "feature_sim_bwd": quick_ms(lambda: ops.feature_sim_bwd(dsim, cos, gt, torch.ones_like(loss), 0.3, tf, pf,
+                                                                        tn, pn, tnorm, pnorm), reps, dev=dev),
+            }
+        # algorithmic bytes per launch (fp32 planes): every plane the kernel must see, once
+        alg = {
+            "iou_counts_dual": B * ((N + 2 * M) * HW * 4 + 2 * M * N * 4),               # proposals + templates + targets
+            "mask_mix (train mode)": nnz * HW * 4 + B * M * HW * 4,                         # selected planes in, M planes out
+            "mask_mix_bwd": nnz * HW * 4 + B * M * HW * 4,                                  # selected planes + d full_outmask
+        }
+        kern = {}
+        for k, ms in t.items():
+            e = {"ms": round(ms, 4)}
+            if k in alg:
+                gbs = alg[k] / (ms * 1e-3) / 1e9
+                e.update(bound="hbm", algorithmic_bytes=int(alg[k]), achieved_GBps=round(gbs, 1),
+                         frac=round(gbs / HBM_PEAK_GBS, 4))
+            else:
+                e.update(bound="latency / VALU (no plane traffic)")
+            kern[k] = e
+        per_B[str(B)] = {"fwd_bwd_ms": round(elapsed / steps * 1e3, 4), "frames_per_s": round(B * steps / elapsed, 1),
+                         "steps": steps, "selected_planes_per_frame": round(nnz / B, 2),
+                         "kernel_sum_ms": round(sum(t.values()), 4), "kernels": kern}
+        del pm, tm, tg, dfull
+        torch.cuda.empty_cache()
+    big = per_B[max(per_B, key=int)]
+    Bbig = int(max(per_B, key=int))
+    dual = big["kernels"]["iou_counts_dual"]
+    out = {
+        "metric": "frames/sec (cost+match layer, TRAINING form: is_test=0 with targets, forward + backward) at N=50 "
+                  "proposals, M=10 templates, 255x255",
+        "value": round(world * big["frames_per_s"], 1), "unit": "frames/s", "n_gpus": world, "steps": big["steps"],
+        "warmup": max(2, args.warmup // 2), "ms_per_step": big["fwd_bwd_ms"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1] shape in the trainer's form: {N} proposals x {M} templates, 255x255 fp32 "
+                               "masks, D=512, targets, is_test=0 (mix over every plane with R > 0.01), 20 x 5 relax "
+                               "iterations, matching loss; forward + backward through autograd.match_layer_batched; "
+                               "uniform-random masks",
+                   "frames_per_gpu_per_step": Bbig, "by_batch": per_B},
+        "roofline": {"bound": "hbm", "kernel": "dmm::iou_counts_tl_kernel / iou_counts_kernel (dual: templates + targets)",
+                     "achieved": dual["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dual["frac"],
+                     "traffic": None, "algorithmic_bytes_per_launch": dual["algorithmic_bytes"],
+                     "frames_per_launch": Bbig, "avg_launch_ms": dual["ms"]},
+    }
+    return out
+
+
 def compact(out):
     """What ``other_configs`` keeps of a workload's line."""
     c = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"],
@@ -751,6 +872,11 @@ def compact(out):
               "mean_outer_iterations"):
         if k in out["config"]:
             c[k] = out["config"][k]
+    if "by_batch" in out["config"]:                              # training form: per-kernel ms / fraction of the HBM peak
+        c["by_batch"] = {b: {"fwd_bwd_ms": v["fwd_bwd_ms"], "selected_planes_per_frame": v["selected_planes_per_frame"],
+                             "kernels": {k: ({"ms": e["ms"], "frac": e["frac"]} if "frac" in e else {"ms": e["ms"]})
+                                         for k, e in v["kernels"].items()}}
+                         for b, v in out["config"]["by_batch"].items()}
     return c
 
 
@@ -764,6 +890,8 @@ def main():
         out = bench_config4(R)
     elif args.config == "loop":
         out = bench_frame_loop(R)
+    elif args.config == "train":
+        out = bench_train(R)
     else:
         out = bench_layer(R, args.config)
     if "per_rank" not in out:
@@ -774,7 +902,8 @@ def main():
         others = {}
         for name, fn, kw in (("config5", lambda r: bench_layer(r, 5), dict(steps=30, warmup=5, frames=0)),
                              ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
-                             ("frame_loop", bench_frame_loop, dict(frames=0))):
+                             ("frame_loop", bench_frame_loop, dict(frames=0)),
+                             ("train", bench_train, dict(steps=40, warmup=6, frames=0))):
             a2 = copy.copy(args)
             a2.no_extras = True
             for k, v in kw.items():

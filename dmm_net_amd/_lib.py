@@ -25,7 +25,7 @@ SYMBOLS = (
     "dmm_set_option", "dmm_get_option", "dmm_reset_options",
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_feature_sim_bwd_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
-    "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
+    "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_shared_to", "dmm_mask_mix_shared_frames", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
     "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad",
     "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
@@ -130,6 +130,10 @@ def load():
     L.dmm_mask_mix_to.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_int, c_i64,
                                   c_i64, vp]
     L.dmm_mask_mix_to.restype = c_int
+    L.dmm_mask_mix_shared_to.argtypes = L.dmm_mask_mix_to.argtypes
+    L.dmm_mask_mix_shared_to.restype = c_int
+    L.dmm_mask_mix_shared_frames.argtypes = L.dmm_mask_mix_frames.argtypes
+    L.dmm_mask_mix_shared_frames.restype = c_int
     L.dmm_mask_mix_bwd.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, vp]
     L.dmm_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     L.dmm_workspace_bytes.restype = sz
@@ -191,7 +195,7 @@ def check(rc: int, what: str):
 OPTIONS = {name: k for k, name in enumerate((
     "COST_KERNEL", "COST_TINY_FRAMES", "SOLVER_KERNEL", "FORCE_WIDE", "COSINE_KERNEL", "COST_WGS", "COST_SMALL_WGS",
     "COST_TL_WGS", "COST_XCD", "MIX_XCD", "MIX_WGS", "MIX_STEPQ", "MIX_ALIGN", "MIX_NT", "SOLVER_HELPER_MAX", "NMS_WAVE",
-    "COS_ROWS_MIN_N", "GEMM_TUNE", "PACK_VARIANT", "SMALL_FUSED"))}
+    "COS_ROWS_MIN_N", "GEMM_TUNE", "PACK_VARIANT", "SMALL_FUSED", "MIX_SHARED"))}
 
 
 def set_option(name: str, value: int):

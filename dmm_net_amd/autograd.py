@@ -80,7 +80,7 @@ class _MatchLayerFn(torch.autograd.Function):
             cos = cos / T
         r = ops.relax_match(cos, inter, ap, at, sc, score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter,
                             lr=lr, is_test=is_test, n_valid=n_valid, m_valid=m_valid)
-        full = ops.mask_mix(r["Rb"], pm, n_valid, m_valid)
+        full = ops.mask_mix(r["Rb"], pm, n_valid, m_valid, shared=not is_test)   # train mode: rows share planes
         B = pf.shape[0]
         cost_loss = pf.new_zeros((B,))
         gt, live, cnt = None, None, None

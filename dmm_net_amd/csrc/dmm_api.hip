@@ -24,14 +24,16 @@ static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
     /* COST_XCD */ 1,          /* MIX_XCD */ 1,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
     /* MIX_ALIGN */ 128,       /* MIX_NT */ 3,             /* SOLVER_HELPER_MAX */ 512, /* NMS_WAVE */ 1,
     /* COS_ROWS_MIN_N */ 65,   /* GEMM_TUNE */ 1,          /* PACK_VARIANT */ 4,    /* SMALL_FUSED */ 1,
+    /* MIX_SHARED */ -1,
 };
 static std::atomic<int> g_opts[DMM_OPT_COUNT] = {
     {kOptDefaults[0]},  {kOptDefaults[1]},  {kOptDefaults[2]},  {kOptDefaults[3]},  {kOptDefaults[4]},
     {kOptDefaults[5]},  {kOptDefaults[6]},  {kOptDefaults[7]},  {kOptDefaults[8]},  {kOptDefaults[9]},
     {kOptDefaults[10]}, {kOptDefaults[11]}, {kOptDefaults[12]}, {kOptDefaults[13]}, {kOptDefaults[14]},
     {kOptDefaults[15]}, {kOptDefaults[16]}, {kOptDefaults[17]}, {kOptDefaults[18]}, {kOptDefaults[19]},
+    {kOptDefaults[20]},
 };
-static_assert(DMM_OPT_COUNT == 20, "kOptDefaults / g_opts list every option");
+static_assert(DMM_OPT_COUNT == 21, "kOptDefaults / g_opts list every option");
 int opt(int key) { return g_opts[key].load(std::memory_order_relaxed); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -81,7 +83,8 @@ extern "C" int dmm_abi_version(void) { return DMM_ABI_VERSION; }
 extern "C" int dmm_set_option(int option, int value) {
     if (option < 0 || option >= DMM_OPT_COUNT) return DMM_ERR_BAD_ARG;
     switch (option) {                                            // ranges: a bad value must not reach a launch computation
-        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED:
+            if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD: case DMM_OPT_MIX_XCD:
         case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: if (value < 0 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_ALIGN: if (value != 16 && value != 32 && value != 64 && value != 128) return DMM_ERR_BAD_ARG; break;
@@ -199,6 +202,10 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
                              max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,
                              nullptr, stream);
     if (rc != DMM_OK) return rc;
+    // train mode keeps every R > 0.01: the rows share planes -> the union of the supports is streamed once
+    if (!is_test)
+        return dmm_mask_mix_shared_to(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                                      DMM_F32, (int64_t)M * HW, HW, stream);
     return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
                         (int64_t)M * HW, HW, stream);
 }
@@ -271,6 +278,10 @@ extern "C" int dmm_match_forward_packed(const void *masks_p, const uint64_t *pac
                              max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,
                              nullptr, stream);
     if (rc != DMM_OK) return rc;
+    // train mode keeps every R > 0.01: the rows share planes -> the union of the supports is streamed once
+    if (!is_test)
+        return dmm_mask_mix_shared_to(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                                      DMM_F32, (int64_t)M * HW, HW, stream);
     return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
                         (int64_t)M * HW, HW, stream);
 }

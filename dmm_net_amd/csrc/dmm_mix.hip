@@ -13,6 +13,7 @@
 namespace dmm {
 
 constexpr int kMixThreads = 256;
+static thread_local bool g_mix_shared_call = false;   // set by dmm_mask_mix_shared_* around the common entry point
 
 // ---------------------------------------------------------------------------------------------
 // One workgroup = one output row m of one frame over a pixel range.
@@ -369,6 +370,254 @@ static int mask_mix_typed(const float *Rb, const T *masks_p, int B, int N, int M
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows that SHARE planes (train mode: logic = R > 0.01, match_model.py:126-129 -- at BASELINE configs[1] every template
+// row keeps ~13 of the 50 proposals, 133 (row, plane) pairs per frame over 50 distinct planes).  The row kernel above
+// streams a plane once per ROW that uses it; here one workgroup owns a pixel range of a frame, streams every plane of
+// the UNION of the rows' supports exactly once and fans it into the rows' accumulators: (|union| + M) planes of traffic
+// instead of (pairs + M).  Per row the arithmetic is the row kernel's -- acc = fma(w, v, acc) from zero over the row's
+// non-zero weights in ascending column order -- so both kernels agree bit for bit.  Test mode (one plane per row, nothing
+// shared) stays on the row kernel: one read and one write stream per workgroup beat 2 M streams there (-15 %).
+// grid = (pixel splits, B); LDS: the union's columns, a row bit mask per column, the weights [column][row].
+// ---------------------------------------------------------------------------------------------
+constexpr int kSharedLoads = 8;                                           // planes in flight per lane
+
+// the union of the rows' supports, compacted in column order (one thread per proposal column, one global round trip per
+// row); returns the number of union columns.  rowmask_s[e] bit m = row m uses column col_s[e].
+template <int MT>
+__device__ __forceinline__ int shared_support(const float *__restrict__ Rb_b, int Pp, int Nb, int Mb, int *col_s,
+                                              unsigned *rowmask_s, float *w_c, int *wcnt_s) {
+    const int n = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float w[MT];
+    unsigned mask = 0u;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        w[m] = (m < Mb && n < Nb) ? Rb_b[(int64_t)m * Pp + n] : 0.0f;
+        mask |= (w[m] != 0.0f) ? (1u << m) : 0u;
+    }
+    const unsigned long long bal = __ballot(mask != 0u);
+    if (lane == 0) wcnt_s[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < kMixThreads / 64; ++k) base += k < wave ? wcnt_s[k] : 0;
+    if (mask != 0u) {
+        const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        col_s[pos] = n;
+        rowmask_s[pos] = mask;
+        if (w_c) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) w_c[pos * MT + m] = w[m];
+        }
+    }
+    __syncthreads();
+    return wcnt_s[0] + wcnt_s[1] + wcnt_s[2] + wcnt_s[3];
+}
+
+__device__ __forceinline__ unsigned uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+template <typename T, typename TO, int MT, int NT>
+__global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const float *__restrict__ Rb,
+                                                                      const T *__restrict__ masks_p, int N, int M, int Pp,
+                                                                      int HW, int64_t sp_b, int64_t sp_n,
+                                                                      const int32_t *__restrict__ n_valid,
+                                                                      const int32_t *__restrict__ m_valid,
+                                                                      TO *__restrict__ out, int64_t so_b, int64_t so_m,
+                                                                      int steps_per_wg) {
+    constexpr int E = 4;                                                  // pixels per lane and step (16 bytes of fp32)
+    __shared__ float w_c[DMM_MAX_PROPOSALS * MT];
+    __shared__ int col_s[DMM_MAX_PROPOSALS];
+    __shared__ unsigned rowmask_s[DMM_MAX_PROPOSALS];
+    __shared__ int wcnt_s[kMixThreads / 64];
+    const int b = blockIdx.y;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    const int cnt = shared_support<MT>(Rb + (int64_t)b * M * Pp, Pp, Nb, Mb, col_s, rowmask_s, w_c, wcnt_s);
+    const T *Pb = frame_base(masks_p, b, sp_b);
+    TO *ob = out + (int64_t)b * so_b;
+    const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
+    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_end = min(nsteps, s_begin + steps_per_wg);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int x = (s * kMixThreads + threadIdx.x) * E;
+        float acc[MT][E];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < E; ++k) acc[m][k] = 0.0f;
+        for (int e0 = 0; e0 < cnt; e0 += kSharedLoads) {
+            float v[kSharedLoads][E];
+#pragma unroll
+            for (int u = 0; u < kSharedLoads; ++u) {
+                const int e = e0 + u < cnt ? e0 + u : cnt - 1;
+                mix_load<T, E, (NT & 1) != 0>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kSharedLoads; ++u) {
+                // wave-uniform: scalar branches per row (0 = past the end of the union)
+                const unsigned rows = e0 + u < cnt ? uniform_u32(rowmask_s[e0 + u]) : 0u;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (rows & (1u << m)) {
+                        const float w = uniform_f32(w_c[(e0 + u) * MT + m]);
+#pragma unroll
+                        for (int k = 0; k < E; ++k) acc[m][k] = __builtin_fmaf(w, v[u][k], acc[m][k]);
+                    }
+                }
+            }
+        }
+        if (x >= HW) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m >= M) continue;
+            TO *o = ob + (int64_t)m * so_m + x;
+            if (x + E - 1 < HW) {
+                if (sizeof(TO) == 4) {
+                    float4u t;
+                    t.x = acc[m][0]; t.y = acc[m][1]; t.z = acc[m][2]; t.w = acc[m][3];
+                    if (NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<float4u *>(o));
+                    else *reinterpret_cast<float4u *>(o) = t;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < E; ++k) MixOut<TO>::store1(o + k, acc[m][k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; ++k)
+                    if (x + k < HW) MixOut<TO>::store1(o + k, acc[m][k]);
+            }
+        }
+    }
+}
+
+template <typename T, typename TO>
+static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
+                                 int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
+                                 int64_t so_m, hipStream_t stream) {
+    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    // ~16 k workgroups of 1-2 steps (4-8 KiB of every plane of the union) when the batch is large; one step each otherwise
+    int steps_per_wg = (int)(((int64_t)B * nsteps + 16383) / 16384);
+    if (steps_per_wg < 1) steps_per_wg = 1;
+    if (steps_per_wg > 4) steps_per_wg = 4;
+    const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
+    const int nt_mode = opt(DMM_OPT_MIX_NT);
+#define DMM_MIXS_LAUNCH(MT_, NT_)                                                                                       \
+    hipLaunchKernelGGL((mask_mix_shared_kernel<T, TO, MT_, NT_>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb,    \
+                       masks_p, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg)
+#define DMM_MIXS_PICK(MT_)                       \
+    do {                                         \
+        if ((nt_mode & 3) == 3) DMM_MIXS_LAUNCH(MT_, 3); \
+        else DMM_MIXS_LAUNCH(MT_, 0);            \
+    } while (0)
+    if (M <= 8) DMM_MIXS_PICK(8);
+    else if (M <= 16) DMM_MIXS_PICK(16);
+    else DMM_MIXS_PICK(32);
+#undef DMM_MIXS_PICK
+#undef DMM_MIXS_LAUNCH
+    return check_launch();
+}
+
+// Backward of the mix, rows sharing planes: one workgroup = a pixel range of a frame; d full_outmask of the M rows is
+// loaded once per step (registers), every plane of the union once, and each (row, plane) pair of the support gets its
+// 4-pixel dot product reduced over the wave and added to the pair's LDS accumulator; one global atomic per pair and
+// workgroup at the end.  (pairs + M) -> (|union| + M) planes of traffic; the pair sums are order-free fp32 atomics as in
+// the row kernel (the workgroups of a row already raced there).
+template <typename T, int MT>
+__global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const float *__restrict__ Rb,
+                                                                          const T *__restrict__ masks_p,
+                                                                          const float *__restrict__ dout, int N, int M,
+                                                                          int Pp, int HW, int64_t sp_b, int64_t sp_n,
+                                                                          const int32_t *__restrict__ n_valid,
+                                                                          const int32_t *__restrict__ m_valid,
+                                                                          float *__restrict__ dRb, int steps_per_wg) {
+    constexpr int E = 4;
+    __shared__ float acc_s[DMM_MAX_PROPOSALS * MT];                       // [union column][row]
+    __shared__ int col_s[DMM_MAX_PROPOSALS];
+    __shared__ unsigned rowmask_s[DMM_MAX_PROPOSALS];
+    __shared__ int wcnt_s[kMixThreads / 64];
+    const int b = blockIdx.y;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    if (Mb <= 0) return;
+    const int cnt = shared_support<MT>(Rb + (int64_t)b * M * Pp, Pp, Nb, Mb, col_s, rowmask_s, (float *)nullptr, wcnt_s);
+    if (cnt == 0) return;
+    for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) acc_s[i] = 0.0f;
+    __syncthreads();
+    const T *Pb = frame_base(masks_p, b, sp_b);
+    const float *db = dout + (int64_t)b * M * HW;
+    const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
+    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_end = min(nsteps, s_begin + steps_per_wg);
+    const int lane = threadIdx.x & 63;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int x = (s * kMixThreads + threadIdx.x) * E;
+        float d[MT][E];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < Mb && x + E - 1 < HW) {
+                const float4u t = *reinterpret_cast<const float4u *>(db + (int64_t)m * HW + x);
+                d[m][0] = t.x; d[m][1] = t.y; d[m][2] = t.z; d[m][3] = t.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; ++k) d[m][k] = (m < Mb && x + k < HW) ? db[(int64_t)m * HW + x + k] : 0.0f;
+            }
+        }
+        for (int e0 = 0; e0 < cnt; e0 += kSharedLoads) {
+            float v[kSharedLoads][E];
+#pragma unroll
+            for (int u = 0; u < kSharedLoads; ++u) {
+                const int e = e0 + u < cnt ? e0 + u : cnt - 1;
+                mix_load<T, E, true>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kSharedLoads; ++u) {
+                const unsigned rows = e0 + u < cnt ? uniform_u32(rowmask_s[e0 + u]) : 0u;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (rows & (1u << m)) {
+                        float p = d[m][0] * v[u][0];
+                        p = __builtin_fmaf(d[m][1], v[u][1], p);
+                        p = __builtin_fmaf(d[m][2], v[u][2], p);
+                        p = __builtin_fmaf(d[m][3], v[u][3], p);
+                        p = wave_sum(p);
+                        if (lane == 0) atomicAdd(&acc_s[(e0 + u) * MT + m], p);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) {
+        const int e = i / MT, m = i - e * MT;
+        if (rowmask_s[e] & (1u << m)) atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]], acc_s[i]);
+    }
+}
+
+template <typename T>
+static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp,
+                                     int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                     float *dRb, hipStream_t stream) {
+    DMM_HIP_TRY(hipMemsetAsync(dRb, 0, sizeof(float) * (size_t)B * M * Pp, stream));
+    const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
+    int steps_per_wg = (int)(((int64_t)B * nsteps + 8191) / 8192);
+    if (steps_per_wg < 1) steps_per_wg = 1;
+    if (steps_per_wg > 8) steps_per_wg = 8;
+    const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
+#define DMM_MIXB_LAUNCH(MT_)                                                                                            \
+    hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb, masks_p, \
+                       dout, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg)
+    if (M <= 8) DMM_MIXB_LAUNCH(8);
+    else if (M <= 16) DMM_MIXB_LAUNCH(16);
+    else DMM_MIXB_LAUNCH(32);
+#undef DMM_MIXB_LAUNCH
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // The mix for ANY N, M (tables outside the fast kernel's envelope: it compacts a row's weights into a 256-entry LDS list
 // with one thread per proposal column).  Same arithmetic -- the non-zero weights of the row in ascending column order,
 // acc = fma(w, v, acc) from zero -- with the row walked in place (wave-uniform loads); one thread per pixel.
@@ -442,6 +691,34 @@ extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, 
                 return DMM_ERR_BAD_ARG;
         }
     }
+    // rows that share planes (train mode): DMM_OPT_MIX_SHARED -1 = the caller's entry point decides (dmm_mask_mix_shared_to),
+    // 0 = row kernel always, 1 = union kernel always (tests pin both: bit-identical)
+    const int shared_opt = dmm::opt(DMM_OPT_MIX_SHARED);
+    if (shared_opt == 1 || (shared_opt < 0 && dmm::g_mix_shared_call)) {
+        switch (dtype) {
+            case DMM_F32:
+                return dmm::mask_mix_shared_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n,
+                                                                n_valid, m_valid, (float *)out, so_b, so_m, s);
+            case DMM_F16:
+                if (out_dtype == DMM_F16)
+                    return dmm::mask_mix_shared_typed<dmm::f16_t, dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp,
+                                                                              HW, sp_b, sp_n, n_valid, m_valid,
+                                                                              (dmm::f16_t *)out, so_b, so_m, s);
+                return dmm::mask_mix_shared_typed<dmm::f16_t, float>(Rb, (const dmm::f16_t *)masks_p, B, N, M, Pp, HW,
+                                                                     sp_b, sp_n, n_valid, m_valid, (float *)out, so_b,
+                                                                     so_m, s);
+            case DMM_BF16:
+                if (out_dtype == DMM_BF16)
+                    return dmm::mask_mix_shared_typed<dmm::bf16_t, dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, B, N, M,
+                                                                                Pp, HW, sp_b, sp_n, n_valid, m_valid,
+                                                                                (dmm::bf16_t *)out, so_b, so_m, s);
+                return dmm::mask_mix_shared_typed<dmm::bf16_t, float>(Rb, (const dmm::bf16_t *)masks_p, B, N, M, Pp, HW,
+                                                                      sp_b, sp_n, n_valid, m_valid, (float *)out, so_b,
+                                                                      so_m, s);
+            default:
+                return DMM_ERR_BAD_ARG;
+        }
+    }
     switch (dtype) {
         case DMM_F32:
             return dmm::mask_mix_typed<float, float>(Rb, (const float *)masks_p, B, N, M, Pp, HW, sp_b, sp_n, n_valid,
@@ -464,6 +741,26 @@ extern "C" int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, 
     }
 }
 
+// (4d) the same product for weight tables whose rows share planes: every plane of the union of the supports is streamed
+// once (train mode, match_model.py:126-129,144).  Same result bit for bit.
+extern "C" int dmm_mask_mix_shared_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                                      int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                      void *out, int out_dtype, int64_t so_b, int64_t so_m, dmm_stream_t stream) {
+    dmm::g_mix_shared_call = true;
+    const int rc = dmm_mask_mix_to(Rb, masks_p, dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, out_dtype, so_b,
+                                   so_m, stream);
+    dmm::g_mix_shared_call = false;
+    return rc;
+}
+
+extern "C" int dmm_mask_mix_shared_frames(const float *Rb, const void *const *masks_p_frames, int dtype, int B, int N,
+                                          int M, int Pp, int HW, int64_t sp_n, const int32_t *n_valid,
+                                          const int32_t *m_valid, float *out, int64_t so_b, int64_t so_m,
+                                          dmm_stream_t stream) {
+    return dmm_mask_mix_shared_to(Rb, (const void *)masks_p_frames, dtype, B, N, M, Pp, HW, dmm::kFrameTable, sp_n, n_valid,
+                                  m_valid, out, DMM_F32, so_b, so_m, stream);
+}
+
 extern "C" int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
                             int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *out,
                             int64_t so_b, int64_t so_m, dmm_stream_t stream) {
@@ -480,6 +777,21 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
     if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW) return DMM_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dmm::opt(DMM_OPT_MIX_SHARED) != 0) {                             // default: planes of the union streamed once
+        switch (dtype) {
+            case DMM_F32:
+                return dmm::mask_mix_bwd_shared_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n,
+                                                             n_valid, m_valid, dRb, s);
+            case DMM_F16:
+                return dmm::mask_mix_bwd_shared_typed<dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, dout, B, N, M, Pp, HW,
+                                                                  sp_b, sp_n, n_valid, m_valid, dRb, s);
+            case DMM_BF16:
+                return dmm::mask_mix_bwd_shared_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, dout, B, N, M, Pp, HW,
+                                                                   sp_b, sp_n, n_valid, m_valid, dRb, s);
+            default:
+                return DMM_ERR_BAD_ARG;
+        }
+    }
     switch (dtype) {
         case DMM_F32:
             return dmm::mask_mix_bwd_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n, n_valid,

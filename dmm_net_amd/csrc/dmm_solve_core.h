@@ -829,8 +829,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 template <int MT, int NG>
 __device__ __forceinline__ int relax_core_h(const float (&C)[MT], int n, int m, int col, const RelaxParams prm,
-                                            BlockRed<MT, NG> &red, float *accbuf /* LDS [MT][64 NG] */, float (&X)[MT],
-                                            float (&acc)[MT]) {
+                                            BlockRed<MT, NG> &red, float *accbuf /* LDS [MT][64 NG] */, float (&X)[MT]) {
     constexpr int MP = (MT + 1) / 2;
     constexpr int LD = 64 * NG;
     float *acc_t = accbuf + threadIdx.x;               // sum(X_list) of this thread's column: LDS, touched once per
@@ -950,9 +949,7 @@ __device__ __forceinline__ int relax_core_h(const float (&C)[MT], int n, int m, 
         X[2 * k] = (float)Xh[k].x;
         if (2 * k + 1 < MT) X[2 * k + 1] = (float)Xh[k].y;
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = acc_t[i * LD];
-    return len - 1;
+    return len - 1;                                    // sum(X_list) of column `col` stays in accbuf[i * LD + threadIdx.x]
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1019,12 +1016,17 @@ __device__ __forceinline__ void relax_match_body(
 
     float X[MT], acc[MT];
     int iters;
+    const bool livec = col < Pp;
     if constexpr (HALF) {
-        iters = relax_core_h<MT, NG>(C, Mb, Pp, col, prm, red, xbuf, X, acc);
-        // the fp32 costs are not kept alive across the solver (register budget): sim was stored above, C = -sim_pad
+        // 128-VGPR budget (4 waves per SIMD): nothing fp32-wide stays alive around the solver.  The sum of iterates comes
+        // back in LDS (xbuf, column-major per thread), the final iterate is stored right here, and the epilogue reads the
+        // cost back from sim (stored above; -C = sim_pad) one row at a time.
+        iters = relax_core_h<MT, NG>(C, Mb, Pp, col, prm, red, xbuf, X);
+        if (X_b) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            C[i] = (DMM_ROW(i) && col < Pp) ? -(has_prop ? sim_b[(int64_t)i * N + col] : 0.0f) : 0.0f;
+            for (int i = 0; i < MT; ++i)
+                if (DMM_ROW(i) && col < PpS) X_b[(int64_t)i * PpS + col] = livec ? X[i] : 0.0f;
+        }
     } else {
         iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
                                           RelaxTape{nullptr, nullptr}, hs);
@@ -1034,27 +1036,32 @@ __device__ __forceinline__ void relax_match_body(
     // ---- R = sum(X_list)/len; logic; Rb; scores ----
     const float flen = (float)(iters + 1);
     const float sc = has_prop ? score_p[(int64_t)b * N + col] : 0.0f;
-    const bool livec = col < Pp;
-    float r[MT], rmax[MT], ms[MT], ds[MT];
+    float r[MT], rmax[MT], ms[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        r[i] = acc[i] / flen;                                          // match_model.py:121
+        const float a = HALF ? xbuf[i * (64 * NG) + threadIdx.x] : acc[i];
+        r[i] = a / flen;                                               // match_model.py:121
         rmax[i] = (livec && DMM_ROW(i)) ? r[i] : -__builtin_inff();
     }
     wave_max_rows<MT>(rmax);
-    red.fold(rmax, fmax_op());
+    red.fold(rmax, fmax_op());                                         // (its barrier: every thread has read its sums)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const float lg = is_test ? (r[i] == rmax[i] ? 1.0f : 0.0f) : (r[i] > 0.01f ? 1.0f : 0.0f);
         const float rb = (livec && DMM_ROW(i)) ? r[i] * lg : 0.0f;     // :130
         const float rc = r[i] < 0.0f ? 0.0f : (r[i] > 1.0f ? 1.0f : r[i]);
-        ms[i] = (livec && DMM_ROW(i)) ? rc * (-C[i]) : -__builtin_inff();   // :146
-        ds[i] = sc * rb;                                               // :147
-        if (DMM_ROW(i) && livec) xbuf[i * Pp + col] = ds[i];
+        float simv;                                                    // = -C[i]: sim, +0 in the padded columns
+        if constexpr (HALF) simv = (DMM_ROW(i) && has_prop) ? sim_b[(int64_t)i * N + col] : 0.0f;
+        else simv = -C[i];
+        ms[i] = (livec && DMM_ROW(i)) ? rc * simv : -__builtin_inff();       // :146
+        const float ds = sc * rb;                                      // :147
+        if (DMM_ROW(i) && livec) xbuf[i * Pp + col] = ds;
         if (DMM_ROW(i) && col < PpS) {
             Rb_b[(int64_t)i * PpS + col] = rb;
             if (R_b) R_b[(int64_t)i * PpS + col] = livec ? r[i] : 0.0f;
-            if (X_b) X_b[(int64_t)i * PpS + col] = livec ? X[i] : 0.0f;
+            if constexpr (!HALF) {
+                if (X_b) X_b[(int64_t)i * PpS + col] = livec ? X[i] : 0.0f;
+            }
         }
     }
     wave_max_rows<MT>(ms);

@@ -39,6 +39,21 @@ def _planes(t: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
     return t, t.stride(0), t.stride(1)
 
 
+def alloc_planes(B: int, K: int, H: int, W: int, dtype, device, align_bytes: int = 128, fill=None) -> torch.Tensor:
+    """[B,K,H,W] mask planes whose PLANE STRIDE is rounded up to ``align_bytes`` (every plane then starts on a 128-byte
+    line).  255 x 255 planes are an odd number of elements: contiguous 16-bit planes alternate between dword-aligned and
+    2-bytes-off starts, and every 2 KiB run of a misaligned plane straddles one extra 128-byte line (+5.4 % HBM traffic in
+    the count kernel at BASELINE configs[4], profiles/r03).  The C ABI takes the plane stride (``sp_n`` / ``so_m``), so a
+    producer that owns its buffers just allocates them this way; H*W elements of a plane stay contiguous."""
+    es = torch.empty((), dtype=dtype).element_size()
+    q = max(1, align_bytes // es)
+    S = (H * W + q - 1) // q * q
+    buf = torch.empty((B, K, S), dtype=dtype, device=device)
+    if fill is not None:
+        buf.fill_(fill)
+    return torch.as_strided(buf, (B, K, H, W), (K * S, S, W, 1))
+
+
 class FramePlanes:
     """Proposal planes of B frames held as ONE TENSOR PER FRAME (the reference's ``prop_m[bid]``, dmm_model.py:58 / :111)
     plus the device pointer table the ``*_frames`` entry points of the C ABI take -- the frames go through one launch
@@ -376,8 +391,11 @@ def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_
     return dict(X=X, R=R, cost=cost, iters=iters)
 
 
-def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None, out_dtype=None) -> torch.Tensor:
-    """full_outmask [B,M,H,W] = Rb [B,M,Pp] @ masks_p [B,N,H*W] (zero planes for the padded columns)."""
+def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None, out_dtype=None,
+             shared: bool = False) -> torch.Tensor:
+    """full_outmask [B,M,H,W] = Rb [B,M,Pp] @ masks_p [B,N,H*W] (zero planes for the padded columns).
+    ``shared``: the rows of Rb share planes (train mode keeps every R > 0.01): every plane of the union of the rows'
+    supports is streamed once (``dmm_mask_mix_shared_*``); same result bit for bit."""
     if isinstance(masks_p, FramePlanes):
         fp = masks_p
         _need_gpu(Rb)
@@ -390,7 +408,8 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
             raise ValueError("mask_mix on per-frame plane tables writes fp32 (dmm_mask_mix_frames)")
         out = torch.empty((B, M, H, W), dtype=torch.float32, device=Rb.device)
         with _lib.device_guard(Rb.device):
-            rc = _lib.load().dmm_mask_mix_frames(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], B, N, M, Pp, H * W,
+            L = _lib.load()
+            rc = (L.dmm_mask_mix_shared_frames if shared else L.dmm_mask_mix_frames)(_ptr(Rb), _ptr(fp.table), _DT[fp.dtype], B, N, M, Pp, H * W,
                                                  fp.plane_stride, _ptr(n_valid), _ptr(m_valid), _ptr(out), M * H * W,
                                                  H * W, _stream(Rb))
         _lib.check(rc, "dmm_mask_mix_frames")
@@ -403,7 +422,8 @@ def mask_mix(Rb: torch.Tensor, masks_p: torch.Tensor, n_valid=None, m_valid=None
     out_dtype = out_dtype or torch.float32
     out = torch.empty((B, M, H, W), dtype=out_dtype, device=Rb.device)
     with _lib.device_guard(Rb.device):
-        rc = _lib.load().dmm_mask_mix_to(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], B, N, M, Pp, H * W, sp_b, sp_n,
+        L = _lib.load()
+        rc = (L.dmm_mask_mix_shared_to if shared else L.dmm_mask_mix_to)(_ptr(Rb), _ptr(masks_p), _DT[masks_p.dtype], B, N, M, Pp, H * W, sp_b, sp_n,
                                          _ptr(n_valid), _ptr(m_valid), _ptr(out), _DT[out_dtype], M * H * W, H * W,
                                          _stream(Rb))
     _lib.check(rc, "dmm_mask_mix_to")
@@ -577,7 +597,7 @@ class ForwardPlan:
 
     def __init__(self, B, N, M, H, W, D, device, mask_dtype=torch.float32, want_tables=False, pipeline=None,
                  split=0.5, time_kernels=False, graph=None, out_dtype=None, parts=2, graph_fork=False,
-                 solver_state="f32"):
+                 solver_state="f32", out_plane_align=0):
         self.B, self.N, self.M, self.H, self.W, self.D = B, N, M, H, W, D
         self.Pp = padded_width(N, M)
         self.device = torch.device(device)
@@ -610,7 +630,15 @@ class ForwardPlan:
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
-        self.full_outmask = torch.empty((B, M, H, W), dtype=self.out_dtype, device=self.device)
+        # out_plane_align: plane stride of full_outmask rounded up to that many bytes (alloc_planes) -- the matched masks of
+        # config 5 are the next frame's 16-bit templates, so their producer writes them line aligned
+        if out_plane_align:
+            self.full_outmask = alloc_planes(B, M, H, W, self.out_dtype, self.device, int(out_plane_align))
+        else:
+            self.full_outmask = torch.empty((B, M, H, W), dtype=self.out_dtype, device=self.device)
+        self.so_b, self.so_m = self.full_outmask.stride(0), self.full_outmask.stride(1)
+        self.time_kernels = self.time_kernels or bool(out_plane_align)     # the fused C call writes contiguous fp32 only
+        self.graph_mode = self.graph_mode and not out_plane_align
         self.match_score = torch.empty((B, M), **f32)
         self.det_score = torch.empty((B, M), **f32)
         self.iters = torch.empty((B,), **i32)
@@ -694,7 +722,7 @@ class ForwardPlan:
                                float(lr), int(is_test), _ptr(self.sim), _ptr(self.R), _ptr(self.Rb),
                                _ptr(self.match_score), _ptr(self.det_score), _ptr(self.iters), None, ms)
         rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
-                                _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], M * HW, HW, ms)
+                                _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], self.so_b, self.so_m, ms)
         _lib.check(rc, "ForwardPlan.run (forked)")
 
     def _solver(self, L):
@@ -783,7 +811,7 @@ class ForwardPlan:
                 self._mark("solver", main, False)
                 self._mark("mix", main, True)
                 rc |= L.dmm_mask_mix_to(_ptr(self.Rb), _ptr(masks_p), dt, B, N, M, Pp, HW, sp_b, sp_n, _ptr(n_valid),
-                                        _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], M * HW, HW, ms)
+                                        _ptr(m_valid), _ptr(self.full_outmask), _DT[self.out_dtype], self.so_b, self.so_m, ms)
                 self._mark("mix", main, False)
             _lib.check(rc, "ForwardPlan.run (granular, timed)")
             return self.full_outmask, self.match_score, self.det_score
@@ -835,8 +863,8 @@ class ForwardPlan:
                 self._mark("mix", main, True)
                 rc |= L.dmm_mask_mix_to(self.Rb.data_ptr() + 4 * b * M * Pp, masks_p.data_ptr() + es * b * sp_b, dt,
                                         e - b, N, M, Pp, HW, sp_b, sp_n, nv(n_valid, b), nv(m_valid, b),
-                                        self.full_outmask.data_ptr() + self.full_outmask.element_size() * b * M * HW,
-                                        _DT[self.out_dtype], M * HW, HW, ms)
+                                        self.full_outmask.data_ptr() + self.full_outmask.element_size() * b * self.so_b,
+                                        _DT[self.out_dtype], self.so_b, self.so_m, ms)
                 self._mark("mix", main, False)
         _lib.check(rc, "ForwardPlan.run (pipelined)")
         return self.full_outmask, self.match_score, self.det_score

@@ -95,7 +95,9 @@ typedef enum dmm_option {
     DMM_OPT_GEMM_TUNE = 17,         /* dmm_conv1x1_bf16: hipBLASLt heuristic candidates timed per new shape (1 = none)     */
     DMM_OPT_PACK_VARIANT = 18,      /* dmm_pack_masks: 4 = 128-block segments x 8 loads (default), 0 = 256 x 4             */
     DMM_OPT_SMALL_FUSED = 19,       /* dmm_match_forward at B <= 8: 1 = feature similarity inside the count launch (default) */
-    DMM_OPT_COUNT = 20
+    DMM_OPT_MIX_SHARED = 20,        /* mix / mix backward: -1 by entry point (default: dmm_mask_mix_shared_* and the backward
+                                       stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
+    DMM_OPT_COUNT = 21
 } dmm_option;
 DMM_API int dmm_set_option(int option, int value);
 DMM_API int dmm_get_option(int option);
@@ -297,6 +299,20 @@ DMM_API int dmm_mask_mix(const float *Rb, const void *masks_p, int dtype, int B,
 DMM_API int dmm_mask_mix_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
                             int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, void *out,
                             int out_dtype, int64_t so_b, int64_t so_m, dmm_stream_t stream);
+
+/* (4d) dmm_mask_mix_to for weight tables whose ROWS SHARE PLANES -- train mode: logic = (R > 0.01) keeps many entries per
+ * row (match_model.py:126-129), torch.mm then reads every plane once for all rows (:144).  One workgroup streams each
+ * plane of the union of the rows' supports once and fans it into the rows; per row the accumulation is the one of
+ * dmm_mask_mix_to (non-zero weights in ascending column order), so the two entries agree bit for bit.  M <= 32, N <= 256
+ * take the union kernel, anything else the general one.  dmm_mask_mix_shared_frames: proposal planes as a device table of
+ * per-frame base pointers (see (4c)). */
+DMM_API int dmm_mask_mix_shared_to(const float *Rb, const void *masks_p, int dtype, int B, int N, int M, int Pp, int HW,
+                                   int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                   void *out, int out_dtype, int64_t so_b, int64_t so_m, dmm_stream_t stream);
+DMM_API int dmm_mask_mix_shared_frames(const float *Rb, const void *const *masks_p_frames, int dtype, int B, int N,
+                                       int M, int Pp, int HW, int64_t sp_n, const int32_t *n_valid,
+                                       const int32_t *m_valid, float *out, int64_t so_b, int64_t so_m,
+                                       dmm_stream_t stream);
 
 /* (4b) Backward of (4) w.r.t. Rb: dRb[b,m,n] = <dout[b,m,:], masks_p[b,n,:]> on the support of Rb (entries with
  * Rb == 0 were masked by the constant logic mask, match_model.py:124-130, and get 0).  dout: [B,M,HW] fp32
