@@ -797,7 +797,8 @@ def bench_train(R, Bs=(64, 512)):
             cos = ops.cosine(tn, pn)
             r = ops.relax_match(cos, inter, ap, at, sc, **cfg)
             Rb, sim = r["Rb"], r["sim"]
-            nnz = int((Rb[:, :, :N] != 0).sum())                           # planes the train-mode mix streams (R > 0.01)
+            nnz = int((Rb[:, :, :N] != 0).sum())                           # (row, plane) pairs with R > 0.01
+            n_union = int((Rb[:, :, :N] != 0).any(1).sum())                # distinct planes the rows of a frame select
             loss, gt, _ = autograd.matching_loss(pm, tg, cos, counts=(gi, ap, gat))
             dRb = ops.mask_mix_bwd(Rb, pm, dfull)
             dsim = ops.relax_match_bwd(sim, sc, dRb, None, None, max_iter=20, proj_iter=5, lr=0.1, is_test=0)
@@ -807,7 +808,7 @@ def bench_train(R, Bs=(64, 512)):
                 "feature_sim_fwd (normalise x2 + cosine)": quick_ms(lambda: ops.cosine(
                     ops.feature_normalize(tf, want_norms=True)[0], ops.feature_normalize(pf, want_norms=True)[0]), reps, dev=dev),
                 "relax_match (train mode)": quick_ms(lambda: ops.relax_match(cos, inter, ap, at, sc, **cfg), reps, dev=dev),
-                "mask_mix (train mode)": quick_ms(lambda: ops.mask_mix(Rb, pm), reps, dev=dev),
+                "mask_mix (train mode)": quick_ms(lambda: ops.mask_mix(Rb, pm, shared=True), reps, dev=dev),
                 "matching_loss (greedy one-hot + mse)": quick_ms(lambda: autograd.matching_loss(pm, tg, cos, counts=(gi, ap, gat)),
                                                                  reps, dev=dev),
                 "mask_mix_bwd": quick_ms(lambda: ops.mask_mix_bwd(Rb, pm, dfull), reps, dev=dev),
@@ -819,8 +820,9 @@ def bench_train(R, Bs=(64, 512)):
         # algorithmic bytes per launch (fp32 planes): every plane the kernel must see, once
         alg = {
             "iou_counts_dual": B * ((N + 2 * M) * HW * 4 + 2 * M * N * 4),               # proposals + templates + targets
-            "mask_mix (train mode)": nnz * HW * 4 + B * M * HW * 4,                         # selected planes in, M planes out
-            "mask_mix_bwd": nnz * HW * 4 + B * M * HW * 4,                                  # selected planes + d full_outmask
+            # every selected plane ONCE (the union of the rows' supports) + M planes out / M planes of d full_outmask in
+            "mask_mix (train mode)": n_union * HW * 4 + B * M * HW * 4,
+            "mask_mix_bwd": n_union * HW * 4 + B * M * HW * 4,
         }
         kern = {}
         for k, ms in t.items():
@@ -833,7 +835,8 @@ def bench_train(R, Bs=(64, 512)):
                 e.update(bound="latency / VALU (no plane traffic)")
             kern[k] = e
         per_B[str(B)] = {"fwd_bwd_ms": round(elapsed / steps * 1e3, 4), "frames_per_s": round(B * steps / elapsed, 1),
-                         "steps": steps, "selected_planes_per_frame": round(nnz / B, 2),
+                         "steps": steps, "selected_planes_per_frame": round(n_union / B, 2),
+                         "selected_row_plane_pairs_per_frame": round(nnz / B, 2),
                          "kernel_sum_ms": round(sum(t.values()), 4), "kernels": kern}
         del pm, tm, tg, dfull
         torch.cuda.empty_cache()

@@ -256,9 +256,31 @@ template <> struct MaskIO<bf16_t> {
 
 }  // namespace dmm
 
+// ---- zero fill as a KERNEL ------------------------------------------------------------------
+// The library's tables (count tables, dRb) are cleared by this launch, not by hipMemsetAsync.  A memset captured into a HIP
+// graph becomes a memset NODE, and on this stack (ROCm 7.0.2, torch 2.10 hipGraph capture) a replayed graph did not order
+// the kernel node that follows it behind that node: the count kernel of a replayed frame step accumulated onto the previous
+// step's tables (found by tests/test_gpu_video.py::test_frame_loop_equals_an_oracle_computed_clip -- only on the path that
+// clears with a memset, i.e. feature widths the fused similarity kernel does not take; eager launches were never affected).
+// A kernel node is ordered like every other kernel of the chain.  bytes must be a multiple of 4 (all tables are 32-bit).
+namespace dmm {
+static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+}  // namespace dmm
+
 // ---- host side ------------------------------------------------------------------------------
 namespace dmm {
 void set_last_hip_error(int e);
+inline hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
+    const size_t words = bytes / 4;
+    if (words == 0) return hipSuccess;
+    size_t blocks = (words + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)p, words);
+    return hipGetLastError();
+}
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -518,15 +518,15 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
         // dmm_match_forward: the feature-similarity launch in front of this one already cleared the three tables
     } else if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
         // the three tables are one contiguous block (dmm_match_forward's workspace): one memset node
-        DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
+        DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
     } else {
-        DMM_HIP_TRY(hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)B * M * N, stream));
-        DMM_HIP_TRY(hipMemsetAsync(area_p, 0, sizeof(int32_t) * (size_t)B * N, stream));
-        DMM_HIP_TRY(hipMemsetAsync(area_t, 0, sizeof(int32_t) * (size_t)B * M, stream));
+        DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * (size_t)B * M * N, stream));
+        DMM_HIP_TRY(zero_async(area_p, sizeof(int32_t) * (size_t)B * N, stream));
+        DMM_HIP_TRY(zero_async(area_t, sizeof(int32_t) * (size_t)B * M, stream));
     }
     if (masks_t2) {
-        DMM_HIP_TRY(hipMemsetAsync(inter2, 0, sizeof(int32_t) * (size_t)B * M * N, stream));
-        DMM_HIP_TRY(hipMemsetAsync(area_t2, 0, sizeof(int32_t) * (size_t)B * M, stream));
+        DMM_HIP_TRY(zero_async(inter2, sizeof(int32_t) * (size_t)B * M * N, stream));
+        DMM_HIP_TRY(zero_async(area_t2, sizeof(int32_t) * (size_t)B * M, stream));
     }
     if (HW == 0) return DMM_OK;
     // Tile the (N, M) table over the compiled envelopes: <= 32 template rows per launch (<= 16 when a second

@@ -322,7 +322,7 @@ template <typename T>
 static int mask_mix_bwd_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
                               int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
                               hipStream_t stream) {
-    DMM_HIP_TRY(hipMemsetAsync(dRb, 0, sizeof(float) * (size_t)B * M * Pp, stream));
+    DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
     int splits = (8192 + B * M - 1) / (B * M);
     if (splits > nsteps) splits = nsteps;
@@ -534,7 +534,10 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           const int32_t *__restrict__ m_valid,
                                                                           float *__restrict__ dRb, int steps_per_wg) {
     constexpr int E = 4;
-    __shared__ float acc_s[DMM_MAX_PROPOSALS * MT];                       // [union column][row]
+    // pair sums, one table PER WAVE ([wave][union column][row], dynamic LDS: 4 * N * MT floats): lane 0 of a wave adds to
+    // its own table in program order, the four tables are folded in a fixed order -- a workgroup's result does not depend
+    // on how its waves interleave
+    extern __shared__ float acc_s[];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int wcnt_s[kMixThreads / 64];
@@ -545,8 +548,10 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     if (Mb <= 0) return;
     const int cnt = shared_support<MT>(Rb + (int64_t)b * M * Pp, Pp, Nb, Mb, col_s, rowmask_s, (float *)nullptr, wcnt_s);
     if (cnt == 0) return;
-    for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) acc_s[i] = 0.0f;
+    const int tbl = N * MT;                                               // floats per wave table (cnt <= Nb <= N)
+    for (int i = threadIdx.x; i < (kMixThreads / 64) * tbl; i += kMixThreads) acc_s[i] = 0.0f;
     __syncthreads();
+    float *acc_w = acc_s + (threadIdx.x >> 6) * tbl;
     const T *Pb = frame_base(masks_p, b, sp_b);
     const float *db = dout + (int64_t)b * M * HW;
     const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                         p = __builtin_fmaf(d[m][2], v[u][2], p);
                         p = __builtin_fmaf(d[m][3], v[u][3], p);
                         p = wave_sum(p);
-                        if (lane == 0) atomicAdd(&acc_s[(e0 + u) * MT + m], p);
+                        if (lane == 0) acc_w[(e0 + u) * MT + m] += p;
                     }
                 }
             }
@@ -593,7 +598,9 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     __syncthreads();
     for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) {
         const int e = i / MT, m = i - e * MT;
-        if (rowmask_s[e] & (1u << m)) atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]], acc_s[i]);
+        if (rowmask_s[e] & (1u << m))
+            atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]],
+                      ((acc_s[i] + acc_s[tbl + i]) + acc_s[2 * tbl + i]) + acc_s[3 * tbl + i]);
     }
 }
 
@@ -601,15 +608,16 @@ template <typename T>
 static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp,
                                      int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
                                      float *dRb, hipStream_t stream) {
-    DMM_HIP_TRY(hipMemsetAsync(dRb, 0, sizeof(float) * (size_t)B * M * Pp, stream));
+    DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
     int steps_per_wg = (int)(((int64_t)B * nsteps + 8191) / 8192);
     if (steps_per_wg < 1) steps_per_wg = 1;
     if (steps_per_wg > 8) steps_per_wg = 8;
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
-#define DMM_MIXB_LAUNCH(MT_)                                                                                            \
-    hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb, masks_p, \
-                       dout, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg)
+#define DMM_MIXB_LAUNCH(MT_)                                                                                        \
+    hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads),                    \
+                       sizeof(float) * (kMixThreads / 64) * (size_t)N * MT_, stream, Rb, masks_p, dout, N, M, Pp, HW, \
+                       sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg)
     if (M <= 8) DMM_MIXB_LAUNCH(8);
     else if (M <= 16) DMM_MIXB_LAUNCH(16);
     else DMM_MIXB_LAUNCH(32);
@@ -777,7 +785,10 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
     if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW) return DMM_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dmm::opt(DMM_OPT_MIX_SHARED) != 0) {                             // default: planes of the union streamed once
+    // default: planes of the union streamed once -- while the four per-wave pair tables fit the default dynamic-LDS limit
+    // (4 * N * MT floats <= 60 KB: everything up to 120 proposals x 32 rows or 240 x 16); wider tables keep the row kernel
+    const int mt = M <= 8 ? 8 : (M <= 16 ? 16 : 32);
+    if (dmm::opt(DMM_OPT_MIX_SHARED) != 0 && sizeof(float) * 4 * (size_t)N * mt <= 60 * 1024) {
         switch (dtype) {
             case DMM_F32:
                 return dmm::mask_mix_bwd_shared_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n,

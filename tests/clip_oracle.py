@@ -23,14 +23,20 @@ import oracle
 
 
 def run_clip(feats, first, raw, n_frames, *, max_iter=40, proj_iter=5, lr=0.1, score_weight=0.3, nms_thresh=0.4,
-             max_proposals=50, mask_thresh=0.4, padding=1):
+             max_proposals=50, mask_thresh=0.4, padding=1, roi_fn=None):
     """feats[t]: 4 arrays [B,C,h_l,w_l] (the encoder's backbone features of frame t, strides 4..32);
     first [B,O,H,W] frame-0 annotation; raw[b][t] = (prob [R,M,M], boxes [R,4], scores [R]) (the last entry is reused for
     missing frames, evaluator.py:101-106); n_frames[b] = real length of video b.
+    ``roi_fn(t, rois [R,5]) -> [R, D]``: where the ROI features come from; default the oracle's own ROIAlign on
+    ``feats[t]``.  (relax_matching leaves its loops on EXACT fp32 equalities, relax_match.py:88-89,96-98: a 1e-7 difference
+    between two correct ROIAlign implementations can move an exit by dozens of steps, and the layer returns the MEAN of the
+    iterates -- so a test that wants equal iteration counts in every frame hands the SAME feature rows to both sides.)
     Returns hist [T,B,O,H,W] fp32 (``outs`` per frame), labels [T,B,H,W] uint8 (meaningful where t < n_frames[b]),
     iters [T,B] int32 (solver iterations executed; -1 where the layer did not run), kept [T,B] proposals after NMS."""
     T = len(feats)
     B, O, H, W = first.shape
+    if roi_fn is None:
+        roi_fn = lambda t, rois: oracle.roialign4_mean([f for f in feats[t]], rois)
     hist_out = np.zeros((T, B, O, H, W), np.float32)
     labels = np.zeros((T, B, H, W), np.uint8)
     iters = -np.ones((T, B), np.int32)
@@ -40,7 +46,7 @@ def run_clip(feats, first, raw, n_frames, *, max_iter=40, proj_iter=5, lr=0.1, s
         tboxes, valid = oracle.mask_boxes(y0, 0.0)                      # utils.py:179-210
         n_live = int(valid.sum())
         rois = np.concatenate([np.full((O, 1), b, np.float32), tboxes], 1)
-        tfeat = oracle.roialign4_mean([f for f in feats[0]], rois)      # [O, D], fixed from frame 0
+        tfeat = roi_fn(0, rois)                                         # [O, D], fixed from frame 0
         tfv = tfeat[:n_live] * valid[:n_live, None].astype(np.float32)  # OF_matrix @ feat: rows i < O scaled by valid[i]
         mask_hist = y0.copy()
         for t in range(T):
@@ -55,7 +61,7 @@ def run_clip(feats, first, raw, n_frames, *, max_iter=40, proj_iter=5, lr=0.1, s
                 kept[t, b] = len(keep)
                 pm, sc = planes[keep], np.ascontiguousarray(scores[keep], np.float32)
                 prois = np.concatenate([np.full((len(keep), 1), b, np.float32), tight[keep]], 1)
-                pfeat = oracle.roialign4_mean([f for f in feats[t]], prois)
+                pfeat = roi_fn(t, prois)
                 o = oracle.match_forward(pm, mask_hist[:n_live], pfeat, tfv, sc, score_weight=score_weight,
                                          max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=1)
                 iters[t, b] = o["iters"]

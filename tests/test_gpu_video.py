@@ -438,32 +438,49 @@ def _clip_case(seed, B, T, O, H, W, objs, n_frames, n_raw):
 def test_frame_loop_equals_an_oracle_computed_clip():
     """the DEFAULT product path of the frame loop (fixed slots, one HIP-graph replay per frame:
     dmm_match_solve_packed + dmm_step_finish_f32 + the device frame cursor + the template history carried from frame to
-    frame) against a clip computed WITHOUT this package: tests/clip_oracle.py chains oracle.paste_masks -> nms ->
-    roialign4_mean -> match_forward -> merge_labels per frame with the evaluator's carry-over (evaluator.py:131-139,205;
+    frame) against a clip computed WITHOUT this package's loop: tests/clip_oracle.py chains oracle.paste_masks -> nms ->
+    ROI features -> match_forward -> merge_labels per frame with the evaluator's carry-over (evaluator.py:131-139,205;
     dmm_model.py:66-80).  Ragged proposal counts, O in {2, 0, 4 non-prefix, 3}, one video with 'extra' frames, one
-    without templates.  Label maps bit exact, masks <= 1e-5, solver iteration counts (data-dependent exits) identical;
-    the BoxList path and the unfused epilogue are held to the same clip."""
+    without templates, top-k cutting (K = 20) and not cutting (K = 48).
+
+    Two comparisons.  STRICT: the chain is handed the same ROI feature rows the device computes (the ROI kernel has its own
+    fixtures, G12 / G17) -- then everything else must agree exactly: solver iteration counts incl. the data-dependent
+    exits, label maps bit for bit, masks <= 1e-5, in every frame, for the graph path, the unfused epilogue and the BoxList
+    path.  INDEPENDENT: the chain on the oracle's own ROIAlign -- the reference's exits fire on exact fp32 equalities, so a
+    1e-7 feature difference may move an exit and with it the mean of the iterates; per video the frames up to the first
+    differing iteration count are held to the same bounds, and at least half of all live frames must be covered."""
     import clip_oracle
+    from dmm_net_amd.roi_features import roialign4_mean_into
     B, T, O, H, W = 4, 4, 5, 96, 128
     objs = [(0, 1), (), (0, 2, 3, 4), (0, 1, 2)]                          # video 2: slot 1 is empty in frame 0 (non-prefix)
     n_frames = [2, 4, 4, 4]                                              # video 0: frames 2, 3 are 'extra'
     enc = _PoolEncoder()
-    worst = 0.0
+    worst, covered, live_total = 0.0, 0, 0
     for seed, (max_iter, proj_iter) in [(31, (40, 5)), (32, (10, 5)), (33, (40, 5))]:
         cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": max_iter, "relax_proj_iter": proj_iter,
                 "relax_learning_rate": 0.1, "score_weight": 0.3}
         frames, first, props = _clip_case(seed, B, T, O, H, W, objs, n_frames, lambda b, t: 18 + 7 * b + 3 * t)
-        feats = [[f.cpu().numpy() for f in enc(frames[:, t])["backbone_feature"]] for t in range(T)]
+        dfeat = [[f.contiguous() for f in enc(frames[:, t])["backbone_feature"]] for t in range(T)]
+        feats = [[f.cpu().numpy() for f in lv] for lv in dfeat]
         raw = [[(p.get_field("mask").numpy()[:, 0], p.bbox.numpy(), p.get_field("scores").numpy()) for p in row]
                for row in props]
-        exp_h, exp_l, exp_it, kept = clip_oracle.run_clip(feats, first, raw, n_frames, max_iter=max_iter,
-                                                          proj_iter=proj_iter, max_proposals=20)
-        assert kept[1:, 2:].min() >= 5 and len(set(kept[1:, 2:].ravel().tolist())) > 1      # ragged, non-trivial
-        live = exp_it >= 0
+        K = 20 if seed == 31 else 48                                    # top-k cuts every frame / no frame
+
+        def device_roi(t, rois):
+            rr = torch.from_numpy(np.ascontiguousarray(rois, np.float32)).to(DEV)
+            out = torch.empty((rr.shape[0], 4 * dfeat[t][0].shape[1]), dtype=torch.float32, device=DEV)
+            return roialign4_mean_into(rr, dfeat[t], out).cpu().numpy()
+        kw = dict(max_iter=max_iter, proj_iter=proj_iter, max_proposals=K)
+        strict = clip_oracle.run_clip(feats, first, raw, n_frames, roi_fn=device_roi, **kw)
+        indep = clip_oracle.run_clip(feats, first, raw, n_frames, **kw)
+        kept = strict[3]
+        assert np.array_equal(kept, indep[3])                            # paste + NMS do not depend on the features
+        assert kept[1:, 2:].min() >= 5 and (K == 20 or len(set(kept[1:, 2:].ravel().tolist())) > 1)   # ragged counts
+        live = strict[2] >= 0
         assert live[1:, 2:].all() and not live[:, 1].any() and not live[2:, 0].any() and live[1, 0]
         for (slots, graph, kn) in [(True, True, {}), (True, False, dict(fuse_epilogue=False)), (False, False, {})]:
             lp = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4,
-                                 max_proposals=20)
+                                 max_proposals=K)
             lp.slots, lp.graph, lp.record_iters = slots, graph, True
             for k, v in kn.items():
                 setattr(lp, k, v)
@@ -472,19 +489,36 @@ def test_frame_loop_equals_an_oracle_computed_clip():
                 h = lp.run(frames, torch.from_numpy(first).to(DEV).view(B, O, H * W), props, n_frames,
                            on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()))
                 got = torch.stack([x.view(B, O, H, W) for x in h], 0).cpu().numpy()
+                assert sorted(labs) == sorted((b, t) for b in range(B) for t in range(n_frames[b]))
+                # ---- STRICT: every frame
+                exp_h, exp_l, exp_it, _ = strict
                 if slots:
                     it = lp.last_iters.cpu().numpy()
                     assert np.array_equal(it[live], exp_it[live]), (seed, slots, graph, it, exp_it)
                 err = float(np.abs(got - exp_h).max())
                 worst = max(worst, err)
                 assert err <= 1e-5, (seed, slots, graph, kn, rep, err)
-                assert sorted(labs) == sorted((b, t) for b in range(B) for t in range(n_frames[b]))
                 for (b, t), lab in labs.items():
                     assert np.array_equal(lab.cpu().numpy(), exp_l[t, b]), (seed, slots, graph, kn, rep, b, t)
-        assert exp_l[1:, 2:].max() >= 2                                  # several objects really show up in the label maps
-    assert (exp_it[live] < 40).any() or True
+                # ---- INDEPENDENT: per video, the frames before the first differing iteration count
+                ind_h, ind_l, ind_it, _ = indep
+                for b in range(B):
+                    upto = T
+                    for t in range(T):
+                        if live[t, b] and ind_it[t, b] != exp_it[t, b]:
+                            upto = t
+                            break
+                    if rep == 0 and slots and graph:
+                        covered += int(live[:upto, b].sum())
+                        live_total += int(live[:, b].sum())
+                    assert float(np.abs(got[:upto, b] - ind_h[:upto, b]).max(initial=0.0)) <= 1e-5, (seed, b, upto)
+                    for t in range(min(upto, n_frames[b])):
+                        assert np.array_equal(labs[(b, t)].cpu().numpy(), ind_l[t, b]), (seed, b, t)
+        assert strict[1][1:, 2:].max() >= 2                              # several objects really show up in the label maps
+    assert covered * 2 >= live_total, (covered, live_total)
     from conftest import record_achieved
-    record_achieved("frame_loop_vs_oracle_clip", max_abs_mask_err=worst)
+    record_achieved("frame_loop_vs_oracle_clip/max_abs_mask_err", worst)
+    record_achieved("frame_loop_vs_oracle_clip/independent_roi_frames_covered", covered / max(live_total, 1))
 
 
 def test_frame_loop_plan_follows_thresholds_and_solver_settings():
