@@ -427,9 +427,9 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
                                                                       TO *__restrict__ out, int64_t so_b, int64_t so_m,
                                                                       int steps_per_wg) {
     constexpr int E = 4;                                                  // pixels per lane and step (16 bytes of fp32)
-    __shared__ float w_c[DMM_MAX_PROPOSALS * MT];
+    __shared__ __attribute__((aligned(16))) float w_c[DMM_MAX_PROPOSALS * MT];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
-    __shared__ unsigned rowmask_s[DMM_MAX_PROPOSALS];
+    __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int wcnt_s[kMixThreads / 64];
     const int b = blockIdx.y;
     int Nb = n_valid ? n_valid[b] : N;
@@ -455,6 +455,11 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
                 const int e = e0 + u < cnt ? e0 + u : cnt - 1;
                 mix_load<T, E, (NT & 1) != 0>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v[u]);
             }
+            // Weights and row masks come out of LDS one at a time through readfirstlane (scalar operands, scalar branches).
+            // Tried and measured SLOWER at B = 512, 50 x 10 (1.57 ms): a column's weights as vector LDS reads with 4 planes
+            // in flight (the accumulators + 8 planes + MT weights do not fit 128 VGPRs): 1.80 ms.  The kernel sits at the
+            // ceiling of its ACCESS PATTERN, not of its instruction stream: tools/mix_shared_probe.py streams 48 planes +
+            // 10 written rows per frame with no arithmetic at 5.1 TB/s (6.4 read-only).
 #pragma unroll
             for (int u = 0; u < kSharedLoads; ++u) {
                 // wave-uniform: scalar branches per row (0 = past the end of the union)
@@ -498,10 +503,10 @@ static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N
                                  int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
                                  int64_t so_m, hipStream_t stream) {
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    // ~16 k workgroups of 1-2 steps (4-8 KiB of every plane of the union) when the batch is large; one step each otherwise
-    int steps_per_wg = (int)(((int64_t)B * nsteps + 16383) / 16384);
+    // ONE step (4 KiB of every plane of the union) per workgroup: the access-pattern probe (tools/mix_shared_probe.py) loses
+    // 4 % / 8 % with 2 / 4 steps per workgroup, whatever the batch (DMM_OPT_MIX_SHARED_STEPS)
+    int steps_per_wg = opt(DMM_OPT_MIX_SHARED_STEPS);
     if (steps_per_wg < 1) steps_per_wg = 1;
-    if (steps_per_wg > 4) steps_per_wg = 4;
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
     const int nt_mode = opt(DMM_OPT_MIX_NT);
 #define DMM_MIXS_LAUNCH(MT_, NT_)                                                                                       \
@@ -521,10 +526,14 @@ static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N
 }
 
 // Backward of the mix, rows sharing planes: one workgroup = a pixel range of a frame; d full_outmask of the M rows is
-// loaded once per step (registers), every plane of the union once, and each (row, plane) pair of the support gets its
-// 4-pixel dot product reduced over the wave and added to the pair's LDS accumulator; one global atomic per pair and
-// workgroup at the end.  (pairs + M) -> (|union| + M) planes of traffic; the pair sums are order-free fp32 atomics as in
-// the row kernel (the workgroups of a row already raced there).
+// loaded once per step (registers), every plane of the union once.  Each (row, plane) pair of the support has a SLOT
+// (pairs in column-major order, <= kPairSlots per frame: more fall back to the row kernel): its 4-pixel dot product is
+// reduced over the wave (DPP) and added into lane (slot & 63) of accumulator register (slot >> 6) -- no LDS round trip in
+// the loop.  At the end the four waves' registers are folded through LDS in a fixed order (a workgroup's result does not
+// depend on how its waves interleave) and one global atomic per pair and workgroup goes to dRb.  (pairs + M) ->
+// (|union| + M) planes of traffic.
+constexpr int kPairSlots = 256;
+
 template <typename T, int MT>
 __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const float *__restrict__ Rb,
                                                                           const T *__restrict__ masks_p,
@@ -534,12 +543,11 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           const int32_t *__restrict__ m_valid,
                                                                           float *__restrict__ dRb, int steps_per_wg) {
     constexpr int E = 4;
-    // pair sums, one table PER WAVE ([wave][union column][row], dynamic LDS: 4 * N * MT floats): lane 0 of a wave adds to
-    // its own table in program order, the four tables are folded in a fixed order -- a workgroup's result does not depend
-    // on how its waves interleave
-    extern __shared__ float acc_s[];
+    constexpr int AV = kPairSlots / 64;
     __shared__ int col_s[DMM_MAX_PROPOSALS];
-    __shared__ unsigned rowmask_s[DMM_MAX_PROPOSALS];
+    __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
+    __shared__ int pbase_s[DMM_MAX_PROPOSALS + 1];                        // first slot of a union column
+    __shared__ float fold_s[kMixThreads / 64][kPairSlots];
     __shared__ int wcnt_s[kMixThreads / 64];
     const int b = blockIdx.y;
     int Nb = n_valid ? n_valid[b] : N;
@@ -548,16 +556,73 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     if (Mb <= 0) return;
     const int cnt = shared_support<MT>(Rb + (int64_t)b * M * Pp, Pp, Nb, Mb, col_s, rowmask_s, (float *)nullptr, wcnt_s);
     if (cnt == 0) return;
-    const int tbl = N * MT;                                               // floats per wave table (cnt <= Nb <= N)
-    for (int i = threadIdx.x; i < (kMixThreads / 64) * tbl; i += kMixThreads) acc_s[i] = 0.0f;
+    {                                                                     // exclusive prefix sum of the columns' pair counts
+        const int e = threadIdx.x, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const int pc = e < cnt ? __builtin_popcount(rowmask_s[e]) : 0;
+        int inc = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (ln >= d) inc += t;
+        }
+        __syncthreads();                                                  // wcnt_s is free again (shared_support read it)
+        if (ln == 63) wcnt_s[wv] = inc;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < kMixThreads / 64; ++k) base += k < wv ? wcnt_s[k] : 0;
+        if (e < cnt) pbase_s[e] = base + inc - pc;
+        if (e == cnt - 1) pbase_s[cnt] = base + inc;
+    }
     __syncthreads();
-    float *acc_w = acc_s + (threadIdx.x >> 6) * tbl;
+    const int pairs = pbase_s[cnt];
     const T *Pb = frame_base(masks_p, b, sp_b);
     const float *db = dout + (int64_t)b * M * HW;
     const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
     const int s_begin = blockIdx.x * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    if (pairs > kPairSlots) {
+        // a dense support (more pairs than slots): pair sums in LDS, one table PER WAVE ([wave][union column][row], dynamic
+        // LDS: 4 * N * MT floats) -- lane 0 of a wave adds to its own table in program order, the tables are folded in a
+        // fixed order.  One LDS round trip per pair: slower, and only here.
+        extern __shared__ float acc_s[];
+        const int tbl = N * MT;
+        for (int i = threadIdx.x; i < (kMixThreads / 64) * tbl; i += kMixThreads) acc_s[i] = 0.0f;
+        __syncthreads();
+        float *acc_w = acc_s + wave * tbl;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int x = (s * kMixThreads + threadIdx.x) * E;
+            for (int e = 0; e < cnt; ++e) {
+                float v[E];
+                mix_load<T, E, true>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v);
+                const unsigned rows = uniform_u32(rowmask_s[e]);
+                for (int m = 0; m < Mb; ++m) {
+                    if (!(rows & (1u << m))) continue;
+                    float p = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < E; ++k) {
+                        const float dv = x + k < HW ? db[(int64_t)m * HW + x + k] : 0.0f;
+                        p = k == 0 ? dv * v[0] : __builtin_fmaf(dv, v[k], p);
+                    }
+                    p = wave_sum(p);
+                    if (lane == 0) acc_w[e * MT + m] += p;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) {
+            const int e = i / MT, m = i - e * MT;
+            if (rowmask_s[e] & (1u << m))
+                atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]],
+                          ((acc_s[i] + acc_s[tbl + i]) + acc_s[2 * tbl + i]) + acc_s[3 * tbl + i]);
+        }
+        return;
+    }
+    float accv[AV];
+#pragma unroll
+    for (int q = 0; q < AV; ++q) accv[q] = 0.0f;
     for (int s = s_begin; s < s_end; ++s) {
         const int x = (s * kMixThreads + threadIdx.x) * E;
         float d[MT][E];
@@ -578,29 +643,44 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                 const int e = e0 + u < cnt ? e0 + u : cnt - 1;
                 mix_load<T, E, true>(Pb + (int64_t)col_s[e] * sp_n, x, HW, true, v[u]);
             }
+            const uint4v ma = *reinterpret_cast<const uint4v *>(&rowmask_s[e0]);
+            const uint4v mb = *reinterpret_cast<const uint4v *>(&rowmask_s[e0 + 4]);
+            int slot = __builtin_amdgcn_readfirstlane(pbase_s[e0]);
 #pragma unroll
             for (int u = 0; u < kSharedLoads; ++u) {
-                const unsigned rows = e0 + u < cnt ? uniform_u32(rowmask_s[e0 + u]) : 0u;
+                const unsigned rows = e0 + u < cnt ? uniform_u32(u < 4 ? ma[u & 3] : mb[u & 3]) : 0u;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    if (rows & (1u << m)) {
+                    if (rows & (1u << m)) {                                // wave-uniform
                         float p = d[m][0] * v[u][0];
                         p = __builtin_fmaf(d[m][1], v[u][1], p);
                         p = __builtin_fmaf(d[m][2], v[u][2], p);
                         p = __builtin_fmaf(d[m][3], v[u][3], p);
-                        p = wave_sum(p);
-                        if (lane == 0) acc_w[(e0 + u) * MT + m] += p;
+                        p = wave_sum(p);                                   // wave-uniform result
+                        const int r = slot >> 6, l = slot & 63;
+#pragma unroll
+                        for (int q = 0; q < AV; ++q) accv[q] = accv[q] + ((q == r && lane == l) ? p : 0.0f);
+                        ++slot;
                     }
                 }
             }
         }
     }
+#pragma unroll
+    for (int q = 0; q < AV; ++q) fold_s[wave][q * 64 + lane] = accv[q];
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt * MT; i += kMixThreads) {
-        const int e = i / MT, m = i - e * MT;
-        if (rowmask_s[e] & (1u << m))
-            atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]],
-                      ((acc_s[i] + acc_s[tbl + i]) + acc_s[2 * tbl + i]) + acc_s[3 * tbl + i]);
+    // slot -> (column, row): walk the union again, one thread per slot
+    for (int i = threadIdx.x; i < pairs; i += kMixThreads) {
+        int lo = 0, hi = cnt;                                             // pbase_s[lo] <= i < pbase_s[lo + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pbase_s[mid] <= i) lo = mid; else hi = mid;
+        }
+        unsigned rows = rowmask_s[lo];
+        for (int k = i - pbase_s[lo]; k > 0; --k) rows &= rows - 1;       // drop the k lowest set bits
+        const int m = __builtin_ctz(rows);
+        const float t = ((fold_s[0][i] + fold_s[1][i]) + fold_s[2][i]) + fold_s[3][i];
+        atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[lo]], t);
     }
 }
 
@@ -610,9 +690,10 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
                                      float *dRb, hipStream_t stream) {
     DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    int steps_per_wg = (int)(((int64_t)B * nsteps + 8191) / 8192);
+    // two steps per workgroup (twice the forward's): every workgroup ends with a fold through LDS and one atomic per pair --
+    // measured at B = 512, 50 x 10: 1.51 / 1.42 / 1.42 ms at 1 / 2 / 4 steps (the forward: 1.42 / 1.47 / 1.60)
+    int steps_per_wg = 2 * opt(DMM_OPT_MIX_SHARED_STEPS);
     if (steps_per_wg < 1) steps_per_wg = 1;
-    if (steps_per_wg > 8) steps_per_wg = 8;
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
 #define DMM_MIXB_LAUNCH(MT_)                                                                                        \
     hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads),                    \
