@@ -127,9 +127,34 @@ def cpu_baseline(seconds, ci=2):
         t.join()
     dt = time.perf_counter() - t0
     n = sum(counts)
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-            "sample": f"{n} frames of the same workload (N={c['P']}, M={c['O']}, 255x255, 20x5 iters) in {dt:.1f} s, "
-                      f"oracle/dmm_oracle.c, {cores} threads (one frame per call per thread)"}
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "sample": f"{n} frames of the same workload (N={c['P']}, M={c['O']}, 255x255, 20x5 iters) in {dt:.1f} s, "
+                     f"oracle/dmm_oracle.c, {cores} threads (one frame per call per thread)"}
+    # SURVEY 8(d) / north_star: "the reference PyTorch-CPU path timed on the host cores" -- the op-for-op torch restatement
+    # (oracle/torch_ref.py: the reference's own tensor ops per frame, expands and .item() syncs included) with intra-op
+    # parallelism over all cores, one frame at a time like the reference's per-frame call; a few seconds of frames
+    try:
+        from oracle import torch_ref
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(cores)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        args_t = (tt(fr.proposed_feature), tt(pm), tt(fr.template_feature), tt(tm), tt(fr.proposal_score))
+        for _ in range(2):
+            torch_ref.match_forward(*args_t, max_iter=20, proj_iter=5, is_test=1)
+        times = []
+        t1 = time.perf_counter()
+        while len(times) < 20 and time.perf_counter() - t1 < max(3.0, seconds / 3):
+            t2 = time.perf_counter()
+            torch_ref.match_forward(*args_t, max_iter=20, proj_iter=5, is_test=1)
+            times.append(time.perf_counter() - t2)
+        torch.set_num_threads(old_threads)
+        out["torch_ops"] = {"value": round(1.0 / float(np.mean(times)), 3), "unit": "frames/s", "cores": cores,
+                            "kind": "port (op-for-op torch restatement of match_model.py:24-148, oracle/torch_ref.py)",
+                            "sample": f"{len(times)} frames, one per call, torch intra-op threads = {cores}, "
+                                      f"{np.mean(times) * 1e3:.0f} +- {np.std(times) * 1e3:.0f} ms per frame"}
+    except Exception as e:                                   # a side figure must not cost the line
+        out["torch_ops"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def pmc_traffic(extra_args, kernel_prefixes):

@@ -314,3 +314,25 @@ def test_g19_tables_outside_the_fast_kernels_envelope(k):
     assert fr.checksum() == str(g[f"c{k}/checksum"])
     o = check_layer(fr, g.group(f"c{k}"), 12, 4, is_test, big=True)
     assert o["R"].shape == (O, max(P, O + 1))
+
+
+def test_torch_restatement_for_the_cpu_baseline_agrees_with_the_oracle():
+    """oracle/torch_ref.py -- the op-for-op torch (CPU) form bench.py times as ``cpu_baseline.torch_ops`` (the
+    reference PyTorch-CPU path on the host cores) -- runs the same number of solver iterations as the C oracle (both
+    data-dependent exits included) and lands within 1e-6 of its outputs on plumbing-sized frames, test and train mode."""
+    import torch
+    from oracle import torch_ref
+    t = torch.from_numpy
+    for (P, O, H, W, D, it, pj, kind) in [(8, 3, 64, 64, 512, 20, 5, "structured"), (3, 5, 16, 16, 64, 10, 5, "uniform"),
+                                          (50, 10, 32, 32, 512, 40, 5, "structured"), (17, 3, 24, 24, 64, 400, 50, "structured")]:
+        fr = synth.make_frame(P, O, H, W, D, seed=11 + P, kind=kind)
+        for is_test in (1, 0):
+            o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                                     fr.proposal_score, max_iter=it, proj_iter=pj, is_test=is_test)
+            r = torch_ref.match_forward(t(fr.proposed_feature), t(fr.proposed_mask), t(fr.template_feature),
+                                        t(fr.mask_last_occurence), t(fr.proposal_score), max_iter=it, proj_iter=pj,
+                                        is_test=is_test)
+            assert r["iters"] == o["iters"], (P, O, is_test)
+            assert np.abs(r["match_score"].numpy() - o["match_score"]).max() <= 1e-6
+            assert np.abs(r["det_score"].numpy() - o["det_score"]).max() <= 1e-6
+            assert np.abs(r["full_outmask"].numpy() - o["full_outmask"]).max() <= 1e-5
