@@ -573,7 +573,7 @@ __global__ __launch_bounds__(128) void feature_sim_bwd_kernel(
     const float *__restrict__ featn_t, const float *__restrict__ featn_p, const float *__restrict__ norm_t,
     const float *__restrict__ norm_p, int N, int M, int D, const int32_t *__restrict__ n_valid,
     const int32_t *__restrict__ m_valid, float *__restrict__ g_t, float *__restrict__ g_p) {
-    __shared__ float coef[DMM_MAX_PROPOSALS];               // dcos slice of this row
+    extern __shared__ float coef[];                         // dcos slice of this row: max(N, M) floats (dynamic LDS)
     __shared__ float red[2];
     const int b = blockIdx.y, r = blockIdx.x;
     const bool is_p = r < N;
@@ -651,9 +651,11 @@ extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, con
     if (!dsim || !feat_t || !feat_p || !featn_t || !featn_p || !norm_t || !norm_p || !g_feat_t || !g_feat_p)
         return DMM_ERR_BAD_ARG;
     if ((gt || d_loss) && !(gt && d_loss && cosv)) return DMM_ERR_BAD_ARG;
-    if (N > DMM_MAX_PROPOSALS || M > DMM_MAX_PROPOSALS || B > 65535) return DMM_ERR_UNSUPPORTED;
+    // any N, M whose longer side fits the default dynamic-LDS limit (the row's dcos slice: 4 bytes per entry)
+    const size_t coef_bytes = sizeof(float) * (size_t)(N > M ? N : M);
+    if (coef_bytes > 60 * 1024 || B > 65535 || (int64_t)N + M > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
     const float w_feat = (float)(1.0 - (double)score_weight);
-    hipLaunchKernelGGL(dmm::feature_sim_bwd_kernel, dim3(N + M, B), dim3(128), 0, (hipStream_t)stream, dsim, cosv, gt,
+    hipLaunchKernelGGL(dmm::feature_sim_bwd_kernel, dim3(N + M, B), dim3(128), coef_bytes, (hipStream_t)stream, dsim, cosv, gt,
                        d_loss, w_feat, feat_t, feat_p, featn_t, featn_p, norm_t, norm_p, N, M, D, n_valid, m_valid,
                        g_feat_t, g_feat_p);
     return dmm::check_launch();

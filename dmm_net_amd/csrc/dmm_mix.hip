@@ -736,6 +736,46 @@ __global__ __launch_bounds__(256) void mask_mix_wide_kernel(const float *__restr
     MixOut<TO>::store1(out + (int64_t)b * so_b + (int64_t)m * so_m + x, acc);
 }
 
+// dRb for ANY N, M: one workgroup per (proposal column, template row, frame); entries outside the support of Rb are zero
+// without touching a plane.  Deterministic (a fixed-order block reduction, no atomics).  Correctness path.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_mix_bwd_wide_kernel(const float *__restrict__ Rb, const T *__restrict__ masks_p,
+                                                                const float *__restrict__ dout, int N, int M, int Pp,
+                                                                int HW, int64_t sp_b, int64_t sp_n,
+                                                                const int32_t *__restrict__ n_valid,
+                                                                const int32_t *__restrict__ m_valid,
+                                                                float *__restrict__ dRb) {
+    __shared__ float part[4];
+    const int b = blockIdx.z, m = blockIdx.y, nn = blockIdx.x;
+    int Nb = n_valid ? n_valid[b] : N;
+    int Mb = m_valid ? m_valid[b] : M;
+    if (Nb <= 0) Mb = 0;
+    float *o = dRb + ((int64_t)b * M + m) * Pp + nn;
+    const bool live = m < Mb && nn < Nb && Rb[((int64_t)b * M + m) * Pp + nn] != 0.0f;
+    if (!live) {
+        if (threadIdx.x == 0) *o = 0.0f;
+        return;
+    }
+    const T *plane = frame_base(masks_p, b, sp_b) + (int64_t)nn * sp_n;
+    const float *drow = dout + ((int64_t)b * M + m) * HW;
+    float acc = 0.0f;
+    for (int x = threadIdx.x; x < HW; x += 256) acc = __builtin_fmaf(drow[x], MaskIO<T>::load1(plane + x), acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *o = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+template <typename T>
+static int mask_mix_bwd_wide_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
+                                   int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
+                                   hipStream_t stream) {
+    if (Pp > N) DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));   // the padded columns
+    hipLaunchKernelGGL((mask_mix_bwd_wide_kernel<T>), dim3(N, M, B), dim3(256), 0, stream, Rb, masks_p, dout, N, M, Pp, HW,
+                       sp_b, sp_n, n_valid, m_valid, dRb);
+    return check_launch();
+}
+
 template <typename T, typename TO>
 static int mask_mix_wide_typed(const float *Rb, const T *masks_p, int B, int N, int M, int Pp, int HW, int64_t sp_b,
                                int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, TO *out, int64_t so_b,
@@ -863,9 +903,24 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
     if (B < 0 || N < 0 || M < 0 || HW < 0 || Pp < N) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
     if (!Rb || !masks_p || !dout || !dRb) return DMM_ERR_BAD_ARG;
-    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
+    if (M > 65535 || B > 65535) return DMM_ERR_UNSUPPORTED;
     if (sp_n < HW) return DMM_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (M > DMM_MAX_TEMPLATES || N > DMM_MAX_PROPOSALS || dmm::opt(DMM_OPT_FORCE_WIDE) == 1) {   // any N, M: the general kernel
+        switch (dtype) {
+            case DMM_F32:
+                return dmm::mask_mix_bwd_wide_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n,
+                                                           n_valid, m_valid, dRb, s);
+            case DMM_F16:
+                return dmm::mask_mix_bwd_wide_typed<dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, dout, B, N, M, Pp, HW, sp_b,
+                                                                sp_n, n_valid, m_valid, dRb, s);
+            case DMM_BF16:
+                return dmm::mask_mix_bwd_wide_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, dout, B, N, M, Pp, HW,
+                                                                 sp_b, sp_n, n_valid, m_valid, dRb, s);
+            default:
+                return DMM_ERR_BAD_ARG;
+        }
+    }
     // default: planes of the union streamed once -- while the four per-wave pair tables fit the default dynamic-LDS limit
     // (4 * N * MT floats <= 60 KB: everything up to 120 proposals x 32 rows or 240 x 16); wider tables keep the row kernel
     const int mt = M <= 8 ? 8 : (M <= 16 ? 16 : 32);

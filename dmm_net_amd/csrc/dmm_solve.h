@@ -41,4 +41,10 @@ int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int
                             float *Rb_out, float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                             float *scratch, hipStream_t stream);
 
+// backward of the solver at any table size (dmm_wide.hip): workspace bytes PER FRAME, and the launch
+size_t wide_bwd_bytes(int N, int M, int max_iter, int proj_iter);
+int launch_relax_match_bwd_wide(const float *sim, const float *score_p, int B, int N, int M, const int32_t *n_valid,
+                                const int32_t *m_valid, RelaxParams prm, int is_test, const float *dRb, const float *dms,
+                                const float *dds, float *dsim_out, void *workspace, hipStream_t stream);
+
 }  // namespace dmm

@@ -427,6 +427,9 @@ extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const in
 extern "C" size_t dmm_relax_bwd_workspace_bytes(int B, int N, int M, int max_iter, int proj_iter) {
     if (B <= 0 || N <= 0 || M <= 0 || max_iter < 0 || proj_iter < 0) return 0;
     const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || max_iter > dmm::kMaxTapeOuter ||
+        dmm::opt(DMM_OPT_FORCE_WIDE) == 1)                       // the general kernel: all of its state lives here
+        return (size_t)B * dmm::wide_bwd_bytes(N, M, max_iter, proj_iter) + 256;
     const size_t threads = 64 * (size_t)((Pp + 63) / 64 == 3 ? 4 : (Pp + 63) / 64);
     return sizeof(uint2) * (size_t)B * (size_t)max_iter * (size_t)proj_iter * threads + 256;
 }
@@ -440,10 +443,17 @@ extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, i
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0 || !sim || !score_p || !dsim_out) return DMM_ERR_BAD_ARG;
     const int Pp = N > M ? N : M + 1;
-    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || max_iter > dmm::kMaxTapeOuter) return DMM_ERR_UNSUPPORTED;
     if (workspace_bytes < dmm_relax_bwd_workspace_bytes(B, N, M, max_iter, proj_iter)) return DMM_ERR_WORKSPACE;
-    if (!workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
     const dmm::RelaxParams prm{max_iter, proj_iter, lr};
+    if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || max_iter > dmm::kMaxTapeOuter ||
+        dmm::opt(DMM_OPT_FORCE_WIDE) == 1) {
+        // tables outside the register-resident kernel's envelope (or more outer iterations than its tape index holds):
+        // the general backward of dmm_wide.hip -- training at ANY N, M (the reference's autograd is unbounded)
+        if (!workspace) return DMM_ERR_BAD_ARG;
+        return dmm::launch_relax_match_bwd_wide(sim, score_p, B, N, M, n_valid, m_valid, prm, is_test, dRb, d_match_score,
+                                                d_det_score, dsim_out, workspace, (hipStream_t)stream);
+    }
+    if (!workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
     const bool exact_ok = (m_valid == nullptr);
     uint2 *tape = (uint2 *)workspace;
 #define DMM_CALL(MT_, NG_, EX_)                                                                                       \

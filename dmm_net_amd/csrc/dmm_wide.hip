@@ -323,4 +323,279 @@ int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the solver for ANY table size: d loss / d sim from d Rb, d match_score, d det_score -- the reference's autograd
+// through relax_matching (relax_match.py:36-105) and the epilogue of match_with_first_frame (match_model.py:118-147), which
+// is unbounded; the register-resident kernel of dmm_solve.hip covers M <= 32, Pp <= 256.  Same scheme as that kernel: the
+// forward is re-run from the saved sim (same operations in the same order as relax_match_wide_kernel -> same iterates, same
+// exits), every projection sweep tapes one byte per element (the relu's gate) and per column (the column projection's
+// gate), then the tape is walked backwards: given its gates a sweep is a linear map.  One workgroup per frame, all state
+// in the caller's workspace (wide_bwd_bytes).  Correctness path: dependent chains through L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideBwdTables = 15;        // C X P0 P1 P2 Xs acc tmp | gX gP0 gP1 gP2 gC gl gy1
+
+size_t wide_bwd_bytes(int N, int M, int max_iter, int proj_iter) {
+    const size_t PpS = (size_t)(N > M ? N : M + 1), cap = (size_t)M * PpS;
+    const size_t floats = kWideBwdTables * cap + 4 * PpS + 6 * (size_t)M + 64;
+    const size_t ints = (size_t)M + (size_t)max_iter + 64;
+    const size_t tape = (size_t)max_iter * (size_t)proj_iter * (cap + PpS);
+    return (4 * (floats + ints) + tape + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ float wide_wave_sum(float v) { return wave_sum(v); }
+
+__global__ __launch_bounds__(kWideSolverThreads) void relax_match_bwd_wide_kernel(
+    const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
+    const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
+    float *__restrict__ dsim_out, unsigned char *__restrict__ ws, size_t ws_stride) {
+    __shared__ float sh[kWideSolverThreads / 64 + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, l = tid & 7, grp = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = kWideSolverThreads, NGRP = kWideSolverThreads / 8, NW = kWideSolverThreads / 64;
+    const int Nb = n_valid ? n_valid[b] : N;
+    const int Mb = m_valid ? m_valid[b] : M;
+    const int PpS = N > M ? N : M + 1;
+    float *dsim_b = dsim_out + (int64_t)b * M * N;
+    if (Mb <= 0 || Nb <= 0) {
+        for (int e = tid; e < M * N; e += NT) dsim_b[e] = 0.0f;
+        return;
+    }
+    const int n = Mb, m = Nb > Mb ? Nb : Mb + 1, cnt = n * m;
+    const size_t cap = (size_t)M * PpS;
+    float *base = reinterpret_cast<float *>(ws + (size_t)b * ws_stride);
+    float *C = base, *X = C + cap, *P0 = X + cap, *P1 = P0 + cap, *P2 = P1 + cap, *Xs = P2 + cap, *acc = Xs + cap,
+          *tmp = acc + cap, *gX = tmp + cap, *gP0 = gX + cap, *gP1 = gP0 + cap, *gP2 = gP1 + cap, *gC = gP2 + cap,
+          *gl = gC + cap, *gy1 = gl + cap;
+    float *tc = gy1 + cap, *cg = tc + PpS, *aux_c = cg + PpS, *aux_c2 = aux_c + PpS;
+    float *rt = aux_c2 + PpS, *rs = rt + M, *rmaxv = rs + M, *vmaxv = rmaxv + M, *gdir = vmaxv + M, *aux_r = gdir + M;
+    int *idx = reinterpret_cast<int *>(aux_r + M + 64), *sweeps = idx + M;
+    unsigned char *tape = reinterpret_cast<unsigned char *>(sweeps + prm.max_iter + 64);
+    const size_t tape_stride = (size_t)cnt + (size_t)m;               // per sweep: cnt relu gates, then m column gates
+    (void)aux_c; (void)aux_c2; (void)aux_r; (void)gdir;
+
+    // ---- C = -sim_pad ----
+    for (int e = tid; e < cnt; e += NT) {
+        const int i = e / m, c = e - i * m;
+        const float sv = c < Nb ? sim_in[(int64_t)b * M * N + (int64_t)i * N + c] : 0.0f;
+        C[e] = -sv;
+    }
+    __syncthreads();
+    // ---- greedy init (no gradient) ----
+    {
+        float cm = -__builtin_inff();
+        for (int e = tid; e < cnt; e += NT) cm = C[e] > cm ? C[e] : cm;
+        const float cmax = wide_block_max(cm, sh);
+        for (int c = tid; c < m; c += NT) {
+            int best = 0;
+            float bv = C[c];
+            for (int i = 1; i < n; ++i)
+                if (C[i * m + c] < bv) { bv = C[i * m + c]; best = i; }
+            for (int i = 0; i < n; ++i) tmp[i * m + c] = i == best ? C[i * m + c] : cmax;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            int best = 0;
+            float bv = tmp[i * m];
+            for (int c = 1; c < m; ++c)
+                if (tmp[i * m + c] < bv) { bv = tmp[i * m + c]; best = c; }
+            idx[i] = best;
+        }
+        __syncthreads();
+        for (int e = tid; e < cnt; e += NT) {
+            const int i = e / m, c = e - i * m;
+            const float x0 = c == idx[i] ? 1.0f : 0.0f;
+            X[e] = x0;
+            acc[e] = 0.0f + x0;
+            P0[e] = 0.0f; P1[e] = 0.0f; P2[e] = 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- forward, taped (the loop of relax_match_wide_kernel) ----
+    const float fn = (float)n, fm = (float)m;
+    const int cbound = torder::outer_class_bound(m);
+    int len = 1, pos = 0;
+    float cost_prev = 0.0f;
+    for (int it = 0; it < prm.max_iter; ++it) {
+        for (int e = tid; e < cnt; e += NT) {
+            const float g = prm.lr * C[e];
+            const float x = X[e] - g;
+            X[e] = x;
+            tmp[e] = x * C[e];
+            acc[e] = acc[e] + x;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float c = torder::norm2_group8(cnt, tid, [&](long i) { return tmp[i]; });
+            if (tid == 0) sh[NW] = c;
+        }
+        __syncthreads();
+        const float cost = sh[NW];
+        ++len;
+        int ns = 0;
+        for (int j = 0; j < prm.proj_iter; ++j) {
+            unsigned char *tp = tape + (size_t)pos * tape_stride;
+            for (int e = tid; e < cnt; e += NT) {
+                const float xs = X[e];
+                Xs[e] = xs;
+                const float x = xs + P0[e];
+                const float y = x > 0.0f ? x : 0.0f;
+                tp[e] = x > 0.0f ? 1 : 0;                              // relu gate
+                P0[e] = x - y;
+                X[e] = y + P1[e];
+            }
+            __syncthreads();
+            for (int c = tid; c < m; c += NT) {
+                const float cs = torder::outer_sum_col(n, c < cbound, [&](long i) { return X[i * m + c]; });
+                const bool over = !(cs <= 1.0f);
+                tp[cnt + c] = over ? 1 : 0;                            // column gate
+                tc[c] = cs <= 1.0f ? 0.0f : (cs - 1.0f) / fn;
+            }
+            __syncthreads();
+            for (int e = tid; e < cnt; e += NT) {
+                const int c = e % m;
+                const float x = X[e];
+                const float y = x - tc[c];
+                P1[e] = x - y;
+                X[e] = y + P2[e];
+            }
+            __syncthreads();
+            for (int i = grp; i < n; i += NGRP) {
+                const float s = torder::inner_sum_group8(m, l, [&](long k) { return X[i * m + k]; });
+                if (l == 0) rt[i] = (s - 1.0f) / fm;
+            }
+            __syncthreads();
+            int moved = 0;
+            for (int e = tid; e < cnt; e += NT) {
+                const int i = e / m;
+                const float x = X[e];
+                const float y = x - rt[i];
+                P2[e] = x - y;
+                X[e] = y;
+                const float d = y - Xs[e];
+                const float sq = d * d;
+                moved |= !(sq == 0.0f);
+            }
+            ++pos;
+            ++ns;
+            if (!__syncthreads_or(moved)) break;
+        }
+        if (tid == 0) sweeps[it] = ns;
+        if (cost_prev == cost) break;
+        cost_prev = cost;
+    }
+    const int iters = len - 1;
+    __syncthreads();
+
+    // ---- epilogue adjoints: R = acc / len; logic; Rb; match_score = max_c clamp(R) * sim_pad; det_score = sum_c sc * Rb ----
+    const float flen = (float)len;
+    for (int i = wave; i < n; i += NW) {                               // row maxima of R and of clamp(R) * sim_pad
+        float mx = -__builtin_inff(), vx = -__builtin_inff();
+        for (int c = lane; c < m; c += 64) {
+            const float r = acc[i * m + c] / flen;
+            const float rc = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            const float v = rc * (-C[i * m + c]);
+            mx = r > mx ? r : mx;
+            vx = v > vx ? v : vx;
+        }
+        mx = wave_max(mx);
+        vx = wave_max(vx);
+        int cand = 0x7fffffff;                                         // torch.max(dim) backward: the first maximal index
+        for (int c = lane; c < m; c += 64) {
+            const float r = acc[i * m + c] / flen;
+            const float rc = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            if (rc * (-C[i * m + c]) == vx && c < cand) cand = c;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(cand, d);
+            cand = o < cand ? o : cand;
+        }
+        if (lane == 0) { rmaxv[i] = mx; idx[i] = cand; }
+    }
+    __syncthreads();
+    for (int e = tid; e < cnt; e += NT) {
+        const int i = e / m, c = e - i * m;
+        const float r = acc[e] / flen;
+        const float lg = is_test ? (r == rmaxv[i] ? 1.0f : 0.0f) : (r > 0.01f ? 1.0f : 0.0f);
+        const float sc = c < Nb ? score_p[(int64_t)b * N + c] : 0.0f;
+        const float dms = dms_in ? dms_in[(int64_t)b * M + i] : 0.0f;
+        const float dds = dds_in ? dds_in[(int64_t)b * M + i] : 0.0f;
+        float dR = ((dRb_in ? dRb_in[(int64_t)b * M * PpS + (int64_t)i * PpS + c] : 0.0f) + dds * sc) * lg;
+        float gd = 0.0f;
+        if (c == idx[i]) {
+            const float rc = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            if (r >= 0.0f && r <= 1.0f) dR += dms * (-C[e]);            // clamp passes its gradient on [0, 1]
+            gd = dms * rc;                                             // d / d sim_pad of clamp(R) * sim_pad
+        }
+        gl[e] = dR / flen;
+        tmp[e] = gd;                                                   // (tmp is free now: the direct term)
+        gX[e] = 0.0f; gP0[e] = 0.0f; gP1[e] = 0.0f; gP2[e] = 0.0f; gC[e] = 0.0f;
+    }
+    __syncthreads();
+
+    // ---- reverse sweep through the tape ----
+    const float inv_m = 1.0f / fm, inv_n = 1.0f / fn;
+    for (int it = iters - 1; it >= 0; --it) {
+        const int ns = sweeps[it];
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            --pos;
+            const unsigned char *tp = tape + (size_t)pos * tape_stride;
+            // row projection: y2 = c - (rowsum(c) - 1) / m; P2' = c - y2; X' = y2
+            for (int i = wave; i < n; i += NW) {
+                float s = 0.0f;
+                for (int c = lane; c < m; c += 64) s += gX[i * m + c] - gP2[i * m + c];
+                s = wide_wave_sum(s);
+                if (lane == 0) rs[i] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < cnt; e += NT) {
+                const int i = e / m;
+                const float gy2 = gX[e] - gP2[e];
+                const float gc = gP2[e] + gy2 - rs[i] * inv_m;
+                gP2[e] = gc;                                           // c = y1 + P2
+                gy1[e] = gc - gP1[e];                                  // P1' = b - y1
+            }
+            __syncthreads();
+            // column projection: y1 = b - over * (colsum(b) - 1) / n
+            for (int c = tid; c < m; c += NT) {
+                float s = 0.0f;
+                for (int i = 0; i < n; ++i) s += gy1[i * m + c];
+                cg[c] = tp[cnt + c] ? s * inv_n : 0.0f;
+            }
+            __syncthreads();
+            for (int e = tid; e < cnt; e += NT) {
+                const int c = e % m;
+                const float gb = gP1[e] + gy1[e] - cg[c];
+                gP1[e] = gb;                                           // b = y0 + P1
+                const float gy0 = gb - gP0[e];                         // P0' = a - y0
+                const float ga = gP0[e] + (tp[e] ? gy0 : 0.0f);        // y0 = relu(a)
+                gX[e] = ga;                                            // a = X + P0
+                gP0[e] = ga;
+            }
+            __syncthreads();
+        }
+        // gradient step X_pre = X_prev - lr * C; X_pre is this iteration's entry of X_list
+        for (int e = tid; e < cnt; e += NT) {
+            const float g = gX[e] + gl[e];
+            gC[e] = gC[e] - prm.lr * g;
+            gX[e] = g;
+        }
+        __syncthreads();
+    }
+    // C = -sim_pad -> dsim = -dC (+ the direct match_score term); padded columns are dropped, dead entries zero
+    for (int e = tid; e < M * N; e += NT) {
+        const int i = e / N, c = e - i * N;
+        dsim_b[e] = (i < n && c < Nb) ? tmp[i * m + c] - gC[i * m + c] : 0.0f;
+    }
+}
+
+int launch_relax_match_bwd_wide(const float *sim, const float *score_p, int B, int N, int M, const int32_t *n_valid,
+                                const int32_t *m_valid, RelaxParams prm, int is_test, const float *dRb, const float *dms,
+                                const float *dds, float *dsim_out, void *workspace, hipStream_t stream) {
+    const size_t stride = wide_bwd_bytes(N, M, prm.max_iter, prm.proj_iter);
+    hipLaunchKernelGGL(relax_match_bwd_wide_kernel, dim3(B), dim3(kWideSolverThreads), 0, stream, sim, score_p, N, M, n_valid,
+                       m_valid, prm, is_test, dRb, dms, dds, dsim_out, (unsigned char *)workspace, stride);
+    return check_launch();
+}
+
 }  // namespace dmm

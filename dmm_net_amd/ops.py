@@ -373,12 +373,39 @@ def feature_sim_bwd(dsim, cos, gt, d_loss, score_weight, feat_t, feat_p, featn_t
     return g_t, g_p
 
 
+def _greedy_init_any(C: torch.Tensor, rows_valid=None, cols_valid=None):
+    """relax_matching(C, 0, 0, 0) -- the greedy one-hot initialisation alone (relax_match.py:45-55), what
+    compute_matching_loss asks for (match_helper.py:44) -- for tables OUTSIDE the solver kernels' envelope: a handful of
+    device tensor ops (order-free: max, first argmin over rows per column, first argmin over columns per row; torch's
+    argmin returns the first minimal index).  Inside the envelope ``dmm_relax_solve_f32`` does it in its prologue."""
+    B, n, m = C.shape
+    dev = C.device
+    rv = torch.full((B,), n, dtype=torch.int64, device=dev) if rows_valid is None else rows_valid.long()
+    cv = torch.full((B,), m, dtype=torch.int64, device=dev) if cols_valid is None else cols_valid.long()
+    live = (torch.arange(n, device=dev)[None, :, None] < rv[:, None, None]) & \
+           (torch.arange(m, device=dev)[None, None, :] < cv[:, None, None])
+    inf = torch.tensor(float("inf"), device=dev)
+    cmax = torch.where(live, C, -inf).flatten(1).max(1)[0]                               # C.max() over the live block
+    col_best = torch.where(live, C, inf).argmin(1)                                       # [B, m]: first argmin over rows
+    keep = torch.arange(n, device=dev)[None, :, None] == col_best[:, None, :]
+    crm = torch.where(live, torch.where(keep, C, cmax[:, None, None].expand_as(C)), inf)
+    idx = crm.argmin(2)                                                                  # [B, n]: first argmin over columns
+    X = torch.zeros_like(C)
+    X.scatter_(2, idx[:, :, None], 1.0)
+    X = torch.where(live & (torch.arange(n, device=dev)[None, :, None] < rv[:, None, None]), X, torch.zeros_like(X))
+    X = X * ((rv > 0) & (cv > 0))[:, None, None].to(X.dtype)
+    return dict(X=X, R=X.clone(), cost=torch.zeros((B, 1), dtype=torch.float32, device=dev),
+                iters=torch.zeros((B,), dtype=torch.int32, device=dev))
+
+
 def relax_solve(C: torch.Tensor, max_iter: int, proj_iter: int, lr: float, rows_valid=None, cols_valid=None):
     """relax_matching on cost matrices C [B,n,m] -> dict(X, R, cost [B,max_iter+1], iters [B]).
     rows_valid / cols_valid (int32 [B]) restrict each frame to its top-left live block."""
     _need_gpu(C)
     C = C.contiguous().float()
     B, n, m = C.shape
+    if (n > _lib.MAX_TEMPLATES or m > _lib.MAX_PROPOSALS) and max_iter == 0:
+        return _greedy_init_any(C, rows_valid, cols_valid)
     X = torch.empty_like(C)
     R = torch.empty_like(C)
     cost = torch.zeros((B, max_iter + 1), dtype=torch.float32, device=C.device)

@@ -56,12 +56,13 @@ typedef void *dmm_stream_t; /* hipStream_t */
 
 /* Envelope of the FAST kernels: the solver keeps a frame's table in registers (M rows, Pp = max(N, M+1) columns).
  * DMM-Net's configurations sit well inside it (<= 100 proposals, a handful of objects).  The reference itself is
- * unbounded (relax_match.py:36-105), and so is the layer here: dmm_match_forward (5), dmm_cosine_f32 (2) and dmm_mask_mix*
- * (4) take ANY N and M -- beyond the envelope through general kernels (same operations in the same order, bit identical
- * to the reference's CPU path there too; written for correctness, not speed), dmm_iou_counts_* tiles any N x M.  The
- * granular solver entries dmm_relax_match_f32 / _f16s / dmm_relax_solve_* (no argument to hold the general solver's state:
- * use dmm_relax_match_any_f32 (3d)), the backward entries, the 1-bit forms (5b) / (5c) and the frame-step entries keep the envelope and answer
- * DMM_ERR_UNSUPPORTED outside it. */
+ * unbounded (relax_match.py:36-105), and so is the layer here, FORWARD AND BACKWARD: dmm_match_forward (5), dmm_cosine_f32
+ * (2), dmm_mask_mix* (4), dmm_mask_mix_bwd, dmm_relax_match_bwd_f32 (its workspace holds the general kernel's state: ask
+ * dmm_relax_bwd_workspace_bytes) and dmm_feature_sim_bwd_f32 take ANY N and M -- beyond the envelope through general kernels
+ * (same operations in the same order, bit identical to the reference's CPU path in the forward; written for correctness,
+ * not speed), dmm_iou_counts_* tiles any N x M.  The granular solver entries dmm_relax_match_f32 / _f16s / dmm_relax_solve_*
+ * (no argument to hold the general solver's state: use dmm_relax_match_any_f32 (3d)), the 1-bit forms (5b) / (5c) and the
+ * frame-step entries keep the envelope and answer DMM_ERR_UNSUPPORTED outside it. */
 #define DMM_MAX_TEMPLATES 32  /* M  */
 #define DMM_MAX_PROPOSALS 256 /* Pp */
 
