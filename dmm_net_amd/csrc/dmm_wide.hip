@@ -72,6 +72,7 @@ int launch_cosine_wide(const float *featn_t, const float *featn_p, int B, int N,
 // ---------------------------------------------------------------------------------------------
 size_t wide_scratch_floats(int M, int PpS) { return (size_t)9 * M * PpS + (size_t)PpS + 2 * (size_t)M + 64; }
 
+template <int THREADS = kWideSolverThreads>
 __device__ __forceinline__ float wide_block_max(float v, float *sh) {
     v = wave_max(v);
     __syncthreads();
@@ -79,7 +80,7 @@ __device__ __forceinline__ float wide_block_max(float v, float *sh) {
     __syncthreads();
     float r = sh[0];
 #pragma unroll
-    for (int k = 1; k < kWideSolverThreads / 64; ++k) r = sh[k] > r ? sh[k] : r;
+    for (int k = 1; k < THREADS / 64; ++k) r = sh[k] > r ? sh[k] : r;
     return r;
 }
 // max over the aligned 8-lane group (every lane gets it)
@@ -300,6 +301,255 @@ __global__ __launch_bounds__(kWideSolverThreads) void relax_match_wide_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same solver with its state in REGISTERS (the L2-resident form above spends its time in latency:
+// 12 dependent global round trips per element-wise pass and thread, 2.8 ms for 300 x 40 at 20 x 5).  Thread t owns elements
+// t, t + 512, ... (K of them, K = ceil(M * Pp / 512) <= 24) and keeps their C, X, the three Dykstra increments, the
+// sweep's start copy and the sum of iterates in registers for the whole solve; only what OTHER threads read goes through
+// LDS: the iterate X (column / row sums) and the products X * C (cost norm) -- two M x Pp tables.  Same operations in the
+// same order as relax_match_wide_kernel (element-wise steps are order free; the sums are the same torder:: routines on the
+// same values), so the results stay bit identical.  Tables of more than 12288 entries keep the kernel above.
+// 512 threads per frame: 8 waves = 2 per SIMD = 256 VGPRs for 7 K + a few registers (1024 threads would cap at 128: spills).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideRegThreads = 512;
+template <int K>
+__global__ __launch_bounds__(kWideRegThreads) void relax_match_wide_reg_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou, RelaxParams prm,
+    int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    float *__restrict__ X_final, float *__restrict__ scratch, int64_t scratch_stride) {
+    __shared__ float sh[kWideRegThreads / 64 + 1];
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];      // XL [cap] | PL [cap] | SL [cap] | tc [PpS] | rt [M] | idx [M]
+    const int b = blockIdx.x, tid = threadIdx.x, l = tid & 7, grp = tid >> 3;
+    constexpr int NT = kWideRegThreads, NGRP = kWideRegThreads / 8;
+    const int Nb = n_valid ? n_valid[b] : N;
+    const int Mb = m_valid ? m_valid[b] : M;
+    const int PpS = N > M ? N : M + 1;
+    float *Rb_b = Rb_out + (int64_t)b * M * PpS;
+    float *R_b = R_out ? R_out + (int64_t)b * M * PpS : nullptr;
+    float *X_b = X_final ? X_final + (int64_t)b * M * PpS : nullptr;
+    float *sim_b = sim_out + (int64_t)b * M * N;
+    const bool dead = Mb <= 0 || Nb <= 0;
+    const int n = dead ? 0 : Mb;
+    const int m = dead ? 0 : (Nb > Mb ? Nb : Mb + 1);
+    for (int e = tid; e < M * PpS; e += NT) {
+        const int i = e / PpS, c = e - i * PpS;
+        if (i >= n || c >= m) {
+            Rb_b[e] = 0.0f;
+            if (R_b) R_b[e] = 0.0f;
+            if (X_b) X_b[e] = 0.0f;
+        }
+    }
+    for (int e = tid; e < M * N; e += NT) {
+        const int i = e / N, c = e - i * N;
+        if (i >= n || c >= Nb) sim_b[e] = 0.0f;
+    }
+    for (int i = n + tid; i < M; i += NT) {
+        match_score[(int64_t)b * M + i] = 0.0f;
+        det_score[(int64_t)b * M + i] = 0.0f;
+    }
+    if (dead) {
+        if (iters_out && tid == 0) iters_out[b] = 0;
+        return;
+    }
+    const int cnt = n * m;
+    const size_t cap = (size_t)M * PpS;
+    // XL: the iterate (what the sums read); PL: X * C for the cost norm; SL: the sweep's start copy (read back once per
+    // sweep by its owner -- keeping it in registers cost 1/7 of the register budget); the sum of iterates is touched once
+    // per OUTER iteration and lives in the caller's scratch (L2)
+    float *XL = lds_t, *PL = XL + cap, *SL = PL + cap, *tc = SL + cap, *rt = tc + PpS;
+    int *idx = reinterpret_cast<int *>(rt + M);
+    // ... and so does the cost C (read once per outer iteration: the gradient step and the cost norm's products)
+    float *Cg = scratch + (int64_t)b * scratch_stride, *accg = Cg + cap;
+
+    float Xr[K], P0[K], P1[K], P2[K];
+    int ic[K];                                                         // (row << 16) | column of element k
+    bool on[K];
+    // ---- sim = (1-w)*cos + w*iou (match_model.py:90, match_helper.py:24-27); pad; C = -sim ----
+    {
+        const float *cos_b = cos_in + (int64_t)b * M * N;
+        const int32_t *inter_b = inter + (int64_t)b * M * N;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = tid + k * NT;
+            on[k] = e < cnt;
+            const int i = on[k] ? e / m : 0, c = on[k] ? e - i * m : 0;
+            ic[k] = (i << 16) | c;
+            float simv = 0.0f;
+            if (on[k] && c < Nb) {
+                const int in = inter_b[(int64_t)i * N + c];
+                const int un = area_p[(int64_t)b * N + c] + area_t[(int64_t)b * M + i] - in;
+                const float iou = (float)in / ((float)un + 1e-6f);
+                const float a = cos_b[(int64_t)i * N + c] * w_feat, cc = iou * w_iou;
+                simv = a + cc;
+                sim_b[(int64_t)i * N + c] = simv;
+            }
+            if (on[k]) {
+                XL[e] = -simv;                                         // padded columns: -0.0
+                Cg[e] = -simv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- greedy row-min initialisation (relax_match.py:45-55) on the LDS copy of C; max / first-argmin are order free ----
+    {
+        float cm = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (on[k]) cm = XL[tid + k * NT] > cm ? XL[tid + k * NT] : cm;
+        const float cmax = wide_block_max<kWideRegThreads>(cm, sh);
+        for (int c = tid; c < m; c += NT) {
+            int best = 0;
+            float bv = XL[c];
+            for (int i = 1; i < n; ++i)
+                if (XL[i * m + c] < bv) { bv = XL[i * m + c]; best = i; }
+            for (int i = 0; i < n; ++i) PL[i * m + c] = i == best ? XL[i * m + c] : cmax;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            int best = 0;
+            float bv = PL[i * m];
+            for (int c = 1; c < m; ++c)
+                if (PL[i * m + c] < bv) { bv = PL[i * m + c]; best = c; }
+            idx[i] = best;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float x0 = (on[k] && (ic[k] & 0xffff) == idx[ic[k] >> 16]) ? 1.0f : 0.0f;
+            Xr[k] = x0;
+            if (on[k]) accg[tid + k * NT] = 0.0f + x0;
+            P0[k] = 0.0f; P1[k] = 0.0f; P2[k] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const float fn = (float)n, fm = (float)m;
+    const int cbound = torder::outer_class_bound(m);
+    int len = 1;
+    float cost_prev = 0.0f;
+    for (int it = 0; it < prm.max_iter; ++it) {
+        // gradient step X = X - lr*C (:69); cost = ||X*C||_F (:70); X_list.append(X) (:71)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float cv = on[k] ? Cg[tid + k * NT] : 0.0f;
+            const float g = prm.lr * cv;
+            const float x = Xr[k] - g;
+            Xr[k] = x;
+            if (on[k]) {
+                PL[tid + k * NT] = x * cv;
+                accg[tid + k * NT] = accg[tid + k * NT] + x;
+            }
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float c = torder::norm2_group8(cnt, tid, [&](long i) { return PL[i]; });
+            if (tid == 0) sh[kWideRegThreads / 64] = c;
+        }
+        __syncthreads();
+        const float cost = sh[kWideRegThreads / 64];
+        ++len;
+        for (int j = 0; j < prm.proj_iter; ++j) {
+            // {X >= 0} (:74-76), then X = Y + P1 (:78)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float xs = Xr[k];
+                if (on[k]) SL[tid + k * NT] = xs;
+                const float x = xs + P0[k];
+                const float y = x > 0.0f ? x : 0.0f;
+                P0[k] = x - y;
+                Xr[k] = y + P1[k];
+                if (on[k]) XL[tid + k * NT] = Xr[k];
+            }
+            __syncthreads();
+            // project_col (:21-34): column sums in ATen's outer-sum order
+            for (int c = tid; c < m; c += NT) {
+                const float cs = torder::outer_sum_col(n, c < cbound, [&](long i) { return XL[i * m + c]; });
+                tc[c] = cs <= 1.0f ? 0.0f : (cs - 1.0f) / fn;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float x = Xr[k];
+                const float y = x - (on[k] ? tc[ic[k] & 0xffff] : 0.0f);
+                P1[k] = x - y;
+                Xr[k] = y + P2[k];                                     // (:82)
+                if (on[k]) XL[tid + k * NT] = Xr[k];
+            }
+            __syncthreads();
+            // project_row (:9-19): row sums in ATen's inner-sum order, one 8-lane group per row
+            for (int i = grp; i < n; i += NGRP) {
+                const float s = torder::inner_sum_group8(m, l, [&](long q) { return XL[i * m + q]; });
+                if (l == 0) rt[i] = (s - 1.0f) / fm;
+            }
+            __syncthreads();
+            int moved = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float x = Xr[k];
+                const float y = x - (on[k] ? rt[ic[k] >> 16] : 0.0f);
+                P2[k] = x - y;
+                Xr[k] = y;                                             // (:86)
+                const float d = y - (on[k] ? SL[tid + k * NT] : y);
+                const float sq = d * d;
+                moved |= on[k] && !(sq == 0.0f);                       // ||X - X_start|| == 0 (:88): every square is zero
+            }
+            if (!__syncthreads_or(moved)) break;
+        }
+        if (cost_prev == cost) break;                                  // (:96-98)
+        cost_prev = cost;
+    }
+    const int iters = len - 1;
+    if (iters_out && tid == 0) iters_out[b] = iters;
+
+    // ---- R = sum(X_list)/len; logic; Rb; scores (match_model.py:121-147): acc -> XL, C -> PL, X (if asked) straight out ----
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (on[k]) {
+            XL[tid + k * NT] = accg[tid + k * NT];
+            PL[tid + k * NT] = Cg[tid + k * NT];
+            if (X_b) X_b[(int64_t)(ic[k] >> 16) * PpS + (ic[k] & 0xffff)] = Xr[k];
+        }
+    }
+    __syncthreads();
+    const float flen = (float)len;
+    for (int i = grp; i < n; i += NGRP) {
+        float mx = -__builtin_inff();
+        for (int c = l; c < m; c += 8) {
+            const float r = XL[i * m + c] / flen;
+            mx = r > mx ? r : mx;
+        }
+        mx = group8_max(mx);
+        auto rb_of = [&](int c) {
+            const float r = XL[i * m + c] / flen;
+            const float lg = is_test ? (r == mx ? 1.0f : 0.0f) : (r > 0.01f ? 1.0f : 0.0f);
+            return r * lg;                                             // (:130)
+        };
+        float ms = -__builtin_inff();
+        for (int c = l; c < m; c += 8) {
+            const float r = XL[i * m + c] / flen;
+            const float rb = rb_of(c);
+            const float rc = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            const float v = rc * (-PL[i * m + c]);                     // (:146)
+            ms = v > ms ? v : ms;
+            Rb_b[(int64_t)i * PpS + c] = rb;
+            if (R_b) R_b[(int64_t)i * PpS + c] = r;
+        }
+        ms = group8_max(ms);
+        const float ds = torder::inner_sum_group8(m, l, [&](long q) {     // (score * Rb).sum(1) (:147)
+            const float sc = q < Nb ? score_p[(int64_t)b * N + q] : 0.0f;
+            return sc * rb_of((int)q);
+        });
+        if (l == 0) {
+            match_score[(int64_t)b * M + i] = ms;
+            det_score[(int64_t)b * M + i] = ds;
+        }
+    }
+}
+
 int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
                             const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
                             float w_feat, float w_iou, RelaxParams prm, int is_test, float *sim_out, float *R_out,
@@ -307,6 +557,29 @@ int launch_relax_match_wide(const float *cos_in, const int32_t *inter, const int
                             float *scratch, hipStream_t stream) {
     const int PpS = N > M ? N : M + 1;
     const int64_t stride = (int64_t)wide_scratch_floats(M, PpS);
+    // register-resident form while a thread's share of the table is <= 12 elements and the two LDS tables fit
+    {
+        const size_t cap = (size_t)M * PpS;
+        const size_t lds_reg = sizeof(float) * (3 * cap + (size_t)PpS + 2 * (size_t)M + 16);
+        if (cap <= 24 * (size_t)kWideRegThreads && lds_reg <= 150 * 1024 && M < 65536 && PpS < 65536) {
+#define DMM_WREG(K_)                                                                                                    \
+    do {                                                                                                                \
+        if (lds_reg > 64 * 1024) {                                                                                      \
+            hipError_t e = hipFuncSetAttribute((const void *)relax_match_wide_reg_kernel<K_>,                           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);               \
+            if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }                                 \
+        }                                                                                                               \
+        hipLaunchKernelGGL(relax_match_wide_reg_kernel<K_>, dim3(B), dim3(kWideRegThreads), lds_reg, stream, cos_in,    \
+                           inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, \
+                           R_out, Rb_out, match_score, det_score, iters_out, X_final, scratch, stride);                 \
+    } while (0)
+            if (cap <= 8 * (size_t)kWideRegThreads) DMM_WREG(8);
+            else if (cap <= 16 * (size_t)kWideRegThreads) DMM_WREG(16);
+            else DMM_WREG(24);
+#undef DMM_WREG
+            return check_launch();
+        }
+    }
     // the iterate X is what the column / row sums read element by element: in LDS while M x Pp floats fit (152 KB), else
     // with the rest of the state in the L2-resident scratch (300 x 40 at 20 x 5: 3.6 ms from L2, see tools/wide_timing.py)
     size_t lds = sizeof(float) * (size_t)M * PpS;
