@@ -90,8 +90,10 @@ def _overlap_worker(rank, world, port, q):
         x = torch.randn(8, 16, generator=torch.Generator().manual_seed(100 * step + rank))
         for p in params:
             p.grad = None
+        # this rank's own gradients WITHOUT the hooks (autograd.grad does not accumulate): with bucket views a gradient may
+        # already hold the reduced value when backward() returns
+        local = list(torch.autograd.grad(net(x).pow(2).sum(), params[:-1])) + [None]
         net(x).pow(2).sum().backward()
-        local = [None if p.grad is None else p.grad.clone() for p in params]
         launched = sum(h is not None for h in gb._handles)
         # step 0: the idle parameter sits in bucket 0 and nothing may overtake it (fixed issue order); from step 1 on
         # it is known idle on every rank and the collectives are in flight when backward() returns
@@ -150,11 +152,13 @@ def _diverging_worker(rank, world, port, q):
     gb = GradBucketer(params, bucket_mb=0.003, overlap=True)
     ok = gb.num_collectives() >= 3
     x = torch.randn(4, 8, generator=torch.Generator().manual_seed(7 + rank))
-    loss = a(x).sum() + c(x).pow(2).sum()
-    if rank == 0:
-        loss = loss + b(x).sum()                              # the middle layer only exists in rank 0's graph
-    loss.backward()
-    local = [None if p.grad is None else p.grad.clone() for p in params]
+    def fwd():
+        loss = a(x).sum() + c(x).pow(2).sum()
+        return loss + b(x).sum() if rank == 0 else loss       # the middle layer only exists in rank 0's graph
+    used = [p for p in params if rank == 0 or all(p is not q for q in b.parameters())]
+    own = dict(zip(map(id, used), torch.autograd.grad(fwd(), used)))       # this rank's gradients, without the hooks
+    local = [own.get(id(p)) for p in params]
+    fwd().backward()
     gb.finish()
     ok &= gb.launch_log == list(range(gb.num_collectives()))
     for p, g in zip(params, local):
@@ -198,8 +202,9 @@ def _late_grad_worker(rank, world, port, q):
         for p in params:
             p.grad = None
         use = step == 1 and rank == 1                          # idle everywhere in step 0; one rank uses it in step 1
-        l3(torch.relu(l2(torch.relu(l1(x + shift if use else x))))).pow(2).sum().backward()
-        local = [None if p.grad is None else p.grad.clone() for p in params]
+        fwd = lambda: l3(torch.relu(l2(torch.relu(l1(x + shift if use else x))))).pow(2).sum()
+        local = list(torch.autograd.grad(fwd(), params if use else params[:-1])) + ([] if use else [None])
+        fwd().backward()
         if step == 1:
             ok &= gb._launched[0]                              # bucket 0 left before shift's gradient existed
         gb.finish()

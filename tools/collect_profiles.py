@@ -49,12 +49,15 @@ if not only_pmc and os.environ.get("ONLY_STATS") is None:
     open(os.path.join(out, f"{tag}_bench_frame_loop.json"), "w").write(
         last_json(run(bench + ["--config", "loop"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_config4_1gpu.json"), "w").write(
-        last_json(run(bench + ["--config", "4", "--steps", "10", "--warmup", "4"]).stdout) + "\n")
+        last_json(run(bench + ["--config", "4", "--steps", "20", "--warmup", "4"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_train.json"), "w").write(
+        last_json(run(bench + ["--config", "train", "--steps", "40", "--warmup", "6"]).stdout) + "\n")
 
 only = os.environ.get("ONLY_STATS")                       # e.g. ONLY_STATS=_config3: just that kernel-stats pass
 for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]), ("_config5", ["--config", "5"]),
                                            ("_config3", ["--config", "3", "--steps", "50"]),
-                                           ("_frame_loop", ["--config", "loop"]))):
+                                           ("_frame_loop", ["--config", "loop"]),
+                                           ("_train", ["--config", "train", "--frames", "512", "--steps", "16", "--warmup", "4"]))):
     if only is not None and suffix != only:
         continue
     d = f"/tmp/prof_stats{suffix}"
@@ -109,6 +112,29 @@ if cost:
     res["hbm_bytes_per_launch_at_frames"] = {"512": cost[0]["hbm_bytes_per_launch"]}
     res["algorithmic_bytes_per_launch_at_frames"] = {"512": 512 * (60 * 65025 * 4 + 2000)}
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+# the training form of the layer (bench.py --config train, 512 frames): the same two passes
+tk = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = f"/tmp/prof_train_{ctr}"
+    shutil.rmtree(d, ignore_errors=True)
+    run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + bench +
+        ["--config", "train", "--frames", "512", "--steps", "4", "--warmup", "2"])
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0]
+            name = name[5:] if name.startswith("void ") else name
+            if not name.startswith("dmm::") or row["Counter_Name"] != ctr:
+                continue
+            tk.setdefault(name, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
+tres = {"round": tag, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --config train "
+                                 "--frames 512 --steps 4 --warmup 2 (separate passes)",
+        "units": res["units"], "gfx950_correction": res["gfx950_correction"], "kernels": {}}
+for name, k in tk.items():
+    f, w = k.get("FETCH_SIZE", []), k.get("WRITE_SIZE", [])
+    fa, wa = (sum(f) / len(f) if f else 0.0), (sum(w) / len(w) if w else 0.0)
+    tres["kernels"][name] = {"FETCH_SIZE_KiB_avg": fa, "WRITE_SIZE_KiB_avg": wa, "samples": len(f),
+                             "hbm_bytes_per_launch": int(fa * 1024 * 2 + wa * 1024)}
+json.dump(tres, open(os.path.join(out, f"{tag}_pmc_traffic_train.json"), "w"), indent=1)
 print(json.dumps({n: v["hbm_bytes_per_launch"] for n, v in res["kernels"].items()}, indent=1))
 if not only_pmc:
     print(open(os.path.join(out, f"{tag}_bench.json")).read())
