@@ -639,6 +639,109 @@ __global__ __launch_bounds__(128) void feature_sim_bwd_kernel(
     }
 }
 
+// The same backward, one workgroup per FRAME with thread = feature column d (D threads, D <= 1024): the block-per-row form
+// above re-reads the other side's normalised rows for every row and twice (0.55 ms per 512 frames of 50 x 10, D = 512: L2
+// traffic of ~4 MB per frame for 250 KB of operands).  Here a thread keeps its column of the M normalised template rows in
+// registers, walks the proposal rows once -- g_hat_p[n, d] (stored raw) and g_hat_t[m, d] (M accumulators) out of the same
+// loads --, the per-row <g_hat, x> and ||x||^2 are wave sums folded over the waves in a fixed order, and a second pass over
+// its own column applies the normalisation's backward.  g_hat itself is accumulated in the same order as above (fma over
+// ascending k), only the two row reductions differ in order.
+template <int MT>
+__global__ __launch_bounds__(1024) void feature_sim_bwd_frame_kernel(
+    const float *__restrict__ dsim, const float *__restrict__ cosv, const float *__restrict__ gt,
+    const float *__restrict__ d_loss, float w_feat, const float *__restrict__ feat_t, const float *__restrict__ feat_p,
+    const float *__restrict__ featn_t, const float *__restrict__ featn_p, const float *__restrict__ norm_t,
+    const float *__restrict__ norm_p, int N, int M, int D, const int32_t *__restrict__ n_valid,
+    const int32_t *__restrict__ m_valid, float *__restrict__ g_t, float *__restrict__ g_p) {
+    extern __shared__ float lds[];                          // coef [M*N] | part [NW][2][N+M] | corr [N+M]
+    const int b = blockIdx.x, d = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int Nb = n_valid ? n_valid[b] : N, Mb = m_valid ? m_valid[b] : M;
+    float *coef = lds, *part = coef + M * N, *corr = part + NW * 2 * (N + M);
+    float *gp_b = g_p + (int64_t)b * N * D, *gt_b = g_t + (int64_t)b * M * D;
+    if (Nb <= 0 || Mb <= 0) {                               // nothing is live: every gradient row is zero
+        for (int n = 0; n < N; ++n) gp_b[(int64_t)n * D + d] = 0.0f;
+        for (int m = 0; m < M; ++m) gt_b[(int64_t)m * D + d] = 0.0f;
+        return;
+    }
+    const float lscale = (gt && d_loss) ? 2.0f * d_loss[b] / (float)(Nb * Mb) : 0.0f;
+    for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
+        const int m = e / N, n = e - m * N;
+        float c = 0.0f;
+        if (m < Mb && n < Nb) {
+            const int64_t idx = ((int64_t)b * M + m) * N + n;
+            c = dsim[idx] * w_feat;
+            if (gt && d_loss) c += (cosv[idx] - gt[idx]) * lscale;
+        }
+        coef[e] = c;
+    }
+    __syncthreads();
+    const float *tn_b = featn_t + (int64_t)b * M * D, *pn_b = featn_p + (int64_t)b * N * D;
+    const float *xt_b = feat_t + (int64_t)b * M * D, *xp_b = feat_p + (int64_t)b * N * D;
+    float tnr[MT], ght[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        tnr[m] = m < Mb ? tn_b[(int64_t)m * D + d] : 0.0f;
+        ght[m] = 0.0f;
+    }
+    float *pw = part + wave * 2 * (N + M);
+    for (int n = 0; n < Nb; ++n) {
+        const float pnv = pn_b[(int64_t)n * D + d];
+        float ghp = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < Mb) {
+                const float c = coef[m * N + n];
+                ghp = __builtin_fmaf(c, tnr[m], ghp);
+                ght[m] = __builtin_fmaf(c, pnv, ght[m]);
+            }
+        }
+        const float xp = xp_b[(int64_t)n * D + d];
+        gp_b[(int64_t)n * D + d] = ghp;                     // raw g_hat; fixed up below by the same thread
+        const float sd = wave_sum(ghp * xp), sq = wave_sum(xp * xp);
+        if (lane == 0) { pw[n] = sd; pw[N + M + n] = sq; }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < Mb) {
+            const float xt = xt_b[(int64_t)m * D + d];
+            const float sd = wave_sum(ght[m] * xt), sq = wave_sum(xt * xt);
+            if (lane == 0) { pw[N + m] = sd; pw[N + M + N + m] = sq; }
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < N + M; r += blockDim.x) {
+        const bool is_p = r < N;
+        const int row = is_p ? r : r - N;
+        const bool live = is_p ? row < Nb : row < Mb;
+        float cr = 0.0f;
+        if (live) {
+            float dot = 0.0f, nn = 0.0f;
+            for (int w = 0; w < NW; ++w) {
+                dot += part[w * 2 * (N + M) + r];
+                nn += part[w * 2 * (N + M) + N + M + r];
+            }
+            const float c = is_p ? norm_p[(int64_t)b * N + row] : norm_t[(int64_t)b * M + row];
+            const float nrm = __builtin_sqrtf(nn);
+            cr = nrm > 0.0f ? dot / (c * c * (nrm > 1e-30f ? nrm : 1e-30f)) : 0.0f;
+        }
+        corr[r] = cr;
+    }
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        float g = 0.0f;
+        if (n < Nb) g = gp_b[(int64_t)n * D + d] / norm_p[(int64_t)b * N + n] - xp_b[(int64_t)n * D + d] * corr[n];
+        gp_b[(int64_t)n * D + d] = g;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < M) {
+            float g = 0.0f;
+            if (m < Mb) g = ght[m] / norm_t[(int64_t)b * M + m] - xt_b[(int64_t)m * D + d] * corr[N + m];
+            gt_b[(int64_t)m * D + d] = g;
+        }
+    }
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, const float *gt, const float *d_loss,
@@ -655,6 +758,22 @@ extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, con
     const size_t coef_bytes = sizeof(float) * (size_t)(N > M ? N : M);
     if (coef_bytes > 60 * 1024 || B > 65535 || (int64_t)N + M > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
     const float w_feat = (float)(1.0 - (double)score_weight);
+    // one workgroup per frame, thread = feature column, while the template rows fit a thread's registers (M <= 32) and D is
+    // a whole number of waves up to one workgroup; anything else: the block-per-row form
+    const int nw = D / 64;
+    const size_t frame_lds = sizeof(float) * ((size_t)M * N + (size_t)nw * 2 * (N + M) + (size_t)(N + M));
+    if (dmm::opt(DMM_OPT_FEAT_BWD_FRAME) != 0 && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
+        frame_lds <= 60 * 1024) {
+#define DMM_FSB(MT_)                                                                                                     \
+    hipLaunchKernelGGL((dmm::feature_sim_bwd_frame_kernel<MT_>), dim3(B), dim3(D), frame_lds, (hipStream_t)stream, dsim, \
+                       cosv, gt, d_loss, w_feat, feat_t, feat_p, featn_t, featn_p, norm_t, norm_p, N, M, D, n_valid,     \
+                       m_valid, g_feat_t, g_feat_p)
+        if (M <= 8) DMM_FSB(8);
+        else if (M <= 16) DMM_FSB(16);
+        else DMM_FSB(32);
+#undef DMM_FSB
+        return dmm::check_launch();
+    }
     hipLaunchKernelGGL(dmm::feature_sim_bwd_kernel, dim3(N + M, B), dim3(128), coef_bytes, (hipStream_t)stream, dsim, cosv, gt,
                        d_loss, w_feat, feat_t, feat_p, featn_t, featn_p, norm_t, norm_p, N, M, D, n_valid, m_valid,
                        g_feat_t, g_feat_p);

@@ -99,7 +99,8 @@ typedef enum dmm_option {
     DMM_OPT_MIX_SHARED = 20,        /* mix / mix backward: -1 by entry point (default: dmm_mask_mix_shared_* and the backward
                                        stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
     DMM_OPT_MIX_SHARED_STEPS = 21,  /* union kernels: 4 KiB steps of every plane per workgroup (1)                         */
-    DMM_OPT_COUNT = 22
+    DMM_OPT_FEAT_BWD_FRAME = 22,    /* dmm_feature_sim_bwd_f32: 1 one workgroup per frame (default), 0 one per feature row   */
+    DMM_OPT_COUNT = 23
 } dmm_option;
 DMM_API int dmm_set_option(int option, int value);
 DMM_API int dmm_get_option(int option);

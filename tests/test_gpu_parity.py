@@ -1425,3 +1425,37 @@ def test_shared_plane_mix_equals_the_row_kernel_bit_for_bit(N, M, H, W):
             assert float(dunion[:, :, N:].abs().sum()) == 0.0
     if (N, M) == (50, 10):
         record_achieved("mix_shared/bwd_rel_err_50x10", float((dunion[:, :, :N].double() - dref).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("B,N,M,D", [(3, 50, 10, 512), (2, 200, 20, 256), (4, 7, 32, 64), (2, 256, 1, 1024), (1, 3, 5, 128)])
+def test_frame_form_of_the_feature_backward_agrees_with_the_row_form(B, N, M, D):
+    """dmm_feature_sim_bwd_f32 has two kernels (option FEAT_BWD_FRAME): one workgroup per feature row (rounds 2-3) and one per
+    FRAME with thread = feature column.  Both accumulate g_hat in the same order; the two per-row reductions of the
+    normalisation's backward differ in order: agreement within 2e-5 of the largest entry, with and without the matching-loss
+    term, ragged batches, dead frames, zero feature rows."""
+    g = torch.Generator(device=DEV).manual_seed(40 + N + M)
+    tf = torch.randn((B, M, D), generator=g, device=DEV)
+    pf = torch.relu(torch.randn((B, N, D), generator=g, device=DEV))
+    pf[0, 0] = 0                                                          # a zero row: norm clamps to eps, corr = 0
+    tn, tnorm = ops.feature_normalize(tf, want_norms=True)
+    pn, pnorm = ops.feature_normalize(pf, want_norms=True)
+    cos = ops.cosine(tn, pn)
+    dsim = torch.randn((B, M, N), generator=g, device=DEV)
+    gt = (torch.rand((B, M, N), generator=g, device=DEV) > 0.9).float()
+    dl = torch.rand((B,), generator=g, device=DEV)
+    for ragged in (False, True):
+        nv = mv = None
+        if ragged:
+            nv = torch.tensor(([N, max(1, N // 2), 0, N])[:B], dtype=torch.int32, device=DEV)
+            mv = torch.tensor(([M, M, M, 0])[:B], dtype=torch.int32, device=DEV)
+        for loss in (False, True):
+            args = (dsim, cos if loss else None, gt if loss else None, dl if loss else None, 0.3, tf, pf, tn, pn, tnorm, pnorm,
+                    nv, mv)
+            with _lib.options(FEAT_BWD_FRAME=0):
+                rt, rp = ops.feature_sim_bwd(*args)
+            with _lib.options(FEAT_BWD_FRAME=1):
+                ft, fp = ops.feature_sim_bwd(*args)
+            for a, b_ in ((rt, ft), (rp, fp)):
+                scale = max(float(a.abs().max()), 1e-12)
+                assert bool(torch.isfinite(b_).all())
+                assert float((a - b_).abs().max()) <= 2e-5 * scale, (ragged, loss, float((a - b_).abs().max()), scale)
