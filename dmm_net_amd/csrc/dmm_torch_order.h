@@ -98,6 +98,66 @@ __device__ __forceinline__ float outer_sum_col(long size, bool class_a, F x) {
     return row_sum_scalar(size, x);
 }
 
+// outer_sum_col with the reads BATCHED (16 values fetched before any add; the loop form keeps one LDS / L2 round trip per
+// element in front of every add).  Same add order, same result: class A = one cascade chain with 16-row level steps (lp == 4
+// for every size below 2^20), class B = four plain chains while no chain reaches a level step (size < 64), else generic.
+template <typename F>
+__device__ __forceinline__ float outer_sum_col_batched(int size, bool class_a, F x) {
+    if (size >= (1 << 19)) return outer_sum_col(size, class_a, x);
+    if (class_a) {
+        Cascade c;
+        c.init(size);
+        int i = 0;
+        for (; i + 16 <= size; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = x(i + u);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c.a0 = c.a0 + v[u];
+            c.block16_done();
+        }
+        if (i < size) {
+            float v[15];
+#pragma unroll
+            for (int u = 0; u < 15; ++u) v[u] = x(i + u < size ? i + u : size - 1);
+#pragma unroll
+            for (int u = 0; u < 15; ++u)
+                if (i + u < size) c.a0 = c.a0 + v[u];              // an incomplete block stays in a0
+        }
+        return c.finish();
+    }
+    const int g = size / 4;
+    if (g >= 16) return row_sum_scalar(size, x);
+    Cascade c0, c1, c2, c3;
+    c0.init(g); c1.init(g); c2.init(g); c3.init(g);
+    for (int q0 = 0; q0 < g; q0 += 4) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = 4 * q0 + u;
+            v[u] = x(e < 4 * g ? e : 4 * g - 1);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            if (q0 + qq < g) {
+                c0.a0 = c0.a0 + v[4 * qq]; c1.a0 = c1.a0 + v[4 * qq + 1];
+                c2.a0 = c2.a0 + v[4 * qq + 2]; c3.a0 = c3.a0 + v[4 * qq + 3];
+            }
+    }
+    float p0 = c0.finish();
+    const float p1 = c1.finish(), p2 = c2.finish(), p3 = c3.finish();
+    float r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = x(4 * g + j < size ? 4 * g + j : size - 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (4 * g + j < size) p0 = p0 + r[j];
+    p0 = p0 + p1;
+    p0 = p0 + p2;
+    p0 = p0 + p3;
+    return p0;
+}
+
 // DPP row_shl:K -- lane i reads lane i+K of its 16-lane row (K <= 7 keeps an 8-lane group inside it).
 template <int K>
 __device__ __forceinline__ float shl_f32(float v) {

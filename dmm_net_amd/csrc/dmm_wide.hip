@@ -309,7 +309,9 @@ __global__ __launch_bounds__(kWideSolverThreads) void relax_match_wide_kernel(
 // LDS: the iterate X (column / row sums) and the products X * C (cost norm) -- two M x Pp tables.  Same operations in the
 // same order as relax_match_wide_kernel (element-wise steps are order free; the sums are the same torder:: routines on the
 // same values), so the results stay bit identical.  Tables of more than 12288 entries keep the kernel above.
-// 512 threads per frame: 8 waves = 2 per SIMD = 256 VGPRs for 7 K + a few registers (1024 threads would cap at 128: spills).
+// 512 threads per frame: 8 waves = 2 per SIMD = 256 VGPRs (1024 threads would cap at 128).  Measured (tools/wide_breakdown.py,
+// one frame, 20 x 5): 50 x 40 solver 0.49 ms, 300 x 40 1.29 ms (L2-resident form: 0.95 / 2.5): the K = 24 instantiation still
+// spills ~150 registers inside the sweep (~100 registers of fixed cost from the inlined ATen-order sums + ~13 per element).
 // ---------------------------------------------------------------------------------------------
 constexpr int kWideRegThreads = 512;
 template <int K>
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kWideRegThreads) void relax_match_wide_reg_kernel(
             __syncthreads();
             // project_col (:21-34): column sums in ATen's outer-sum order
             for (int c = tid; c < m; c += NT) {
-                const float cs = torder::outer_sum_col(n, c < cbound, [&](long i) { return XL[i * m + c]; });
+                const float cs = torder::outer_sum_col_batched(n, c < cbound, [&](int i) { return XL[i * m + c]; });
                 tc[c] = cs <= 1.0f ? 0.0f : (cs - 1.0f) / fn;
             }
             __syncthreads();
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(kWideRegThreads) void relax_match_wide_reg_kernel(
             __syncthreads();
             // project_row (:9-19): row sums in ATen's inner-sum order, one 8-lane group per row
             for (int i = grp; i < n; i += NGRP) {
-                const float s = torder::inner_sum_group8(m, l, [&](long q) { return XL[i * m + q]; });
+                const float s = m < 512 ? torder::inner_sum_group8_batched(m, l, [&](int q) { return XL[i * m + q]; })
+                                        : torder::inner_sum_group8(m, l, [&](long q) { return XL[i * m + q]; });
                 if (l == 0) rt[i] = (s - 1.0f) / fm;
             }
             __syncthreads();
