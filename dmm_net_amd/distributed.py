@@ -197,8 +197,10 @@ class GradBucketer:
             # slices will hold the mean once the (in-place) collective has run, and nothing reads a gradient before
             # finish() has waited for it.  (Done in finish(), the ~340 ``p.grad = view`` assignments of a ResNet-101 were
             # ~1 ms of host time AFTER backward() -- exposed whenever the host is not far ahead of the GPU.)
+            # (not the parameters that were idle everywhere so far: should one wake up, finish() needs its LOCAL gradient)
+            idle = self._idle[bi]
             for q, v in zip(self.buckets[bi], self._views[bi]):
-                if q.grad is not None and q.grad is not v:
+                if q.grad is not None and q.grad is not v and id(q) not in idle:
                     q.grad = v
             self._adopted[bi] = True
             self._ready[bi] = True

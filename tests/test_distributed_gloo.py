@@ -221,6 +221,55 @@ def _late_grad_worker(rank, world, port, q):
     q.put((rank, bool(ok)))
 
 
+def _wakeup_worker(rank, world, port, q):
+    """A parameter that was idle on every rank wakes up on ONE rank, IN TIME (its gradient exists before its bucket goes
+    out -- it sits in the last bucket): the bucket carries it, finish() still reduces it from the LOCAL gradients (views
+    adopted early must not be reduced twice), every rank ends up with the plain mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    l1, l2 = torch.nn.Linear(16, 64), torch.nn.Linear(64, 4)
+    extra = torch.nn.Parameter(torch.ones(4))                  # multiplies the OUTPUT: its gradient is the first to arrive
+    params = [extra] + list(l1.parameters()) + list(l2.parameters())
+    gb = GradBucketer(params, bucket_mb=0.004, overlap=True, steady_after=None)
+    ok = gb.buckets[-1][-1] is extra                           # reverse order: it sits in the LAST bucket to go out
+    for step in range(3):
+        x = torch.randn(8, 16, generator=torch.Generator().manual_seed(70 * step + rank))
+        for p in params:
+            p.grad = None
+        use = step == 1 and rank == 0
+        fwd = lambda: (l2(torch.relu(l1(x))) * (extra if use else 1.0)).pow(2).sum()
+        used = params if use else params[1:]
+        own = dict(zip(map(id, used), torch.autograd.grad(fwd(), used)))
+        fwd().backward()
+        gb.finish()
+        for p in params:
+            ref = own[id(p)].clone() if id(p) in own else torch.zeros_like(p)
+            dist.all_reduce(ref)
+            if p is extra and step != 1:
+                ok &= p.grad is None
+            else:
+                ok &= p.grad is not None and bool(torch.allclose(p.grad, ref / world, rtol=1e-6, atol=1e-7))
+    gb.remove_hooks()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world2_idle_parameter_waking_up_in_time_on_one_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wakeup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_gloo_world2_late_gradient_of_a_previously_idle_parameter():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
