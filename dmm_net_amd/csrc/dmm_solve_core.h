@@ -388,9 +388,119 @@ __device__ __forceinline__ void row_steps_wave_vs(const float *rowbuf, int n, in
         for (int k = 0; k < 8; ++k)
             if (p * 8 + k < MT) tr[p * 8 + k] = readlane_f32(step[p], 8 * k);
 }
+// The same row steps for MORE THAN 8 ROWS with 4 lanes per row: lane q of an aligned 4-lane group carries ATen's vector
+// lanes q and q + 4 of its row as the two halves of a packed fp32 pair, so 16 rows go through one pass -- for 9..16 rows
+// one pass instead of two.  The one-wave sweep is ISSUE bound (~260 instructions x ~3.6 cycles, r04 ISA count in LABLOG),
+// so the second pass was not free: this form issues ~30 instructions less per sweep.  Same adds in the same order:
+// v_pk_add_f32 rounds its halves separately, and the in-order combine acc + vec[0] + ... + vec[7] walks the four low
+// halves, then the four high halves, of the group.
+template <int MT, int VS>
+__device__ __forceinline__ void row_steps_wave_pk(const float *rowbuf, int n, int m, float fm, float rcp_m, float (&tr)[MT]) {
+    constexpr int NP = (MT + 15) / 16;
+    const int lane = threadIdx.x & 63, q = lane & 3, g = lane >> 2;
+    f32x2 v[NP][VS > 0 ? VS : 1];
+    f32x4 ta[NP], tb[NP];
+    const bool long_tail = (m & 7) > 4;                // wave-uniform: more than 4 trailing scalars
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = p * 16 + g;
+        const float *x = rowbuf + (r < n ? r : n - 1) * kRowStride;
+#pragma unroll
+        for (int i = 0; i < VS; ++i) v[p][i] = f32x2{x[8 * i + q], x[8 * i + q + 4]};
+        ta[p] = *reinterpret_cast<const f32x4 *>(x + 8 * VS);                    // zero from column m on
+        tb[p] = *reinterpret_cast<const f32x4 *>(x + 8 * VS + 4);
+    }
+    static_assert(VS >= 1, "rows shorter than 8 columns take the scalar form");
+    constexpr int GQ = VS / 4;
+    const f32x2 z2 = f32x2{0.0f, 0.0f};
+    f32x2 p0[NP], p1[NP], p2[NP], p3[NP];
+    float a[NP], s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { p0[p] = z2; p1[p] = z2; p2[p] = z2; p3[p] = z2; }
+    if (GQ >= 1) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { p0[p] = p0[p] + v[p][0]; p1[p] = p1[p] + v[p][1]; p2[p] = p2[p] + v[p][2]; p3[p] = p3[p] + v[p][3]; }
+    }
+    if (GQ >= 2) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { p0[p] = p0[p] + v[p][4]; p1[p] = p1[p] + v[p][5]; p2[p] = p2[p] + v[p][6]; p3[p] = p3[p] + v[p][7]; }
+    }
+#pragma unroll
+    for (int i = 4 * GQ; i < VS; ++i)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) p0[p] = p0[p] + v[p][i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p1[p];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p2[p];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) p0[p] = p0[p] + p3[p];                          // {vec[q], vec[q + 4]}
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = 0.0f + ta[p].x;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].y;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].z;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p] = a[p] + ta[p].w;
+    if (long_tail) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].x;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].y;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = a[p] + tb[p].z;
+    }
+    // acc + vec[0] + vec[1] + ... + vec[7] in that order, valid in lane 0 of every 4-lane group
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = a[p] + p0[p].x;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<1>(p0[p].x);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<2>(p0[p].x);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<3>(p0[p].x);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + p0[p].y;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<1>(p0[p].y);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<2>(p0[p].y);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] + torder::shl_f32<3>(p0[p].y);
+    float q0[NP], rr[NP], step[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = s[p] - 1.0f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) q0[p] = s[p] * rcp_m;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) rr[p] = __builtin_fmaf(-q0[p], fm, s[p]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) step[p] = __builtin_fmaf(rr[p], rcp_m, q0[p]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (p * 16 + k < MT) tr[p * 16 + k] = readlane_f32(step[p], 4 * k);
+}
+
 template <int MT>
 __device__ __forceinline__ void row_steps_wave(const float *rowbuf, int n, int m, float fm, float rcp_m, float (&tr)[MT]) {
     __builtin_amdgcn_wave_barrier();                   // scheduling fence only: the wave's own LDS writes are ordered
+    if constexpr (MT > 8) {
+        switch (m >> 3) {
+            case 0: row_steps_wave_vs<MT, 0>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 1: row_steps_wave_pk<MT, 1>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 2: row_steps_wave_pk<MT, 2>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 3: row_steps_wave_pk<MT, 3>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 4: row_steps_wave_pk<MT, 4>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 5: row_steps_wave_pk<MT, 5>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 6: row_steps_wave_pk<MT, 6>(rowbuf, n, m, fm, rcp_m, tr); break;
+            case 7: row_steps_wave_pk<MT, 7>(rowbuf, n, m, fm, rcp_m, tr); break;
+            default: row_steps_wave_pk<MT, 8>(rowbuf, n, m, fm, rcp_m, tr); break;
+        }
+        return;
+    }
     switch (m >> 3) {
         case 0: row_steps_wave_vs<MT, 0>(rowbuf, n, m, fm, rcp_m, tr); break;
         case 1: row_steps_wave_vs<MT, 1>(rowbuf, n, m, fm, rcp_m, tr); break;
