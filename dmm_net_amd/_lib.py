@@ -25,7 +25,7 @@ SYMBOLS = (
     "dmm_set_option", "dmm_get_option", "dmm_reset_options",
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_feature_sim_bwd_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
-    "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_shared_to", "dmm_mask_mix_shared_frames", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
+    "dmm_mask_mix", "dmm_mask_mix_to", "dmm_mask_mix_shared_to", "dmm_mask_mix_shared_frames", "dmm_mask_mix_bwd", "dmm_workspace_bytes", "dmm_match_forward", "dmm_match_forward_ws", "dmm_roialign4_mean_fwd", "dmm_roialign4_mean_bwd",
     "dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
     "dmm_bias_act_bf16", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_words", "dmm_pack_masks", "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad",
     "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
@@ -140,6 +140,9 @@ def load():
     L.dmm_match_forward.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                     c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
                                     vp, vp, vp, vp, sz, vp]
+    L.dmm_match_forward_ws.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
+                                       c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, sz, ctypes.POINTER(c_int), vp]
     L.dmm_workspace_bytes_packed.argtypes = [c_int, c_int, c_int, c_int, c_int]
     L.dmm_workspace_bytes_packed.restype = sz
     L.dmm_match_forward_packed.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
@@ -163,7 +166,7 @@ def load():
         getattr(L, f).restype = c_int
     for f in ("dmm_iou_counts_frames", "dmm_iou_counts_dual_frames", "dmm_mask_mix_frames", "dmm_mask_mix_bwd_frames",
               "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
-              "dmm_mask_mix", "dmm_match_forward", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
+              "dmm_mask_mix", "dmm_match_forward", "dmm_match_forward_ws", "dmm_relax_match_bwd_f32", "dmm_roialign4_mean_fwd",
               "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks",
               "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad"):
         getattr(L, f).restype = c_int

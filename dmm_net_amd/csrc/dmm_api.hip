@@ -11,6 +11,9 @@
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
                         hipStream_t stream, int32_t *zero_ptr, int64_t zero_words);
+int front_small_launch(const void *masks_p, const void *masks_t, int dtype, const float *feat_t, const float *feat_p, int B,
+                       int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, float *cos_out,
+                       int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream);
 int iou_counts_prezeroed(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW, int64_t sp_b,
                          int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid,
                          int32_t *inter, int32_t *area_p, int32_t *area_t, dmm_stream_t stream);
@@ -135,6 +138,27 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
                                  int is_test, float *full_outmask, float *match_score, float *det_score,
                                  float *sim_out, float *R_out, float *Rb_out, int32_t *iters_out, void *workspace,
                                  size_t workspace_bytes, dmm_stream_t stream) {
+    return dmm_match_forward_ws(masks_p, masks_t, mask_dtype, feat_p, feat_t, score_p, B, N, M, HW, D, sp_b, sp_n, st_b, st_m,
+                                n_valid, m_valid, score_weight, max_iter, proj_iter, lr, is_test, full_outmask, match_score,
+                                det_score, sim_out, R_out, Rb_out, iters_out, workspace, workspace_bytes, nullptr, stream);
+}
+
+// (5a') dmm_match_forward for a caller that keeps ONE workspace for a sequence of calls and lets the library remember
+// what it left there.  *ws_state in: DMM_WS_TABLES_ZERO if the previous call on this workspace (same B, N, M) returned
+// that value, DMM_WS_UNKNOWN otherwise; out: the state the work enqueued by this call leaves behind.  A handful of dense
+// frames (the small-batch front kernel) then run without the clearing launch in front of the counts -- a launch is
+// ~4.5 us of a ~95 us one-frame call: the solver zeroes every table entry right after reading it.  Every other path
+// returns DMM_WS_UNKNOWN.  On an error return the state is DMM_WS_UNKNOWN.
+extern "C" int dmm_match_forward_ws(const void *masks_p, const void *masks_t, int mask_dtype, const float *feat_p,
+                                    const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,
+                                    int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                                    const int32_t *m_valid, float score_weight, int max_iter, int proj_iter, float lr,
+                                    int is_test, float *full_outmask, float *match_score, float *det_score,
+                                    float *sim_out, float *R_out, float *Rb_out, int32_t *iters_out, void *workspace,
+                                    size_t workspace_bytes, int *ws_state, dmm_stream_t stream) {
+    const bool tables_zero = ws_state && *ws_state == DMM_WS_TABLES_ZERO;
+    if (ws_state) *ws_state = DMM_WS_UNKNOWN;
+    int cleared = 0;
     if (B < 0 || N < 0 || M < 0 || HW < 0 || D < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0) return DMM_ERR_BAD_ARG;
@@ -175,6 +199,20 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
     // one-frame call's 135.  Otherwise counts (with their memset), then the tile kernel or normalise x 2 + cosine.
     const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     int rc = DMM_ERR_UNSUPPORTED;
+    // a handful of dense frames: table clear, then similarity and counts beside each other in ONE launch
+    if (!n_valid && !m_valid && !force_tile) {
+        rc = dmm::front_small_launch(masks_p, masks_t, mask_dtype, feat_t, feat_p, B, N, M, HW, D, sp_b, sp_n, st_b, st_m,
+                                     w.cosv, w.inter, w.area_p, w.area_t, tables_zero, (hipStream_t)stream);
+        if (rc == DMM_OK) {
+            // the solver reads the tables and (asked to) leaves them zero for the next call on this workspace
+            rc = dmm::relax_match_launch(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid,
+                                         score_weight, max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score,
+                                         det_score, iters_out, nullptr, ws_state != nullptr, &cleared, stream);
+            if (rc != DMM_OK) return rc;
+            goto mix;
+        }
+        if (rc != DMM_ERR_UNSUPPORTED) return rc;
+    }
     if (!n_valid && !m_valid && !force_tile)
         rc = dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
                                       (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
@@ -203,12 +241,16 @@ extern "C" int dmm_match_forward(const void *masks_p, const void *masks_t, int m
                              max_iter, proj_iter, lr, is_test, sim, R_out, Rb, match_score, det_score, iters_out,
                              nullptr, stream);
     if (rc != DMM_OK) return rc;
+mix:
     // train mode keeps every R > 0.01: the rows share planes -> the union of the supports is streamed once
     if (!is_test)
-        return dmm_mask_mix_shared_to(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
-                                      DMM_F32, (int64_t)M * HW, HW, stream);
-    return dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
-                        (int64_t)M * HW, HW, stream);
+        rc = dmm_mask_mix_shared_to(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                                    DMM_F32, (int64_t)M * HW, HW, stream);
+    else
+        rc = dmm_mask_mix(Rb, masks_p, mask_dtype, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, full_outmask,
+                          (int64_t)M * HW, HW, stream);
+    if (rc == DMM_OK && ws_state && cleared) *ws_state = DMM_WS_TABLES_ZERO;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "dmm_common.h"
+#include "dmm_cosine_lanes.h"
 
 namespace dmm {
 
@@ -196,21 +197,33 @@ __device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &rang
         range = within >> 3;
     }
 }
+// the same for a workgroup that is number (bx, by) of a (gx, gy) sub-grid of its launch (the small-batch front kernel)
+__device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &range, int bx, int by, int gx, int gy) {
+    b = by;
+    range = bx;
+    if (xcd_remap && by < (gy & ~7)) {
+        const int splits = gx;
+        const int id = bx + splits * by;
+        const int grp = id / (8 * splits), within = id - grp * 8 * splits;
+        b = grp * 8 + (within & 7);
+        range = within >> 3;
+    }
+}
 
 // grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
 
 
 template <typename T, int MT, int NG, int CH = kChunk, int LB = kLoadBytes>
-__global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
+__device__ __forceinline__ void iou_counts_body(
     const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
     int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
     int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
     int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t,
-    int xcd_remap, int sub_count, int n_sub) {
+    int xcd_remap, int sub_count, int n_sub, int bx, int by, int gx, int gy) {
     int b, range;
-    xcd_frame_range(xcd_remap, b, range);
+    xcd_frame_range(xcd_remap, b, range, bx, by, gx, gy);
     // small batches: the proposal tile is cut into sub_count sub-tiles of n_sub planes, one workgroup each, so that a
     // handful of frames still spreads over the chip (the templates are re-read per sub-tile: latency, not bandwidth,
     // is what a B = 1 launch pays for)
@@ -284,6 +297,130 @@ __global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
         if (threadIdx.x < Mb) atomicAdd(&area_t[(int64_t)b * M + m0 + threadIdx.x], (int)red_at[threadIdx.x]);
         else atomicAdd(&area_t2[(int64_t)b * M + m0 + threadIdx.x - Mb], (int)red_at[threadIdx.x]);
     }
+}
+
+template <typename T, int MT, int NG, int CH = kChunk, int LB = kLoadBytes>
+__global__ __launch_bounds__(kCostThreads) void iou_counts_kernel(
+    const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M, int HW,
+    int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
+    int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
+    int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t,
+    int xcd_remap, int sub_count, int n_sub) {
+    iou_counts_body<T, MT, NG, CH, LB>(masks_p, masks_t, masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid,
+                                       m_valid, inter, area_p, area_t, inter2, area_t2, n0, m0, chunks_per_wg, write_area_p,
+                                       write_area_t, xcd_remap, sub_count, n_sub, blockIdx.x, blockIdx.y, gridDim.x,
+                                       gridDim.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-batch front kernel of dmm_match_forward (DMM_OPT_SMALL_FUSED): the feature similarity and the counts of a handful
+// of frames in ONE launch.  At B = 1 the similarity is 2 workgroups busy for ~10 us (a dependent chain, 120 KB of
+// features) and the counts ~450 workgroups for ~13 us (16 MB of planes); as two launches they queue behind each other.
+// Here the first cos_parts workgroups of every frame run cosine_lanes_body, the rest iou_counts_body in its small-batch
+// shape (one 16-byte lane load per plane and chunk, sub-tiles of proposals) -- neither depends on the other, both feed the
+// solver.  The count tables must be zero on entry (dmm_front_small clears them with one launch in front).
+// grid = (cos_parts + splits * sub_count, B), block = 256, dynamic LDS = lanes_geom<LPC>().lds.
+// ---------------------------------------------------------------------------------------------
+template <int LPC, typename T, int MT>
+__global__ __launch_bounds__(kCostThreads) void front_small_kernel(
+    const float *__restrict__ feat_t, const float *__restrict__ feat_p, float *__restrict__ cos_out, int cos_parts,
+    int cos_waves, const T *__restrict__ masks_p, const T *__restrict__ masks_t, const T *__restrict__ masks_t2, int N, int M,
+    int HW,
+    int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, int32_t *__restrict__ inter,
+    int32_t *__restrict__ area_p, int32_t *__restrict__ area_t, int32_t *__restrict__ inter2,
+    int32_t *__restrict__ area_t2, int n0, int m0, int chunks_per_wg, int write_area_p, int write_area_t,
+    int xcd_remap, int sub_count, int n_sub) {
+    extern __shared__ __attribute__((aligned(16))) float front_lds[];
+    if ((int)blockIdx.x < cos_parts) {
+        cosine_lanes_body<LPC>(feat_t, feat_p, N, M, cos_out, front_lds, blockIdx.x, cos_parts, blockIdx.y, cos_waves);
+        return;
+    }
+    // every count argument arrives as a kernel argument, as in iou_counts_kernel (with the unused ones as literals the
+    // optimizer of this toolchain crashed)
+    constexpr int CHS = 64 * MaskIO<T>::kVec, LBS = 16384;
+    iou_counts_body<T, MT, 1, CHS, LBS>(masks_p, masks_t, masks_t2, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, n_valid,
+                                        m_valid, inter, area_p, area_t, inter2, area_t2, n0, m0, chunks_per_wg, write_area_p,
+                                        write_area_t, xcd_remap, sub_count, n_sub, (int)blockIdx.x - cos_parts, blockIdx.y,
+                                        (int)gridDim.x - cos_parts, gridDim.y);
+}
+
+template <typename T, int MT>
+static int launch_front_small(const float *feat_t, const float *feat_p, float *cos_out, const T *masks_p, const T *masks_t,
+                              int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
+                              int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream) {
+    constexpr int LPC = 32;                                          // D = 512, the model's ROI feature width
+    // similarity workgroups: 2 of the 4 waves take steps (every workgroup of the launch carries their LDS; with 4 wave
+    // buffers only 2 workgroups fit a CU, with 2 three do)
+    typedef CfGeom<LPC> G;
+    const int A = N >= 8 ? 32 * (N / 32) : 4 * (N / 4), S = (A + 7) / 8 + (N - A + 7) / 8;
+    LanesGeom g;
+    g.nw = S < 2 ? S : 2;
+    g.parts = (S + g.nw - 1) / g.nw;
+    g.lds = sizeof(float) * ((size_t)M * G::PITCH + 32 + (size_t)g.nw * G::WAVE_FLOATS);
+    // the small-batch shape of launch_tile below
+    constexpr int CHS = 64 * MaskIO<T>::kVec;
+    const int small_wgs = opt(DMM_OPT_COST_SMALL_WGS);
+    const int nch = (HW + CHS - 1) / CHS;
+    const int splits_s = (nch + kCostThreads / kWave - 1) / (kCostThreads / kWave);
+    int sub_count = 1, n_sub = kWave;
+    if ((int64_t)B * splits_s < small_wgs && N > 8) {
+        sub_count = (int)((small_wgs + (int64_t)B * splits_s - 1) / ((int64_t)B * splits_s));
+        const int max_sub = (N + 7) / 8;
+        if (sub_count > max_sub) sub_count = max_sub;
+        n_sub = (N + sub_count - 1) / sub_count;
+        sub_count = (N + n_sub - 1) / n_sub;
+    }
+    // every workgroup of the launch carries the similarity's LDS, so only a few fit a CU; the launch must stay ONE
+    // resident wave of workgroups (a second wave would queue the counts behind the similarity's 10 us):
+    // fewer sub-tiles of proposals if that does it, the separate launches otherwise
+    {
+        const int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(g.lds + 8 * 1024);
+        const int64_t slots = 256 * (per_cu < 1 ? 1 : per_cu) - (int64_t)B * g.parts;
+        while (sub_count > 1 && (int64_t)B * splits_s * sub_count > slots) {
+            --sub_count;
+            n_sub = (N + sub_count - 1) / sub_count;
+            sub_count = (N + n_sub - 1) / n_sub;
+        }
+        if ((int64_t)B * splits_s * sub_count > slots) return DMM_ERR_UNSUPPORTED;
+    }
+    if (g.lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)front_small_kernel<LPC, T, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+        if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
+    }
+    if (!tables_zero)
+        DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
+    hipLaunchKernelGGL((front_small_kernel<LPC, T, MT>), dim3(g.parts + splits_s * sub_count, B), dim3(kCostThreads), g.lds,
+                       stream, feat_t, feat_p, cos_out, g.parts, g.nw, masks_p, masks_t, (const T *)nullptr, N, M, HW, sp_b, sp_n,
+                       st_b, st_m, (int64_t)0, (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, inter, area_p,
+                       area_t, (int32_t *)nullptr, (int32_t *)nullptr, 0, 0, kCostThreads / kWave, 1, 1, 0, sub_count, n_sub);
+    return check_launch();
+}
+
+// DMM_ERR_UNSUPPORTED (nothing launched) outside its envelope: B <= DMM_OPT_COST_TINY_FRAMES dense frames, N <= 64,
+// M <= 16, D = 512, float / half / bfloat16 planes, the three tables contiguous (dmm_match_forward's workspace).
+// tables_zero: the caller vouches that the tables are zero already (dmm_match_forward_ws) -- no clearing launch.
+int front_small_launch(const void *masks_p, const void *masks_t, int dtype, const float *feat_t, const float *feat_p, int B,
+                       int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, float *cos_out,
+                       int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream) {
+    if (opt(DMM_OPT_SMALL_FUSED) != 1 || B > opt(DMM_OPT_COST_TINY_FRAMES) || opt(DMM_OPT_COST_KERNEL) == 1)
+        return DMM_ERR_UNSUPPORTED;
+    if (D != 512 || N < 2 || N > 64 || M < 1 || M > 16 || HW <= 0 || sp_n < HW || st_m < HW) return DMM_ERR_UNSUPPORTED;
+    if (area_p != inter + (size_t)B * M * N || area_t != area_p + (size_t)B * N) return DMM_ERR_UNSUPPORTED;
+#define DMM_FRONT_CASE(T_)                                                                                              \
+    return M <= 8 ? launch_front_small<T_, 8>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t, B, N, M, HW, \
+                                              sp_b, sp_n, st_b, st_m, inter, area_p, area_t, tables_zero, stream)         \
+                  : launch_front_small<T_, 16>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t, B, N, M,  \
+                                               HW, sp_b, sp_n, st_b, st_m, inter, area_p, area_t, tables_zero, stream)
+    switch (dtype) {
+        case DMM_F32: DMM_FRONT_CASE(float);
+        case DMM_F16: DMM_FRONT_CASE(f16_t);
+        case DMM_BF16: DMM_FRONT_CASE(bf16_t);
+        default: return DMM_ERR_UNSUPPORTED;
+    }
+#undef DMM_FRONT_CASE
 }
 
 template <typename T, int MT, int NG>

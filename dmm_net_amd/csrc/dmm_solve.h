@@ -30,6 +30,13 @@ int launch_relax_solve_rs(const float *C, int B, int n, int m, const int32_t *ro
                           RelaxParams prm, float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
                           hipStream_t stream);
 
+// dmm_relax_match_f32 with the table-clearing request of dmm_match_forward_ws (dmm_solve.hip)
+int relax_match_launch(const float *cos_in, const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
+                       const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
+                       float score_weight, int max_iter, int proj_iter, float lr, int is_test, float *sim_out, float *R_out,
+                       float *Rb_out, float *match_score, float *det_score, int32_t *iters_out, float *X_final,
+                       int clear_tables, int *cleared, dmm_stream_t stream);
+
 // General forms for tables outside the compiled envelope (dmm_wide.hip): any N, M; the solver keeps its state in
 // `scratch` (B x wide_scratch_floats(M, max(N, M + 1)) floats).
 size_t wide_scratch_floats(int M, int PpS);

@@ -343,6 +343,21 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
                                    int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
                                    float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                                    dmm_stream_t stream) {
+    return dmm::relax_match_launch(cos_in, inter, area_p, area_t, score_p, B, N, M, n_valid, m_valid, score_weight, max_iter,
+                                   proj_iter, lr, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
+                                   X_final, 0, nullptr, stream);
+}
+
+// dmm_relax_match_f32 proper.  clear_tables (dmm_match_forward_ws only; the tables are then its workspace, not the
+// caller's): ask the kernel to zero inter / area_p / area_t once it has read them; *cleared says whether the kernel that
+// was launched does that (the thread-per-column kernels on dense frames do, the other mappings do not).
+int dmm::relax_match_launch(const float *cos_in, const int32_t *inter, const int32_t *area_p, const int32_t *area_t,
+                            const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
+                            float score_weight, int max_iter, int proj_iter, float lr, int is_test, float *sim_out,
+                            float *R_out, float *Rb_out, float *match_score, float *det_score, int32_t *iters_out,
+                            float *X_final, int clear_tables, int *cleared, dmm_stream_t stream) {
+    if (cleared) *cleared = 0;
+    is_test = is_test != 0;                       // the upper bits of the kernels' argument are the library's own
     if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0) return DMM_ERR_BAD_ARG;
@@ -368,6 +383,10 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
     hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream,   \
                        cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, \
                        sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
+    if (clear_tables && cleared && !n_valid && !m_valid) {
+        is_test |= dmm::kRelaxClearTables;
+        *cleared = 1;
+    }
     DMM_DISPATCH_SOLVER(M, Pp, exact_ok, DMM_CALL);
 #undef DMM_CALL
     return dmm::check_launch();

@@ -613,7 +613,9 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
         // the wave for the whole compare -> scalar -> branch latency, ~0.1 us per sweep); when sweep j turns out to have
         // moved nothing, the relu step of sweep j + 1 -- all that was done since: it only touches X and P0 -- is undone.
         unsigned long long moved_prev = ~0ull;
-        for (int j = 0; j < prm.proj_iter; ++j) {
+        // one sweep; true = the sweep before it moved nothing (stop).  Called twice per trip of the loop below: X and
+        // X_start trade registers from one sweep to the next, and a rolled loop paid for that with 20 v_mov per sweep.
+        auto sweep = [&]() -> bool {
             f32x2 Xs[MP], P0s[MP];
             // {X >= 0} (:74-76) then X = Y + P1 (:78)
 #pragma unroll
@@ -655,7 +657,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             if (moved_prev == 0ull) {                          // sweep j - 1 was the last one (:88-89)
 #pragma unroll
                 for (int k = 0; k < MP; ++k) { Xp[k] = Xs[k]; P0[k] = P0s[k]; }
-                break;
+                return true;
             }
             // {column sums <= 1}: project_col (:21-34, :79-80); then X = Y + P2 (:82)
             const bool over = cs > 1.0f;                       // mask = (X_col_sum <= 1)
@@ -694,6 +696,12 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             }
             // a sum of squares is zero iff every square rounds to zero: "no lane saw a move" is the reference's test
             moved_prev = __ballot(moved);
+            return false;
+        };
+        for (int j = 0; j < prm.proj_iter; j += 2) {
+            if (sweep()) break;
+            if (j + 1 >= prm.proj_iter) break;
+            if (sweep()) break;
         }
         if (with_helper) {
             while (hs_load(&hs[1]) != it + 1) {}
@@ -1066,6 +1074,10 @@ __device__ __forceinline__ int relax_core_h(const float (&C)[MT], int n, int m, 
 // Layer kernel: iou + mix with the cosine table + pad + solver + scores.  grid = B, block = 64*NG.
 // ---------------------------------------------------------------------------------------------
 // One frame: red_buf [2 * NG * (MT + 1)], xbuf [MT * 64 * NG], rsbuf [MT + 1] floats of LDS.
+// bit 1 of the kernels' `is_test` argument: clear the count tables after reading them (internal; set only by
+// relax_match_launch for the kernels built on relax_match_body)
+constexpr int kRelaxClearTables = 2;
+
 template <int MT, int NG, bool EXACT, bool HALF = false>
 __device__ __forceinline__ void relax_match_body(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
@@ -1122,6 +1134,22 @@ __device__ __forceinline__ void relax_match_body(
             }
             if (DMM_ROW(i) && col < Pp) C[i] = -simv;                  // padded columns: -0.0
         }
+        // kRelaxClearTables (dmm_match_forward_ws, dense frames only): every table entry has been read by now -- each
+        // inter / area_p entry by exactly one thread, area_t by every thread -- so the frame's tables go back to zero
+        // here and the next call on this workspace starts its counts without a clearing launch in front.
+        if (is_test & kRelaxClearTables) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loads above have returned (same addresses below)
+            if (NG > 1) __syncthreads();
+            int32_t *wi = const_cast<int32_t *>(inter_b);
+            if (has_prop) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (DMM_ROW(i)) wi[(int64_t)i * N + col] = 0;
+                const_cast<int32_t *>(area_p)[(int64_t)b * N + col] = 0;
+            }
+            if (col < Mb) const_cast<int32_t *>(area_t)[(int64_t)b * M + col] = 0;
+        }
+        is_test &= 1;
     }
 
     float X[MT], acc[MT];

@@ -35,6 +35,7 @@ extern "C" int dmm_relax_match_f16s(const float *cos_in, const int32_t *inter, c
                                     int proj_iter, float lr, int is_test, float *sim_out, float *R_out, float *Rb_out,
                                     float *match_score, float *det_score, int32_t *iters_out, float *X_final,
                                     dmm_stream_t stream) {
+    is_test = is_test != 0;                       // the upper bits of the kernels' argument are the library's own
     if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0) return DMM_ERR_BAD_ARG;

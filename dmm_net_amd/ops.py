@@ -6,6 +6,7 @@ batch ragged.  No function here has a CPU implementation: CPU tensors raise.
 """
 from __future__ import annotations
 
+import ctypes
 import threading
 from typing import Optional, Tuple
 
@@ -653,7 +654,10 @@ class ForwardPlan:
         # took as long as the counts (18 us vs 19 us at B = 1); with the lanes kernel (10 us) and the small-chunk count
         # launch (round 2) the ~18 us a cross-queue fork + join costs is more than the branch saves: default off
         self.graph_fork = bool(graph_fork)
-        self._graphs, self._last_key = {}, None                   # key -> (graph, tensors it holds addresses of)
+        self._graphs, self._last_key = {}, None                   # key -> (graph, tensors it holds addresses of, ws in / out)
+        # dmm_match_forward_ws: what the last call of this plan left in ITS workspace (DMM_WS_UNKNOWN / _TABLES_ZERO).
+        # From _TABLES_ZERO a handful of dense frames start their counts without a clearing launch (include/dmm_match.h 5a').
+        self._ws_state = ctypes.c_int(0)
         L = _lib.load()
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
@@ -727,12 +731,13 @@ class ForwardPlan:
         main = torch.cuda.current_stream(self.device)
         if not self.graph_fork:
             # one chain: the fused C call (its feature-similarity launch also clears the count tables: no memset node)
-            _lib.check(L.dmm_match_forward(
+            _lib.check(L.dmm_match_forward_ws(
                 _ptr(masks_p), _ptr(masks_t), dt, _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M, HW, D, sp_b, sp_n,
                 st_b, st_m, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter), float(lr),
                 int(is_test), _ptr(self.full_outmask), _ptr(self.match_score), _ptr(self.det_score), _ptr(self.sim),
-                _ptr(self.R), _ptr(self.Rb), _ptr(self.iters), _ptr(self.workspace), self.ws_bytes, main.cuda_stream),
-                "dmm_match_forward (graph capture)")
+                _ptr(self.R), _ptr(self.Rb), _ptr(self.iters), _ptr(self.workspace), self.ws_bytes,
+                ctypes.byref(self._ws_state), main.cuda_stream),
+                "dmm_match_forward_ws (graph capture)")
             return
         side = self.side
         inter, ap, at = self._tables(0)
@@ -804,19 +809,26 @@ class ForwardPlan:
             key = (masks_p.data_ptr(), masks_t.data_ptr(), feat_p.data_ptr(), feat_t.data_ptr(), score_p.data_ptr(),
                    sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), cfg)
             hit = self._graphs.get(key)
-            if hit is not None:
+            # a captured call must find the workspace in the state it was captured with; if something else ran in between
+            # (another tensor set, a direct call that took a different path) this call goes directly -- which heals it
+            if hit is not None and hit[2] in (0, self._ws_state.value):
                 hit[0].replay()
+                self._ws_state.value = hit[3]
                 return self.full_outmask, self.match_score, self.det_score
-            if key == self._last_key and len(self._graphs) < 4:
+            if hit is None and key == self._last_key and len(self._graphs) < 4:
                 # second call in a row on the same tensors: capture (the first one ran directly = the warm-up)
+                ws_in = self._ws_state.value
                 with _CAPTURE_LOCK, torch.cuda.device(self.device):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._launch_forked(L, masks_p, masks_t, feat_p, feat_t, score_p, dt, (sp_b, sp_n, st_b, st_m),
                                             n_valid, m_valid, cfg)
+                ws_out = self._ws_state.value                       # what a replay leaves (nothing ran during the capture)
+                self._ws_state.value = ws_in
                 # the graph holds raw addresses: keep the tensors alive with it
-                self._graphs[key] = (g, (masks_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid))
+                self._graphs[key] = (g, (masks_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid), ws_in, ws_out)
                 g.replay()
+                self._ws_state.value = ws_out
                 return self.full_outmask, self.match_score, self.det_score
             self._last_key = key
         if not self.pipeline and self.time_kernels:
@@ -844,13 +856,13 @@ class ForwardPlan:
             return self.full_outmask, self.match_score, self.det_score
         if not self.pipeline:
             with _lib.device_guard(self.device):
-                rc = L.dmm_match_forward(
+                rc = L.dmm_match_forward_ws(
                     _ptr(masks_p), _ptr(masks_t), dt, _ptr(feat_p), _ptr(feat_t), _ptr(score_p), B, N, M, HW, D, sp_b,
                     sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid), float(score_weight), int(max_iter), int(proj_iter),
                     float(lr), int(is_test), _ptr(self.full_outmask), _ptr(self.match_score), _ptr(self.det_score),
                     _ptr(self.sim), _ptr(self.R), _ptr(self.Rb), _ptr(self.iters), _ptr(self.workspace), self.ws_bytes,
-                    _stream(masks_p))
-            _lib.check(rc, "dmm_match_forward")
+                    ctypes.byref(self._ws_state), _stream(masks_p))
+            _lib.check(rc, "dmm_match_forward_ws")
             return self.full_outmask, self.match_score, self.det_score
 
         es = masks_p.element_size()

@@ -95,7 +95,8 @@ typedef enum dmm_option {
     DMM_OPT_COS_ROWS_MIN_N = 16,    /* dmm_cosine_f32: from which N the row-blocked form is used (65)                      */
     DMM_OPT_GEMM_TUNE = 17,         /* dmm_conv1x1_bf16: hipBLASLt heuristic candidates timed per new shape (1 = none)     */
     DMM_OPT_PACK_VARIANT = 18,      /* dmm_pack_masks: 4 = 128-block segments x 8 loads (default), 0 = 256 x 4             */
-    DMM_OPT_SMALL_FUSED = 19,       /* dmm_match_forward at B <= 8: 1 = feature similarity inside the count launch (default) */
+    DMM_OPT_SMALL_FUSED = 19,       /* dmm_match_forward, a handful of dense frames: 1 = the feature similarity rides in the
+                                       count launch (similarity workgroups beside count workgroups; default), 0 = two launches */
     DMM_OPT_MIX_SHARED = 20,        /* mix / mix backward: -1 by entry point (default: dmm_mask_mix_shared_* and the backward
                                        stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
     DMM_OPT_MIX_SHARED_STEPS = 21,  /* union kernels: 4 KiB steps of every plane per workgroup (1)                         */
@@ -344,6 +345,24 @@ DMM_API int dmm_match_forward(const void *masks_p, const void *masks_t, int mask
                       float *R_out /*[B,M,Pp] or NULL*/, float *Rb_out /*[B,M,Pp] or NULL*/,
                       int32_t *iters_out /*[B] or NULL*/,
                       void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
+/* (5a') dmm_match_forward for a caller that keeps ONE workspace over a sequence of calls (the per-frame use) and carries
+ * the library's note about what it left there: *ws_state in = the value the previous call on this workspace wrote (same
+ * B, N, M, D; DMM_WS_UNKNOWN for a fresh or otherwise touched workspace), out = the state the work enqueued by this call
+ * leaves behind.  With DMM_WS_TABLES_ZERO a handful of dense frames run without a clearing launch in front of the IoU
+ * counts (the solver zeroes each count-table entry right after reading it); results are the same either way.  The state
+ * describes the workspace AFTER the enqueued work: calls that share a workspace must be ordered on one stream, and a
+ * captured call must be replayed with the workspace in the state it was captured with (it is, if nothing else touches
+ * the workspace between replays: a call that starts from DMM_WS_TABLES_ZERO and returns it leaves what it found).
+ * ws_state == NULL: exactly dmm_match_forward. */
+enum { DMM_WS_UNKNOWN = 0, DMM_WS_TABLES_ZERO = 1 };
+DMM_API int dmm_match_forward_ws(const void *masks_p, const void *masks_t, int mask_dtype, const float *feat_p,
+                                 const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,
+                                 int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid,
+                                 const int32_t *m_valid, float score_weight, int max_iter, int proj_iter, float lr,
+                                 int is_test, float *full_outmask, float *match_score, float *det_score, float *sim_out,
+                                 float *R_out, float *Rb_out, int32_t *iters_out, void *workspace, size_t workspace_bytes,
+                                 int *ws_state, dmm_stream_t stream);
 
 /* (5b) The same forward with the proposal side of the cost pass on 1-bit planes the caller already holds
  * (dmm_paste_masks_f32 / dmm_paste_kept_f32 emit them next to the soft planes): packed_p [B,N,words] uint64, strides

@@ -1459,3 +1459,133 @@ def test_frame_form_of_the_feature_backward_agrees_with_the_row_form(B, N, M, D)
                 scale = max(float(a.abs().max()), 1e-12)
                 assert bool(torch.isfinite(b_).all())
                 assert float((a - b_).abs().max()) <= 2e-5 * scale, (ragged, loss, float((a - b_).abs().max()), scale)
+
+
+def _forward_raw(L, bufs, B, N, M, H, W, D, ws, state=None, is_test=1, max_iter=20, proj_iter=5):
+    """dmm_match_forward / dmm_match_forward_ws through ctypes on caller-held buffers; returns the outputs (new tensors)."""
+    import ctypes
+    mp, mt, fp, ft, sc = bufs
+    Pp = max(N, M + 1)
+    out = torch.empty((B, M, H, W), device=DEV)
+    ms, ds = torch.empty((B, M), device=DEV), torch.empty((B, M), device=DEV)
+    sim, R, Rb = torch.empty((B, M, N), device=DEV), torch.empty((B, M, Pp), device=DEV), torch.empty((B, M, Pp), device=DEV)
+    it = torch.empty((B,), dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    head = (mp.data_ptr(), mt.data_ptr(), ops._DT[mp.dtype], fp.data_ptr(), ft.data_ptr(), sc.data_ptr(), B, N, M, H * W, D, N * H * W, H * W, M * H * W, H * W, None, None,
+            0.3, max_iter, proj_iter, 0.1, is_test, out.data_ptr(), ms.data_ptr(), ds.data_ptr(), sim.data_ptr(),
+            R.data_ptr(), Rb.data_ptr(), it.data_ptr(), ws.data_ptr(), ws.numel())
+    if state is None:
+        rc = L.dmm_match_forward(*head, st)
+    else:
+        rc = L.dmm_match_forward_ws(*head, ctypes.byref(state), st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out, ms, ds, sim, R, Rb, it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M,H,W,dt", [(1, 50, 10, 255, 255, torch.float32), (3, 50, 10, 64, 64, torch.float32),
+                                          (4, 64, 16, 33, 41, torch.float16), (8, 25, 3, 17, 31, torch.bfloat16),
+                                          (2, 8, 3, 64, 64, torch.float32), (1, 2, 1, 9, 7, torch.float32)])
+@pytest.mark.parametrize("is_test", [0, 1])
+def test_small_batch_front_kernel_changes_no_result(B, N, M, H, W, dt, is_test):
+    """DMM_OPT_SMALL_FUSED: a handful of dense frames run the feature similarity INSIDE the count launch (similarity
+    workgroups beside count workgroups).  Same kernels' bodies, same tables: every output of dmm_match_forward is bit-equal
+    to the two-launch form."""
+    L = _lib.load()
+    D = 512
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + N)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    bufs = [mk(B, N, H, W).to(dt), mk(B, M, H, W).to(dt), mk(B, N, D) - 0.5, mk(B, M, D) - 0.5, mk(B, N)]
+    ws = torch.empty((int(L.dmm_workspace_bytes(B, N, M, D)),), dtype=torch.uint8, device=DEV)
+    res = {}
+    for v in (0, 1):
+        with _lib.options(SMALL_FUSED=v):
+            ws.fill_(0xA5)                                       # the call must not depend on what the workspace holds
+            res[v] = _forward_raw(L, bufs, B, N, M, H, W, D, ws, is_test=is_test)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_forward_ws_state_chain_equals_fresh_calls():
+    """dmm_match_forward_ws: one workspace over a sequence of calls with the library's state note threaded through.  From
+    DMM_WS_TABLES_ZERO the counts start without a clearing launch -- the solver zeroed the tables of the previous call -- and
+    every call still equals dmm_match_forward on a fresh workspace; the tables really are zero after such a call; paths that
+    do not clear say DMM_WS_UNKNOWN and ignore a stale note."""
+    import ctypes
+    L = _lib.load()
+    B, N, M, H, W, D = 2, 50, 10, 48, 40, 512
+    g = torch.Generator(device=DEV).manual_seed(77)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    ws = torch.empty((int(L.dmm_workspace_bytes(B, N, M, D)),), dtype=torch.uint8, device=DEV)
+    ws.fill_(0x5A)
+    state = ctypes.c_int(0)
+    tables = B * (M * N + N + M)
+    seen = []
+    for k in range(6):
+        bufs = [mk(B, N, H, W), mk(B, M, H, W), mk(B, N, D) - 0.5, mk(B, M, D) - 0.5, mk(B, N)]
+        fresh = torch.empty_like(ws).fill_(k)
+        want = _forward_raw(L, bufs, B, N, M, H, W, D, fresh, is_test=k % 2)
+        if k == 3:                                               # a call that takes the two-launch path in between
+            with _lib.options(SMALL_FUSED=0):
+                got = _forward_raw(L, bufs, B, N, M, H, W, D, ws, state=state, is_test=k % 2)
+            assert state.value == 0
+        else:
+            got = _forward_raw(L, bufs, B, N, M, H, W, D, ws, state=state, is_test=k % 2)
+            assert state.value == 1
+            assert int(ws[:4 * tables].view(torch.int32).abs().sum()) == 0
+        seen.append(state.value)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+    assert seen == [1, 1, 1, 0, 1, 1]
+    # ragged frames never clear: the note comes back unknown, the result is right, a stale "zero" note is not believed
+    nv = torch.tensor([N, N - 3], dtype=torch.int32, device=DEV)
+    bufs = [mk(B, N, H, W), mk(B, M, H, W), mk(B, N, D) - 0.5, mk(B, M, D) - 0.5, mk(B, N)]
+    plan = ops.ForwardPlan(B, N, M, H, W, D, DEV, pipeline=False)
+    ref = ops.ForwardPlan(B, N, M, H, W, D, DEV, pipeline=False)
+    plan._ws_state.value = 1
+    plan.workspace.fill_(0x33)                                   # dirty tables + a (wrong) "zero" note: must not matter here
+    plan.run(*bufs, n_valid=nv)
+    ref.run(*bufs, n_valid=nv)
+    torch.cuda.synchronize()
+    assert plan._ws_state.value == 0
+    assert torch.equal(plan.full_outmask, ref.full_outmask) and torch.equal(plan.match_score, ref.match_score)
+
+
+@pytest.mark.gpu
+def test_forward_plan_graph_replays_carry_the_workspace_state():
+    """ForwardPlan(graph=True) at one frame: the captured call starts from zero tables (no clearing node in the graph),
+    every replay leaves them zero again; a direct call on other tensors that takes the two-launch path in between leaves
+    the state unknown, the next call on the captured tensors then runs directly (healing it) and replays resume."""
+    c = synth.CONFIGS[2]
+    B, N, M, H, W, D = 1, c["P"], c["O"], 96, 80, c["D"]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    bufs = [mk(B, N, H, W), mk(B, M, H, W), mk(B, N, D) - 0.5, mk(B, M, D) - 0.5, mk(B, N)]
+    plan = ops.ForwardPlan(B, N, M, H, W, D, DEV, want_tables=True, graph=True)
+    ref = ops.ForwardPlan(B, N, M, H, W, D, DEV, want_tables=True, pipeline=False)
+    def same(inputs):
+        plan.run(*inputs)
+        with _lib.options(SMALL_FUSED=0):
+            ref.run(*inputs)
+        torch.cuda.synchronize()
+        return all(torch.equal(a, b) for a, b in zip((plan.full_outmask, plan.match_score, plan.det_score, plan.R, plan.iters),
+                                                     (ref.full_outmask, ref.match_score, ref.det_score, ref.R, ref.iters)))
+    assert same(bufs) and plan._ws_state.value == 1 and len(plan._graphs) == 0
+    assert same(bufs) and len(plan._graphs) == 1
+    (gr, _, ws_in, ws_out), = plan._graphs.values()
+    assert (ws_in, ws_out) == (1, 1)
+    for k in range(4):
+        for t in bufs:
+            t.copy_(mk(*t.shape) - (0.5 if t.dim() == 3 else 0.0))
+        assert same(bufs) and plan._ws_state.value == 1
+    other = [t.clone() for t in bufs]
+    with _lib.options(SMALL_FUSED=0):                            # direct call, two-launch path: state unknown afterwards
+        plan.run(*other)
+    assert plan._ws_state.value == 0
+    plan.workspace[:4 * B * (M * N + N + M)].fill_(0x7F)         # and the tables really are dirty
+    assert same(bufs) and plan._ws_state.value == 1              # direct call (the graph expects zero tables): heals
+    for t in bufs:
+        t.copy_(mk(*t.shape) - (0.5 if t.dim() == 3 else 0.0))
+    assert same(bufs) and plan._ws_state.value == 1              # replay again
