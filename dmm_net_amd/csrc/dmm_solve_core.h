@@ -484,9 +484,15 @@ __device__ __forceinline__ void row_steps_wave_pk(const float *rowbuf, int n, in
             if (p * 16 + k < MT) tr[p * 16 + k] = readlane_f32(step[p], 4 * k);
 }
 
-template <int MT>
+// VSC >= 0: m >> 3 == VSC is known at compile time (relax_core_w1 is compiled once more for the model's width); -1: any m.
+template <int MT, int VSC = -1>
 __device__ __forceinline__ void row_steps_wave(const float *rowbuf, int n, int m, float fm, float rcp_m, float (&tr)[MT]) {
     __builtin_amdgcn_wave_barrier();                   // scheduling fence only: the wave's own LDS writes are ordered
+    if constexpr (VSC >= 1) {
+        if constexpr (MT > 8) row_steps_wave_pk<MT, VSC>(rowbuf, n, m, fm, rcp_m, tr);
+        else row_steps_wave_vs<MT, VSC>(rowbuf, n, m, fm, rcp_m, tr);
+        return;
+    }
     if constexpr (MT > 8) {
         switch (m >> 3) {
             case 0: row_steps_wave_vs<MT, 0>(rowbuf, n, m, fm, rcp_m, tr); break;
@@ -521,15 +527,19 @@ __device__ __forceinline__ void row_steps_wave(const float *rowbuf, int n, int m
 // for all of them.  Bit identical through every solver golden, but SLOWER: 10 x 50: 107.5 vs 72.6 us, 5 x 50 at 40 x 5:
 // 145.5 vs 99.3 us -- the permlane swaps cost far more than the LDS turn-around they replace.)
 
-template <int MT, bool EXACT>
+// VSC: see row_steps_wave.  The switch over the width class inside the sweep cost ~10 % of it (the compare tree's taken
+// branches are instruction-fetch bubbles for a wave alone on its SIMD, and the row sums could not be scheduled into the
+// element-wise work around them): 10 x 50 at 20 x 5 64.5 -> 58.3 us, 5 x 50 50.5 -> 44.7 us with the width class fixed.
+// So the core is compiled for the model's width classes (4, 5, 6: 32..55 columns -- the evaluator keeps up to 50 proposals
+// per frame, 30..50 after NMS) and once more for any width.
+template <int MT, bool EXACT, int VSC = -1>
 __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                              float *xbuf, float *rsbuf, int *hs, float (&X)[MT], float (&acc)[MT],
-                                             float *cost_out) {
+                                             float *cost_out, float *rowbuf /* LDS, MT * kRowStride + 8 floats, 16-byte aligned */) {
     constexpr int MP = (MT + 1) / 2;                   // row pairs; an odd MT leaves a dummy slot that stays zero
     const int n = EXACT ? MT : n_rt;
     const bool with_helper = blockDim.x > 64;          // wave 1 computes the cost norms (norm_helper_wave)
     if (with_helper && threadIdx.x == 0) hs[3] = n * m;
-    __shared__ __attribute__((aligned(16))) float rowbuf[MT * kRowStride + 8];
     if (threadIdx.x < 8) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) rowbuf[i * kRowStride + 64 + threadIdx.x] = 0.0f;
@@ -678,7 +688,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
                 rowbuf[(2 * k) * kRowStride + col] = Xp[k].x;
                 if (2 * k + 1 < MT) rowbuf[(2 * k + 1) * kRowStride + col] = Xp[k].y;
             }
-            row_steps_wave<MT>(rowbuf, n, m, fm, rcp_m, tr);
+            row_steps_wave<MT, VSC>(rowbuf, n, m, fm, rcp_m, tr);
             bool moved = false;
             if (live) {                                        // dead columns keep their zeros
 #pragma unroll
@@ -744,7 +754,13 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
 #ifndef DMM_SOLVER_NO_W1
     if constexpr (NG == 1 && !TAPE) {                  // forward, one wave per frame: the latency form
         (void)red;
-        return relax_core_w1<MT, EXACT>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out);
+        __shared__ __attribute__((aligned(16))) float rowbuf_w1[MT * kRowStride + 8];   // one buffer for all the variants
+        switch (m >> 3) {                              // the evaluator's frames: 50 proposals, 32..55 columns after NMS
+            case 4: return relax_core_w1<MT, EXACT, 4>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
+            case 5: return relax_core_w1<MT, EXACT, 5>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
+            case 6: return relax_core_w1<MT, EXACT, 6>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
+            default: return relax_core_w1<MT, EXACT>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
+        }
     }
 #endif
     int tape_pos = 0;
