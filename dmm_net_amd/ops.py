@@ -719,7 +719,7 @@ class ForwardPlan:
             if not self._graphs:
                 return "single stream (HIP graph armed: captured on the 2nd call with the same tensors)"
             return "HIP graph replay (IoU counts | feature similarity in parallel -> solver -> mix)" if self.graph_fork \
-                else "HIP graph replay (feature similarity -> IoU counts -> solver -> mix, one chain)"
+                else "HIP graph replay (feature similarity + IoU counts [one launch at <= 8 dense frames] -> solver -> mix, one chain)"
         return "single stream"
 
     def _launch_forked(self, L, masks_p, masks_t, feat_p, feat_t, score_p, dt, strides, n_valid, m_valid, cfg):
