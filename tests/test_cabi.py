@@ -105,7 +105,7 @@ def test_dispatch_options_go_through_the_abi_and_not_through_the_environment(mon
     """VERDICT r3 hygiene: kernel choices / tuning values are integers set with dmm_set_option (include/dmm_match.h (0));
     the library contains no getenv call, so a stray variable cannot change what production dispatches."""
     L = _lib.load()
-    names = re.findall(r"\b(DMM_OPT_[A-Z_]+)\s*=\s*(\d+)", open(os.path.join(ROOT, "include", "dmm_match.h")).read())
+    names = re.findall(r"\b(DMM_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", open(os.path.join(ROOT, "include", "dmm_match.h")).read())
     count = dict(names).pop("DMM_OPT_COUNT")
     assert int(count) == len(_lib.OPTIONS) == len(names) - 1
     for name, k in names:
