@@ -708,10 +708,14 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             moved_prev = __ballot(moved);
             return false;
         };
-        for (int j = 0; j < prm.proj_iter; j += 2) {
-            if (sweep()) break;
-            if (j + 1 >= prm.proj_iter) break;
-            if (sweep()) break;
+        if (prm.proj_iter == 5) {                             // the reference's setting (relax_proj_iter: 5), straight line
+            if (!sweep() && !sweep() && !sweep() && !sweep()) (void)sweep();
+        } else {
+            for (int j = 0; j < prm.proj_iter; j += 2) {
+                if (sweep()) break;
+                if (j + 1 >= prm.proj_iter) break;
+                if (sweep()) break;
+            }
         }
         if (with_helper) {
             while (hs_load(&hs[1]) != it + 1) {}
