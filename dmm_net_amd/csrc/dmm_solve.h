@@ -55,3 +55,43 @@ int launch_relax_match_bwd_wide(const float *sim, const float *score_p, int B, i
                                 const float *dds, float *dsim_out, void *workspace, hipStream_t stream);
 
 }  // namespace dmm
+
+namespace dmm {
+int opt(int key);
+// Threads per workgroup: the one-wave solver gets a second wave (the cost-norm helper, norm_helper_wave) while few frames
+// are in flight -- two waves per frame then still sit on different SIMDs; DMM_OPT_SOLVER_HELPER_MAX (default 512 frames,
+// 0 = never) moves the switch.
+static inline int solver_block(int ng, int B) {
+    if (ng != 1) return 64 * ng;
+    const int helper_max = opt(DMM_OPT_SOLVER_HELPER_MAX);
+    return B <= helper_max ? 128 : 64;
+}
+}  // namespace dmm
+
+// Kernel selection: exact-row-count instantiations for the common small problems (one wave per
+// frame), guarded generic ones (MT in {8,16,32}) otherwise.
+#define DMM_DISPATCH_SOLVER(M_, W_, EXACT_OK, CALL)                                                          \
+    do {                                                                                                     \
+        const int ng_ = ((W_) + 63) / 64;                                                                    \
+        if (ng_ <= 1 && (EXACT_OK)) {                                                                        \
+            switch (M_) {                                                                                    \
+                case 1: CALL(1, 1, true); break;   case 2: CALL(2, 1, true); break;                          \
+                case 3: CALL(3, 1, true); break;   case 4: CALL(4, 1, true); break;                          \
+                case 5: CALL(5, 1, true); break;   case 6: CALL(6, 1, true); break;                          \
+                case 7: CALL(7, 1, true); break;   case 8: CALL(8, 1, true); break;                          \
+                case 9: CALL(9, 1, true); break;   case 10: CALL(10, 1, true); break;                        \
+                case 11: CALL(11, 1, true); break; case 12: CALL(12, 1, true); break;                        \
+                case 13: CALL(13, 1, true); break; case 14: CALL(14, 1, true); break;                        \
+                case 15: CALL(15, 1, true); break; case 16: CALL(16, 1, true); break;                        \
+                default: CALL(32, 1, false); break;                                                          \
+            }                                                                                                \
+        } else if (ng_ <= 1) {                                                                               \
+            if ((M_) <= 8) CALL(8, 1, false); else if ((M_) <= 16) CALL(16, 1, false); else CALL(32, 1, false); \
+        } else if (ng_ == 2) {                                                                               \
+            if ((M_) <= 8) CALL(8, 2, false); else if ((M_) <= 16) CALL(16, 2, false); else CALL(32, 2, false); \
+        } else {                                                                                             \
+            if ((M_) <= 8) CALL(8, 4, false); else if ((M_) <= 16) CALL(16, 4, false);                       \
+            else if ((M_) == 20 && (EXACT_OK)) CALL(20, 4, true); else CALL(32, 4, false);                   \
+        }                                                                                                    \
+    } while (0)
+

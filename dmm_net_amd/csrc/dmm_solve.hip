@@ -94,53 +94,6 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
     solver_helper_stop(hs);
 }
 
-// Solver-only kernel on a caller-provided C [B, n, m].
-template <int MT, int NG, bool EXACT>
-__global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG) void relax_solve_kernel(const float *__restrict__ Cin, int n_max, int m_max,
-                                                              const int32_t *__restrict__ rows_valid,
-                                                              const int32_t *__restrict__ cols_valid,
-                                                              RelaxParams prm, float *__restrict__ X_final,
-                                                              float *__restrict__ R_out, float *__restrict__ cost_out,
-                                                              int32_t *__restrict__ iters_out) {
-    __shared__ float red_buf[2 * NG * (MT + 1)];
-    __shared__ float xbuf[MT * 64 * NG];
-    __shared__ float rsbuf[MT + 1];
-    __shared__ int hs[4];
-    if (NG == 1 && solver_helper_entry(xbuf, hs)) return;
-    const int b = blockIdx.x, col = threadIdx.x;
-    BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
-    const int n = EXACT ? MT : (rows_valid ? rows_valid[b] : n_max);
-    const int m = cols_valid ? cols_valid[b] : m_max;
-    float C[MT], X[MT], acc[MT];
-    if (n <= 0 || m <= 0) {                                     // dead frame
-        for (int i = threadIdx.x; i < n_max * m_max; i += 64 * NG) {
-            if (X_final) X_final[(int64_t)b * n_max * m_max + i] = 0.0f;
-            if (R_out) R_out[(int64_t)b * n_max * m_max + i] = 0.0f;
-        }
-        if (iters_out && threadIdx.x == 0) iters_out[b] = 0;
-        if (NG == 1) solver_helper_stop(hs);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) C[i] = (i < n && col < m) ? Cin[((int64_t)b * n_max + i) * m_max + col] : 0.0f;
-    const int iters = relax_core<MT, NG, EXACT>(C, n, m, col, prm, red, xbuf, rsbuf, X, acc,
-                                                cost_out ? cost_out + (int64_t)b * (prm.max_iter + 1) : nullptr,
-                                                RelaxTape{nullptr, nullptr}, hs);
-    const float flen = (float)(iters + 1);
-    for (int i = 0; i < n_max; ++i) {
-        if (col < m_max) {
-            const bool lv = i < n && col < m;
-            float xv = 0.0f, rv = 0.0f;
-#pragma unroll
-            for (int k = 0; k < MT; ++k)
-                if (k == i) { xv = X[k]; rv = acc[k] / flen; }
-            if (X_final) X_final[((int64_t)b * n_max + i) * m_max + col] = lv ? xv : 0.0f;
-            if (R_out) R_out[((int64_t)b * n_max + i) * m_max + col] = lv ? rv : 0.0f;
-        }
-    }
-    if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Backward of the layer kernel with respect to sim (reference: torch autograd through relax_matching,
 // relax_match.py:68-98, and match_model.py:121-147).  One workgroup per frame:
@@ -299,44 +252,6 @@ __global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
 
 }  // namespace dmm
 
-namespace dmm {
-// Threads per workgroup: the one-wave solver gets a second wave (the cost-norm helper, norm_helper_wave) while few frames
-// are in flight -- two waves per frame then still sit on different SIMDs; DMM_OPT_SOLVER_HELPER_MAX (default 512 frames,
-// 0 = never) moves the switch.
-static int solver_block(int ng, int B) {
-    if (ng != 1) return 64 * ng;
-    const int helper_max = opt(DMM_OPT_SOLVER_HELPER_MAX);
-    return B <= helper_max ? 128 : 64;
-}
-}  // namespace dmm
-
-// Kernel selection: exact-row-count instantiations for the common small problems (one wave per
-// frame), guarded generic ones (MT in {8,16,32}) otherwise.
-#define DMM_DISPATCH_SOLVER(M_, W_, EXACT_OK, CALL)                                                          \
-    do {                                                                                                     \
-        const int ng_ = ((W_) + 63) / 64;                                                                    \
-        if (ng_ <= 1 && (EXACT_OK)) {                                                                        \
-            switch (M_) {                                                                                    \
-                case 1: CALL(1, 1, true); break;   case 2: CALL(2, 1, true); break;                          \
-                case 3: CALL(3, 1, true); break;   case 4: CALL(4, 1, true); break;                          \
-                case 5: CALL(5, 1, true); break;   case 6: CALL(6, 1, true); break;                          \
-                case 7: CALL(7, 1, true); break;   case 8: CALL(8, 1, true); break;                          \
-                case 9: CALL(9, 1, true); break;   case 10: CALL(10, 1, true); break;                        \
-                case 11: CALL(11, 1, true); break; case 12: CALL(12, 1, true); break;                        \
-                case 13: CALL(13, 1, true); break; case 14: CALL(14, 1, true); break;                        \
-                case 15: CALL(15, 1, true); break; case 16: CALL(16, 1, true); break;                        \
-                default: CALL(32, 1, false); break;                                                          \
-            }                                                                                                \
-        } else if (ng_ <= 1) {                                                                               \
-            if ((M_) <= 8) CALL(8, 1, false); else if ((M_) <= 16) CALL(16, 1, false); else CALL(32, 1, false); \
-        } else if (ng_ == 2) {                                                                               \
-            if ((M_) <= 8) CALL(8, 2, false); else if ((M_) <= 16) CALL(16, 2, false); else CALL(32, 2, false); \
-        } else {                                                                                             \
-            if ((M_) <= 8) CALL(8, 4, false); else if ((M_) <= 16) CALL(16, 4, false);                       \
-            else if ((M_) == 20 && (EXACT_OK)) CALL(20, 4, true); else CALL(32, 4, false);                   \
-        }                                                                                                    \
-    } while (0)
-
 extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const int32_t *area_p,
                                    const int32_t *area_t, const float *score_p, int B, int N, int M,
                                    const int32_t *n_valid, const int32_t *m_valid, float score_weight, int max_iter,
@@ -421,26 +336,6 @@ extern "C" int dmm_relax_match_any_f32(const float *cos_in, const int32_t *inter
                                         score_weight, dmm::RelaxParams{max_iter, proj_iter, lr}, is_test, sim_out, R_out,
                                         Rb_out, match_score, det_score, iters_out, X_final, (float *)scratch,
                                         (hipStream_t)stream);
-}
-
-extern "C" int dmm_relax_solve_f32(const float *C, int B, int n, int m, const int32_t *rows_valid,
-                                   const int32_t *cols_valid, int max_iter, int proj_iter, float lr,
-                                   float *X_final, float *R_out, float *cost_out, int32_t *iters_out,
-                                   dmm_stream_t stream) {
-    if (B < 0 || n <= 0 || m <= 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
-    if (B == 0) return DMM_OK;
-    if (!C) return DMM_ERR_BAD_ARG;
-    if (n > DMM_MAX_TEMPLATES || m > DMM_MAX_PROPOSALS) return DMM_ERR_UNSUPPORTED;
-    const dmm::RelaxParams prm{max_iter, proj_iter, lr};
-    if (dmm::use_row_split(B, n, m))
-        return dmm::launch_relax_solve_rs(C, B, n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out,
-                                          (hipStream_t)stream);
-#define DMM_CALL(MT_, NG_, EX_)                                                                                     \
-    hipLaunchKernelGGL((dmm::relax_solve_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream, C, \
-                       n, m, rows_valid, cols_valid, prm, X_final, R_out, cost_out, iters_out)
-    DMM_DISPATCH_SOLVER(n, m, rows_valid == nullptr, DMM_CALL);
-#undef DMM_CALL
-    return dmm::check_launch();
 }
 
 extern "C" size_t dmm_relax_bwd_workspace_bytes(int B, int N, int M, int max_iter, int proj_iter) {
