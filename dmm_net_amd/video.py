@@ -373,6 +373,7 @@ class FrameLoop:
         self.lookahead = True                                    # proposals of frame t + 1 on a side stream (see run)
         self.encode_ahead = 0                                    # frames per encoder batch (see run); 1 = the reference's order;
                                                                  # 0 = by clip length: ceil(T / 3) within [4, 9]
+        self.steps_priority = 0                                  # HIP stream priority of the steps' stream (-1: 0.412 -> 0.407 ms per step, within noise)
         self.encode_overlap = True                               # next chunk's encoder on its own stream (see run)
         # fixed-slot frame step (StepPlan): raw proposals of the whole clip on the device, two-phase paste, kept counts
         # stay on the device, and -- ``graph`` -- the whole step replayed from one HIP graph.  Off = the BoxList path
@@ -405,7 +406,7 @@ class FrameLoop:
         return max(4, min(9, -(-int(T) // 3)))
 
     def _side_stream(self, dev, role="proposals", beside=()):
-        prio = int(self.encoder_priority) if role == "encoder" else 0
+        prio = int(self.encoder_priority) if role == "encoder" else (int(self.steps_priority) if role == "steps" else 0)
         key = (role, dev.index if dev.index is not None else torch.cuda.current_device(), prio)
         if key not in self._side:
             if beside and not torch.cuda.is_current_stream_capturing():
