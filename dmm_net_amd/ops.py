@@ -491,6 +491,7 @@ def mask_mix_bwd(Rb: torch.Tensor, masks_p: torch.Tensor, dout: torch.Tensor, n_
 
 
 _WORKSPACES = {}
+_WS_STATE = {}                       # (device, stream) -> ((B, N, M, D), ctypes.c_int): dmm_match_forward_ws's note
 # HIP stream capture is process-global by default: a second host thread that touches the runtime while one captures
 # aborts the process.  Captures are serialised and run in thread-local capture mode (nn.DataParallel-style callers).
 _CAPTURE_LOCK = threading.Lock()
@@ -519,6 +520,18 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
         ws = _WORKSPACES[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _WS_STATE.pop(key, None)
+    # dmm_match_forward_ws: the library's note about what the previous call left in THIS workspace; it only holds for the
+    # same table layout (B, N, M, D), so another shape starts from "unknown"
+    # (a call recorded into a graph is replayed behind our back, on this workspace: from then on no note is kept for it)
+    note = None
+    if torch.cuda.is_current_stream_capturing() or _WS_STATE.get(key) == "captured":
+        _WS_STATE[key] = "captured"
+    else:
+        shape, note = _WS_STATE.get(key, (None, None))
+        if shape != (B, N, M, D):
+            note = ctypes.c_int(0)
+            _WS_STATE[key] = ((B, N, M, D), note)
     f32 = dict(dtype=torch.float32, device=dev)
     full = torch.empty((B, M, H, W), **f32)
     ms, ds = torch.empty((B, M), **f32), torch.empty((B, M), **f32)
@@ -530,11 +543,12 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
                   "Rb": torch.empty((B, M, Pp), **f32)}
     tp = (lambda k: _ptr(tables[k])) if tables else (lambda k: None)
     with _lib.device_guard(dev):
-        rc = L.dmm_match_forward(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p), _ptr(feat_t),
-                                 _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
-                                 float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(full),
-                                 _ptr(ms), _ptr(ds), tp("sim"), tp("R"), tp("Rb"), _ptr(iters), _ptr(ws), ws.numel(), stream)
-    _lib.check(rc, "dmm_match_forward")
+        rc = L.dmm_match_forward_ws(_ptr(masks_p), _ptr(masks_t), _DT[masks_p.dtype], _ptr(feat_p), _ptr(feat_t),
+                                    _ptr(score_p), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, _ptr(n_valid), _ptr(m_valid),
+                                    float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), _ptr(full),
+                                    _ptr(ms), _ptr(ds), tp("sim"), tp("R"), tp("Rb"), _ptr(iters), _ptr(ws), ws.numel(),
+                                    None if note is None else ctypes.byref(note), stream)
+    _lib.check(rc, "dmm_match_forward_ws")
     if return_tables:
         return full, ms, ds, iters, tables
     return full, ms, ds, iters

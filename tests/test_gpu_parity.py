@@ -1589,3 +1589,47 @@ def test_forward_plan_graph_replays_carry_the_workspace_state():
     for t in bufs:
         t.copy_(mk(*t.shape) - (0.5 if t.dim() == 3 else 0.0))
     assert same(bufs) and plan._ws_state.value == 1              # replay again
+
+
+@pytest.mark.gpu
+def test_match_forward_keeps_its_workspace_note_per_shape_and_drops_it_under_capture():
+    """ops.match_forward (MatchModel's inference path) threads dmm_match_forward_ws's note through its per-stream workspace:
+    the note holds for one table layout only, and a call recorded into a graph -- replayed later behind the module's
+    back, on the same workspace -- ends note keeping for that workspace.  Results never depend on any of it."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda *s: torch.rand(s, generator=g, device=DEV)
+    kw = dict(score_weight=0.3, max_iter=10, proj_iter=5, lr=0.1, is_test=1)
+
+    def inputs(B, N, M):
+        return [mk(B, N, 40, 48), mk(B, M, 40, 48), mk(B, N, 512) - 0.5, mk(B, M, 512) - 0.5, mk(B, N)]
+
+    def check(inp):
+        got = ops.match_forward(*inp, **kw)
+        with _lib.options(SMALL_FUSED=0):
+            ref = ops.ForwardPlan(inp[0].shape[0], inp[0].shape[1], inp[1].shape[1], 40, 48, 512, DEV, pipeline=False)
+            ref.run(*inp, max_iter=10, proj_iter=5, is_test=1)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref.full_outmask) and torch.equal(got[1], ref.match_score)
+
+    key = (torch.device(DEV).index, torch.cuda.current_stream().cuda_stream)
+    a, b = inputs(1, 50, 10), inputs(2, 30, 4)
+    for inp in (a, a, b, a, b, b):                               # alternating layouts on one workspace
+        check(inp)
+        assert ops._WS_STATE[key][0] == (inp[0].shape[0], inp[0].shape[1], inp[1].shape[1], 512)
+        assert ops._WS_STATE[key][1].value == 1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.match_forward(*a, **kw)                              # warm-up on the capture stream's own workspace
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            out = ops.match_forward(*a, **kw)
+        skey = (torch.device(DEV).index, side.cuda_stream)
+        assert ops._WS_STATE[skey] == "captured"
+        want = ops.match_forward(*a, **kw)                       # direct call on that workspace: no note any more
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0])
+        check(a)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0])
