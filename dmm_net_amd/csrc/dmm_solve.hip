@@ -19,8 +19,11 @@
 // data-dependent early exits (relax_match.py:88-89, :96-98) and the executed-iteration count are bit
 // exact against the reference.
 //
-// Roofline: neither HBM nor MFMA -- a latency-bound dependent chain (~400 VALU ops per sweep);
-// throughput comes from running one frame per wave on all 1024 SIMDs.
+// Roofline: neither HBM nor MFMA.  One wave per frame issues ~145 (5 rows) to ~230 (10 rows) instructions per projection
+// sweep at ~5-6 cycles each (one wave on a SIMD: nothing hides a dependent VALU op's 6 cycles, a DPP add's 13, an LDS
+// turn-around's 76 -- tools/clock_probe.py), so the sweep is ISSUE bound and every compile-time fact the scheduler gets
+// pays: the row count (exact instantiations), the width class of the model's frames, the reference's 5 sweeps as
+// straight-line code (dmm_solve_core.h).  Throughput comes from running one frame per wave on all 1024 SIMDs.
 #include "dmm_solve_core.h"
 
 namespace dmm {
