@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="2", choices=("2", "3", "4", "5", "loop", "train"),
+    ap.add_argument("--config", default="2", choices=("2", "3", "4", "5", "loop", "train", "dropin"),
                     help="BASELINE configs index + 1; loop = the evaluator's frame loop; train = the layer's training "
-                         "form (forward + backward) with per-kernel rooflines")
+                         "form (forward + backward) with per-kernel rooflines; dropin = host-inclusive cost per call of "
+                         "the drop-in classes themselves (MatchModel.forward, DMM_Model)")
     ap.add_argument("--no-others", action="store_true", help="default run: skip the compact other_configs entries")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default 1024 / 8 / 512 for "
                                                           "config 2 / 3 / 5)")
@@ -77,7 +78,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank control flow on a single-GPU box)")
     a = ap.parse_args()
-    a.config = a.config if a.config in ("loop", "train") else int(a.config)
+    a.config = a.config if a.config in ("loop", "train", "dropin") else int(a.config)
     return a
 
 
@@ -894,6 +895,149 @@ def bench_train(R, Bs=(64, 512)):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the drop-in itself: what ONE call of the reference's classes costs, host included
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_dropin(R):
+    """north_star's deliverable is ``MatchModel`` dropped into train.py / eval.py, called once per (video, frame)
+    (dmm/modules/dmm_model.py:75-77 evaluator, :130-132 trainer).  Per call, for each case: WALL time (host clock around n
+    back-to-back calls + one synchronize -- what the caller's loop pays), DEVICE time (HIP events around the same calls)
+    and the library's kernel launches per call (``dmm_launch_count``).  wall > device = the call is host bound."""
+    from dmm_net_amd import _lib, autograd
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd.match_model import MatchModel
+    from dmm_net_amd.proposals import SimpleBoxList
+    args, dev, rank, world = R.args, R.dev, R.rank, R.world
+    L = _lib.load()
+    H, W, D = 255, 448, 512
+    g = torch.Generator(device=dev).manual_seed(4321 + 1000 * rank)
+    n_calls = max(50, args.steps)
+
+    def cfgs(mi):
+        return {"matching": {"algo": "relax"}, "relax_max_iter": mi, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+                "score_weight": 0.3}
+
+    def frame(P, O):
+        return dict(pf=torch.randn((P, D), generator=g, device=dev), tf=torch.randn((O, D), generator=g, device=dev),
+                    pm=torch.rand((P, H, W), generator=g, device=dev), tm=torch.rand((O, H, W), generator=g, device=dev),
+                    sc=torch.rand((P,), generator=g, device=dev),
+                    tg=(torch.rand((O, H, W), generator=g, device=dev) > 0.5).float())
+
+    def measure(call, n=n_calls, reps=3):
+        """median (and min / max) over ``reps`` repeats of n back-to-back calls: wall us, device us, launches per call."""
+        for _ in range(10):
+            call()
+        torch.cuda.synchronize(dev)
+        walls, devs = [], []
+        l0 = L.dmm_launch_count()
+        call()
+        launches = int(L.dmm_launch_count() - l0)
+        torch.cuda.synchronize(dev)
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            a.record()
+            for _ in range(n):
+                call()
+            b.record()
+            torch.cuda.synchronize(dev)
+            walls.append((time.perf_counter() - t0) / n * 1e6)
+            devs.append(a.elapsed_time(b) / n * 1e3)
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {"wall_us": round(med(walls), 1), "wall_us_min_max": [round(min(walls), 1), round(max(walls), 1)],
+                "device_us": round(med(devs), 1), "library_launches": launches,
+                "wall_over_device": round(med(walls) / max(med(devs), 1e-9), 3), "calls": n, "repeats": reps}
+
+    cases = {}
+    # (a) the evaluator's call: MatchModel(cfg, is_test=1).forward under no_grad, eval solver setting 40 x 5
+    ev = MatchModel(cfgs(40), is_test=1)
+    for (P, O) in ((50, 5), (50, 10)):
+        f = frame(P, O)
+
+        def call_eval(f=f):
+            with torch.no_grad():
+                return ev(f["pf"], f["pm"], [f["tf"]], f["tm"], f["sc"])
+        cases[f"eval_forward_{P}x{O}"] = dict(measure(call_eval), what=f"MatchModel(cfgs, is_test=1).forward, {P} proposals x "
+                                              f"{O} templates, {H}x{W} fp32, 40 x 5 iterations, no_grad "
+                                              "(dmm_model.py:75-77)")
+    # (b) the trainer's call: MatchModel(cfg, 0).forward with targets + backward, train solver setting 10 x 5
+    tr = MatchModel(cfgs(10), is_test=0)
+    f = frame(50, 5)
+    pf = f["pf"].clone().requires_grad_(True)
+    tf = f["tf"].clone().requires_grad_(True)
+    dfull = torch.rand((5, H, W), generator=g, device=dev)
+    one = torch.ones((), device=dev)
+
+    def call_train():
+        pf.grad = tf.grad = None
+        fo, ms, ds, _, loss = tr(pf, f["pm"], [tf], f["tm"], f["sc"], f["tg"])
+        torch.autograd.backward([fo, loss["cost_loss"]], [dfull, one])
+    what_b = (f"MatchModel(cfgs, 0).forward with targets + backward(), 50 proposals x 5 templates, {H}x{W} fp32, 10 x 5 "
+              "iterations (dmm_model.py:130-132)")
+    cases["train_fwd_bwd_50x5"] = dict(measure(call_train), what=what_b)
+    assert pf.grad is not None and bool(torch.isfinite(pf.grad).all()) and float(pf.grad.abs().sum()) > 0
+    old = autograd._FUSED_TRAIN
+    autograd._FUSED_TRAIN = False                                # the pre-fusion chain, for the record
+    try:
+        cases["train_fwd_bwd_50x5_granular_chain"] = dict(measure(call_train), what=what_b + " -- through the granular entries "
+                                                          "(12 library calls + tensor ops), what round 4 shipped")
+    finally:
+        autograd._FUSED_TRAIN = old
+    # (c) DMM_Model for 4 videos (all videos of the step through one ragged launch sequence)
+    B, F, P = 4, 5, 50
+
+    def boxes(n):
+        x1 = torch.rand(n, generator=g, device=dev) * (W - 60)
+        y1 = torch.rand(n, generator=g, device=dev) * (H - 60)
+        return torch.stack([x1, y1, x1 + 10 + torch.rand(n, generator=g, device=dev) * 150,
+                            y1 + 10 + torch.rand(n, generator=g, device=dev) * 100], 1).clamp(max=W - 1)
+    props = []
+    for b in range(B):
+        bl = SimpleBoxList(boxes(P), (W, H))
+        bl.add_field("mask", torch.rand((P, 1, H, W), generator=g, device=dev))
+        bl.add_field("scores", torch.rand(P, generator=g, device=dev))
+        props.append(bl)
+    feats_p = [torch.randn((P, D), generator=g, device=dev) for _ in range(B)]
+    feats_pg = [x.clone().requires_grad_(True) for x in feats_p]
+    tplt = {b: {"feat": [torch.randn((F, D), generator=g, device=dev)], "refine_input_feat": [()]} for b in range(B)}
+    mask_last = torch.rand((B, F, H, W), generator=g, device=dev)
+    targets = (torch.rand((B, F, H, W), generator=g, device=dev) > 0.5).float()
+    valid = torch.ones(B, F, device=dev)
+    # the ROI feature extractor is not what is measured here: hand the rows over
+    m_ev = DMM_Model(cfgs(40), is_test=1, feature_extractor=lambda feats, pr: torch.cat(feats_p, 0))
+    m_tr = DMM_Model(cfgs(10), is_test=0, feature_extractor=lambda feats, pr: torch.cat(feats_pg, 0))
+    infos = {"extra_frame": [False] * B, "valid": valid}
+
+    def call_inf():
+        with torch.no_grad():
+            m_ev.inference(infos, props, None, mask_last, tplt)
+
+    def call_fwd():
+        for x in feats_pg:
+            x.grad = None
+        out, _, ml, _ = m_tr(None, props, None, mask_last, tplt, valid, targets)
+        (out.sum() + sum(ml)).backward()
+    cases["dmm_model_inference_4_videos"] = dict(measure(call_inf, n=max(20, n_calls // 4)),
+                                                 what=f"DMM_Model.inference, {B} videos x {P} proposals x {F} templates, {H}x{W}, "
+                                                      "40 x 5 (dmm_model.py:48-86); ROI feature rows handed over")
+    cases["dmm_model_forward_backward_4_videos"] = dict(measure(call_fwd, n=max(20, n_calls // 4)),
+                                                        what=f"DMM_Model.forward + backward, {B} videos, 10 x 5 "
+                                                             "(dmm_model.py:88-142)")
+    head = cases["eval_forward_50x5"]
+    out = {
+        "metric": "calls/sec of the drop-in (MatchModel.forward as the evaluator calls it: 50 proposals x 5 templates, "
+                  "255x448, one frame per call), host inclusive",
+        "value": round(world * 1e6 / head["wall_us"], 1), "unit": "calls/s", "n_gpus": world, "steps": head["calls"],
+        "warmup": 10, "ms_per_step": round(head["wall_us"] / 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "the drop-in classes called as the reference calls them (one frame of one video per "
+                               "MatchModel call; 4 videos per DMM_Model call); wall = host clock around n back-to-back calls "
+                               "+ one synchronize, device = HIP events around the same calls; median of 3 repeats",
+                   "cases": cases},
+    }
+    return out
+
+
 def compact(out):
     """What ``other_configs`` keeps of a workload's line."""
     c = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"],
@@ -907,6 +1051,9 @@ def compact(out):
               "mean_outer_iterations"):
         if k in out["config"]:
             c[k] = out["config"][k]
+    if "cases" in out["config"]:                                 # the drop-in: per-call wall / device / launches
+        c["cases"] = {k: {kk: v[kk] for kk in ("wall_us", "device_us", "library_launches", "wall_over_device")}
+                      for k, v in out["config"]["cases"].items()}
     if "by_batch" in out["config"]:                              # training form: per-kernel ms / fraction of the HBM peak
         c["by_batch"] = {b: {"fwd_bwd_ms": v["fwd_bwd_ms"], "selected_planes_per_frame": v["selected_planes_per_frame"],
                              "kernels": {k: ({"ms": e["ms"], "frac": e["frac"]} if "frac" in e else {"ms": e["ms"]})
@@ -927,6 +1074,8 @@ def main():
         out = bench_frame_loop(R)
     elif args.config == "train":
         out = bench_train(R)
+    elif args.config == "dropin":
+        out = bench_dropin(R)
     else:
         out = bench_layer(R, args.config)
     if "per_rank" not in out:
@@ -938,7 +1087,8 @@ def main():
         for name, fn, kw in (("config5", lambda r: bench_layer(r, 5), dict(steps=30, warmup=5, frames=0)),
                              ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
                              ("frame_loop", bench_frame_loop, dict(frames=0)),
-                             ("train", bench_train, dict(steps=40, warmup=6, frames=0))):
+                             ("train", bench_train, dict(steps=40, warmup=6, frames=0)),
+                             ("dropin", bench_dropin, dict(steps=100, warmup=0, frames=0))):
             a2 = copy.copy(args)
             a2.no_extras = True
             for k, v in kw.items():

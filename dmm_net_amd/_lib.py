@@ -18,10 +18,11 @@ DMM_OK = 0
 DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_PACKED1 = 0, 1, 2, 3
 MAX_TEMPLATES = 32
 MAX_PROPOSALS = 256
+FRAME_TABLE = -(1 << 63)          # DMM_FRAME_TABLE: sp_b sentinel, masks_p = device table of per-frame base pointers
 
 # every symbol include/dmm_match.h declares
 SYMBOLS = (
-    "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info",
+    "dmm_abi_version", "dmm_status_string", "dmm_last_hip_error", "dmm_build_info", "dmm_launch_count",
     "dmm_set_option", "dmm_get_option", "dmm_reset_options",
     "dmm_iou_counts", "dmm_iou_counts_dual", "dmm_feature_normalize_f32", "dmm_cosine_f32", "dmm_cosine_features_f32", "dmm_feature_sim_bwd_f32", "dmm_relax_match_f32", "dmm_relax_solve_f32",
     "dmm_relax_bwd_workspace_bytes", "dmm_relax_match_bwd_f32",
@@ -31,6 +32,8 @@ SYMBOLS = (
     "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
     "dmm_paste_kept_f32", "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32", "dmm_roialign4_mean_nhwc_fwd",
     "dmm_conv1x1_bf16", "dmm_im2col3x3_bf16", "dmm_bias_relu_maxpool_bf16", "dmm_relax_any_scratch_bytes", "dmm_relax_match_any_f32", "dmm_relax_match_f16s", "dmm_match_solve_packed", "dmm_step_finish_f32",
+    "dmm_matching_loss_f32", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
+    "dmm_match_train_backward_workspace_bytes", "dmm_match_train_backward",
 )
 
 _lib = None
@@ -69,6 +72,7 @@ def load():
     L.dmm_status_string.argtypes = [c_int]
     L.dmm_last_hip_error.restype = c_int
     L.dmm_build_info.restype = ctypes.c_char_p
+    L.dmm_launch_count.restype = ctypes.c_longlong
     L.dmm_set_option.argtypes = [c_int, c_int]
     L.dmm_set_option.restype = c_int
     L.dmm_get_option.argtypes = [c_int]
@@ -161,6 +165,20 @@ def load():
     L.dmm_step_select_i32.argtypes = [vp, vp, c_int, vp, vp]
     L.dmm_step_advance.argtypes = [vp, vp]
     L.dmm_commit_masks_f32.argtypes = [vp, vp, vp, c_int, c_i64, vp]
+    L.dmm_matching_loss_f32.argtypes = [vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, vp]
+    L.dmm_matching_loss_f32.restype = c_int
+    L.dmm_match_train_forward_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    L.dmm_match_train_forward_workspace_bytes.restype = sz
+    L.dmm_match_train_forward.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
+                                          c_i64, c_i64, c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp,
+                                          vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.dmm_match_train_forward.restype = c_int
+    L.dmm_match_train_backward_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
+    L.dmm_match_train_backward_workspace_bytes.restype = sz
+    L.dmm_match_train_backward.argtypes = [vp, c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int,
+                                           c_int, c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp,
+                                           sz, vp]
+    L.dmm_match_train_backward.restype = c_int
     for f in ("dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32", "dmm_paste_kept_f32",
               "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32"):
         getattr(L, f).restype = c_int

@@ -13,7 +13,7 @@ from typing import List, Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 def hungarian_onehot(cost: torch.Tensor) -> torch.Tensor:
@@ -52,6 +52,11 @@ def matching_loss(pm_b, targets_b, cos, n_valid=None, m_valid=None, counts=None)
     return sq.flatten(1).sum(1) / cnt, gt, (live, cnt)
 
 
+# the training call as one fused library call each way (tests pin the granular chain against it by switching this off)
+_FUSED_TRAIN = True
+_EMPTY = torch.zeros(())
+
+
 class _MatchLayerFn(torch.autograd.Function):
     """pf [B,P,D], tf [T,B,O,D] (T template-feature entries, DMM-Net uses T = 1), pm [B,P,H,W], tm [B,O,H,W],
     sc [B,P], targets [B,O,H,W] | None."""
@@ -61,6 +66,29 @@ class _MatchLayerFn(torch.autograd.Function):
                 counts=None):
         T = tf.shape[0]
         tcounts = None
+        ctx.set_materialize_grads(False)             # an unused output's gradient arrives as None, not as a zero tensor
+        ctx.fused = False
+        if counts is None and T == 1 and _FUSED_TRAIN and not (isinstance(pm, torch.Tensor) and pm.requires_grad):
+            # the common case as ONE library call each way (dmm_match_train_forward / _backward): a one-frame call is
+            # host bound otherwise (bench.py --config dropin)
+            pf_c, tf_c, sc_c = pf.contiguous(), tf[0].contiguous(), sc.contiguous()
+            got = ops.match_train_forward(pm, tm, targets, pf_c, tf_c, sc_c, n_valid, m_valid, score_weight=score_weight,
+                                          max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+            if got is not None:
+                full, ms, ds, loss, iters, saved = got
+                ctx.fused = True
+                ctx.frame_planes = pm if isinstance(pm, ops.FramePlanes) else None
+                empty = _EMPTY
+                ctx.save_for_backward(pf_c, tf_c, sc_c, saved, empty if ctx.frame_planes is not None else pm,
+                                      n_valid if n_valid is not None else empty, m_valid if m_valid is not None else empty)
+                ctx.has_targets = targets is not None
+                ctx.ragged = (n_valid is not None, m_valid is not None)
+                ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
+                ctx.n_tplt = tm.shape[1]
+                ctx.mark_non_differentiable(iters)
+                if loss is None:
+                    loss = pf.new_zeros((pf.shape[0],))
+                return full, ms, ds, loss, iters
         if counts is not None:                       # integer tables from elsewhere (1-bit planes of the paste kernel)
             inter, ap, at = counts
         elif targets is not None and tm.shape[1] <= 16:
@@ -103,8 +131,63 @@ class _MatchLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_full, d_ms, d_ds, d_loss, _d_iters):
+        if ctx.fused:
+            need_pf, need_tf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+            if not (need_pf or need_tf):
+                return (None,) * 14
+            pf, tf, sc, saved, pm, n_valid, m_valid = ctx.saved_tensors
+            score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
+            g_t, g_p = ops.match_train_backward(
+                ctx.frame_planes if ctx.frame_planes is not None else pm, pf, tf, sc, saved, ctx.has_targets, d_full, d_ms,
+                d_ds, d_loss, n_valid if ctx.ragged[0] else None, m_valid if ctx.ragged[1] else None, ctx.n_tplt,
+                score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+            return (g_p if need_pf else None, g_t.unsqueeze(0) if need_tf else None) + (None,) * 12
         from .backward import match_layer_backward
         return match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss)
+
+
+class _MatchFrameFn(torch.autograd.Function):
+    """ONE frame exactly as the reference's trainer hands it over (dmm_model.py:130-132): pf [P,D], tf [O,D], pm [P,H,W],
+    tm [O,H,W], sc [P], targets [O,H,W] | None -> (full [O,H,W], match_score [O], det_score [O], cost_loss ()).  The
+    fused library calls of ``_MatchLayerFn`` without the batch axis: no unsqueeze / select nodes around the layer in the
+    autograd graph (a one-frame call is host bound; bench.py --config dropin)."""
+
+    @staticmethod
+    def forward(ctx, pf, tf, pm, tm, sc, targets, score_weight, max_iter, proj_iter, lr, is_test):
+        ctx.set_materialize_grads(False)
+        pf_c, tf_c, sc_c = pf.contiguous(), tf.contiguous(), sc.contiguous()
+        got = ops.match_train_forward(pm, tm, targets, pf_c, tf_c, sc_c, None, None, score_weight=score_weight,
+                                      max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test, one_frame=True)
+        if got is None:
+            raise _lib.DmmError("dmm_match_train_forward refused a shape frame_fused_ok() accepted")
+        full, ms, ds, loss, iters, saved = got
+        ctx.save_for_backward(pf_c, tf_c, sc_c, saved, pm)
+        ctx.has_targets = targets is not None
+        ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
+        ctx.n_tplt = tm.shape[0]
+        if loss is None:
+            return full, ms, ds
+        return full, ms, ds, loss
+
+    @staticmethod
+    def backward(ctx, d_full, d_ms, d_ds, d_loss=None):
+        need_pf, need_tf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_pf or need_tf):
+            return (None,) * 11
+        pf, tf, sc, saved, pm = ctx.saved_tensors
+        score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
+        g_t, g_p = ops.match_train_backward(pm, pf, tf, sc, saved, ctx.has_targets, d_full, d_ms, d_ds, d_loss, None, None,
+                                            ctx.n_tplt, score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter,
+                                            lr=lr, is_test=is_test, one_frame=True)
+        return (g_p if need_pf else None, g_t if need_tf else None) + (None,) * 9
+
+
+def frame_fused_ok(pm, tm) -> bool:
+    """Shapes ``dmm_match_train_forward`` takes (the fast kernels' envelope) -- decided BEFORE the autograd function is
+    chosen, from the shapes alone."""
+    P, O = pm.shape[0], tm.shape[0]
+    return (_FUSED_TRAIN and 0 < O <= _lib.MAX_TEMPLATES and 0 < P and ops.padded_width(P, O) <= _lib.MAX_PROPOSALS
+            and not pm.requires_grad and _lib.get_option("FORCE_WIDE") != 1)
 
 
 def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
@@ -155,10 +238,18 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
         pm, tm = proposed_mask, mask_last_occurence
         if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
             pm, tm = pm.float(), tm.float()
-        full, ms, ds, _ = ops.match_forward(pm.unsqueeze(0), tm.unsqueeze(0), proposed_feature.unsqueeze(0),
-                                            tf.unsqueeze(0), proposal_score.unsqueeze(0), score_weight=score_weight,
-                                            max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
-        return full[0], ms[0], ds[0], proposed_feature.new_zeros(())
+        full, ms, ds = ops.match_forward_frame(pm, tm, proposed_feature, tf, proposal_score, score_weight=score_weight,
+                                               max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+        return full, ms, ds, None                            # (no targets: MatchModel returns an empty loss dict)
+    if tf.dim() == 2:
+        pm, tm, tg = proposed_mask, mask_last_occurence, targets
+        if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
+            pm, tm = pm.float(), tm.float()
+        if frame_fused_ok(pm, tm):
+            out = _MatchFrameFn.apply(proposed_feature.float(), tf.float(), pm, tm, proposal_score.float(),
+                                      None if tg is None else tg.to(pm.dtype), float(score_weight), int(max_iter),
+                                      int(proj_iter), float(lr), int(is_test))
+            return out if tg is not None else out + (None,)
     full, ms, ds, loss, _ = match_layer_batched(
         proposed_feature.unsqueeze(0), proposed_mask.unsqueeze(0),
         tf.unsqueeze(0) if tf.dim() == 2 else tf.unsqueeze(1), mask_last_occurence.unsqueeze(0),

@@ -11,14 +11,17 @@
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
                         hipStream_t stream, int32_t *zero_ptr, int64_t zero_words);
-int front_small_launch(const void *masks_p, const void *masks_t, int dtype, const float *feat_t, const float *feat_p, int B,
-                       int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, float *cos_out,
-                       int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream);
+int front_small_launch(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, const float *feat_t,
+                       const float *feat_p, int B, int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b,
+                       int64_t st_m, int64_t st2_b, int64_t st2_m, float *cos_out, int32_t *inter, int32_t *area_p,
+                       int32_t *area_t, int32_t *inter2, int32_t *area_t2, bool tables_zero, hipStream_t stream);
 int iou_counts_prezeroed(const void *masks_p, const void *masks_t, int dtype, int B, int N, int M, int HW, int64_t sp_b,
                          int64_t sp_n, int64_t st_b, int64_t st_m, const int32_t *n_valid, const int32_t *m_valid,
                          int32_t *inter, int32_t *area_p, int32_t *area_t, dmm_stream_t stream);
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
+static std::atomic<long long> g_launches{0};
+void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
 // ---- dispatch options -------------------------------------------------------------------------------------------------
 static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
@@ -124,6 +127,8 @@ extern "C" const char *dmm_status_string(int status) {
 
 extern "C" int dmm_last_hip_error(void) { return dmm::g_last_hip_error; }
 
+extern "C" long long dmm_launch_count(void) { return dmm::g_launches.load(std::memory_order_relaxed); }
+
 extern "C" const char *dmm_build_info(void) { return "libdmm_match gfx950 (CDNA4, wave64) abi " "1"; }
 
 extern "C" size_t dmm_workspace_bytes(int B, int N, int M, int D) {
@@ -201,8 +206,9 @@ extern "C" int dmm_match_forward_ws(const void *masks_p, const void *masks_t, in
     int rc = DMM_ERR_UNSUPPORTED;
     // a handful of dense frames: table clear, then similarity and counts beside each other in ONE launch
     if (!n_valid && !m_valid && !force_tile) {
-        rc = dmm::front_small_launch(masks_p, masks_t, mask_dtype, feat_t, feat_p, B, N, M, HW, D, sp_b, sp_n, st_b, st_m,
-                                     w.cosv, w.inter, w.area_p, w.area_t, tables_zero, (hipStream_t)stream);
+        rc = dmm::front_small_launch(masks_p, masks_t, nullptr, mask_dtype, feat_t, feat_p, B, N, M, HW, D, sp_b, sp_n, st_b,
+                                     st_m, 0, 0, w.cosv, w.inter, w.area_p, w.area_t, nullptr, nullptr, tables_zero,
+                                     (hipStream_t)stream);
         if (rc == DMM_OK) {
             // the solver reads the tables and (asked to) leaves them zero for the next call on this workspace
             rc = dmm::relax_match_launch(w.cosv, w.inter, w.area_p, w.area_t, score_p, B, N, M, n_valid, m_valid,

@@ -273,15 +273,18 @@ static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__rest
 // ---- host side ------------------------------------------------------------------------------
 namespace dmm {
 void set_last_hip_error(int e);
+void note_launch();                  // dmm_launch_count (diagnostic): one relaxed atomic increment per enqueued kernel
 inline hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
     const size_t words = bytes / 4;
     if (words == 0) return hipSuccess;
     size_t blocks = (words + 256 * 4 - 1) / (256 * 4);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)p, words);
+    note_launch();
     return hipGetLastError();
 }
 inline int check_launch() {
+    note_launch();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_hip_error((int)e);

@@ -17,9 +17,9 @@ namespace dmm {
 // out[r,:] = in[r,:] / max(||in[r,:]||_2, 1e-8); one aligned 8-lane group per row (8 rows per wave),
 // the group plays the 8 AVX2 lanes of ATen's 2-norm fast path.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__restrict__ in, int64_t rows, int D,
-                                                                float *__restrict__ out, float *__restrict__ norms) {
-    const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+__device__ __forceinline__ void feature_normalize_rows(const float *__restrict__ in, int64_t rows, int D,
+                                                       float *__restrict__ out, float *__restrict__ norms, int64_t block) {
+    const int64_t r = block * 32 + (threadIdx.x >> 3);
     const int l = threadIdx.x & 7;
     const bool valid = r < rows;
     const float *x = in + (valid ? r : 0) * D;
@@ -37,6 +37,22 @@ __global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__r
         for (int d = l; d < D; d += 8) out[r * D + d] = x[d] / nr;
     }
     if (norms && l == 0) norms[r] = nr;
+}
+
+__global__ __launch_bounds__(256) void feature_normalize_kernel(const float *__restrict__ in, int64_t rows, int D,
+                                                                float *__restrict__ out, float *__restrict__ norms) {
+    feature_normalize_rows(in, rows, D, out, norms, blockIdx.x);
+}
+
+// two row sets in ONE launch (the proposal and the template features of a training step's backward, which normalises
+// both again instead of keeping 2 x [rows, D] alive from the forward): blocks [0, blocks_a) take set a, the rest set b
+__global__ __launch_bounds__(256) void feature_normalize2_kernel(const float *__restrict__ in_a, int64_t rows_a,
+                                                                 float *__restrict__ out_a, float *__restrict__ norms_a,
+                                                                 const float *__restrict__ in_b, int64_t rows_b,
+                                                                 float *__restrict__ out_b, float *__restrict__ norms_b,
+                                                                 int D, int blocks_a) {
+    if ((int)blockIdx.x < blocks_a) feature_normalize_rows(in_a, rows_a, D, out_a, norms_a, blockIdx.x);
+    else feature_normalize_rows(in_b, rows_b, D, out_b, norms_b, (int64_t)blockIdx.x - blocks_a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,6 +481,19 @@ extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, f
                        rows, D, out, norms);
     return dmm::check_launch();
 }
+
+namespace dmm {
+// dmm_feature_normalize_f32 on two row sets with one launch (same kernel body: bit identical)
+int feature_normalize2_launch(const float *in_a, int64_t rows_a, float *out_a, float *norms_a, const float *in_b,
+                              int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream) {
+    if (rows_a <= 0 || rows_b <= 0 || D <= 0 || !in_a || !in_b || !out_a || !out_b) return DMM_ERR_BAD_ARG;
+    const int64_t ba = (rows_a + 31) / 32, bb = (rows_b + 31) / 32;
+    if (ba + bb > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(feature_normalize2_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, stream, in_a, rows_a, out_a,
+                       norms_a, in_b, rows_b, out_b, norms_b, D, (int)ba);
+    return check_launch();
+}
+}  // namespace dmm
 
 extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B, int N, int M, int D,
                               const int32_t *n_valid, const int32_t *m_valid, float *cos_out, dmm_stream_t stream) {

@@ -348,8 +348,9 @@ __global__ __launch_bounds__(kCostThreads) void front_small_kernel(
 
 template <typename T, int MT>
 static int launch_front_small(const float *feat_t, const float *feat_p, float *cos_out, const T *masks_p, const T *masks_t,
-                              int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m,
-                              int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream) {
+                              const T *masks_t2, int B, int N, int M, int HW, int64_t sp_b, int64_t sp_n, int64_t st_b,
+                              int64_t st_m, int64_t st2_b, int64_t st2_m, int32_t *inter, int32_t *area_p, int32_t *area_t,
+                              int32_t *inter2, int32_t *area_t2, bool tables_zero, hipStream_t stream) {
     constexpr int LPC = 32;                                          // D = 512, the model's ROI feature width
     // similarity workgroups: 2 of the 4 waves take steps (every workgroup of the launch carries their LDS; with 4 wave
     // buffers only 2 workgroups fit a CU, with 2 three do)
@@ -390,30 +391,40 @@ static int launch_front_small(const float *feat_t, const float *feat_p, float *c
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
+    // (training: the targets' tables inter2 | area_t2 follow the three tables in the caller's block -- one clearing launch)
     if (!tables_zero)
-        DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
+        DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * (((size_t)B * M * N + (size_t)B * M) * (masks_t2 ? 2 : 1) + (size_t)B * N),
+                               stream));
     hipLaunchKernelGGL((front_small_kernel<LPC, T, MT>), dim3(g.parts + splits_s * sub_count, B), dim3(kCostThreads), g.lds,
-                       stream, feat_t, feat_p, cos_out, g.parts, g.nw, masks_p, masks_t, (const T *)nullptr, N, M, HW, sp_b, sp_n,
-                       st_b, st_m, (int64_t)0, (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, inter, area_p,
-                       area_t, (int32_t *)nullptr, (int32_t *)nullptr, 0, 0, kCostThreads / kWave, 1, 1, 0, sub_count, n_sub);
+                       stream, feat_t, feat_p, cos_out, g.parts, g.nw, masks_p, masks_t, masks_t2, N, M, HW, sp_b, sp_n,
+                       st_b, st_m, st2_b, st2_m, (const int32_t *)nullptr, (const int32_t *)nullptr, inter, area_p,
+                       area_t, inter2, area_t2, 0, 0, kCostThreads / kWave, 1, 1, 0, sub_count, n_sub);
     return check_launch();
 }
 
 // DMM_ERR_UNSUPPORTED (nothing launched) outside its envelope: B <= DMM_OPT_COST_TINY_FRAMES dense frames, N <= 64,
 // M <= 16, D = 512, float / half / bfloat16 planes, the three tables contiguous (dmm_match_forward's workspace).
 // tables_zero: the caller vouches that the tables are zero already (dmm_match_forward_ws) -- no clearing launch.
-int front_small_launch(const void *masks_p, const void *masks_t, int dtype, const float *feat_t, const float *feat_p, int B,
-                       int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, float *cos_out,
-                       int32_t *inter, int32_t *area_p, int32_t *area_t, bool tables_zero, hipStream_t stream) {
+// masks_t2 (training, dmm_match_train_forward): a second template set -- the targets of compute_matching_loss -- rides in
+// the same tile (rows M..2M-1), M <= 8; its tables inter2 | area_t2 must follow area_t in the same block.
+int front_small_launch(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, const float *feat_t,
+                       const float *feat_p, int B, int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b,
+                       int64_t st_m, int64_t st2_b, int64_t st2_m, float *cos_out, int32_t *inter, int32_t *area_p,
+                       int32_t *area_t, int32_t *inter2, int32_t *area_t2, bool tables_zero, hipStream_t stream) {
     if (opt(DMM_OPT_SMALL_FUSED) != 1 || B > opt(DMM_OPT_COST_TINY_FRAMES) || opt(DMM_OPT_COST_KERNEL) == 1)
         return DMM_ERR_UNSUPPORTED;
-    if (D != 512 || N < 2 || N > 64 || M < 1 || M > 16 || HW <= 0 || sp_n < HW || st_m < HW) return DMM_ERR_UNSUPPORTED;
+    const int rows = masks_t2 ? 2 * M : M;
+    if (D != 512 || N < 2 || N > 64 || M < 1 || rows > 16 || HW <= 0 || sp_n < HW || st_m < HW) return DMM_ERR_UNSUPPORTED;
     if (area_p != inter + (size_t)B * M * N || area_t != area_p + (size_t)B * N) return DMM_ERR_UNSUPPORTED;
+    if (masks_t2 && (st2_m < HW || inter2 != area_t + (size_t)B * M || area_t2 != inter2 + (size_t)B * M * N))
+        return DMM_ERR_UNSUPPORTED;
 #define DMM_FRONT_CASE(T_)                                                                                              \
-    return M <= 8 ? launch_front_small<T_, 8>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t, B, N, M, HW, \
-                                              sp_b, sp_n, st_b, st_m, inter, area_p, area_t, tables_zero, stream)         \
-                  : launch_front_small<T_, 16>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t, B, N, M,  \
-                                               HW, sp_b, sp_n, st_b, st_m, inter, area_p, area_t, tables_zero, stream)
+    return rows <= 8 ? launch_front_small<T_, 8>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t,       \
+                                                 (const T_ *)masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, \
+                                                 inter, area_p, area_t, inter2, area_t2, tables_zero, stream)            \
+                     : launch_front_small<T_, 16>(feat_t, feat_p, cos_out, (const T_ *)masks_p, (const T_ *)masks_t,      \
+                                                  (const T_ *)masks_t2, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m, \
+                                                  inter, area_p, area_t, inter2, area_t2, tables_zero, stream)
     switch (dtype) {
         case DMM_F32: DMM_FRONT_CASE(float);
         case DMM_F16: DMM_FRONT_CASE(f16_t);
@@ -651,8 +662,9 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
                             int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
                             const int32_t *n_valid, const int32_t *m_valid, int32_t *inter, int32_t *area_p,
                             int32_t *area_t, int32_t *inter2, int32_t *area_t2, hipStream_t stream) {
-    if (g_tables_prezeroed && !masks_t2) {
-        // dmm_match_forward: the feature-similarity launch in front of this one already cleared the three tables
+    if (g_tables_prezeroed) {
+        // dmm_match_forward / dmm_match_train_forward: the feature-similarity launch in front of this one already cleared
+        // the tables (all five of them in the dual form)
     } else if (area_p == inter + (size_t)B * M * N && area_t == area_p + (size_t)B * N) {
         // the three tables are one contiguous block (dmm_match_forward's workspace): one memset node
         DMM_HIP_TRY(zero_async(inter, sizeof(int32_t) * ((size_t)B * M * N + (size_t)B * N + (size_t)B * M), stream));
@@ -661,7 +673,7 @@ static int iou_counts_typed(const T *masks_p, const T *masks_t, const T *masks_t
         DMM_HIP_TRY(zero_async(area_p, sizeof(int32_t) * (size_t)B * N, stream));
         DMM_HIP_TRY(zero_async(area_t, sizeof(int32_t) * (size_t)B * M, stream));
     }
-    if (masks_t2) {
+    if (masks_t2 && !g_tables_prezeroed) {
         DMM_HIP_TRY(zero_async(inter2, sizeof(int32_t) * (size_t)B * M * N, stream));
         DMM_HIP_TRY(zero_async(area_t2, sizeof(int32_t) * (size_t)B * M, stream));
     }
@@ -795,6 +807,18 @@ int iou_counts_prezeroed(const void *masks_p, const void *masks_t, int dtype, in
     g_tables_prezeroed = true;
     const int rc = dmm_iou_counts(masks_p, masks_t, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid, inter,
                                   area_p, area_t, stream);
+    g_tables_prezeroed = false;
+    return rc;
+}
+// the dual form (templates + targets) on tables the caller has already zeroed; sp_b may be kFrameTable (masks_p = the
+// device table of per-frame base pointers)
+int iou_counts_dual_prezeroed(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, int B, int N, int M,
+                              int HW, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t st2_b, int64_t st2_m,
+                              const int32_t *n_valid, const int32_t *m_valid, int32_t *inter, int32_t *area_p,
+                              int32_t *area_t, int32_t *inter2, int32_t *area_t2, dmm_stream_t stream) {
+    g_tables_prezeroed = true;
+    const int rc = iou_counts_dispatch(masks_p, masks_t, masks_t2, dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, st2_b, st2_m,
+                                       n_valid, m_valid, inter, area_p, area_t, inter2, area_t2, stream);
     g_tables_prezeroed = false;
     return rc;
 }

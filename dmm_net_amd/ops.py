@@ -554,6 +554,192 @@ def match_forward(masks_p, masks_t, feat_p, feat_t, score_p, *, score_weight, ma
     return full, ms, ds, iters
 
 
+def match_forward_frame(proposed_mask, mask_last, feat_p, feat_t, score_p, *, score_weight, max_iter, proj_iter, lr, is_test):
+    """ONE frame exactly as the reference's evaluator hands it over (``MatchModel.forward`` without targets,
+    dmm_model.py:75-77): proposed_mask [P,H,W], mask_last [O,H,W], feat_p [P,D], feat_t [O,D], score_p [P] ->
+    (full_outmask [O,H,W], match_score [O], det_score [O]).  ``match_forward`` with B = 1 minus everything a one-frame
+    call does not need on the HOST (the call is host bound otherwise): no unsqueeze / index views around the C call, no
+    iteration-count or table outputs, three allocations."""
+    _need_gpu(proposed_mask, mask_last, feat_p, feat_t, score_p)
+    pm, tm = proposed_mask, mask_last
+    assert pm.dtype == tm.dtype and pm.dtype in _DT and pm.dim() == 3 and tm.dim() == 3
+    N, H, W = pm.shape
+    M, D = tm.shape[0], feat_p.shape[-1]
+    if N * H * W and not (pm.stride(2) == 1 and pm.stride(1) == W and pm.stride(0) >= H * W):
+        pm = pm.contiguous()
+    if M * H * W and not (tm.stride(2) == 1 and tm.stride(1) == W and tm.stride(0) >= H * W):
+        tm = tm.contiguous()
+    feat_p, feat_t, score_p = feat_p.contiguous().float(), feat_t.contiguous().float(), score_p.contiguous().float()
+    dev = pm.device
+    L = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, stream)
+    ws = _WORKSPACES.get(key)
+    need = _WS_NEED.get((1, N, M, D))
+    if need is None:
+        need = _WS_NEED[(1, N, M, D)] = int(L.dmm_workspace_bytes(1, N, M, D))
+    if ws is None or ws.numel() < need:
+        ws = _WORKSPACES[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _WS_STATE.pop(key, None)
+    note = None
+    if torch.cuda.is_current_stream_capturing() or _WS_STATE.get(key) == "captured":
+        _WS_STATE[key] = "captured"
+    else:
+        shape, note = _WS_STATE.get(key, (None, None))
+        if shape != (1, N, M, D):
+            note = ctypes.c_int(0)
+            _WS_STATE[key] = ((1, N, M, D), note)
+    full = torch.empty((M, H, W), dtype=torch.float32, device=dev)
+    ms = torch.empty((M,), dtype=torch.float32, device=dev)
+    ds = torch.empty((M,), dtype=torch.float32, device=dev)
+    with _lib.device_guard(dev):
+        rc = L.dmm_match_forward_ws(pm.data_ptr(), tm.data_ptr(), _DT[pm.dtype], feat_p.data_ptr(), feat_t.data_ptr(),
+                                    score_p.data_ptr(), 1, N, M, H * W, D, N * pm.stride(0) if N else 0, pm.stride(0),
+                                    M * tm.stride(0) if M else 0, tm.stride(0), None, None, score_weight, max_iter,
+                                    proj_iter, lr, is_test, full.data_ptr(), ms.data_ptr(), ds.data_ptr(), None, None, None,
+                                    None, ws.data_ptr(), ws.numel(), None if note is None else ctypes.byref(note), stream)
+    if rc:
+        _lib.check(rc, "dmm_match_forward_ws")
+    return full, ms, ds
+
+
+_WS_NEED = {}                        # (B, N, M, D) [+ solver setting] -> workspace bytes (a C call saved per layer call)
+
+
+def _cached_ws(key, need, dev):
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WORKSPACES[key] = torch.empty((max(need, 256),), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _planes3(t: torch.Tensor):
+    """[K,H,W] with contiguous H*W planes -> (tensor, plane stride in elements)."""
+    K, H, W = t.shape
+    if K * H * W and not (t.stride(2) == 1 and t.stride(1) == W and t.stride(0) >= H * W):
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_valid, m_valid, *, score_weight, max_iter,
+                        proj_iter, lr, is_test, one_frame=False):
+    """The training call of B frames as ONE C-ABI call (``dmm_match_train_forward``, include/dmm_match.h (5d)): feature
+    similarity -> counts against templates AND targets -> solver -> mix -> matching loss.  masks_p: [B,N,H,W] tensor or
+    ``FramePlanes``; targets [B,M,H,W] of the masks' dtype or None.  ``one_frame``: the tensors are ONE frame without the
+    batch axis, as the reference's trainer hands them over (masks_p [N,H,W], masks_t / targets [M,H,W], feat_p [N,D],
+    feat_t [M,D], score_p [N]) and so are the results -- no unsqueeze / select views around the call.  Returns None when the
+    shape is outside the entry's envelope (the caller then runs the granular ops), else
+    (full [B,M,H,W], match_score [B,M], det_score [B,M], cost_loss [B] | None, iters [B], saved) with ``saved`` = the flat
+    fp32 block cos | sim | Rb | gt that ``match_train_backward`` reads."""
+    fp = masks_p if isinstance(masks_p, FramePlanes) else None
+    if one_frame:
+        masks_p, sp_n = _planes3(masks_p)
+        B, (N, H, W) = 1, masks_p.shape
+        sp_b = N * sp_n
+        dt, p_ptr, dev = masks_p.dtype, masks_p.data_ptr(), masks_p.device
+        masks_t, st_m = _planes3(masks_t)
+        M = masks_t.shape[0]
+        st_b = M * st_m
+    else:
+        if fp is not None:
+            B, N, H, W, dt = fp.B, fp.N, fp.H, fp.W, fp.dtype
+            sp_b, sp_n, p_ptr, dev = _lib.FRAME_TABLE, fp.plane_stride, fp.table.data_ptr(), fp.device
+        else:
+            masks_p, sp_b, sp_n = _planes(masks_p)
+            B, N, H, W = masks_p.shape
+            dt, p_ptr, dev = masks_p.dtype, masks_p.data_ptr(), masks_p.device
+        masks_t, st_b, st_m = _planes(masks_t)
+        M = masks_t.shape[1]
+    D = feat_p.shape[-1]
+    Pp = padded_width(N, M)
+    if M > _lib.MAX_TEMPLATES or Pp > _lib.MAX_PROPOSALS or B > 65535 or N == 0 or M == 0 or B == 0 or dt not in _DT \
+            or masks_t.dtype != dt:
+        return None
+    sg_b = sg_m = 0
+    g_ptr = None
+    if targets is not None:
+        if targets.dtype != dt:
+            targets = targets.to(dt)
+        if one_frame:
+            targets, sg_m = _planes3(targets)
+            sg_b = M * sg_m
+        else:
+            targets, sg_b, sg_m = _planes(targets)
+        g_ptr = targets.data_ptr()
+    L = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    need = _WS_NEED.get(("tf", B, N, M, D))
+    if need is None:
+        need = _WS_NEED[("tf", B, N, M, D)] = int(L.dmm_match_train_forward_workspace_bytes(B, N, M, D))
+    ws = _cached_ws((dev.index, stream, "train_fwd"), need, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    lead = () if one_frame else (B,)
+    full = torch.empty(lead + (M, H, W), **f32)
+    ms, ds = torch.empty(lead + (M,), **f32), torch.empty(lead + (M,), **f32)
+    loss = torch.empty(lead, **f32) if targets is not None else None
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_cs, n_rb = B * M * N, B * M * Pp
+    saved = torch.empty((3 * n_cs + n_rb,), **f32)
+    sp = saved.data_ptr()
+    with _lib.device_guard(dev):
+        rc = L.dmm_match_train_forward(p_ptr, masks_t.data_ptr(), g_ptr, _DT[dt], feat_p.data_ptr(), feat_t.data_ptr(),
+                                       score_p.data_ptr(), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, sg_b, sg_m,
+                                       _ptr(n_valid), _ptr(m_valid), score_weight, max_iter, proj_iter, lr, is_test,
+                                       full.data_ptr(), ms.data_ptr(), ds.data_ptr(), _ptr(loss), iters.data_ptr(), sp,
+                                       sp + 4 * n_cs, sp + 8 * n_cs, (sp + 8 * n_cs + 4 * n_rb) if targets is not None else None,
+                                       ws.data_ptr(), ws.numel(), stream)
+    if rc == 2:                                               # DMM_ERR_UNSUPPORTED: nothing was launched
+        return None
+    if rc:
+        _lib.check(rc, "dmm_match_train_forward")
+    return full, ms, ds, loss, iters, saved
+
+
+def match_train_backward(masks_p, feat_p, feat_t, score_p, saved, has_loss, d_full, d_ms, d_ds, d_loss, n_valid, m_valid,
+                         M, *, score_weight, max_iter, proj_iter, lr, is_test, one_frame=False):
+    """-> (g_feat_t [B,M,D], g_feat_p [B,N,D]): the whole backward of ``match_train_forward`` as ONE C-ABI call
+    (``dmm_match_train_backward``, (5e)): normalise both feature sets -> mix backward -> taped solver backward ->
+    feature-similarity backward.  ``saved`` is the forward's block; d_* may be None.  ``one_frame``: as in the forward."""
+    fp = masks_p if isinstance(masks_p, FramePlanes) else None
+    if one_frame:
+        masks_p, sp_n = _planes3(masks_p)
+        B, (N, H, W) = 1, masks_p.shape
+        sp_b = N * sp_n
+        dt, p_ptr, dev = masks_p.dtype, masks_p.data_ptr(), masks_p.device
+    elif fp is not None:
+        B, N, H, W, dt = fp.B, fp.N, fp.H, fp.W, fp.dtype
+        sp_b, sp_n, p_ptr, dev = _lib.FRAME_TABLE, fp.plane_stride, fp.table.data_ptr(), fp.device
+    else:
+        masks_p, sp_b, sp_n = _planes(masks_p)
+        B, N, H, W = masks_p.shape
+        dt, p_ptr, dev = masks_p.dtype, masks_p.data_ptr(), masks_p.device
+    D = feat_p.shape[-1]
+    Pp = padded_width(N, M)
+    n_cs, n_rb = B * M * N, B * M * Pp
+    L = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = ("tb", B, N, M, D, max_iter, proj_iter)
+    need = _WS_NEED.get(k)
+    if need is None:
+        need = _WS_NEED[k] = int(L.dmm_match_train_backward_workspace_bytes(B, N, M, D, max_iter, proj_iter))
+    ws = _cached_ws((dev.index, stream, "train_bwd"), need, dev)
+    cf = lambda t: None if t is None else t.contiguous().float()
+    d_full, d_ms, d_ds, d_loss = cf(d_full), cf(d_ms), cf(d_ds), cf(d_loss)
+    use_loss = has_loss and d_loss is not None
+    g_t, g_p = torch.empty_like(feat_t), torch.empty_like(feat_p)
+    sp = saved.data_ptr()
+    with _lib.device_guard(dev):
+        rc = L.dmm_match_train_backward(p_ptr, _DT[dt], feat_p.data_ptr(), feat_t.data_ptr(), score_p.data_ptr(),
+                                        sp if use_loss else None, sp + 4 * n_cs, sp + 8 * n_cs,
+                                        (sp + 8 * n_cs + 4 * n_rb) if use_loss else None, _ptr(d_full), _ptr(d_ms),
+                                        _ptr(d_ds), _ptr(d_loss) if use_loss else None, B, N, M, H * W, D, sp_b, sp_n,
+                                        _ptr(n_valid), _ptr(m_valid), score_weight, max_iter, proj_iter, lr, is_test,
+                                        g_t.data_ptr(), g_p.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+    if rc:
+        _lib.check(rc, "dmm_match_train_backward")
+    return g_t, g_p
+
+
 def match_forward_packed(masks_p, packed_p, masks_t, feat_p, feat_t, score_p, n_valid, m_valid, *, score_weight, max_iter,
                          proj_iter, lr, is_test, out=None, workspace=None):
     """``match_forward`` with the proposal side of the cost pass on the 1-bit planes ``packed_p`` [B,N,words] the caller

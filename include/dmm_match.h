@@ -66,6 +66,11 @@ typedef void *dmm_stream_t; /* hipStream_t */
 #define DMM_MAX_TEMPLATES 32  /* M  */
 #define DMM_MAX_PROPOSALS 256 /* Pp */
 
+/* Frame-stride sentinel of the entries that take (masks_p, sp_b): with sp_b == DMM_FRAME_TABLE, masks_p is a DEVICE array of
+ * B pointers to each frame's first proposal plane (what the *_frames entries of (1d) / (4c) pass on) instead of the base
+ * of B equally spaced frames. */
+#define DMM_FRAME_TABLE INT64_MIN
+
 /* ---------------------------------------------------------------------------------------------
  * (0) Dispatch options.  Where an entry point has two kernels (or a tuning value worth A/B-ing) the choice is a
  * process-wide integer set THROUGH THIS ABI.  The library never reads the environment: a stray variable cannot change what
@@ -114,6 +119,9 @@ DMM_API int dmm_abi_version(void);
 DMM_API const char *dmm_status_string(int status);
 DMM_API int dmm_last_hip_error(void);         /* hipError_t of the last DMM_ERR_LAUNCH on this thread */
 DMM_API const char *dmm_build_info(void);     /* "gfx950 ..." */
+/* Diagnostic: kernels this library has enqueued in this process so far (every launch, the table-clearing ones included;
+ * a replayed HIP graph is not counted again).  bench.py reports launches per call from differences of it. */
+DMM_API long long dmm_launch_count(void);
 
 /* ---------------------------------------------------------------------------------------------
  * (1) Pairwise binary-mask intersection / area tables.
@@ -394,6 +402,56 @@ DMM_API int dmm_match_solve_packed(const uint64_t *packed_p, const uint64_t *pac
                                    int proj_iter, float lr, int is_test, float *Rb_out, float *match_score,
                                    float *det_score, float *sim_out, float *R_out, int32_t *iters_out, void *workspace,
                                    size_t workspace_bytes, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (1e) The tail of compute_matching_loss (match_helper.py:43-48) on the device, after the counts of (1b):
+ *   gt_iou = inter2 / (area_p + area_t2 - inter2 + 1e-6)  (compute_iou_binary_mask_2D on proposals x targets, :9-28, :43)
+ *   gt     = relax_matching(-gt_iou, 0, 0, 0)[0]          (the greedy one-hot initialisation, relax_match.py:45-55; :44)
+ *   loss   = F.mse_loss(feature_sim, gt)                   (:48; feature_sim = cos, BEFORE the IoU mix)
+ * gt [B,M,N] (zeros outside a ragged frame's live [m_valid, n_valid] block), loss [B] (0 for a frame without live
+ * templates or proposals, dmm_model.py:118-122).  One launch; N <= 8192, M <= 4096.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_matching_loss_f32(const int32_t *inter2 /*[B,M,N]*/, const int32_t *area_p /*[B,N]*/,
+                                  const int32_t *area_t2 /*[B,M]*/, const float *cos /*[B,M,N]*/, int B, int N, int M,
+                                  const int32_t *n_valid, const int32_t *m_valid, float *gt /*[B,M,N]*/,
+                                  float *loss /*[B]*/, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5d) / (5e) The TRAINING call of the layer -- MatchModel.forward with targets as the trainer issues it once per (video,
+ * frame), dmm_model.py:130-132, and torch autograd back through it -- as ONE entry each way, so that a one-frame call
+ * costs the host two library calls instead of twelve (the drop-in was host bound there).
+ *
+ * dmm_match_train_forward: (2c) feature similarity -> (1b) counts against templates AND targets in one pass over the
+ *   proposal planes (targets == NULL: (1) and no loss) -> (3) -> (4d) [is_test: (4)] -> (1e).  Same kernels, same results
+ *   bit for bit as the granular entries.  sp_b may be DMM_FRAME_TABLE.  targets: M planes per frame of the masks' dtype,
+ *   strides sg_b / sg_m.  Outputs full_outmask [B,M,HW] fp32 contiguous, match_score / det_score [B,M], cost_loss [B]
+ *   (NULL without targets), iters [B] (may be NULL); and what (5e) needs: cos, sim [B,M,N], Rb [B,M,Pp], gt [B,M,N]
+ *   (NULL without targets).  Inside the fast kernels' envelope only (DMM_ERR_UNSUPPORTED otherwise: wider tables train
+ *   through the granular entries).  workspace >= dmm_match_train_forward_workspace_bytes(B, N, M, D).
+ * dmm_match_train_backward: d/d feat_t, d/d feat_p of
+ *     sum(d_full * full_outmask) + sum(d_match_score * match_score) + sum(d_det_score * det_score) + sum(d_loss * cost_loss)
+ *   = (2) on both feature sets (one launch; the forward keeps no normalised rows) -> (4b) -> (3b) -> (2d).  Any of d_full
+ *   [B,M,HW], d_match_score, d_det_score [B,M] may be NULL (no gradient from that output); gt / d_loss / cos NULL together
+ *   (no loss term).  Any N, M.  workspace >= dmm_match_train_backward_workspace_bytes(B, N, M, D, max_iter, proj_iter).
+ * ------------------------------------------------------------------------------------------- */
+DMM_API size_t dmm_match_train_forward_workspace_bytes(int B, int N, int M, int D);
+DMM_API int dmm_match_train_forward(const void *masks_p, const void *masks_t, const void *targets, int mask_dtype,
+                                    const float *feat_p, const float *feat_t, const float *score_p, int B, int N, int M,
+                                    int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b, int64_t st_m, int64_t sg_b,
+                                    int64_t sg_m, const int32_t *n_valid, const int32_t *m_valid, float score_weight,
+                                    int max_iter, int proj_iter, float lr, int is_test, float *full_outmask,
+                                    float *match_score, float *det_score, float *cost_loss, int32_t *iters_out,
+                                    float *cos_out, float *sim_out, float *Rb_out, float *gt_out, void *workspace,
+                                    size_t workspace_bytes, dmm_stream_t stream);
+DMM_API size_t dmm_match_train_backward_workspace_bytes(int B, int N, int M, int D, int max_iter, int proj_iter);
+DMM_API int dmm_match_train_backward(const void *masks_p, int mask_dtype, const float *feat_p, const float *feat_t,
+                                     const float *score_p, const float *cos, const float *sim, const float *Rb,
+                                     const float *gt, const float *d_full, const float *d_match_score,
+                                     const float *d_det_score, const float *d_loss, int B, int N, int M, int HW, int D,
+                                     int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
+                                     float score_weight, int max_iter, int proj_iter, float lr, int is_test,
+                                     float *g_feat_t /*[B,M,D]*/, float *g_feat_p /*[B,N,D]*/, void *workspace,
+                                     size_t workspace_bytes, dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) Fused 4-level ROIAlign + spatial mean: the reference's ROI feature extractor

@@ -1,0 +1,225 @@
+"""The training call as ONE library call each way (include/dmm_match.h (5d) / (5e) / (1e)).
+
+``dmm_match_train_forward`` / ``_backward`` chain the same kernels as the granular entries, so everything they return must
+equal the granular chain BIT FOR BIT (only the loss tail is new arithmetic: checked against the oracle, which is pinned on
+the reference by G2 / G3 / G17 / G20, and against the granular tensor-op form).  The reference's own autograd numbers for
+the same path are the goldens G6 / G10 / G17 / G20 in test_gpu_parity.py / test_gpu_features.py, which run THROUGH these
+entries since they are the default.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from dmm_net_amd import _lib, autograd, ops, synth
+from dmm_net_amd.match_model import MatchModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def cfg(max_iter, proj_iter, lr=0.1, w=0.3):
+    return {"matching": {"algo": "relax"}, "relax_max_iter": max_iter, "relax_proj_iter": proj_iter,
+            "relax_learning_rate": lr, "score_weight": w}
+
+
+class granular:
+    """Pin the pre-fusion chain (separate library calls + tensor ops for the loss tail)."""
+
+    def __enter__(self):
+        self.old = autograd._FUSED_TRAIN
+        autograd._FUSED_TRAIN = False
+
+    def __exit__(self, *exc):
+        autograd._FUSED_TRAIN = self.old
+        return False
+
+
+def batch(B, N, M, H, W, D, seed, dtype=torch.float32, kind="structured"):
+    frs = [synth.make_frame(N, M, H, W, D, seed=seed + 17 * b, kind=kind, with_targets=True) for b in range(B)]
+    st = lambda k, dt=None: dev(np.stack([getattr(f, k) for f in frs], 0), dt)
+    return dict(pf=st("proposed_feature"), tf=st("template_feature"), pm=st("proposed_mask", dtype),
+                tm=st("mask_last_occurence", dtype), sc=st("proposal_score"), tg=st("targets", dtype), frames=frs)
+
+
+def run_layer(d, *, n_valid=None, m_valid=None, with_targets=True, is_test=0, max_iter=10, proj_iter=5, pm=None, seed=0):
+    pf = d["pf"].clone().requires_grad_(True)
+    tf = d["tf"].clone().requires_grad_(True)
+    full, ms, ds, loss, iters = autograd.match_layer_batched(
+        pf, d["pm"] if pm is None else pm, tf, d["tm"], d["sc"], d["tg"] if with_targets else None, n_valid, m_valid,
+        score_weight=0.3, max_iter=max_iter, proj_iter=proj_iter, lr=0.1, is_test=is_test)
+    g = torch.Generator(device=DEV).manual_seed(1234 + seed)
+    w_full = torch.rand(full.shape, generator=g, device=DEV)
+    w_ms = torch.rand(ms.shape, generator=g, device=DEV)
+    w_ds = torch.rand(ds.shape, generator=g, device=DEV)
+    obj = (full * w_full).sum() + (ms * w_ms).sum() + (ds * w_ds).sum() + 2.0 * loss.sum()
+    obj.backward()
+    torch.cuda.synchronize()
+    return [t.detach().cpu().numpy() for t in (full, ms, ds, loss, iters, pf.grad, tf.grad)]
+
+
+NAMES = ("full_outmask", "match_score", "det_score", "cost_loss", "iters", "d proposed_feature", "d template_feature")
+
+
+def assert_same(a, b):
+    for name, x, y in zip(NAMES, a, b):
+        assert x.shape == y.shape, name
+        assert np.array_equal(x, y), (name, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+
+
+@pytest.mark.parametrize("B,N,M,H,W,D", [(1, 50, 5, 64, 72, 512),      # the trainer's call: front kernel with the targets
+                                         (4, 50, 5, 33, 47, 512),      # ... for a handful of frames
+                                         (1, 10, 8, 40, 40, 512),      # 2 x 8 rows: the front kernel's widest dual tile
+                                         (3, 50, 10, 40, 56, 512),     # 2 x 10 rows: lanes similarity + dual count pass
+                                         (16, 50, 10, 31, 29, 512),    # more frames than the front kernel takes
+                                         (2, 40, 20, 24, 40, 512),     # > 16 rows per set: the targets in a pass of their own
+                                         (2, 30, 4, 20, 20, 256),      # D the lanes kernel takes, the front kernel does not
+                                         (2, 30, 4, 20, 20, 96),       # D neither takes: normalise + cosine
+                                         (2, 3, 5, 16, 16, 512),       # P <= O: the padded solver width
+                                         (1, 1, 1, 9, 9, 64),          # one proposal, one template
+                                         (2, 130, 6, 20, 24, 512)])    # more than one wave of columns
+def test_fused_training_call_equals_the_granular_chain_bit_for_bit(B, N, M, H, W, D):
+    d = batch(B, N, M, H, W, D, seed=300 + N + M)
+    with granular():
+        ref = run_layer(d)
+    got = run_layer(d)
+    assert_same(got, ref)
+    assert float(np.abs(got[5]).sum()) > 0 and float(np.abs(got[6]).sum()) > 0
+
+
+@pytest.mark.parametrize("is_test,with_targets", [(1, True), (0, False), (1, False)])
+def test_fused_call_without_targets_and_in_test_mode(is_test, with_targets):
+    d = batch(3, 50, 5, 40, 40, 512, seed=77)
+    with granular():
+        ref = run_layer(d, is_test=is_test, with_targets=with_targets)
+    assert_same(run_layer(d, is_test=is_test, with_targets=with_targets), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_call_on_16_bit_planes(dtype):
+    d = batch(2, 50, 5, 40, 44, 512, seed=5, dtype=dtype)
+    with granular():
+        ref = run_layer(d)
+    assert_same(run_layer(d), ref)
+
+
+def test_fused_call_on_ragged_batches_and_per_frame_plane_tables():
+    B, N, M, H, W, D = 5, 40, 6, 32, 36, 512
+    d = batch(B, N, M, H, W, D, seed=11)
+    counts_n, counts_m = [40, 17, 1, 33, 40], [6, 3, 0, 1, 5]
+    nv = torch.tensor(counts_n, dtype=torch.int32, device=DEV)
+    mv = torch.tensor(counts_m, dtype=torch.int32, device=DEV)
+    with granular():
+        ref = run_layer(d, n_valid=nv, m_valid=mv)
+    got = run_layer(d, n_valid=nv, m_valid=mv)
+    assert_same(got, ref)
+    assert got[3][2] == 0.0                                           # a frame without live templates has no loss
+    # one tensor per frame (DMM_Model's per-video proposal planes): the pointer-table forms inside the same entries
+    planes = [d["pm"][b, :counts_n[b]].clone() for b in range(B)]
+    with granular():
+        ref2 = run_layer(d, m_valid=mv, pm=planes)
+    assert_same(run_layer(d, m_valid=mv, pm=planes), ref2)
+    assert_same(ref2[:5], ref[:5])
+
+
+def test_matching_loss_kernel_against_the_oracle():
+    """(1e) alone: gt IoU -> greedy one-hot -> mse, against oracle.matching_loss (pinned on the reference by G2 / G3)."""
+    L = _lib.load()
+    for (N, M, H, W, seed, kind) in [(8, 3, 64, 64, 1, "structured"), (50, 10, 40, 40, 2, "uniform"), (3, 5, 16, 16, 3, "uniform"),
+                                     (1, 1, 8, 8, 4, "uniform"), (200, 20, 24, 24, 5, "structured"), (300, 40, 12, 12, 6, "uniform")]:
+        fr = synth.make_frame(N, M, H, W, 16, seed=seed, kind=kind, with_targets=True)
+        rng = np.random.default_rng(seed)
+        cos = rng.standard_normal((M, N)).astype(np.float32)
+        (gi, ap, at), (gi2, at2) = ops.iou_counts_dual(dev(fr.proposed_mask)[None], dev(fr.mask_last_occurence)[None],
+                                                       dev(fr.targets)[None])
+        gt = torch.empty((1, M, N), dtype=torch.float32, device=DEV)
+        loss = torch.empty((1,), dtype=torch.float32, device=DEV)
+        cos_d = dev(cos)
+        rc = L.dmm_matching_loss_f32(gi2.data_ptr(), ap.data_ptr(), at2.data_ptr(), cos_d.data_ptr(), 1, N, M, None, None,
+                                     gt.data_ptr(), loss.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        o_loss, _, o_gt = oracle.matching_loss(fr.proposed_mask, fr.targets, cos)
+        assert np.array_equal(gt[0].cpu().numpy(), o_gt), (N, M)
+        assert abs(float(loss[0]) - o_loss) <= 1e-6 * max(1.0, abs(o_loss)), (float(loss[0]), o_loss)
+
+
+def test_matching_loss_kernel_ties_and_empty_masks():
+    """All-zero masks (every IoU 0: every argmin is a tie -> row i takes ... the reference's first-index rule) and duplicate
+    proposals (tied columns), against the oracle's greedy init."""
+    L = _lib.load()
+    N, M, HW = 6, 4, 64
+    rng = np.random.default_rng(0)
+    for case in ("zeros", "duplicates"):
+        P = np.zeros((N, 8, 8), np.float32)
+        T = np.zeros((M, 8, 8), np.float32)
+        if case == "duplicates":
+            base = (rng.random((8, 8)) > 0.5).astype(np.float32)
+            P[:] = base
+            T[:] = base
+            T[2] = 0
+        cos = rng.standard_normal((M, N)).astype(np.float32)
+        (gi, ap, at), (gi2, at2) = ops.iou_counts_dual(dev(P)[None], dev(T)[None], dev(T)[None])
+        gt = torch.empty((1, M, N), dtype=torch.float32, device=DEV)
+        loss = torch.empty((1,), dtype=torch.float32, device=DEV)
+        cos_d = dev(cos)
+        assert L.dmm_matching_loss_f32(gi2.data_ptr(), ap.data_ptr(), at2.data_ptr(), cos_d.data_ptr(), 1, N, M, None, None,
+                                       gt.data_ptr(), loss.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        o_loss, _, o_gt = oracle.matching_loss(P, T, cos)
+        assert np.array_equal(gt[0].cpu().numpy(), o_gt), case
+        assert abs(float(loss[0]) - o_loss) <= 1e-6
+
+
+def test_matchmodel_training_call_takes_the_one_frame_function():
+    """The drop-in's training call (dmm_model.py:130-132) goes through ``_MatchFrameFn`` (no batch axis around the fused
+    entries): outputs and gradients equal the batched granular chain bit for bit, and the forward the oracle's."""
+    fr = synth.make_config_frame(1, kind="structured", with_targets=True)
+    t = lambda a: dev(a)
+
+    def call(fused):
+        pf = t(fr.proposed_feature).requires_grad_(True)
+        tf = t(fr.template_feature).requires_grad_(True)
+        model = MatchModel(cfg(10, 5), is_test=0)
+        if fused:
+            fo, ms, ds, fo2, loss = model(pf, t(fr.proposed_mask), [tf], t(fr.mask_last_occurence), t(fr.proposal_score),
+                                          t(fr.targets))
+        else:
+            with granular():
+                fo, ms, ds, fo2, loss = model(pf, t(fr.proposed_mask), [tf], t(fr.mask_last_occurence),
+                                              t(fr.proposal_score), t(fr.targets))
+        assert fo2 is fo and set(loss) == {"cost_loss"}
+        (fo.sum() + 3.0 * loss["cost_loss"] + ms.sum()).backward()
+        return [x.detach().cpu().numpy() for x in (fo, ms, ds, loss["cost_loss"], pf.grad, tf.grad)]
+    a, b = call(True), call(False)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
+                             fr.proposal_score, max_iter=10, proj_iter=5, is_test=0)
+    assert np.array_equal(a[1], o["match_score"]) and np.array_equal(a[2], o["det_score"])
+    assert float(np.abs(a[0] - o["full_outmask"]).max()) <= 1e-5
+    o_loss = oracle.matching_loss(fr.proposed_mask, fr.targets, o["cos"])[0]
+    assert abs(float(a[3]) - o_loss) <= 1e-6
+
+
+def test_unused_outputs_send_no_gradient_tensors():
+    """Only full_outmask feeds the objective: the score / loss gradients arrive as None (no zero-filled stand-ins) and the
+    feature gradients equal the granular chain's."""
+    d = batch(1, 50, 5, 40, 40, 512, seed=3)
+
+    def grads():
+        pf = d["pf"].clone().requires_grad_(True)
+        tf = d["tf"].clone().requires_grad_(True)
+        full = autograd.match_layer_batched(pf, d["pm"], tf, d["tm"], d["sc"], d["tg"], score_weight=0.3, max_iter=10,
+                                            proj_iter=5, lr=0.1, is_test=0)[0]
+        full.square().sum().backward()
+        return pf.grad.cpu().numpy(), tf.grad.cpu().numpy()
+    with granular():
+        ref = grads()
+    got = grads()
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
