@@ -27,10 +27,6 @@
 #include "dmm_common.h"
 
 namespace dmm {
-int conv1x1_stream_launch(const void *x, const void *w, const float *bias, const void *residual, int64_t rows, int cin,
-                          int cout, int relu, void *y, hipStream_t stream);
-}
-namespace dmm {
 namespace {
 
 struct GemmPlan {
@@ -150,10 +146,6 @@ extern "C" int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias,
     if (rows < 0 || cin <= 0 || cout <= 0) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!x || !w || !bias || !y) return DMM_ERR_BAD_ARG;
-    {   // the HBM-bound shapes: weights in registers, activations streamed (dmm_conv1x1_stream.hip)
-        const int rc = dmm::conv1x1_stream_launch(x, w, bias, residual, rows, cin, cout, relu, y, (hipStream_t)stream);
-        if (rc != DMM_ERR_UNSUPPORTED) return rc;
-    }
     int dev = 0;
     DMM_HIP_TRY(hipGetDevice(&dev));
     dmm::GemmPlan *plan = nullptr;

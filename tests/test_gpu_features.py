@@ -498,46 +498,3 @@ def test_stem_tail_bias_relu_maxpool_is_bit_identical_to_the_two_passes():
         _lib.check(_lib.load().dmm_bias_relu_maxpool_bf16(x.data_ptr(), bias.data_ptr(), B, H, W, C, out.data_ptr(),
                                                           torch.cuda.current_stream().cuda_stream), "stem tail")
         assert out.shape == want.shape and torch.equal(out, want)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,rows", [(64, 64, 32768), (64, 64, 114688 + 13), (256, 64, 114688), (256, 64, 98304 + 31)])
-@pytest.mark.parametrize("res_on,relu", [(False, True), (True, True), (False, False), (True, False)])
-def test_streaming_conv1x1_kernel_against_fp32_and_the_library_gemm(cin, cout, rows, res_on, relu):
-    """dmm_conv1x1_bf16's streaming MFMA kernel (dmm_conv1x1_stream.hip: weights in registers, product transposed, outputs
-    stored from the accumulators) on the shapes it is dispatched for, incl. a ragged last tile: fp32 accumulation and ONE
-    rounding -- every output within half a bf16 ulp (+ fp32 summation noise) of the fp32 product of the same bf16
-    inputs, rows past the end untouched, and within one bf16 ulp of the library GEMM (option CONV1X1_STREAM = 0)."""
-    from conftest import record_achieved
-    from dmm_net_amd import _lib
-    L = _lib.load()
-    g = torch.Generator(device=DEV).manual_seed(cin * 7 + rows % 97)
-    x = torch.randn((rows, cin), generator=g, device=DEV).to(torch.bfloat16)
-    w = (torch.randn((cin, cout), generator=g, device=DEV) / cin ** 0.5).to(torch.bfloat16)
-    b = torch.randn((cout,), generator=g, device=DEV)
-    res = torch.randn((rows, cout), generator=g, device=DEV).to(torch.bfloat16) if res_on else None
-    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=DEV)
-    ref = x.double() @ w.double() + b.double()
-    if res is not None:
-        ref = ref + res.double()
-    if relu:
-        ref = ref.clamp_min(0)
-    out = {}
-    for v in (0, 1):
-        with _lib.options(CONV1X1_STREAM=v):
-            y = torch.full((rows + 64, cout), 7.0, dtype=torch.bfloat16, device=DEV)      # 64 guard rows behind the end
-            rc = L.dmm_conv1x1_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), rows,
-                                    cin, cout, int(relu), y.data_ptr(), ws.data_ptr(), ws.numel(),
-                                    torch.cuda.current_stream().cuda_stream)
-            assert rc == 0
-            torch.cuda.synchronize()
-            assert bool((y[rows:] == 7.0).all())
-            out[v] = y[:rows].double()
-    # allowed: half a bf16 ulp of the result + the fp32 summation noise of a cin-term sum of O(1) products (matters only
-    # where the result itself is tiny)
-    ulp = torch.maximum(ref.abs(), torch.tensor(1e-30, dtype=torch.float64, device=DEV)).log2().floor().exp2() * 2.0 ** -7
-    noise = 2e-5
-    err = (((out[1] - ref).abs() - noise).clamp_min(0) / ulp).max().item()
-    record_achieved(f"conv1x1_stream/{cin}to{cout}_rows{rows}_res{int(res_on)}_relu{int(relu)}/err_in_bf16_ulp", err)
-    assert err <= 0.5 + 0.02                                      # one rounding of an fp32 sum
-    assert (((out[1] - out[0]).abs() - 2 * noise).clamp_min(0) / ulp).max().item() <= 1.0 + 0.02
