@@ -688,7 +688,9 @@ def bench_config4(R):
                        "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
     params = list(enc.get_skip_params()) + list(enc.get_backbone_para())
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)          # one multi-tensor kernel (foreach form: 2.3 ms per step)
-    bucketer = GradBucketer(params, bucket_mb=64.0, overlap=True)
+    # (steady mode is opt-in: every synthetic step uses the same parameters -- a fixed graph -- so the used-mask exchange
+    # may run one step late; a trainer whose videos can be skipped keeps the default per-step exchange)
+    bucketer = GradBucketer(params, bucket_mb=64.0, overlap=True, steady_after=2)
     img = torch.randn(B, 3, H, W, device=dev)
 
     def boxes(n):

@@ -10,7 +10,7 @@
 
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
-                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words);
+                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words, const int32_t *n_valid);
 int front_small_launch(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, const float *feat_t,
                        const float *feat_p, int B, int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b,
                        int64_t st_m, int64_t st2_b, int64_t st2_m, float *cos_out, int32_t *inter, int32_t *area_p,
@@ -221,7 +221,7 @@ extern "C" int dmm_match_forward_ws(const void *masks_p, const void *masks_t, in
     }
     if (!n_valid && !m_valid && !force_tile)
         rc = dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
-                                      (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
+                                      (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M, nullptr);
     if (rc == DMM_OK) {
         rc = dmm::iou_counts_prezeroed(masks_p, masks_t, mask_dtype, B, N, M, HW, sp_b, sp_n, st_b, st_m, n_valid, m_valid,
                                        w.inter, w.area_p, w.area_t, stream);
@@ -299,13 +299,14 @@ extern "C" int dmm_match_forward_packed(const void *masks_p, const uint64_t *pac
     float *Rb = Rb_out ? Rb_out : w.Rb;
     int rc = dmm_pack_masks(masks_t, mask_dtype, (int64_t)B * M, HW, st_m, packed_t, wd, stream);
     if (rc != DMM_OK) return rc;
-    // Feature similarity of ALL slots as a dense batch (rows past a frame's n_valid / m_valid are computed and never
-    // read: the solver masks them) -- the one-launch kernel, which also clears the count tables; bit identical to the
-    // ragged three-launch form on every live entry.
+    // Feature similarity of all frames in the one-launch kernel, which also clears the count tables: every frame in the
+    // summation order of ITS live proposal count (n_valid), template rows past m_valid are computed and never read (the
+    // solver masks them; the order over D does not depend on the template count) -- bit identical to the ragged
+    // three-launch form on every live entry.
     const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     rc = force_tile ? DMM_ERR_UNSUPPORTED
                     : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
-                                               (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
+                                               (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M, n_valid);
     if (rc == DMM_OK) {
         rc = dmm::iou_counts_prezeroed(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, pk_b, pk_n, (int64_t)M * wd, wd,
                                        n_valid, m_valid, w.inter, w.area_p, w.area_t, stream);
@@ -358,7 +359,7 @@ extern "C" int dmm_match_solve_packed(const uint64_t *packed_p, const uint64_t *
     const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     int rc = force_tile ? DMM_ERR_UNSUPPORTED
                         : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, w.cosv, (hipStream_t)stream, w.inter,
-                                                   (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M);
+                                                   (int64_t)B * M * N + (int64_t)B * N + (int64_t)B * M, n_valid);
     if (rc == DMM_OK) {
         rc = dmm::iou_counts_prezeroed(packed_p, packed_t, DMM_PACKED1, B, N, M, HW, (int64_t)N * wd, wd, (int64_t)M * wd,
                                        wd, n_valid, m_valid, w.inter, w.area_p, w.area_t, stream);

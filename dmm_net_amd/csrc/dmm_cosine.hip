@@ -538,7 +538,8 @@ extern "C" int dmm_cosine_f32(const float *featn_t, const float *featn_p, int B,
 
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
-                        hipStream_t stream, int32_t *zero_ptr = nullptr, int64_t zero_words = 0);
+                        hipStream_t stream, int32_t *zero_ptr = nullptr, int64_t zero_words = 0,
+                        const int32_t *n_valid = nullptr);
 }
 
 extern "C" int dmm_cosine_features_f32(const float *feat_t, const float *feat_p, int B, int N, int M, int D,

@@ -200,16 +200,30 @@ __device__ __forceinline__ void cf_step(const float *__restrict__ pp, const floa
 // The whole similarity of frame b for the workgroup with index bx of gx along the steps axis: the first nw waves of the
 // block take the steps (wave (bx, wave): bx * nw + wave, + gx * nw, ...), all of its waves stage the templates.
 // lds: M * PITCH + 32 + nw * WAVE_FLOATS floats, see lanes_geom().
+// ``n_valid`` (may be NULL): live proposals per frame.  ATen's order over the [D, P] slab of products depends on P -- the
+// class bound of dmm_torch_order.h -- and the reference is called per frame with ITS proposals, so a ragged frame is
+// reduced in the order of its own count Nb (columns from Nb on are zero filled), and Nb == 1 takes torch's contiguous
+// inner reduction like cosine_kernel does.  (Round 5: the packed / fused entries used to run ragged batches through the
+// dense order of the slot count, which differs from the reference's in the last bit for columns whose class changes.)
 template <int LPC>
 __device__ __forceinline__ void cosine_lanes_body(const float *__restrict__ feat_t, const float *__restrict__ feat_p, int N,
                                                   int M, float *__restrict__ cos_out, float *lds, int bx, int gx, int b,
-                                                  int nw) {
+                                                  int nw, const int32_t *__restrict__ n_valid = nullptr) {
     typedef CfGeom<LPC> G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *Q = lds;                                          // [M][PITCH] normalised templates
     float *nq = Q + (size_t)M * G::PITCH;                    // [32] their clamped norms
     float *wb = nq + 32 + (size_t)(wave < nw ? wave : 0) * G::WAVE_FLOATS;   // this wave's buffer
     float *np = wb + G::ROWBUF;                              // 8 floats: the norms of the staged rows
+    int Nb = N;
+    if (n_valid) Nb = min(max(n_valid[b], 0), N);
+    float *cos_bm = cos_out + (int64_t)b * M * N;
+    if (Nb < N && bx == 0)                                   // the dead columns of a ragged frame
+        for (int i = threadIdx.x; i < M * (N - Nb); i += blockDim.x) {
+            const int m = i / (N - Nb), j = Nb + (i - m * (N - Nb));
+            cos_bm[(int64_t)m * N + j] = 0.0f;
+        }
+    if (Nb == 0) return;                                     // (uniform per block)
     // ---- templates: stage, norm, divide (whole block) ----
     const float *tq = feat_t + (int64_t)b * M * G::D;
     for (int i = threadIdx.x; i < M * G::D4; i += blockDim.x) {
@@ -236,18 +250,39 @@ __device__ __forceinline__ void cosine_lanes_body(const float *__restrict__ feat
         *p = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-    // ---- columns: autonomous waves ----
-    const int A = torder::outer_class_bound(N);
-    const int sa = (A + 7) >> 3, sb = (N - A + 7) >> 3;
     const float *pp = feat_p + (int64_t)b * N * G::D;
-    float *cos_bm = cos_out + (int64_t)b * M * N;
     if (wave >= nw) return;
+    if (Nb == 1) {
+        // ONE live proposal: torch reduces the [D, 1] slab as a contiguous inner sum (cosine_kernel's Nb == 1 path): the
+        // normalised row, the D products of a template and inner_sum_group8 over them -- wave 0 of the frame's first block
+        if (bx != 0 || wave != 0) return;
+        for (int d = lane; d < G::D; d += 64) wb[cf_pos(d)] = pp[d];
+        wave_lds_fence();
+        float nr = torder::norm2_group8(G::D, lane & 7, [&](long i) { return wb[cf_pos((int)i)]; });
+        nr = nr > 1e-8f ? nr : 1e-8f;
+        nr = __shfl(nr, 0);
+        wave_lds_fence();
+        for (int d = lane; d < G::D; d += 64) wb[cf_pos(d)] = wb[cf_pos(d)] / nr;
+        wave_lds_fence();
+        float *prod = wb + 2 * G::PITCH;                     // rows 2, 3 of the wave's buffer: D contiguous floats
+        for (int m = 0; m < M; ++m) {
+            for (int d = lane; d < G::D; d += 64) prod[d] = Q[(size_t)m * G::PITCH + cf_pos(d)] * wb[cf_pos(d)];
+            wave_lds_fence();
+            const float s = torder::inner_sum_group8(G::D, lane & 7, [&](long i) { return prod[i]; });
+            if (lane == 0) cos_bm[(int64_t)m * N] = s;
+            wave_lds_fence();
+        }
+        return;
+    }
+    // ---- columns: autonomous waves ----
+    const int A = torder::outer_class_bound(Nb);
+    const int sa = (A + 7) >> 3, sb = (Nb - A + 7) >> 3;
     for (int s = bx * nw + wave; s < sa + sb; s += gx * nw) {
         if (s < sa) {
             const int c_lo = 8 * s, w = (A - c_lo) < 8 ? (A - c_lo) : 8;
             cf_step<LPC, true>(pp, Q, wb, np, lane, N, M, c_lo, w, cos_bm);
         } else {
-            const int c_lo = A + 8 * (s - sa), w = (N - c_lo) < 8 ? (N - c_lo) : 8;
+            const int c_lo = A + 8 * (s - sa), w = (Nb - c_lo) < 8 ? (Nb - c_lo) : 8;
             cf_step<LPC, false>(pp, Q, wb, np, lane, N, M, c_lo, w, cos_bm);
         }
     }

@@ -33,7 +33,7 @@ template <int LPC>
 __global__ __launch_bounds__(512) void cosine_lanes_kernel(const float *__restrict__ feat_t,
                                                            const float *__restrict__ feat_p, int N, int M,
                                                            float *__restrict__ cos_out, int32_t *__restrict__ zero_ptr,
-                                                           int64_t zero_words) {
+                                                           int64_t zero_words, const int32_t *__restrict__ n_valid) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (zero_ptr) {
         const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = blockIdx.x + (int64_t)gridDim.x * blockIdx.y;
@@ -41,12 +41,12 @@ __global__ __launch_bounds__(512) void cosine_lanes_kernel(const float *__restri
         const int64_t hi = lo + per < zero_words ? lo + per : zero_words;
         for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) zero_ptr[i] = 0;
     }
-    cosine_lanes_body<LPC>(feat_t, feat_p, N, M, cos_out, lds, blockIdx.x, gridDim.x, blockIdx.y, blockDim.x >> 6);
+    cosine_lanes_body<LPC>(feat_t, feat_p, N, M, cos_out, lds, blockIdx.x, gridDim.x, blockIdx.y, blockDim.x >> 6, n_valid);
 }
 
 template <int LPC>
 static int launch_lanes(const float *feat_t, const float *feat_p, int B, int N, int M, float *cos_out, int32_t *zero_ptr,
-                        int64_t zero_words, hipStream_t stream) {
+                        int64_t zero_words, const int32_t *n_valid, hipStream_t stream) {
     const LanesGeom g = lanes_geom<LPC>(B, N, M);
     if (!g.ok) return DMM_ERR_UNSUPPORTED;
     if (g.lds > 64 * 1024) {
@@ -55,18 +55,19 @@ static int launch_lanes(const float *feat_t, const float *feat_p, int B, int N, 
         if (e != hipSuccess) { set_last_hip_error((int)e); return DMM_ERR_LAUNCH; }
     }
     hipLaunchKernelGGL((cosine_lanes_kernel<LPC>), dim3(g.parts, B), dim3(64 * g.nw), g.lds, stream, feat_t, feat_p, N, M,
-                       cos_out, zero_ptr, zero_words);
+                       cos_out, zero_ptr, zero_words, n_valid);
     return check_launch();
 }
 
 // DMM_ERR_UNSUPPORTED outside the envelope (D in {256, 512, 1024}); the caller then takes the tile kernel.
+// n_valid (may be NULL): live proposals per frame -- every frame is reduced in the order of ITS count (see the body).
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
-                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words) {
+                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words, const int32_t *n_valid) {
     if (N < 2 || M < 1 || M > 32 || B > 65535) return DMM_ERR_UNSUPPORTED;
     switch (D) {
-        case 256: return launch_lanes<16>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
-        case 512: return launch_lanes<32>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
-        case 1024: return launch_lanes<64>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, stream);
+        case 256: return launch_lanes<16>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, n_valid, stream);
+        case 512: return launch_lanes<32>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, n_valid, stream);
+        case 1024: return launch_lanes<64>(feat_t, feat_p, B, N, M, cos_out, zero_ptr, zero_words, n_valid, stream);
         default: return DMM_ERR_UNSUPPORTED;
     }
 }

@@ -16,7 +16,7 @@
 
 namespace dmm {
 int cosine_lanes_launch(const float *feat_t, const float *feat_p, int B, int N, int M, int D, float *cos_out,
-                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words);
+                        hipStream_t stream, int32_t *zero_ptr, int64_t zero_words, const int32_t *n_valid);
 int front_small_launch(const void *masks_p, const void *masks_t, const void *masks_t2, int dtype, const float *feat_t,
                        const float *feat_p, int B, int N, int M, int HW, int D, int64_t sp_b, int64_t sp_n, int64_t st_b,
                        int64_t st_m, int64_t st2_b, int64_t st2_m, float *cos_out, int32_t *inter, int32_t *area_p,
@@ -239,10 +239,11 @@ extern "C" int dmm_match_train_forward(const void *masks_p, const void *masks_t,
         else if (rc != DMM_ERR_UNSUPPORTED) return rc;
     }
     if (!counted) {
-        // the similarity of ALL slots as a dense batch (rows past a frame's n_valid / m_valid are computed and never read:
-        // every consumer masks them) -- the one-launch kernel, which also clears the five count tables
+        // the one-launch similarity kernel, which also clears the five count tables: every frame in the summation order of
+        // ITS live proposal count; template rows past m_valid are computed and never read (every consumer masks them)
         rc = force_tile ? DMM_ERR_UNSUPPORTED
-                        : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, cos_out, s, w.inter, (int64_t)w.table_words);
+                        : dmm::cosine_lanes_launch(feat_t, feat_p, B, N, M, D, cos_out, s, w.inter, (int64_t)w.table_words,
+                                                   n_valid);
         if (rc != DMM_OK && rc != DMM_ERR_UNSUPPORTED) return rc;
         const bool zeroed = rc == DMM_OK;
         if (!zeroed) {

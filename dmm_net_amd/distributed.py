@@ -72,16 +72,21 @@ class GradBucketer:
         on the host -- exact in the same step, but the read drains the stream (what DDP pays every step with
         ``find_unused_parameters``).  A parameter that was idle everywhere and produces a gradient after its bucket
         went out is reduced in one extra collective every rank derives from the mask alike.
-      * STEADY mode (after ``steady_after`` consecutive identical masks): the same reduction is issued asynchronously
+      * STEADY mode (OPT-IN: ``steady_after=k``, after k consecutive identical masks; the default ``None`` stays in VERIFY
+        mode like the reference's DDP with ``find_unused_parameters=True``, train.py:178-184 -- DMM's autograd graphs are data
+        dependent: skipped videos, frames without live templates): the same reduction is issued asynchronously
         into pinned memory and looked at ONE STEP LATER, so nothing on the step waits for the host.  The used set is
         assumed unchanged (DDP's ``static_graph``); if the delayed mask disagrees, every rank falls back to VERIFY
         mode at the same step.  In the one step in between a parameter that was idle everywhere keeps ``grad = None``
         on every rank even if a rank produced a gradient for it (dropped consistently, never applied on one rank
-        only), and a parameter that went idle everywhere receives a zero gradient instead of ``None``.
+        only), and a parameter that went idle everywhere receives a zero gradient instead of ``None``.  Every such
+        fall-back is counted in ``steady_fallbacks`` and logged (``logging.getLogger("dmm_net_amd.distributed")``) --
+        each time, not once per process.  Callers whose used set is fixed (bench.py's synthetic clips, a trainer that
+        never skips a video) switch it on explicitly.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, overlap: bool = False,
-                 track_unused: bool = True, steady_after: Optional[int] = 2):
+                 track_unused: bool = True, steady_after: Optional[int] = None):
         self.track_unused = bool(track_unused)
         self.steady_after = steady_after if (steady_after and track_unused) else None
         self.launch_log: List[int] = []           # bucket indices in the order their collectives were issued
@@ -130,6 +135,7 @@ class GradBucketer:
         # used-mask protocol state
         self.mode = "verify"
         self.host_syncs = 0                       # blocking mask read-backs so far (tests / bench look at it)
+        self.steady_fallbacks = 0                 # times a delayed mask disagreed and sent every rank back to VERIFY mode
         self._stable = 0
         self._last_mask: Optional[torch.Tensor] = None
         self._pending = None                      # steady mode: (pinned host mask, event) of the previous step
@@ -306,9 +312,12 @@ class GradBucketer:
             ev.synchronize()
         used = [bool(x) for x in m.tolist()]
         if used != self._last_mask:
-            import warnings
-            warnings.warn("GradBucketer: the set of parameters that receive gradients changed; back to the per-step "
-                          "used-mask exchange (one host read per step) until it is stable again")
+            import logging
+            self.steady_fallbacks += 1
+            logging.getLogger("dmm_net_amd.distributed").warning(
+                "GradBucketer: the set of parameters that receive gradients changed (fall-back #%d); the step in between "
+                "dropped / zero-filled the gradients of the parameters that changed sides; back to the per-step used-mask "
+                "exchange (one host read per step) until it is stable again", self.steady_fallbacks)
             self.mode, self._stable, self._last_mask = "verify", 0, None
 
     # ------------------------------------------------------------------------------------------------ entry points

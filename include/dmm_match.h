@@ -379,7 +379,9 @@ DMM_API int dmm_match_forward_ws(const void *masks_p, const void *masks_t, int m
  * (dmm_paste_masks_f32 / dmm_paste_kept_f32 emit them next to the soft planes): packed_p [B,N,words] uint64, strides
  * pk_b / pk_n in WORDS.  The M template planes of every frame are packed inside (st_b == M * st_m required), the counts
  * run on the words -- identical integer tables from 1/32 of the proposal bytes -- and the mix reads the soft planes.
- * The feature similarity is computed for every slot as a dense batch (rows past n_valid / m_valid are never read).
+ * The feature similarity runs in the one-launch kernel for all frames, each in the summation order of ITS live proposal
+ * count (the reference is called per frame; ATen's order over the [D, P] products depends on P), template rows past m_valid
+ * are computed and never read.
  * This is the per-frame call of the evaluator's loop (dmm_model.py:75-77 for all videos of the step at once).
  * workspace >= dmm_workspace_bytes_packed(B, N, M, D, HW). */
 DMM_API size_t dmm_workspace_bytes_packed(int B, int N, int M, int D, int HW);

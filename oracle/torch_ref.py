@@ -34,42 +34,43 @@ def iou_binary_2d(x, y):
 
 
 def _project_row(X):
-    n, m = X.shape
-    ones = X.new_ones(m, 1)
-    s = torch.mm(X, ones) - 1.0
-    return X - torch.mm(s, ones.t()) / m
+    """relax_match.py:9-19: the row sums by ``sum(dim=1, keepdim=True)``, broadcast back as a rank-1 ``mm`` with a ones row."""
+    m = X.shape[1]
+    row_sum = X.sum(dim=1, keepdim=True)                 # [n, 1]
+    ones_row = torch.ones(1, m).to(X.device)             # [1, m]
+    return X - (row_sum - 1).mm(ones_row) / m
 
 
 def _project_col(X):
-    n, m = X.shape
-    ones = X.new_ones(n, 1)
-    s = torch.mm(ones.t(), X)
-    mask = (s <= 1).float()
-    Y = X - torch.mm(ones, s - 1.0) / n
-    return mask * X + (1 - mask) * Y
+    """relax_match.py:21-34: column sums by ``sum(dim=0, keepdim=True)``, the correction as ``ones[n,1].mm(.)``, applied only
+    to the columns whose sum exceeds 1 (a 0/1 float mask)."""
+    n = X.shape[0]
+    col_sum = X.sum(dim=0, keepdim=True)                 # [1, m]
+    ones_col = torch.ones(n, 1).to(X.device)             # [n, 1]
+    mask = (col_sum <= 1).float()
+    Y = X - ones_col.mm(col_sum - 1) / n
+    return X * mask + (1 - mask) * Y
 
 
 def relax_matching(C, max_iter, proj_iter, lr):
     n, m = C.shape
     X = torch.zeros_like(C)
     Crm = C.clone()
-    cmax = C.max()
     for j in range(m):                                   # column minima keep their value, everything else the maximum
-        i_star = int(torch.argmin(C[:, j]))
+        i_star = torch.argmin(Crm[:, j])
         for i in range(n):
             if i != i_star:
-                Crm[i, j] = cmax
-    idx = torch.argmin(Crm, dim=1)
-    for i in range(n):
-        X[i, idx[i]] = 1
+                Crm[i, j] = C.max()                      # (a full reduction per element, as the reference issues it: :46-51)
+    _, idx = torch.min(Crm, dim=1)
+    X[torch.arange(n).long(), idx.long()] = 1.0
     X_list, cost = [X], [0.0]
-    P0, P1, P2 = torch.zeros_like(X), torch.zeros_like(X), torch.zeros_like(X)
+    P0, P1, P2 = torch.zeros_like(C), torch.zeros_like(C), torch.zeros_like(C)
     for _ in range(max_iter):
         X = X - lr * C
-        cost.append(float(torch.norm(X * C).item()))
+        cost.append((X * C).norm().item())
         X_list.append(X)
         for _ in range(proj_iter):
-            Xs = X
+            Xs = X.clone()                               # (:74)
             X = X + P0
             Y = F.relu(X)
             P0 = X - Y
@@ -80,8 +81,9 @@ def relax_matching(C, max_iter, proj_iter, lr):
             Y = _project_row(X)
             P2 = X - Y
             X = Y
-            if float(torch.norm(X - Xs).item()) == 0:
+            if (X - Xs).norm().item() == 0:
                 break
+            _ = (X - Xs).norm().item()                   # the reference reads the norm a second time for its log (:91)
         if cost[-2] == cost[-1]:
             break
     return X, cost, X_list

@@ -297,3 +297,25 @@ def test_mix_backward_mfma_fallbacks_keep_their_kernels():
         pm, dout, Rb, nv, mv, want = _mix_bwd_case(2, N, M, 24, 24, seed=N + M)
         got = ops.mask_mix_bwd(Rb, pm, dout).double()
         assert float((got - want).abs().max()) / (float(want.abs().max()) or 1.0) <= 2e-5
+
+
+def test_ragged_frames_get_the_similarity_in_the_order_of_their_own_proposal_count():
+    """The one-launch similarity kernel on a RAGGED batch: ATen reduces the [D, P] slab of products in an order that
+    depends on P (dmm_torch_order.h: columns below 32 * (P / 32) -- 4 * (P / 4) for P < 8 -- by one cascade chain, the rest by
+    the ILP-4 row sum; P = 1 as a contiguous inner sum), and the reference is called per frame with ITS proposals.  Every
+    frame's table must equal the oracle's for that frame's own count, bit for bit -- counts chosen so that the class of
+    many columns differs from the slot count's (50 slots: columns 0-31 class A; 20 live: none; 9 live: 0-7; 5 live: 0-3)."""
+    B, N, M, H, W, D = 6, 50, 5, 12, 12, 512
+    d = batch(B, N, M, H, W, D, seed=91)
+    counts_n, counts_m = [50, 20, 9, 1, 5, 33], [5, 3, 5, 2, 1, 4]
+    nv = torch.tensor(counts_n, dtype=torch.int32, device=DEV)
+    mv = torch.tensor(counts_m, dtype=torch.int32, device=DEV)
+    got = ops.match_train_forward(d["pm"], d["tm"], None, d["pf"], d["tf"], d["sc"], nv, mv, score_weight=0.3, max_iter=5,
+                                  proj_iter=5, lr=0.1, is_test=1)
+    assert got is not None
+    cos = got[5][:B * M * N].view(B, M, N).cpu().numpy()
+    for b in range(B):
+        fr = d["frames"][b]
+        want = oracle.cosine(fr.template_feature[:counts_m[b]], fr.proposed_feature[:counts_n[b]])
+        assert np.array_equal(cos[b, :counts_m[b], :counts_n[b]], want), (b, counts_n[b])
+        assert not cos[b, :, counts_n[b]:].any()

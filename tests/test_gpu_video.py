@@ -521,6 +521,89 @@ def test_frame_loop_equals_an_oracle_computed_clip():
     record_achieved("frame_loop_vs_oracle_clip/independent_roi_frames_covered", covered / max(live_total, 1))
 
 
+class _RecordingEncoder:
+    """Wraps an encoder and keeps a copy of the backbone features of every call (time-major batches of g x B images, in the
+    order the loop issues its chunks) -- the clip chained on the CPU is handed EXACTLY the feature maps the loop matched on
+    (a bf16 convolution stack is not batch invariant: the same frame encoded in another batch differs in the last bits)."""
+
+    def __init__(self, inner):
+        self.inner, self.calls = inner, []
+        self.static_outputs = getattr(inner, "static_outputs", False)
+
+    def __call__(self, xs):
+        out = self.inner(xs)
+        self.calls.append([f.clone() for f in out["backbone_feature"]])
+        return out
+
+    def per_frame(self, B):
+        """-> feats[t] = the 4 levels of frame t for all B videos (chunks are issued in clip order)."""
+        frames = []
+        for lv in self.calls:
+            g = lv[0].shape[0] // B
+            frames += [[f[j * B:(j + 1) * B] for f in lv] for j in range(g)]   # (a batch slice keeps the memory format)
+        return frames
+
+
+def test_frame_loop_equals_an_oracle_computed_clip_at_product_size():
+    """the oracle-computed clip at the sizes the product (and bench.py --config loop) runs -- 4 videos
+    of 255 x 448, ``FastEncoder``(ResNet-50, bf16 NHWC, fixed seed) features, 50 raw 28 x 28 proposals per frame, top-50,
+    F = 5 template slots, eval solver setting 40 x 5 -- against tests/clip_oracle.py (paste -> NMS -> ROI features ->
+    match_forward -> label merge with the evaluator's carry-over, evaluator.py:83-149,151-213).  STRICT mode: the chain
+    gets the feature maps the loop's encoder produced and the device's ROI rows on them (the exits of relax_matching fire on
+    exact fp32 equalities); then labels must agree bit for bit, masks <= 1e-5, iteration counts exactly -- for the captured
+    graph path on its first run AND on a replay."""
+    import clip_oracle
+    from dmm_net_amd.encoder import FastEncoder, FeatureEncoder, GraphedEncoder, fold_batchnorm
+    from dmm_net_amd.roi_features import roialign4_mean_into
+    B, T, O, H, W, R = 4, 4, 5, 255, 448, 50
+    objs = [(0, 1, 2), (0,), (0, 1, 2, 3, 4), (0, 2)]                    # video 3: slot 1 empty in frame 0 (non-prefix)
+    n_frames = [4, 4, 4, 3]                                              # video 3: frame 3 is 'extra'
+    torch.manual_seed(0)
+    enc = _RecordingEncoder(GraphedEncoder(FastEncoder(fold_batchnorm(FeatureEncoder("resnet50").to(DEV).eval())),
+                                           miopen_find=True))
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 40, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    frames, first, props = _clip_case(51, B, T, O, H, W, objs, n_frames, lambda b, t: R)
+    raw = [[(p.get_field("mask").numpy()[:, 0], p.bbox.numpy(), p.get_field("scores").numpy()) for p in row] for row in props]
+    lp = video.FrameLoop(enc, DMM_Model(cfgs, is_test=1, feature_extractor=FeatureExtractor()), nms_thresh=0.4,
+                         max_proposals=50)
+    lp.slots, lp.graph, lp.record_iters = True, True, True
+    worst = 0.0
+    for rep in range(2):                                                 # second run = replay of the captured step
+        enc.calls.clear()
+        labs = {}
+        h = lp.run(frames, torch.from_numpy(first).to(DEV).view(B, O, H * W), props, n_frames,
+                   on_labels=lambda b, t, lab: labs.__setitem__((b, t), lab.clone()))
+        torch.cuda.synchronize()
+        got = torch.stack([x.view(B, O, H, W) for x in h], 0).cpu().numpy()
+        it = lp.last_iters.cpu().numpy()
+        dfeat = enc.per_frame(B)
+        assert len(dfeat) == T
+
+        def device_roi(t, rois):
+            rr = torch.from_numpy(np.ascontiguousarray(rois, np.float32)).to(DEV)
+            out = torch.empty((rr.shape[0], 4 * 128), dtype=torch.float32, device=DEV)
+            return roialign4_mean_into(rr, dfeat[t], out).cpu().numpy()
+        feats = [[None] * 4 for _ in range(T)]                           # the chain only reaches the maps through roi_fn
+        exp_h, exp_l, exp_it, kept = clip_oracle.run_clip(feats, first, raw, n_frames, roi_fn=device_roi, max_iter=40,
+                                                          proj_iter=5, max_proposals=50)
+        live = exp_it >= 0
+        assert live[1:, :3].all() and live[1:3, 3].all() and not live[3, 3] and not live[0].any()
+        assert kept[1:, :3].min() >= 10                                  # NMS leaves a real table to match
+        assert np.array_equal(it[live], exp_it[live]), (rep, it, exp_it)
+        err = float(np.abs(got - exp_h).max())
+        worst = max(worst, err)
+        assert err <= 1e-5, (rep, err)
+        assert sorted(labs) == sorted((b, t) for b in range(B) for t in range(n_frames[b]))
+        for (b, t), lab in labs.items():
+            assert np.array_equal(lab.cpu().numpy(), exp_l[t, b]), (rep, b, t)
+        assert exp_l[1:, 2].max() >= 2                                   # several objects really show up in the label maps
+    from conftest import record_achieved
+    record_achieved("frame_loop_vs_oracle_clip_255x448/max_abs_mask_err", worst)
+    record_achieved("frame_loop_vs_oracle_clip_255x448/iters_min", float(exp_it[live].min()))
+    record_achieved("frame_loop_vs_oracle_clip_255x448/iters_max", float(exp_it[live].max()))
+
+
 def test_frame_loop_plan_follows_thresholds_and_solver_settings():
     """nms_thresh / mask_thresh / padding and the match layer's solver settings are immediates of the captured
     frame step.  Changing them between two runs must rebuild the plan (the BoxList path reads them live); a prefetch is

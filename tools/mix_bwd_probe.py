@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""dmm_mask_mix_bwd at the training bench's shape (50 proposals x 10 rows, 255 x 255, train-mode supports): the fp32 MFMA
+form against the per-pair wave-reduction kernel, HIP-event time per launch and -- with --pmc -- SQ counters of both kernels
+from separate rocprofv3 passes of this script (--kernel-trace --pmc only).
+
+    python tools/mix_bwd_probe.py [--frames 512] [--pmc] [--steps 1,2]"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=512)
+ap.add_argument("--pmc", action="store_true")
+ap.add_argument("--child", action="store_true")
+ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (x16 sub-steps per wave in the MFMA form)")
+ap.add_argument("--reps", type=int, default=8)
+args = ap.parse_args()
+
+PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES"],
+          ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+           "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+          ["FETCH_SIZE"], ["WRITE_SIZE"]]
+
+
+def run():
+    import torch
+    from dmm_net_amd import _lib, ops
+    dev = torch.device("cuda", 0)
+    B, N, M, H, W = args.frames, 50, 10, 255, 255
+    g = torch.Generator(device=dev).manual_seed(7)
+    pm = torch.rand((B, N, H, W), generator=g, device=dev)
+    dout = torch.rand((B, M, H, W), generator=g, device=dev)
+    # train-mode support: ~13 of 50 proposals per row, 48 distinct planes per frame (bench_train's statistics)
+    Rb = torch.rand((B, M, N), generator=g, device=dev)
+    Rb = torch.where(torch.rand((B, M, N), generator=g, device=dev) < 0.27, Rb, torch.zeros_like(Rb))
+    union = int((Rb != 0).any(1).sum())
+    alg = (union + B * M) * H * W * 4
+    out = {"frames": B, "union_planes_per_frame": round(union / B, 2), "algorithmic_bytes": alg, "runs": {}}
+
+    def ms(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+    for steps in [int(v) for v in args.steps.split(",")]:
+        for mode in (1, 0):
+            with _lib.options(MIX_BWD_MFMA=mode, MIX_SHARED_STEPS=steps):
+                t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
+            out["runs"][f"{'mfma' if mode else 'pairs'}_steps{steps}"] = {
+                "ms": round(t, 4), "GBps": round(alg / t / 1e6, 1), "frac_of_8TBps": round(alg / t / 1e6 / 8000, 4)}
+    print(json.dumps(out))
+
+
+if args.child or not args.pmc:
+    run()
+    if not args.pmc:
+        sys.exit(0)
+if args.pmc and not args.child:
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    for i, ctrs in enumerate(PASSES):
+        d = f"/tmp/mixbwd_pmc{i}"
+        shutil.rmtree(d, ignore_errors=True)
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--",
+                            sys.executable, os.path.abspath(__file__), "--child", "--frames", str(args.frames), "--reps", "3",
+                            "--steps", args.steps.split(",")[0]], cwd="/tmp", env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            print("pass failed:", ctrs, r.stderr[-400:])
+            continue
+        for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                name = row["Kernel_Name"].split("(")[0]
+                if "mask_mix_bwd" not in name:
+                    continue
+                name = name.replace("void ", "")
+                res.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if "mask_mix_bwd" in name:
+                    res.setdefault(name, {}).setdefault("duration_us_profiled", []).append(
+                        (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
+    for name, cs in res.items():
+        print(name)
+        print("   ", {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())})
