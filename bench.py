@@ -239,6 +239,28 @@ def self_launch(args):
     os.execve(sys.executable, cmd, env)                        # does not return
 
 
+def bind_to_gpu_numa_node(index):
+    """Pin this process's host threads to the CPUs local to GPU ``index`` (its PCI device's ``local_cpulist`` in sysfs):
+    on an 8-GPU node the launch path of a rank then does not cross sockets.  Returns the NUMA node or None; every failure
+    (no sysfs entry, no permission, a container without the topology) is silent -- the bench runs unpinned."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if node < 0 or not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 class Runner:
     """dist init, fences and the timed loop shared by the three workloads."""
 
@@ -253,7 +275,11 @@ class Runner:
         local = local % max(torch.cuda.device_count(), 1)   # identity on a full node; lets 2 test ranks share 1 GPU
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
+        # host threads next to this rank's GPU when several ranks share the box (silent if the topology is unknown); a
+        # single rank keeps every core -- its cpu_baseline leg uses them
+        self.numa = bind_to_gpu_numa_node(local) if self.world > 1 else None
         self.dist = None
+        self.rccl_ranks = 1
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -261,6 +287,13 @@ class Runner:
                 dist.init_process_group("nccl", device_id=self.dev)   # RCCL over xGMI
             else:
                 dist.init_process_group(args.backend)
+            # the rank count the COLLECTIVE sees, not the one the environment claims: a sum of ones, on the device under RCCL
+            one = torch.ones(1, dtype=torch.float32, device=self.dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(one)
+            got = int(round(float(one.item())))
+            if got != self.world:
+                raise SystemExit(f"bench.py: all_reduce(1) over the process group gave {got}, WORLD_SIZE is {self.world}")
+            self.rccl_ranks = got if args.backend == "nccl" else 0
 
     def fence(self):
         torch.cuda.synchronize(self.dev)
@@ -295,13 +328,17 @@ class Runner:
     def rank_spread(self, out, fps_rank, frac=None):
         """n_gpus comes from the process group actually formed; per-rank min / max so that a slow rank is visible."""
         per = self.gather({"fps": float(fps_rank), "frac": None if frac is None else float(frac),
-                           "dev": torch.cuda.current_device()})
+                           "dev": torch.cuda.current_device(), "numa": self.numa})
         assert len(per) == self.world == out["n_gpus"]
-        out["rccl_ranks"] = self.world if (self.dist is not None and self.args.backend == "nccl") else \
-            (1 if self.dist is None else 0)
+        devices = sorted({p["dev"] for p in per})
+        if self.dist is not None and self.args.backend == "nccl":
+            # one rank per GPU (train_101.sh:27-28): RCCL refuses two ranks on one device anyway; say so before it hangs
+            assert len(devices) == self.world, f"{self.world} RCCL ranks on {len(devices)} distinct devices {devices}"
+        out["rccl_ranks"] = self.rccl_ranks                  # measured: all_reduce(ones) at start-up (0 = not RCCL)
         out["per_rank"] = {"frames_per_s_min": round(min(p["fps"] for p in per), 1),
                            "frames_per_s_max": round(max(p["fps"] for p in per), 1),
-                           "devices": sorted({p["dev"] for p in per}), "backend": self.args.backend if self.dist else None}
+                           "devices": devices, "backend": self.args.backend if self.dist else None,
+                           "numa_nodes": [p.get("numa") for p in per]}
         if frac is not None:
             out["per_rank"]["roofline_frac_min"] = round(min(p["frac"] for p in per), 4)
             out["per_rank"]["roofline_frac_max"] = round(max(p["frac"] for p in per), 4)

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           float *__restrict__ dRb, int steps_per_wg) {
     constexpr int E = 4;
     constexpr int AV = kPairSlots / 64;
+    static_assert(AV == 4, "the parking switch below names the four accumulator registers");
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int pbase_s[DMM_MAX_PROPOSALS + 1];                        // first slot of a union column
@@ -659,9 +660,16 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                         p = __builtin_fmaf(d[m][2], v[u][2], p);
                         p = __builtin_fmaf(d[m][3], v[u][3], p);
                         p = wave_sum(p);                                   // wave-uniform result
-                        const int r = slot >> 6, l = slot & 63;
-#pragma unroll
-                        for (int q = 0; q < AV; ++q) accv[q] = accv[q] + ((q == r && lane == l) ? p : 0.0f);
+                        // park it in lane (slot & 63) of accumulator register (slot >> 6): the register by a SCALAR branch
+                        // (the slot is wave uniform), one compare + select + add -- the select-over-all-registers form
+                        // cost 3 VALU operations per register and pair, a third of this loop's instructions
+                        const float pl = lane == (slot & 63) ? p : 0.0f;
+                        switch (slot >> 6) {
+                            case 0: accv[0] += pl; break;
+                            case 1: accv[1] += pl; break;
+                            case 2: accv[2] += pl; break;
+                            default: accv[3] += pl; break;
+                        }
                         ++slot;
                     }
                 }
@@ -705,208 +713,6 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
     else if (M <= 16) DMM_MIXB_LAUNCH(16);
     else DMM_MIXB_LAUNCH(32);
 #undef DMM_MIXB_LAUNCH
-    return check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward of the mix as a streaming fp32 MFMA product (DMM_OPT_MIX_BWD_MFMA, N <= 64, M <= 16).
-// dRb[m, n] = sum_x dOut[m, x] * P[n, x] is a skinny GEMM with K = HW: [16 rows of d full_outmask] x [<= 64 planes of the
-// union of the rows' supports].  The kernel above reduces every (row, plane) pair across the wave with six DPP steps per
-// 4 KiB step -- 133 pairs at BASELINE configs[1] -- and that VALU / issue work, not bytes, held it 16 % under its read-only
-// access-pattern ceiling (0.68 against the probe's 0.81).  v_mfma_f32_16x16x4_f32 accumulates over K inside the matrix
-// unit: no cross-lane reduction in the loop at all.
-//   * a WAVE walks its own contiguous pixel range in sub-steps of 64 pixels; a row's 64 pixels are 16 lanes x 16 bytes, one
-//     wave load instruction = 4 rows x 256 contiguous bytes (plain coalesced lane loads, non-temporal);
-//   * operands go through a wave-PRIVATE LDS slab ([16 rows][64 + 4] floats per tile: written in load layout, read back in
-//     the MFMA's lane = (row, k) layout; a wave's LDS operations execute in order, so there is no workgroup barrier in the
-//     loop).  LDS moves each byte twice at ~10x the HBM rate per CU;
-//   * A = d full_outmask (rows m, zero rows from M up), B = the planes of one tile of 16 union columns: per sub-step and
-//     tile 16 MFMAs, acc[tile] (4 registers) holds C[m = 4 (lane >> 4) + r][column = lane & 15].  ~31 % of the fp32 MFMA
-//     rate at the HBM-bound pace.  The product is computed for ALL (row, column) entries of the tiles; only the support's
-//     are added into dRb (entries masked by the constant logic mask carry no gradient, match_model.py:124-130);
-//   * epilogue: the four waves' accumulators are folded through LDS in a fixed order, one global atomic per pair and
-//     workgroup.
-// Summation order differs from the pair kernel (MFMA's k-order): both sit inside the backward's 2e-5 bound; the tests pin
-// each against the reference's autograd (G6 / G10 / G17) and against each other.
-// ---------------------------------------------------------------------------------------------
-constexpr int kMfmaSub = 64;                  // pixels per sub-step
-constexpr int kMfmaLd = kMfmaSub + 4;         // LDS row pitch in floats: 16 rows x 4 consecutive banks cover all 64 banks once
-constexpr int kMfmaTiles = 4;                 // <= 64 union columns
-
-typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
-
-// the streaming loop of one wave for a union of NTILES tiles of 16 columns: straight-line code per sub-step (every load
-// unconditional -- rows / columns past the live ones re-read the last live one -- so that all loads of a sub-step are in
-// flight before the first wait), accumulators live in registers across the loop
-template <typename T, int NTILES>
-__device__ __forceinline__ void mfma_bwd_stream(const T *Pb, const float *db, const int *col_s, int64_t sp_n, int cnt, int Mb,
-                                                int HW, int s_begin, int s_end, float *slab_a, float *slab_b,
-                                                mfma_f32x4 (&acc)[kMfmaTiles]) {
-    const int lane = threadIdx.x & 63;
-    const int lr = lane >> 4, lc = lane & 15;                             // load layout: row 4 i + lr, pixels 4 lc .. 4 lc + 3
-    // this lane's load rows: d full_outmask row min(4 i + lr, Mb - 1), union column min(16 t + 4 i + lr, cnt - 1)
-    const float *arow[4];
-    bool alive[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = 4 * i + lr;
-        alive[i] = m < Mb;
-        arow[i] = db + (int64_t)min(m, Mb - 1) * HW + 4 * lc;
-    }
-    // (32-bit element offsets from the frame's first plane: 16 registers less than pointers -- the launcher keeps frames
-    // whose planes span 2^31 elements on the pair kernel)
-    int boff[NTILES][4];
-#pragma unroll
-    for (int t = 0; t < NTILES; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) boff[t][i] = col_s[min(16 * t + 4 * i + lr, cnt - 1)] * (int)sp_n + 4 * lc;
-    float *wa = slab_a + lr * kMfmaLd + 4 * lc, *wb = slab_b + lr * kMfmaLd + 4 * lc;       // + 4 i rows per load
-    const float *ra = slab_a + lc * kMfmaLd + 4 * lr, *rb = slab_b + lc * kMfmaLd + 4 * lr;   // + 16 q per operand group
-    auto substep = [&](int s, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        const int x0 = s * kMfmaSub;
-        float av[4][4], bv[NTILES][4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!TAIL) {
-                const float4u t = __builtin_nontemporal_load(reinterpret_cast<const float4u *>(arow[i] + x0));
-                av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) av[i][k] = x0 + 4 * lc + k < HW ? arow[i][x0 + k] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NTILES; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!TAIL) MaskIO<T>::template load4<true>(Pb + (boff[t][i] + x0), bv[t][i]);
-                else mix_load<T, 4, true>(Pb + (boff[t][i] - 4 * lc), x0 + 4 * lc, HW, true, bv[t][i]);
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // the previous sub-step's operand reads are done
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4a t;                                                    // rows from Mb up are zero rows of A
-            t.x = alive[i] ? av[i][0] : 0.0f; t.y = alive[i] ? av[i][1] : 0.0f;
-            t.z = alive[i] ? av[i][2] : 0.0f; t.w = alive[i] ? av[i][3] : 0.0f;
-            *reinterpret_cast<float4a *>(wa + 4 * i * kMfmaLd) = t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // operand layout: lane = (row, k-slice g) with row = lane & 15, g = lane >> 4; MFMA number 4 q + j of the
-        // sub-step takes pixel 16 q + 4 g + j of its row -- the same map for A and B
-        float a_op[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4a t = *reinterpret_cast<const float4a *>(ra + 16 * q);
-            a_op[4 * q] = t.x; a_op[4 * q + 1] = t.y; a_op[4 * q + 2] = t.z; a_op[4 * q + 3] = t.w;
-        }
-#pragma unroll
-        for (int t = 0; t < NTILES; ++t) {
-            if (t > 0) {                                                  // the previous tile's reads before this one's writes
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4a v;
-                v.x = bv[t][i][0]; v.y = bv[t][i][1]; v.z = bv[t][i][2]; v.w = bv[t][i][3];
-                *reinterpret_cast<float4a *>(wb + 4 * i * kMfmaLd) = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float b_op[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4a v = *reinterpret_cast<const float4a *>(rb + 16 * q);
-                b_op[4 * q] = v.x; b_op[4 * q + 1] = v.y; b_op[4 * q + 2] = v.z; b_op[4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[k], b_op[k], acc[t], 0, 0, 0);
-        }
-    };
-    const int full_subs = HW / kMfmaSub;
-    const int s_mid = min(s_end, full_subs);
-    for (int s = s_begin; s < s_mid; ++s) substep(s, std::false_type());
-    for (int s = max(s_begin, s_mid); s < s_end; ++s) substep(s, std::true_type());
-}
-
-template <typename T>
-__global__ __launch_bounds__(kMixThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void mask_mix_bwd_mfma_kernel(const float *__restrict__ Rb,
-                                                                        const T *__restrict__ masks_p,
-                                                                        const float *__restrict__ dout, int N, int M,
-                                                                        int Pp, int HW, int64_t sp_b, int64_t sp_n,
-                                                                        const int32_t *__restrict__ n_valid,
-                                                                        const int32_t *__restrict__ m_valid,
-                                                                        float *__restrict__ dRb, int subs_per_wave) {
-    constexpr int MT = 16;
-    constexpr int kSlab = 16 * kMfmaLd;                                   // floats of one tile
-    __shared__ int col_s[DMM_MAX_PROPOSALS];
-    __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
-    __shared__ int wcnt_s[kMixThreads / 64];
-    // per wave: the A tile and one B tile; after the loop the same memory holds the four waves' accumulators
-    __shared__ __attribute__((aligned(16))) float slab_s[(kMixThreads / 64) * 2 * kSlab];
-    static_assert((kMixThreads / 64) * 2 * kSlab >= (kMixThreads / 64) * kMfmaTiles * 4 * 64, "the fold fits the slabs");
-    const int b = blockIdx.y;
-    int Nb = n_valid ? n_valid[b] : N;
-    int Mb = m_valid ? m_valid[b] : M;
-    if (Nb <= 0) Mb = 0;
-    if (Mb <= 0) return;
-    const int cnt = shared_support<MT>(Rb + (int64_t)b * M * Pp, Pp, Nb, Mb, col_s, rowmask_s, (float *)nullptr, wcnt_s);
-    if (cnt == 0) return;
-    const int ntiles = (cnt + 15) >> 4;
-    const T *Pb = frame_base(masks_p, b, sp_b);
-    const float *db = dout + (int64_t)b * M * HW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *slab_a = slab_s + wave * 2 * kSlab, *slab_b = slab_a + kSlab;
-    mfma_f32x4 acc[kMfmaTiles];
-#pragma unroll
-    for (int t = 0; t < kMfmaTiles; ++t) acc[t] = (mfma_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const int nsubs = (HW + kMfmaSub - 1) / kMfmaSub;
-    const int s_begin = (blockIdx.x * (kMixThreads / 64) + wave) * subs_per_wave;
-    const int s_end = min(nsubs, s_begin + subs_per_wave);
-    switch (ntiles) {                                                     // wave-uniform
-        case 1: mfma_bwd_stream<T, 1>(Pb, db, col_s, sp_n, cnt, Mb, HW, s_begin, s_end, slab_a, slab_b, acc); break;
-        case 2: mfma_bwd_stream<T, 2>(Pb, db, col_s, sp_n, cnt, Mb, HW, s_begin, s_end, slab_a, slab_b, acc); break;
-        case 3: mfma_bwd_stream<T, 3>(Pb, db, col_s, sp_n, cnt, Mb, HW, s_begin, s_end, slab_a, slab_b, acc); break;
-        default: mfma_bwd_stream<T, 4>(Pb, db, col_s, sp_n, cnt, Mb, HW, s_begin, s_end, slab_a, slab_b, acc); break;
-    }
-    // ---- fold the four waves (fixed order) and add the support's entries into dRb ---------------------------------------
-    __syncthreads();                                                      // every wave is done with its slabs
-    float *fold = slab_s;                                                 // [wave][tile][r][lane]
-#pragma unroll
-    for (int t = 0; t < kMfmaTiles; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fold[((wave * kMfmaTiles + t) * 4 + r) * 64 + lane] = acc[t][r];
-    __syncthreads();
-    constexpr int kPerWave = kMfmaTiles * 4 * 64;
-    for (int i = threadIdx.x; i < ntiles * 4 * 64; i += kMixThreads) {
-        const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
-        const int e = 16 * t + (l & 15), m = 4 * (l >> 4) + r;            // C layout: column = lane & 15, row = 4 (lane >> 4) + r
-        if (e < cnt && m < Mb && (rowmask_s[e] & (1u << m))) {
-            const float v = ((fold[i] + fold[kPerWave + i]) + fold[2 * kPerWave + i]) + fold[3 * kPerWave + i];
-            atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[e]], v);
-        }
-    }
-}
-
-template <typename T>
-static int mask_mix_bwd_mfma_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
-                                   int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
-                                   hipStream_t stream) {
-    DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
-    const int nsubs = (HW + kMfmaSub - 1) / kMfmaSub;
-    // a wave walks 16 sub-steps = 4 KiB of every row (the run length of the count kernels: neighbouring runs share the
-    // 128-byte lines that the 4-byte-aligned planes straddle), a workgroup 16 KiB: 16 workgroups per 255 x 255 frame
-    int subs_per_wave = 16 * opt(DMM_OPT_MIX_SHARED_STEPS);
-    if (subs_per_wave < 1) subs_per_wave = 1;
-    const int per_wg = subs_per_wave * (kMixThreads / 64);
-    const int splits = (nsubs + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL((mask_mix_bwd_mfma_kernel<T>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb, masks_p, dout, N, M,
-                       Pp, HW, sp_b, sp_n, n_valid, m_valid, dRb, subs_per_wave);
     return check_launch();
 }
 
@@ -1128,23 +934,6 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
     // default: planes of the union streamed once -- while the four per-wave pair tables fit the default dynamic-LDS limit
     // (4 * N * MT floats: everything up to 112 proposals x 32 rows or 224 x 16); wider tables keep the row kernel
     const int mt = M <= 8 ? 8 : (M <= 16 ? 16 : 32);
-    // <= 64 proposals x <= 16 rows (the model's shapes): the pair sums as a streaming fp32 MFMA product
-    if (dmm::opt(DMM_OPT_MIX_SHARED) != 0 && dmm::opt(DMM_OPT_MIX_BWD_MFMA) == 1 && N <= 64 && M <= 16 &&
-        (int64_t)N * sp_n + HW < 0x7fffffffLL) {
-        switch (dtype) {
-            case DMM_F32:
-                return dmm::mask_mix_bwd_mfma_typed<float>(Rb, (const float *)masks_p, dout, B, N, M, Pp, HW, sp_b, sp_n,
-                                                           n_valid, m_valid, dRb, s);
-            case DMM_F16:
-                return dmm::mask_mix_bwd_mfma_typed<dmm::f16_t>(Rb, (const dmm::f16_t *)masks_p, dout, B, N, M, Pp, HW, sp_b,
-                                                                sp_n, n_valid, m_valid, dRb, s);
-            case DMM_BF16:
-                return dmm::mask_mix_bwd_mfma_typed<dmm::bf16_t>(Rb, (const dmm::bf16_t *)masks_p, dout, B, N, M, Pp, HW,
-                                                                 sp_b, sp_n, n_valid, m_valid, dRb, s);
-            default:
-                return DMM_ERR_BAD_ARG;
-        }
-    }
     // the union kernel's four per-wave pair tables (dynamic LDS) sit beside ~7.2 KB of static LDS: 4 * N * mt
     // floats <= 56 KB keeps the total under the 64 KB a launch gets without an attribute (wider tables: the row kernel)
     if (dmm::opt(DMM_OPT_MIX_SHARED) != 0 && sizeof(float) * 4 * (size_t)N * mt <= 56 * 1024) {

@@ -106,10 +106,7 @@ typedef enum dmm_option {
                                        stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
     DMM_OPT_MIX_SHARED_STEPS = 21,  /* union kernels: 4 KiB steps of every plane per workgroup (1)                         */
     DMM_OPT_FEAT_BWD_FRAME = 22,    /* dmm_feature_sim_bwd_f32: 1 one workgroup per frame (default), 0 one per feature row   */
-    DMM_OPT_MIX_BWD_MFMA = 23,      /* mix backward, N <= 64 and M <= 16: 1 = the pair sums as a streaming fp32 MFMA product
-                                       (planes and d full_outmask staged through LDS, v_mfma_f32_16x16x4_f32; default), 0 = the
-                                       per-pair wave reductions.  Same sums in another order (the backward's 2e-5 bound) */
-    DMM_OPT_COUNT = 24
+    DMM_OPT_COUNT = 23
 } dmm_option;
 DMM_API int dmm_set_option(int option, int value);
 DMM_API int dmm_get_option(int option);

@@ -234,7 +234,7 @@ def test_unused_outputs_send_no_gradient_tensors():
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
-# ------------------------------------------------------------------------------------ mix backward as an fp32 MFMA product
+# ------------------------------------------------------------------------------------ mix backward against float64
 def _mix_bwd_case(B, N, M, H, W, seed, dtype=torch.float32, density=0.3, ragged=False):
     g = torch.Generator(device=DEV).manual_seed(seed)
     pm = torch.rand((B, N, H, W), generator=g, device=DEV).to(dtype)
@@ -258,45 +258,33 @@ def _mix_bwd_case(B, N, M, H, W, seed, dtype=torch.float32, density=0.3, ragged=
 
 
 @pytest.mark.parametrize("B,N,M,H,W,dtype,ragged", [
-    (2, 50, 10, 64, 64, torch.float32, False),         # three tiles of union columns
-    (1, 64, 16, 255, 255, torch.float32, False),       # the kernel's full envelope at the product's plane size (odd planes, tail)
-    (3, 17, 3, 33, 31, torch.float32, False),          # two tiles, a plane shorter than a wave's run
-    (2, 9, 1, 5, 7, torch.float32, False),             # one tile, 35 pixels: the tail sub-step alone
+    (2, 50, 10, 64, 64, torch.float32, False),
+    (1, 64, 16, 255, 255, torch.float32, False),       # the product's plane size (odd planes, tail)
+    (3, 17, 3, 33, 31, torch.float32, False),
+    (2, 9, 1, 5, 7, torch.float32, False),             # 35 pixels: the tail step alone
     (4, 50, 5, 40, 44, torch.float32, True),           # ragged frames, dead frames
     (2, 50, 10, 48, 52, torch.float16, False),
-    (2, 33, 7, 48, 52, torch.bfloat16, True)])
-def test_mix_backward_mfma_product(B, N, M, H, W, dtype, ragged):
-    """dmm_mask_mix_bwd's streaming fp32 MFMA form (option MIX_BWD_MFMA, default for N <= 64, M <= 16) against the float64
-    product on the support of Rb and against the per-pair wave-reduction kernel: both inside the backward's bound (2e-5 of
-    the largest entry); entries outside the support are exactly zero."""
+    (2, 33, 7, 48, 52, torch.bfloat16, True),
+    (2, 65, 4, 24, 24, torch.float32, False), (2, 20, 17, 24, 24, torch.float32, False),
+    (2, 120, 32, 24, 24, torch.float32, False), (1, 240, 16, 16, 16, torch.float32, False)])   # the LDS gate's edge
+def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
+    """dmm_mask_mix_bwd (union kernel with the scalar-branch slot parking of round 5, and the row kernel it falls back to:
+    option MIX_SHARED) against the float64 product on the support of Rb: inside the backward's bound (2e-5 of the largest
+    entry); entries outside the support are exactly zero; per-frame plane tables take the same kernels."""
     from conftest import record_achieved
     pm, dout, Rb, nv, mv, want = _mix_bwd_case(B, N, M, H, W, seed=N * 31 + M, dtype=dtype, ragged=ragged)
     scale = float(want.abs().max()) or 1.0
-    got = {}
-    for mode in (1, 0):
-        with _lib.options(MIX_BWD_MFMA=mode):
-            l0 = _lib.load().dmm_launch_count()
-            got[mode] = ops.mask_mix_bwd(Rb, pm, dout, nv, mv).double()
-            assert _lib.load().dmm_launch_count() - l0 == 2          # the clearing launch + one kernel
-        assert bool((got[mode][Rb == 0] == 0).all())
-        err = float((got[mode] - want).abs().max()) / scale
+    for mode in (-1, 0):
+        with _lib.options(MIX_SHARED=mode):
+            got = ops.mask_mix_bwd(Rb, pm, dout, nv, mv).double()
+        assert bool((got[Rb == 0] == 0).all())
+        err = float((got - want).abs().max()) / scale
         assert err <= 2e-5, (mode, err)
-        if mode == 1:
-            record_achieved(f"mix_bwd_mfma/{B}x{N}x{M}x{H}x{W}_{str(dtype)[6:]}/rel_err", err)
-    assert float((got[1] - got[0]).abs().max()) / scale <= 2e-5
-    # per-frame plane tables take the same kernel
+        if mode == -1:
+            record_achieved(f"mix_bwd/{B}x{N}x{M}x{H}x{W}_{str(dtype)[6:]}/rel_err", err)
     fp = ops.FramePlanes([pm[b, :(int(nv[b]) if nv is not None else N)] for b in range(B)])
-    with _lib.options(MIX_BWD_MFMA=1):
-        t = ops.mask_mix_bwd(Rb, fp, dout, nv if nv is not None else None, mv).double()
+    t = ops.mask_mix_bwd(Rb, fp, dout, nv if nv is not None else None, mv).double()
     assert float((t - want).abs().max()) / scale <= 2e-5
-
-
-def test_mix_backward_mfma_fallbacks_keep_their_kernels():
-    """Outside the MFMA form's envelope (more than 64 proposals or more than 16 rows) the pair kernels still answer."""
-    for (N, M) in ((65, 4), (20, 17), (120, 32)):
-        pm, dout, Rb, nv, mv, want = _mix_bwd_case(2, N, M, 24, 24, seed=N + M)
-        got = ops.mask_mix_bwd(Rb, pm, dout).double()
-        assert float((got - want).abs().max()) / (float(want.abs().max()) or 1.0) <= 2e-5
 
 
 def test_ragged_frames_get_the_similarity_in_the_order_of_their_own_proposal_count():

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""dmm_mask_mix_bwd at the training bench's shape (50 proposals x 10 rows, 255 x 255, train-mode supports): the fp32 MFMA
-form against the per-pair wave-reduction kernel, HIP-event time per launch and -- with --pmc -- SQ counters of both kernels
-from separate rocprofv3 passes of this script (--kernel-trace --pmc only).
+"""dmm_mask_mix_bwd at the training bench's shape (50 proposals x 10 rows, 255 x 255, train-mode supports): HIP-event time
+per launch of the union kernel (and the row kernel, MIX_SHARED = 0) and -- with --pmc -- SQ / traffic counters from separate
+rocprofv3 passes of this script (--kernel-trace --pmc only).  (Round 5 also ran an LDS-staged fp32 MFMA form through this
+probe: profiles/r05_mix_bwd_mfma_nogo.md.)
 
     python tools/mix_bwd_probe.py [--frames 512] [--pmc] [--steps 1,2]"""
 import argparse
@@ -20,11 +21,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=512)
 ap.add_argument("--pmc", action="store_true")
 ap.add_argument("--child", action="store_true")
-ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (x16 sub-steps per wave in the MFMA form)")
+ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (the backward takes twice as many 4 KiB steps per workgroup)")
 ap.add_argument("--reps", type=int, default=8)
 args = ap.parse_args()
 
-PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES"],
+PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES",
+           "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"],
           ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
            "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
           ["FETCH_SIZE"], ["WRITE_SIZE"]]
@@ -57,10 +59,10 @@ def run():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
     for steps in [int(v) for v in args.steps.split(",")]:
-        for mode in (1, 0):
-            with _lib.options(MIX_BWD_MFMA=mode, MIX_SHARED_STEPS=steps):
+        for mode in (-1, 0):
+            with _lib.options(MIX_SHARED=mode, MIX_SHARED_STEPS=steps):
                 t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
-            out["runs"][f"{'mfma' if mode else 'pairs'}_steps{steps}"] = {
+            out["runs"][f"{'union' if mode else 'rows'}_steps{steps}"] = {
                 "ms": round(t, 4), "GBps": round(alg / t / 1e6, 1), "frac_of_8TBps": round(alg / t / 1e6 / 8000, 4)}
     print(json.dumps(out))
 
