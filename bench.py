@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
                                                               "fp16-state one BASELINE configs[4] names")
+    ap.add_argument("--autocast", action="store_true", help="config 4: run the encoder under bf16 autocast (the reference "
+                                                          "trains in fp32, which is the default here)")
+    ap.add_argument("--repeats", type=int, default=3, help="config 4: timed repeats of K steps each; the line carries the "
+                                                           "median with min / max beside it")
     ap.add_argument("--settle", type=int, default=8, help="config 4: untimed steps before the W warm-ups (MIOpen solver "
                                                           "picks, allocator working set, bucketer steady mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -477,8 +481,9 @@ def bench_layer(R, ci):
         for b in (1, 4, 8, 64, 512, 1024):
             if b > B:
                 continue
-            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt, graph=b <= 32,
-                                                     solver_state=sstate, out_plane_align=128 if aligned else 0)
+            p2 = plan if b == B else ops.ForwardPlan(b, N, M, H, W, D, dev, mask_dtype=mdt, out_dtype=odt,
+                                                     graph=b <= 32 and not aligned, solver_state=sstate,
+                                                     out_plane_align=128 if aligned else 0)
             inp = inputs if b == B else tuple(t[:b] for t in inputs)
             ms = quick_ms(lambda: p2.run(*inp, **kw), 200 if b <= 64 else 30, dev=dev)
             sweep[str(b)] = {"ms": round(ms, 4), "frames_per_s": round(b / ms * 1e3, 1), "schedule": p2.schedule_name()}
@@ -751,8 +756,11 @@ def bench_config4(R):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if k is not None else None
         mark = (lambda i: e[i].record()) if e else (lambda i: None)
         mark(0)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            feats = enc(img)
+        if args.autocast:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                feats = enc(img)
+        else:
+            feats = enc(img)                                      # fp32 like the reference's trainer (train.py: no autocast)
         mark(1)
         tplt = model.fill_template_dict(None, tboxes, feats, None, valid)
         out, _, match_loss, _ = model(None, props, feats["backbone_feature"], mask_last, tplt, valid, targets)
@@ -776,9 +784,20 @@ def bench_config4(R):
     for _ in range(settle):
         step(None)
     syncs0 = bucketer.host_syncs
-    elapsed = R.timed(step, args.steps, args.warmup)
+    # >= 3 repeats of K timed steps each (the step follows the box: MIOpen's picks, clocks): median, min and max in the line
+    reps = max(1, int(getattr(args, "repeats", 3)))
+    rep_ms, rep_ev = [], []
+    for r in range(reps):
+        ev.clear()
+        rep_ms.append(R.timed(step, args.steps, args.warmup if r == 0 else 0) / args.steps * 1e3)
+        rep_ev.append(list(ev))
+    order = sorted(range(reps), key=lambda k: rep_ms[k])
+    mid = order[len(order) // 2]
+    ev[:] = rep_ev[mid]                                          # stage times of the median repeat
+    elapsed = rep_ms[mid] * args.steps / 1e3
     assert bool(torch.isfinite(torch.stack(losses)).all())
     avg = lambda i, j: float(np.mean([e[i].elapsed_time(e[j]) for e in ev]))
+    exposed_all = [float(np.mean([e[3].elapsed_time(e[4]) for e in evs])) for evs in rep_ev]
     grad_bytes = sum(p.numel() * p.element_size() for p in params)
     # the collective alone (nothing to hide under): bus bandwidth of the bucketed all-reduce
     torch.cuda.synchronize(dev)
@@ -800,7 +819,8 @@ def bench_config4(R):
                   "gradient mean over RCCL), YouTube-VOS-shaped synthetic clips (BASELINE configs[3])",
         "value": round(world * B / (step_ms * 1e-3), 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 autocast encoder, f32 matching layer and optimiser", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16 autocast encoder" if args.autocast else "f32 encoder (as the reference trains)") +
+        ", f32 matching layer and optimiser", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3], per-GPU share: {B} frames of 255x448 (4 videos x clip 3), ResNet-101 "
                                "+ heads (torch.nn on MIOpen, random init), 50 proposals, 5 template slots, DMM_Model "
                                "training forward (10x5 solver, dual IoU with the targets) + soft-IoU + matching loss, "
@@ -810,6 +830,11 @@ def bench_config4(R):
                                 "backward_incl_overlapped_allreduce": round(avg(2, 3), 3),
                                 "allreduce_exposed_after_backward": round(avg(3, 4), 3), "adam": round(avg(4, 5), 3)},
                    "settle_steps_before_warmup": settle,
+                   "repeats": {"n": reps, "steps_each": args.steps, "ms_per_step": [round(v, 3) for v in rep_ms],
+                               "ms_per_step_min_median_max": [round(min(rep_ms), 3), round(rep_ms[mid], 3), round(max(rep_ms), 3)],
+                               "allreduce_exposed_ms": [round(v, 3) for v in exposed_all]},
+                   "note_n1": "at N = 1 the collective moves nothing between GPUs: this line shows the per-GPU share and the "
+                              "bucketing / hook overhead, NOT the overlap of communication with the backward" if world == 1 else None,
                    "gradient_mean": {"bytes": grad_bytes, "buckets": bucketer.num_collectives(),
                                      "gradients_are_bucket_views": True, "divide": "in the collective (ReduceOp.AVG)"
                                      if args.backend == "nccl" else "SUM + one divide (backend has no AVG)",
@@ -1102,7 +1127,7 @@ def compact(out):
     if "roofline_layer" in out:
         c["roofline_layer_b_cost_frac"] = out["roofline_layer"]["b_cost_basis"]["frac"]
     for k in ("stage_ms", "single_clip_ms_per_step", "boxlist_path_ms_per_step", "clip_of_36_frames_ms_per_step",
-              "mean_outer_iterations"):
+              "mean_outer_iterations", "repeats", "solver_state", "f32_solver", "contiguous_planes"):
         if k in out["config"]:
             c[k] = out["config"][k]
     if "cases" in out["config"]:                                 # the drop-in: per-call wall / device / launches
@@ -1138,7 +1163,34 @@ def main():
         # the other BASELINE configurations and the frame loop, compact, so that the driver's default run sees them
         import copy
         others = {}
-        for name, fn, kw in (("config5", lambda r: bench_layer(r, 5), dict(steps=30, warmup=5, frames=0)),
+        def config5_both(r):
+            """BASELINE configs[4] names the fp16-state solver (tolerance mode); the bit-exact fp32-state figure beside it"""
+            o = bench_layer(r, 5)
+            a3 = copy.copy(r.args)
+            a3.f32_solver = True
+            keep, r.args = r.args, a3
+            try:
+                o32 = bench_layer(r, 5)
+            finally:
+                r.args = keep
+            a4 = copy.copy(r.args)
+            a4.contiguous_planes = True
+            r.args = a4
+            try:
+                oc = bench_layer(r, 5)                                # ADVICE r4: the packed [B,K,H,W] layout beside the aligned one
+            finally:
+                r.args = keep
+            o["config"]["contiguous_planes"] = {"value": oc["value"], "unit": "frames/s", "ms_per_step": oc["ms_per_step"],
+                                                "roofline_frac": oc["roofline"]["frac"],
+                                                "note": "packed [B,K,255,255] fp16 planes (every other plane starts 2 bytes "
+                                                        "off a dword) instead of the 128-byte-aligned plane stride"}
+            o["config"]["f32_solver"] = {"value": o32["value"], "unit": "frames/s", "ms_per_step": o32["ms_per_step"],
+                                         "roofline_frac": o32["roofline"]["frac"],
+                                         "roofline_layer_b_cost_frac": o32["roofline_layer"]["b_cost_basis"]["frac"],
+                                         "note": "the bit-exact fp32-state solver (--f32-solver) on the same planes"}
+            return o
+        for name, fn, kw in (("config5", config5_both, dict(steps=30, warmup=5, frames=0)),
+                             ("config4", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3)),
                              ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
                              ("frame_loop", bench_frame_loop, dict(frames=0)),
                              ("train", bench_train, dict(steps=40, warmup=6, frames=0)),

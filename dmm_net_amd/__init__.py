@@ -1,4 +1,4 @@
-def use_shipped_miopen_db(develop: bool = False):
+def use_shipped_miopen_db(develop: bool = False, enable: bool = True):
     """Seed MIOpen's USER find-db / perf-db with the solver choices shipped in ``dmm_net_amd/miopen_db`` (what MIOpen's own
     search picked on an MI355X for the encoder shapes of BASELINE configs 3 and 4 and the frame loop; plain-text files
     keyed by problem, entries for other MIOpen builds are simply ignored).
@@ -6,19 +6,25 @@ def use_shipped_miopen_db(develop: bool = False):
     MIOpen WRITES to its user db (every new shape it searches), and the variable is process wide -- so the shipped files
     are never handed to it directly: they are copied once into a per-user cache directory
     (``~/.cache/dmm_net_amd/miopen_db-<fingerprint>``, several ranks may race: files are put in place atomically) and
-    MIOPEN_USER_DB_PATH points there.  An explicit MIOPEN_USER_DB_PATH in the environment always wins, and
-    ``DMM_MIOPEN_DB=off`` leaves MIOpen alone altogether.  ``develop=True`` (or ``DMM_MIOPEN_DB=repo``) points MIOpen at
-    the tracked directory itself -- only to refresh what is shipped.  Must run before the first convolution."""
+    MIOPEN_USER_DB_PATH points there.  MIOpen's OWN variable, MIOPEN_USER_DB_PATH, always wins when the caller has set it;
+    this package reads no variable of its own: ``use_shipped_miopen_db(enable=False)`` (before the first convolution) takes
+    the shipped db out again, ``develop=True`` points MIOpen at the tracked directory itself -- only to refresh what is
+    shipped (tools/).  Must run before the first convolution."""
     import os
     import shutil
-    mode = os.environ.get("DMM_MIOPEN_DB", "")
-    if os.environ.get("MIOPEN_USER_DB_PATH") or mode == "off":
+    global _DB_SET_BY_US
+    if not enable:
+        if _DB_SET_BY_US and os.environ.get("MIOPEN_USER_DB_PATH") == _DB_SET_BY_US:
+            del os.environ["MIOPEN_USER_DB_PATH"]
+        _DB_SET_BY_US = None
+        return None
+    if os.environ.get("MIOPEN_USER_DB_PATH") and os.environ.get("MIOPEN_USER_DB_PATH") != _DB_SET_BY_US:
         return os.environ.get("MIOPEN_USER_DB_PATH")
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
     if not os.path.isdir(src):
         return None
-    if develop or mode == "repo":
-        os.environ["MIOPEN_USER_DB_PATH"] = src
+    if develop:
+        os.environ["MIOPEN_USER_DB_PATH"] = _DB_SET_BY_US = src
         return src
     files = sorted(f for f in os.listdir(src) if os.path.isfile(os.path.join(src, f)))
     import hashlib
@@ -38,8 +44,9 @@ def use_shipped_miopen_db(develop: bool = False):
                 os.replace(tmp, os.path.join(dst, f))
     except OSError:
         return None
-    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    os.environ["MIOPEN_USER_DB_PATH"] = _DB_SET_BY_US = dst
     return dst
 
 
+_DB_SET_BY_US = None
 use_shipped_miopen_db()

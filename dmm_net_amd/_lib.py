@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DMM_LIB_PATH") or os.path.join(_HERE, "libdmm_match.so")   # override: A/B builds of the library
+LIB_PATH = os.path.join(_HERE, "libdmm_match.so")        # no environment override: see use_library()
 CSRC = os.path.join(_HERE, "csrc")
 
 DMM_OK = 0
@@ -52,6 +52,16 @@ def build(verbose: bool = False) -> str:
     if not os.path.exists(LIB_PATH):
         raise DmmError("build did not produce " + LIB_PATH)
     return LIB_PATH
+
+
+def use_library(path: str) -> None:
+    """Load ANOTHER build of the library instead of the in-tree one (A/B builds in tools/: cached instead of non-temporal
+    plane loads, other tile sizes).  An explicit call BEFORE the first ``load()``: no environment variable can change which
+    library production loads."""
+    global LIB_PATH
+    if _lib is not None:
+        raise DmmError("use_library() after the library has been loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def load():
@@ -227,22 +237,35 @@ def get_option(name: str) -> int:
     return int(load().dmm_get_option(OPTIONS[name]))
 
 
+_OPTIONS_LOCK = None
+
+
 class options:
     """``with _lib.options(COST_KERNEL=1, COST_TINY_FRAMES=0): ...`` -- pin dispatch options for a block (tests, A/B
-    timing) and put the previous values back."""
+    timing) and put the previous values back.  The options are PROCESS-WIDE: the block holds a re-entrant lock, so two
+    threads pinning different values run their blocks one after the other instead of seeing each other's settings
+    (ADVICE r4); threads that do not pin anything are not held up -- and see whatever is pinned at the moment."""
 
     def __init__(self, **kw):
         self.kw, self.old = kw, {}
 
     def __enter__(self):
+        global _OPTIONS_LOCK
+        if _OPTIONS_LOCK is None:
+            import threading
+            _OPTIONS_LOCK = threading.RLock()
+        _OPTIONS_LOCK.acquire()
         for k, v in self.kw.items():
             self.old[k] = get_option(k)
             set_option(k, v)
         return self
 
     def __exit__(self, *exc):
-        for k, v in self.old.items():
-            set_option(k, v)
+        try:
+            for k, v in self.old.items():
+                set_option(k, v)
+        finally:
+            _OPTIONS_LOCK.release()
         return False
 
 

@@ -529,11 +529,13 @@ static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N
 
 // Backward of the mix, rows sharing planes: one workgroup = a pixel range of a frame; d full_outmask of the M rows is
 // loaded once per step (registers), every plane of the union once.  Each (row, plane) pair of the support has a SLOT
-// (pairs in column-major order, <= kPairSlots per frame: more fall back to the row kernel): its 4-pixel dot product is
-// reduced over the wave (DPP) and added into lane (slot & 63) of accumulator register (slot >> 6) -- no LDS round trip in
-// the loop.  At the end the four waves' registers are folded through LDS in a fixed order (a workgroup's result does not
-// depend on how its waves interleave) and one global atomic per pair and workgroup goes to dRb.  (pairs + M) ->
-// (|union| + M) planes of traffic.
+// (pairs in column-major order, <= kPairSlots per frame: more fall back to a dense table).  A pair's 4-pixel dot product
+// is reduced inside each 16-lane row of the wave (four DPP adds) and the four row sums go into the wave's LDS slab with ONE
+// ds_add_f32 (lanes 0 / 16 / 32 / 48, four neighbouring words: no same-address serialisation) -- round 5; the round-4 form
+// finished the reduction across the rows (two more DPP steps behind broadcast moves), read the total back into a scalar
+// and parked it in "lane slot of register slot / 64" by selecting over all four accumulator registers: 28 VALU instructions
+// and ~10 hazard no-ops per pair against 9 here (profiles/r05_mix_bwd_*).  At the end the four waves' slabs are folded in
+// a fixed order and one global atomic per pair and workgroup goes to dRb.  (pairs + M) -> (|union| + M) planes of traffic.
 constexpr int kPairSlots = 256;
 
 template <typename T, int MT>
@@ -545,12 +547,10 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           const int32_t *__restrict__ m_valid,
                                                                           float *__restrict__ dRb, int steps_per_wg) {
     constexpr int E = 4;
-    constexpr int AV = kPairSlots / 64;
-    static_assert(AV == 4, "the parking switch below names the four accumulator registers");
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int pbase_s[DMM_MAX_PROPOSALS + 1];                        // first slot of a union column
-    __shared__ float fold_s[kMixThreads / 64][kPairSlots];
+    __shared__ __attribute__((aligned(16))) float fold_s[kMixThreads / 64][kPairSlots][4];   // [wave][slot][16-lane row]
     __shared__ int wcnt_s[kMixThreads / 64];
     const int b = blockIdx.y;
     int Nb = n_valid ? n_valid[b] : N;
@@ -623,9 +623,10 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
         }
         return;
     }
-    float accv[AV];
-#pragma unroll
-    for (int q = 0; q < AV; ++q) accv[q] = 0.0f;
+    for (int i = threadIdx.x; i < (kMixThreads / 64) * kPairSlots * 4; i += kMixThreads) (&fold_s[0][0][0])[i] = 0.0f;
+    __syncthreads();
+    float *acc_w = &fold_s[wave][0][0] + (lane >> 4);                     // + 4 * slot: this lane's row word of a slot
+    const bool row_leader = (lane & 15) == 0;
     for (int s = s_begin; s < s_end; ++s) {
         const int x = (s * kMixThreads + threadIdx.x) * E;
         float d[MT][E];
@@ -659,27 +660,20 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                         p = __builtin_fmaf(d[m][1], v[u][1], p);
                         p = __builtin_fmaf(d[m][2], v[u][2], p);
                         p = __builtin_fmaf(d[m][3], v[u][3], p);
-                        p = wave_sum(p);                                   // wave-uniform result
-                        // park it in lane (slot & 63) of accumulator register (slot >> 6): the register by a SCALAR branch
-                        // (the slot is wave uniform), one compare + select + add -- the select-over-all-registers form
-                        // cost 3 VALU operations per register and pair, a third of this loop's instructions
-                        const float pl = lane == (slot & 63) ? p : 0.0f;
-                        switch (slot >> 6) {
-                            case 0: accv[0] += pl; break;
-                            case 1: accv[1] += pl; break;
-                            case 2: accv[2] += pl; break;
-                            default: accv[3] += pl; break;
-                        }
+                        // the sum of each 16-lane row in all of its lanes (the first four steps of wave_sum)
+                        p = p + dpp_full_f32<DPP_XOR1>(p);
+                        p = p + dpp_full_f32<DPP_XOR2>(p);
+                        p = p + dpp_full_f32<DPP_HALF_MIRROR>(p);
+                        p = p + dpp_full_f32<DPP_MIRROR>(p);
+                        if (row_leader) atomicAdd(acc_w + 4 * slot, p);   // ds_add_f32, no return: 4 lanes, 4 words
                         ++slot;
                     }
                 }
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < AV; ++q) fold_s[wave][q * 64 + lane] = accv[q];
     __syncthreads();
-    // slot -> (column, row): walk the union again, one thread per slot
+    // slot -> (column, row): walk the union again, one thread per slot; waves and rows folded in a fixed order
     for (int i = threadIdx.x; i < pairs; i += kMixThreads) {
         int lo = 0, hi = cnt;                                             // pbase_s[lo] <= i < pbase_s[lo + 1]
         while (hi - lo > 1) {
@@ -689,7 +683,12 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
         unsigned rows = rowmask_s[lo];
         for (int k = i - pbase_s[lo]; k > 0; --k) rows &= rows - 1;       // drop the k lowest set bits
         const int m = __builtin_ctz(rows);
-        const float t = ((fold_s[0][i] + fold_s[1][i]) + fold_s[2][i]) + fold_s[3][i];
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kMixThreads / 64; ++w) {
+            const float4 q = *reinterpret_cast<const float4 *>(&fold_s[w][i][0]);
+            t = t + ((q.x + q.y) + (q.z + q.w));
+        }
         atomicAdd(&dRb[((int64_t)b * M + m) * Pp + col_s[lo]], t);
     }
 }

@@ -38,6 +38,8 @@ def get_skip_dims(model_name: str):
         return [2048, 1024, 512, 256, 64]
     if model_name == "resnet34":
         return [512, 256, 128, 64, 64]
+    if model_name == "vgg16":
+        return [512, 512, 256, 128, 64]
     raise Exception("The base model you chose is not supported ! {}".format(model_name))
 
 
@@ -138,6 +140,40 @@ def ResNet101():
     return ResNetBody(Bottleneck, [3, 4, 23, 3])
 
 
+class VGG16(nn.Module):
+    """The reference's fourth backbone option (``base_model == 'vgg16'``, model_encoder.py:48-49; vision.py:57-115): the
+    13 convolutions of VGG-16 (3x3, ReLU, no BatchNorm) in five stages, each closed by a 2x2 max pool; the five taps
+    are the POOLED stage outputs -- (x5, x4, x3, x2, x1) at strides 32 / 16 / 8 / 4 / 2 with 512 / 512 / 256 / 128 / 64
+    channels (``get_skip_dims('vgg16')``).  ``features`` keeps torchvision's flat conv / ReLU / pool numbering (0..30), so a
+    torchvision VGG-16 state dict loads into it; the classifier is not built (DMM-Net never runs it)."""
+
+    STAGES = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
+
+    def __init__(self):
+        super().__init__()
+        layers, cin, self.taps = [], 3, []
+        for widths in self.STAGES:
+            for cout in widths:
+                layers += [nn.Conv2d(cin, cout, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = cout
+            layers.append(nn.MaxPool2d(2, 2))
+            self.taps.append(len(layers) - 1)                     # index of the stage's pool: 4, 9, 16, 23, 30
+        self.features = nn.Sequential(*layers)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        outs = []
+        for i, layer in enumerate(self.features):
+            x = layer(x)
+            if i in self.taps:
+                outs.append(x)
+        x1, x2, x3, x4, x5 = outs
+        return x5, x4, x3, x2, x1
+
+
 def _prop_head(cin, cmid, cout, k, pad):
     # base.py:43-54: conv -> BN -> ReLU -> conv -> BN
     return nn.Sequential(nn.Conv2d(cin, cmid, k, padding=pad), nn.BatchNorm2d(cmid), nn.ReLU(),
@@ -154,7 +190,10 @@ class FeatureEncoder(nn.Module):
         dims = get_skip_dims(base_model)
         hid, ker = int(hidden_size), int(kernel_size)
         pad = 0 if ker == 1 else 1
-        self.base = {"resnet34": ResNet34, "resnet50": ResNet50, "resnet101": ResNet101}[base_model]()
+        backbones = {"resnet34": ResNet34, "resnet50": ResNet50, "resnet101": ResNet101, "vgg16": VGG16}
+        if base_model not in backbones:                          # model_encoder.py:50-51
+            raise Exception("The base model you chose is not supported ! {} (have: {})".format(base_model, sorted(backbones)))
+        self.base = backbones[base_model]()
         self.sk5 = nn.Conv2d(dims[0], hid, ker, padding=pad)
         self.sk4 = nn.Conv2d(dims[1], hid, ker, padding=pad)
         self.sk3 = nn.Conv2d(dims[2], hid // 2, ker, padding=pad)
@@ -214,15 +253,16 @@ def fold_batchnorm(encoder: "FeatureEncoder") -> "FeatureEncoder":
     assert not encoder.training, "fold_batchnorm needs eval() mode (running statistics)"
     enc = copy.deepcopy(encoder)
     body = enc.base
-    body.conv1, body.bn1 = _fold_pair(body.conv1, body.bn1), nn.Identity()
-    for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
-        for blk in layer:
-            for i in (1, 2, 3):
-                if hasattr(blk, f"conv{i}"):
-                    setattr(blk, f"conv{i}", _fold_pair(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}")))
-                    setattr(blk, f"bn{i}", nn.Identity())
-            if blk.downsample is not None:
-                blk.downsample = nn.Sequential(_fold_pair(blk.downsample[0], blk.downsample[1]), nn.Identity())
+    if not isinstance(body, VGG16):                          # (the VGG body has no BatchNorm: only the heads fold)
+        body.conv1, body.bn1 = _fold_pair(body.conv1, body.bn1), nn.Identity()
+        for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
+            for blk in layer:
+                for i in (1, 2, 3):
+                    if hasattr(blk, f"conv{i}"):
+                        setattr(blk, f"conv{i}", _fold_pair(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}")))
+                        setattr(blk, f"bn{i}", nn.Identity())
+                if blk.downsample is not None:
+                    blk.downsample = nn.Sequential(_fold_pair(blk.downsample[0], blk.downsample[1]), nn.Identity())
     for k in (5, 4, 3, 2):
         setattr(enc, f"sk{k}", _fold_pair(getattr(enc, f"sk{k}"), getattr(enc, f"bn{k}")))
         setattr(enc, f"bn{k}", nn.Identity())
@@ -432,11 +472,15 @@ class FastEncoder(nn.Module):
     # the level is done and run under the deeper levels of the body (at the product's batch sizes every convolution is a
     # 5-30 us launch that fills a fraction of the 256 CUs; the 12 head convolutions are ~30 % of the forward's kernel time
     # and were a serial tail after layer4).  Captured in a HIP graph the fork / join become graph edges.
-    heads_overlap = os.environ.get("DMM_ENCODER_HEADS_OVERLAP", "1") != "0"
+    stem_fused = True          # conv1 + bias + ReLU + max pool tail as one epilogue kernel (dmm_bias_relu_maxpool_bf16)
+    heads_overlap = True       # class attributes, set in code by the A/B tools (no environment switches in the product)
 
     def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
         super().__init__()
         assert not encoder.training, "FastEncoder is an inference form: eval() first"
+        if not isinstance(encoder.base, ResNetBody):
+            raise NotImplementedError("FastEncoder is the bf16 channels-last form of the ResNet bodies (resnet34 / 50 / "
+                                      "101); a vgg16 encoder runs as FeatureEncoder / GraphedEncoder(FeatureEncoder)")
         enc = encoder if not any(isinstance(m, nn.BatchNorm2d) for m in encoder.modules()) else fold_batchnorm(encoder)
         assert dtype == torch.bfloat16, "the fused epilogue kernel is bf16"
         self.dtype = dtype
@@ -532,7 +576,7 @@ class FastEncoder(nn.Module):
     # are timed ONCE per (convolution, input shape) on the first call outside a capture and the faster one is kept.
     # Measured on the config-3 encoder with MIOpen's find-db picks: 0.931 -> 0.922 ms per forward -- MIOpen's CK kernels are
     # hard to beat with an explicit patch matrix, so the default stays "miopen" (= MIOpen for every k x k convolution).
-    patch_mode = os.environ.get("DMM_CONV3X3", "miopen")
+    patch_mode = "miopen"
     PATCH_MAX_BYTES = 16 << 20
 
     @staticmethod
@@ -648,7 +692,7 @@ class FastEncoder(nn.Module):
         x = img.to(self.dtype).contiguous(memory_format=torch.channels_last)
         mp = body.maxpool
         as_int = lambda v: v if isinstance(v, int) else v[0]
-        fusable = (os.environ.get("DMM_STEM_FUSED", "1") != "0" and x.is_cuda and isinstance(mp, nn.MaxPool2d) and as_int(mp.kernel_size) == 3 and as_int(mp.stride) == 2
+        fusable = (self.stem_fused and x.is_cuda and isinstance(mp, nn.MaxPool2d) and as_int(mp.kernel_size) == 3 and as_int(mp.stride) == 2
                    and as_int(mp.padding) == 1 and as_int(mp.dilation) == 1 and not mp.ceil_mode
                    and body.conv1.out_channels % 8 == 0)
         if not fusable:

@@ -868,7 +868,12 @@ class ForwardPlan:
         else:
             self.full_outmask = torch.empty((B, M, H, W), dtype=self.out_dtype, device=self.device)
         self.so_b, self.so_m = self.full_outmask.stride(0), self.full_outmask.stride(1)
-        self.time_kernels = self.time_kernels or bool(out_plane_align)     # the fused C call writes contiguous fp32 only
+        # the fused C call writes contiguous fp32 only: aligned output planes take the granular launches -- which cannot be
+        # the graph-replay form, so asking for both is an error rather than a silent downgrade
+        if out_plane_align and graph:
+            raise ValueError("ForwardPlan(out_plane_align=..., graph=True): line-aligned output planes are written by the "
+                             "granular launches only (no HIP-graph replay); drop one of the two")
+        self.time_kernels = self.time_kernels or bool(out_plane_align)
         self.graph_mode = self.graph_mode and not out_plane_align
         self.match_score = torch.empty((B, M), **f32)
         self.det_score = torch.empty((B, M), **f32)

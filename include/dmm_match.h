@@ -362,7 +362,12 @@ DMM_API int dmm_match_forward(const void *masks_p, const void *masks_t, int mask
  * describes the workspace AFTER the enqueued work: calls that share a workspace must be ordered on one stream, and a
  * captured call must be replayed with the workspace in the state it was captured with (it is, if nothing else touches
  * the workspace between replays: a call that starts from DMM_WS_TABLES_ZERO and returns it leaves what it found).
- * ws_state == NULL: exactly dmm_match_forward. */
+ * ws_state == NULL: exactly dmm_match_forward.
+ * The CALLER owns this note: reset it to DMM_WS_UNKNOWN whenever anything but the previous dmm_match_forward_ws call with
+ * the same (B, N, M, D) may have written the workspace -- another shape (the carving moves), another entry point, a
+ * re-allocation, a second stream or thread sharing it.  A stale DMM_WS_TABLES_ZERO makes the counts accumulate onto old
+ * tables: a silently wrong result the library cannot detect.  (dmm_net_amd/ops.py keeps one note per (device, stream,
+ * shape) and drops it on every such event; the dispatch options of (0) are process-wide and not part of this state.) */
 enum { DMM_WS_UNKNOWN = 0, DMM_WS_TABLES_ZERO = 1 };
 DMM_API int dmm_match_forward_ws(const void *masks_p, const void *masks_t, int mask_dtype, const float *feat_p,
                                  const float *feat_t, const float *score_p, int B, int N, int M, int HW, int D,

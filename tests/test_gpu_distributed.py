@@ -258,3 +258,58 @@ def test_bench_plain_invocation_with_gpus_2_launches_two_ranks_itself():
     r = subprocess.run(cmd[:2] + ["--gpus", "1", "--no-extras"], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process (the nn.DataParallel caller)")
+def test_two_devices_two_threads_like_nn_dataparallel():
+    """The single-process multi-device caller (reference train.py:185-186 / eval.py:64-65: ``nn.DataParallel`` runs one host
+    thread per GPU through the same module): two threads, each on ITS device, drive the drop-in's evaluator call, the fused
+    training call (forward + backward) and the batched fused forward at the same time; every result equals what the same
+    device computes alone.  Workspaces are keyed (device, stream); the launchers run under the tensors' device."""
+    import threading
+    import numpy as np
+    from dmm_net_amd import autograd, ops, synth
+    from dmm_net_amd.match_model import MatchModel
+    cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+            "score_weight": 0.3}
+    frs = [synth.make_frame(30 + 5 * k, 4 + k, 48, 56, 512, seed=70 + k, kind="structured", with_targets=True) for k in range(2)]
+
+    def run_all(k, dev):
+        fr = frs[k]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        with torch.cuda.device(dev):
+            with torch.no_grad():
+                ev = MatchModel(cfgs, is_test=1)(t(fr.proposed_feature), t(fr.proposed_mask), [t(fr.template_feature)],
+                                                 t(fr.mask_last_occurence), t(fr.proposal_score))
+            pf = t(fr.proposed_feature).requires_grad_(True)
+            tf = t(fr.template_feature).requires_grad_(True)
+            fo, ms, ds, _, loss = MatchModel(cfgs, is_test=0)(pf, t(fr.proposed_mask), [tf], t(fr.mask_last_occurence),
+                                                             t(fr.proposal_score), t(fr.targets))
+            (fo.sum() + ms.sum() + 2.0 * loss["cost_loss"]).backward()
+            bat = ops.match_forward(t(fr.proposed_mask)[None].repeat(3, 1, 1, 1), t(fr.mask_last_occurence)[None].repeat(3, 1, 1, 1),
+                                    t(fr.proposed_feature)[None].repeat(3, 1, 1), t(fr.template_feature)[None].repeat(3, 1, 1),
+                                    t(fr.proposal_score)[None].repeat(3, 1), score_weight=0.3, max_iter=10, proj_iter=5,
+                                    lr=0.1, is_test=1)
+            torch.cuda.synchronize(dev)
+            return [x.detach().cpu().numpy() for x in (ev[0], ev[1], ev[2], fo, ms, ds, loss["cost_loss"], pf.grad, tf.grad,
+                                                       bat[0], bat[1], bat[3])]
+    devs = [torch.device("cuda", 0), torch.device("cuda", 1)]
+    alone = [run_all(k, devs[k]) for k in range(2)]
+    got, errors = [None, None], []
+
+    def worker(k):
+        try:
+            for _ in range(4):
+                got[k] = run_all(k, devs[k])
+        except Exception as e:                                    # noqa: BLE001
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k in range(2):
+        for a, b in zip(got[k], alone[k]):
+            assert np.array_equal(a, b), k
