@@ -632,8 +632,8 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
         float d[MT][E];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (m < Mb && x + E - 1 < HW) {
-                const float4u t = *reinterpret_cast<const float4u *>(db + (int64_t)m * HW + x);
+            if (m < Mb && x + E - 1 < HW) {                  // (streamed once like the planes: non-temporal)
+                const float4u t = __builtin_nontemporal_load(reinterpret_cast<const float4u *>(db + (int64_t)m * HW + x));
                 d[m][0] = t.x; d[m][1] = t.y; d[m][2] = t.z; d[m][3] = t.w;
             } else {
 #pragma unroll

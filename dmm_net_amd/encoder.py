@@ -570,7 +570,7 @@ class FastEncoder(nn.Module):
             y = torch.addmm(bl, rows, wt)
         return _from_rows(y, B, H, W)
 
-    # Opt-in (DMM_CONV3X3=auto): 3x3 convolutions on SMALL feature maps as patch matrix + library GEMM.  layer3 / layer4
+    # Opt-in (FastEncoder.patch_mode = "auto", set in code): 3x3 convolutions on SMALL feature maps as patch matrix + library GEMM.  layer3 / layer4
     # and the heads work on 16x16 ... 8x8 maps: the patch matrix is a few MB (one 3-4 us copy kernel) and the product runs
     # with bias (+ residual) + ReLU in its epilogue, against MIOpen's convolution + the separate bias / ReLU pass; both
     # are timed ONCE per (convolution, input shape) on the first call outside a capture and the faster one is kept.

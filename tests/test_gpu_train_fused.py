@@ -76,6 +76,12 @@ def assert_same(a, b):
         if name == "cost_loss":
             assert np.all(np.abs(x.astype(np.float64) - y.astype(np.float64)) <= 2e-7 * np.maximum(1.0, np.abs(y))), (x, y)
             continue
+        if name.startswith("d "):
+            # gradients: dmm_mask_mix_bwd adds the workgroups' partial sums of a frame into dRb with float atomics, in
+            # arrival order (both chains run the SAME kernels; two runs of either may differ in the last bits)
+            scale = float(np.abs(y).max()) or 1.0
+            assert float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()) <= 2e-6 * scale, name
+            continue
         assert np.array_equal(x, y), (name, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
 
 
@@ -206,6 +212,8 @@ def test_matchmodel_training_call_takes_the_one_frame_function():
         assert x.shape == y.shape
         if k == 3:                                                   # cost_loss: last-ulp agreement (see assert_same)
             assert abs(float(x) - float(y)) <= 2e-7 * max(1.0, abs(float(y)))
+        elif k >= 4:                                                 # gradients: float atomics across workgroups
+            assert float(np.abs(x - y).max()) <= 2e-6 * (float(np.abs(y).max()) or 1.0)
         else:
             assert np.array_equal(x, y)
     o = oracle.match_forward(fr.proposed_mask, fr.mask_last_occurence, fr.proposed_feature, fr.template_feature,
@@ -231,7 +239,8 @@ def test_unused_outputs_send_no_gradient_tensors():
     with granular():
         ref = grads()
     got = grads()
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    for a, b in zip(got, ref):
+        assert float(np.abs(a - b).max()) <= 2e-6 * (float(np.abs(b).max()) or 1.0)
 
 
 # ------------------------------------------------------------------------------------ mix backward against float64

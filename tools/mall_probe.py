@@ -2,15 +2,18 @@
 """Go / no-go probe for serving the mix's re-read of the selected proposal planes from the Infinity Cache (VERDICT r2
 item 7).  Config-2 frames (50 x 10, 255x255 fp32), slices of G frames: cost(slice) -> solver(slice) -> mix(slice), the
 mix timed (HIP events) HOT (right behind its slice's cost + solver) and COLD (a 2 GB read in between evicts everything).
-Run once with the product library (non-temporal plane loads) and once with DMM_LIB_PATH=libdmm_cached.so (plain loads).
+Run once with the product library (non-temporal plane loads) and once with --lib libdmm_cached.so (plain loads;
+_lib.use_library() before the first load).
 Under rocprofv3 --pmc FETCH_SIZE the per-dispatch bytes of mask_mix_rows_kernel are the second witness (even dispatches
 hot, odd cold)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dmm_net_amd import ops
+from dmm_net_amd import _lib, ops
 
+if "--lib" in sys.argv:                                       # an A/B build of the library, chosen explicitly
+    _lib.use_library(sys.argv[sys.argv.index("--lib") + 1])
 dev = "cuda:0"
 B, N, M, H, W, D = 64, 50, 10, 255, 255, 512
 G = int(os.environ.get("G", "8"))
@@ -43,4 +46,4 @@ for mode, v in res.items():
     v.sort()
     med = v[len(v) // 2]
     print(f"G={G} mix {mode:4s}: median {med:7.1f} us  min {v[0]:7.1f} us  ({alg / med / 1e3:6.0f} GB/s algorithmic r+w, "
-          f"lib={os.environ.get('DMM_LIB_PATH', 'product')[-20:]})")
+          f"lib={_lib.LIB_PATH[-24:]})")
