@@ -350,10 +350,10 @@ class Runner:
     def finish(self, out):
         if self.dist is not None:
             assert self.dist.get_world_size() == self.args.gpus == out["n_gpus"]
-        if self.rank == 0:
-            print(json.dumps(out), flush=True)
         if self.dist is not None:
             self.dist.destroy_process_group()
+        if self.rank == 0:
+            emit_line(json.dumps(out))
 
 
 def quick_ms(fn, n, warm=3, dev=None):
@@ -1141,9 +1141,33 @@ def compact(out):
     return c
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """ONE JSON line on stdout, whatever the libraries under this process print: RCCL writes its version banner with C
+    stdio to fd 1 when a communicator is created (it surfaced behind the JSON line once the default run created a one-rank
+    group for config 4; every rank of an N-GPU run prints it too).  The real stdout is kept aside for the line and fd 1
+    points at stderr from here on."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
 def main():
     args = parse()
     self_launch(args)
+    own_stdout()
     R = Runner(args)
     if args.config == 3:
         out = bench_config3(R)

@@ -6,7 +6,8 @@
   <tag>_bench.json                  python bench.py                      (all extras: cpu baseline, sweep, in-run traffic)
   <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-extras
   <tag>_bench_config5.json / _config3.json     python bench.py --config 5 / 3
-  <tag>_bench_frame_loop.json / _bench_config4_1gpu.json   python bench.py --config loop / --config 4
+  <tag>_bench_frame_loop.json / _bench_config4_1gpu(_autocast).json   python bench.py --config loop / --config 4 [--autocast]
+  <tag>_bench_dropin.json           python bench.py --config dropin --steps 200   (wall vs device per call of the drop-in)
   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-extras
   <tag>_kernel_stats_single_stream.csv / _config5.csv / _config3.csv   same with --no-pipeline / --config 5 / --config 3
   <tag>_pmc_traffic.json            two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), per-kernel averages;
@@ -48,8 +49,13 @@ if not only_pmc and os.environ.get("ONLY_STATS") is None:
         last_json(run(bench + ["--config", "3"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_frame_loop.json"), "w").write(
         last_json(run(bench + ["--config", "loop"]).stdout) + "\n")
+    # config 4: the reference's precision (fp32 encoder, the default) and the bf16-autocast variant; 3 repeats of 8 steps
     open(os.path.join(out, f"{tag}_bench_config4_1gpu.json"), "w").write(
-        last_json(run(bench + ["--config", "4", "--steps", "20", "--warmup", "4"]).stdout) + "\n")
+        last_json(run(bench + ["--config", "4", "--steps", "8", "--warmup", "2"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_config4_1gpu_autocast.json"), "w").write(
+        last_json(run(bench + ["--config", "4", "--steps", "8", "--warmup", "2", "--autocast"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_dropin.json"), "w").write(
+        last_json(run(bench + ["--config", "dropin", "--steps", "200"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_train.json"), "w").write(
         last_json(run(bench + ["--config", "train", "--steps", "40", "--warmup", "6"]).stdout) + "\n")
 
