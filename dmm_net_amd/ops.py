@@ -836,8 +836,11 @@ class ForwardPlan:
         self.solver_state = solver_state
         # default: two lanes for large batches whose solver fits beside the streaming kernels (one wave per frame, exact
         # row count: M <= 16, Pp <= 64); the multi-wave solvers of wide tables hold up to 256 VGPRs per wave and only
-        # serialise with them (config 5: 2.26 ms single stream vs 2.37 ms two lanes per 256 frames)
-        auto = B >= 64 and ((M <= 16 and self.Pp <= 64) or solver_state == "f16")
+        # serialise with them (config 5, fp32 state: 2.26 ms single stream vs 2.37 ms two lanes per 256 frames)
+        # (round 5, tools/config5_probe.py: with the fp16-state solver the wide tables of config 5 run 3.05 ms per 512 frames
+        # on one stream against 3.08-3.46 on two lanes -- the solver's waves slow the CUs they land on and the statically
+        # partitioned count launch waits for its slowest CU -- so wide tables take one stream whatever the solver state)
+        auto = B >= 64 and M <= 16 and self.Pp <= 64
         self.pipeline = auto if pipeline is None else bool(pipeline)
         # time_kernels: the single-stream form issues the granular C-ABI calls (same kernels as dmm_match_forward) so
         # that HIP events can bracket the cost and mix launches; bench.py sets kernel_events = {} per timed step
