@@ -226,7 +226,8 @@ def check(rc: int, what: str):
 OPTIONS = {name: k for k, name in enumerate((
     "COST_KERNEL", "COST_TINY_FRAMES", "SOLVER_KERNEL", "FORCE_WIDE", "COSINE_KERNEL", "COST_WGS", "COST_SMALL_WGS",
     "COST_TL_WGS", "COST_XCD", "MIX_XCD", "MIX_WGS", "MIX_STEPQ", "MIX_ALIGN", "MIX_NT", "SOLVER_HELPER_MAX", "NMS_WAVE",
-    "COS_ROWS_MIN_N", "GEMM_TUNE", "PACK_VARIANT", "SMALL_FUSED", "MIX_SHARED", "MIX_SHARED_STEPS", "FEAT_BWD_FRAME"))}
+    "COS_ROWS_MIN_N", "GEMM_TUNE", "PACK_VARIANT", "SMALL_FUSED", "MIX_SHARED", "MIX_SHARED_STEPS", "FEAT_BWD_FRAME",
+    "MIX_SHARED_LOCKSTEP"))}
 
 
 def set_option(name: str, value: int):

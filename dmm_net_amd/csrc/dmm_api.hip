@@ -30,16 +30,16 @@ static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
     /* COST_XCD */ 1,          /* MIX_XCD */ 1,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
     /* MIX_ALIGN */ 128,       /* MIX_NT */ 3,             /* SOLVER_HELPER_MAX */ 512, /* NMS_WAVE */ 1,
     /* COS_ROWS_MIN_N */ 65,   /* GEMM_TUNE */ 1,          /* PACK_VARIANT */ 4,    /* SMALL_FUSED */ 1,
-    /* MIX_SHARED */ -1,       /* MIX_SHARED_STEPS */ 1,   /* FEAT_BWD_FRAME */ 1,
+    /* MIX_SHARED */ -1,       /* MIX_SHARED_STEPS */ 1,   /* FEAT_BWD_FRAME */ 1,  /* MIX_SHARED_LOCKSTEP */ 1,
 };
 static std::atomic<int> g_opts[DMM_OPT_COUNT] = {
     {kOptDefaults[0]},  {kOptDefaults[1]},  {kOptDefaults[2]},  {kOptDefaults[3]},  {kOptDefaults[4]},
     {kOptDefaults[5]},  {kOptDefaults[6]},  {kOptDefaults[7]},  {kOptDefaults[8]},  {kOptDefaults[9]},
     {kOptDefaults[10]}, {kOptDefaults[11]}, {kOptDefaults[12]}, {kOptDefaults[13]}, {kOptDefaults[14]},
     {kOptDefaults[15]}, {kOptDefaults[16]}, {kOptDefaults[17]}, {kOptDefaults[18]}, {kOptDefaults[19]},
-    {kOptDefaults[20]}, {kOptDefaults[21]}, {kOptDefaults[22]},
+    {kOptDefaults[20]}, {kOptDefaults[21]}, {kOptDefaults[22]}, {kOptDefaults[23]},
 };
-static_assert(DMM_OPT_COUNT == 23, "kOptDefaults / g_opts list every option");
+static_assert(DMM_OPT_COUNT == 24, "kOptDefaults / g_opts list every option");
 int opt(int key) { return g_opts[key].load(std::memory_order_relaxed); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -92,7 +92,7 @@ extern "C" int dmm_set_option(int option, int value) {
         case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED:
             if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD: case DMM_OPT_MIX_XCD:
-        case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: case DMM_OPT_FEAT_BWD_FRAME:
+        case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: case DMM_OPT_FEAT_BWD_FRAME: case DMM_OPT_MIX_SHARED_LOCKSTEP:
             if (value < 0 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_ALIGN: if (value != 16 && value != 32 && value != 64 && value != 128) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_NT: if (value < 0 || value > 3) return DMM_ERR_BAD_ARG; break;

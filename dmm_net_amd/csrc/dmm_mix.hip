@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
                                                                       const int32_t *__restrict__ n_valid,
                                                                       const int32_t *__restrict__ m_valid,
                                                                       TO *__restrict__ out, int64_t so_b, int64_t so_m,
-                                                                      int steps_per_wg) {
+                                                                      int steps_per_wg, int lockstep) {
     constexpr int E = 4;                                                  // pixels per lane and step (16 bytes of fp32)
     __shared__ __attribute__((aligned(16))) float w_c[DMM_MAX_PROPOSALS * MT];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
@@ -451,6 +451,9 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
 #pragma unroll
             for (int k = 0; k < E; ++k) acc[m][k] = 0.0f;
         for (int e0 = 0; e0 < cnt; e0 += kSharedLoads) {
+            // DMM_OPT_MIX_SHARED_LOCKSTEP: the four waves take the four neighbouring 1 KiB pieces of a plane; kept in step
+            // (one barrier per group of planes) they ask for the 128-byte lines their pieces share at the same time
+            if (lockstep) __syncthreads();
             float v[kSharedLoads][E];
 #pragma unroll
             for (int u = 0; u < kSharedLoads; ++u) {
@@ -513,7 +516,8 @@ static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N
     const int nt_mode = opt(DMM_OPT_MIX_NT);
 #define DMM_MIXS_LAUNCH(MT_, NT_)                                                                                       \
     hipLaunchKernelGGL((mask_mix_shared_kernel<T, TO, MT_, NT_>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb,    \
-                       masks_p, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg)
+                       masks_p, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg,               \
+                       opt(DMM_OPT_MIX_SHARED_LOCKSTEP))
 #define DMM_MIXS_PICK(MT_)                       \
     do {                                         \
         if ((nt_mode & 3) == 3) DMM_MIXS_LAUNCH(MT_, 3); \
@@ -545,7 +549,8 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           int Pp, int HW, int64_t sp_b, int64_t sp_n,
                                                                           const int32_t *__restrict__ n_valid,
                                                                           const int32_t *__restrict__ m_valid,
-                                                                          float *__restrict__ dRb, int steps_per_wg) {
+                                                                          float *__restrict__ dRb, int steps_per_wg,
+                                                                          int lockstep) {
     constexpr int E = 4;
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
@@ -641,6 +646,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
             }
         }
         for (int e0 = 0; e0 < cnt; e0 += kSharedLoads) {
+            if (lockstep) __syncthreads();                                 // see mask_mix_shared_kernel
             float v[kSharedLoads][E];
 #pragma unroll
             for (int u = 0; u < kSharedLoads; ++u) {
@@ -699,15 +705,16 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
                                      float *dRb, hipStream_t stream) {
     DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
-    // two steps per workgroup (twice the forward's): every workgroup ends with a fold through LDS and one atomic per pair --
-    // measured at B = 512, 50 x 10: 1.51 / 1.42 / 1.42 ms at 1 / 2 / 4 steps (the forward: 1.42 / 1.47 / 1.60)
-    int steps_per_wg = 2 * opt(DMM_OPT_MIX_SHARED_STEPS);
+    // four steps per workgroup (the forward: one): every workgroup clears and folds its LDS slabs and ends with one atomic per
+    // pair -- measured at B = 512, 50 x 10 with the waves in lock step: 1.281 / 1.268 ms at 2 / 4 steps (free running: 1.293 /
+    // 1.329; the forward 1.387 / 1.430 at 1 / 2)
+    int steps_per_wg = 4 * opt(DMM_OPT_MIX_SHARED_STEPS);
     if (steps_per_wg < 1) steps_per_wg = 1;
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
 #define DMM_MIXB_LAUNCH(MT_)                                                                                        \
     hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads),                    \
                        sizeof(float) * (kMixThreads / 64) * (size_t)N * MT_, stream, Rb, masks_p, dout, N, M, Pp, HW, \
-                       sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg)
+                       sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg, opt(DMM_OPT_MIX_SHARED_LOCKSTEP))
     if (M <= 8) DMM_MIXB_LAUNCH(8);
     else if (M <= 16) DMM_MIXB_LAUNCH(16);
     else DMM_MIXB_LAUNCH(32);

@@ -106,7 +106,10 @@ typedef enum dmm_option {
                                        stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
     DMM_OPT_MIX_SHARED_STEPS = 21,  /* union kernels: 4 KiB steps of every plane per workgroup (1)                         */
     DMM_OPT_FEAT_BWD_FRAME = 22,    /* dmm_feature_sim_bwd_f32: 1 one workgroup per frame (default), 0 one per feature row   */
-    DMM_OPT_COUNT = 23
+    DMM_OPT_MIX_SHARED_LOCKSTEP = 23, /* union kernels: 1 = one workgroup barrier per group of 8 planes keeps the four waves (four
+                                       neighbouring 1 KiB pieces of every plane) in step (default: the lines the pieces share are
+                                       then asked for at the same time, -2 % traffic), 0 = free-running waves                  */
+    DMM_OPT_COUNT = 24
 } dmm_option;
 DMM_API int dmm_set_option(int option, int value);
 DMM_API int dmm_get_option(int option);

@@ -23,6 +23,7 @@ ap.add_argument("--pmc", action="store_true")
 ap.add_argument("--child", action="store_true")
 ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (the backward takes twice as many 4 KiB steps per workgroup)")
 ap.add_argument("--reps", type=int, default=8)
+ap.add_argument("--lockstep", type=int, default=-1, help="--pmc: pin MIX_SHARED_LOCKSTEP for the counter passes")
 args = ap.parse_args()
 
 PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES",
@@ -35,6 +36,8 @@ PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_
 def run():
     import torch
     from dmm_net_amd import _lib, ops
+    if args.lockstep >= 0 and args.child:                            # counter passes of one setting: no A/B inside
+        _lib.set_option("MIX_SHARED_LOCKSTEP", args.lockstep)
     dev = torch.device("cuda", 0)
     B, N, M, H, W = args.frames, 50, 10, 255, 255
     g = torch.Generator(device=dev).manual_seed(7)
@@ -58,12 +61,18 @@ def run():
         b.record()
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
+    ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 10)                       # clocks up before the first figure
     for steps in [int(v) for v in args.steps.split(",")]:
-        for mode in (-1, 0):
-            with _lib.options(MIX_SHARED=mode, MIX_SHARED_STEPS=steps):
+        for lock in ((args.lockstep,) if args.lockstep >= 0 else (0, 1)):
+            with _lib.options(MIX_SHARED_STEPS=steps, MIX_SHARED_LOCKSTEP=lock):
                 t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
-            out["runs"][f"{'union' if mode else 'rows'}_steps{steps}"] = {
-                "ms": round(t, 4), "GBps": round(alg / t / 1e6, 1), "frac_of_8TBps": round(alg / t / 1e6 / 8000, 4)}
+                tf = ms(lambda: ops.mask_mix(Rb, pm, shared=True), args.reps)
+            for name, tt in (("bwd_union", t), ("fwd_union", tf)):
+                out["runs"][f"{name}_steps{steps}_lockstep{lock}"] = {
+                    "ms": round(tt, 4), "GBps": round(alg / tt / 1e6, 1), "frac_of_8TBps": round(alg / tt / 1e6 / 8000, 4)}
+    with _lib.options(MIX_SHARED=0):
+        t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 3)
+    out["runs"]["bwd_rows"] = {"ms": round(t, 4), "frac_of_8TBps": round(alg / t / 1e6 / 8000, 4)}
     print(json.dumps(out))
 
 
@@ -79,21 +88,22 @@ if args.pmc and not args.child:
         shutil.rmtree(d, ignore_errors=True)
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--",
                             sys.executable, os.path.abspath(__file__), "--child", "--frames", str(args.frames), "--reps", "3",
-                            "--steps", args.steps.split(",")[0]], cwd="/tmp", env=env, capture_output=True, text=True)
+                            "--steps", args.steps.split(",")[0], "--lockstep", str(args.lockstep)], cwd="/tmp", env=env,
+                           capture_output=True, text=True)
         if r.returncode != 0:
             print("pass failed:", ctrs, r.stderr[-400:])
             continue
         for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"].split("(")[0]
-                if "mask_mix_bwd" not in name:
+                if "mask_mix_bwd" not in name and "mask_mix_shared" not in name:
                     continue
                 name = name.replace("void ", "")
                 res.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                if "mask_mix_bwd" in name:
+                if "mask_mix_bwd" in name or "mask_mix_shared" in name:
                     res.setdefault(name, {}).setdefault("duration_us_profiled", []).append(
                         (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
     for name, cs in res.items():
