@@ -30,7 +30,7 @@ static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
     /* COST_XCD */ 1,          /* MIX_XCD */ 1,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
     /* MIX_ALIGN */ 128,       /* MIX_NT */ 3,             /* SOLVER_HELPER_MAX */ 512, /* NMS_WAVE */ 1,
     /* COS_ROWS_MIN_N */ 65,   /* GEMM_TUNE */ 1,          /* PACK_VARIANT */ 4,    /* SMALL_FUSED */ 1,
-    /* MIX_SHARED */ -1,       /* MIX_SHARED_STEPS */ 1,   /* FEAT_BWD_FRAME */ 1,  /* MIX_SHARED_LOCKSTEP */ 1,
+    /* MIX_SHARED */ -1,       /* MIX_SHARED_STEPS */ 1,   /* FEAT_BWD_FRAME */ -1, /* MIX_SHARED_LOCKSTEP */ 1,
 };
 static std::atomic<int> g_opts[DMM_OPT_COUNT] = {
     {kOptDefaults[0]},  {kOptDefaults[1]},  {kOptDefaults[2]},  {kOptDefaults[3]},  {kOptDefaults[4]},
@@ -89,10 +89,10 @@ extern "C" int dmm_abi_version(void) { return DMM_ABI_VERSION; }
 extern "C" int dmm_set_option(int option, int value) {
     if (option < 0 || option >= DMM_OPT_COUNT) return DMM_ERR_BAD_ARG;
     switch (option) {                                            // ranges: a bad value must not reach a launch computation
-        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED:
+        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED: case DMM_OPT_FEAT_BWD_FRAME:
             if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD: case DMM_OPT_MIX_XCD:
-        case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: case DMM_OPT_FEAT_BWD_FRAME: case DMM_OPT_MIX_SHARED_LOCKSTEP:
+        case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: case DMM_OPT_MIX_SHARED_LOCKSTEP:
             if (value < 0 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_ALIGN: if (value != 16 && value != 32 && value != 64 && value != 128) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_NT: if (value < 0 || value > 3) return DMM_ERR_BAD_ARG; break;

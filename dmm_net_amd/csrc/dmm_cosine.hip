@@ -792,7 +792,10 @@ extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, con
     // a whole number of waves up to one workgroup; anything else: the block-per-row form
     const int nw = D / 64;
     const size_t frame_lds = sizeof(float) * ((size_t)M * N + (size_t)nw * 2 * (N + M) + (size_t)(N + M));
-    if (dmm::opt(DMM_OPT_FEAT_BWD_FRAME) != 0 && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
+    // (-1 = by batch size: ONE workgroup per frame is a 46 us chain when there is one frame -- 55 row workgroups finish in a
+    // fraction of that -- and 5x the row form's throughput once every CU has a frame: the crossover sits near 40 frames)
+    const int frame_mode = dmm::opt(DMM_OPT_FEAT_BWD_FRAME);
+    if ((frame_mode == 1 || (frame_mode < 0 && B > 32)) && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
         frame_lds <= 60 * 1024) {
 #define DMM_FSB(MT_)                                                                                                     \
     hipLaunchKernelGGL((dmm::feature_sim_bwd_frame_kernel<MT_>), dim3(B), dim3(D), frame_lds, (hipStream_t)stream, dsim, \

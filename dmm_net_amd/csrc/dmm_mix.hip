@@ -709,6 +709,9 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
     // pair -- measured at B = 512, 50 x 10 with the waves in lock step: 1.281 / 1.268 ms at 2 / 4 steps (free running: 1.293 /
     // 1.329; the forward 1.387 / 1.430 at 1 / 2)
     int steps_per_wg = 4 * opt(DMM_OPT_MIX_SHARED_STEPS);
+    // ... while that still leaves ~1024 workgroups: a one-frame call (112 steps at 255 x 448) took 64 us as 28 workgroups
+    const int64_t fill = ((int64_t)B * nsteps + 1023) / 1024;
+    if (steps_per_wg > fill) steps_per_wg = (int)fill;
     if (steps_per_wg < 1) steps_per_wg = 1;
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
 #define DMM_MIXB_LAUNCH(MT_)                                                                                        \
