@@ -483,6 +483,7 @@ extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, f
 }
 
 namespace dmm {
+constexpr int kFeatBwdRowsMaxB = 0;      // the per-row form up to this many frames (0: never -- see dmm_feature_sim_bwd_f32)
 // dmm_feature_normalize_f32 on two row sets with one launch (same kernel body: bit identical)
 int feature_normalize2_launch(const float *in_a, int64_t rows_a, float *out_a, float *norms_a, const float *in_b,
                               int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream) {
@@ -714,21 +715,41 @@ __global__ __launch_bounds__(1024) void feature_sim_bwd_frame_kernel(
         ght[m] = 0.0f;
     }
     float *pw = part + wave * 2 * (N + M);
-    for (int n = 0; n < Nb; ++n) {
-        const float pnv = pn_b[(int64_t)n * D + d];
-        float ghp = 0.0f;
+    // kFsbUn proposal rows per trip: their loads are issued together (a rolled loop paid one L2 round trip per row -- with ONE
+    // frame in flight that chain was the whole 46 us of the launch) and their 2 x kFsbUn wave sums run interleaved
+    constexpr int kFsbUn = 8;
+    for (int n0 = 0; n0 < Nb; n0 += kFsbUn) {
+        float pnv[kFsbUn], xp[kFsbUn], red[2 * kFsbUn];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (m < Mb) {
-                const float c = coef[m * N + n];
-                ghp = __builtin_fmaf(c, tnr[m], ghp);
-                ght[m] = __builtin_fmaf(c, pnv, ght[m]);
-            }
+        for (int u = 0; u < kFsbUn; ++u) {
+            const int n = n0 + u < Nb ? n0 + u : Nb - 1;
+            pnv[u] = pn_b[(int64_t)n * D + d];
+            xp[u] = xp_b[(int64_t)n * D + d];
         }
-        const float xp = xp_b[(int64_t)n * D + d];
-        gp_b[(int64_t)n * D + d] = ghp;                     // raw g_hat; fixed up below by the same thread
-        const float sd = wave_sum(ghp * xp), sq = wave_sum(xp * xp);
-        if (lane == 0) { pw[n] = sd; pw[N + M + n] = sq; }
+#pragma unroll
+        for (int u = 0; u < kFsbUn; ++u) {
+            const int n = n0 + u < Nb ? n0 + u : Nb - 1;
+            float ghp = 0.0f;
+            if (n0 + u < Nb) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (m < Mb) {
+                        const float c = coef[m * N + n];
+                        ghp = __builtin_fmaf(c, tnr[m], ghp);
+                        ght[m] = __builtin_fmaf(c, pnv[u], ght[m]);
+                    }
+                }
+                gp_b[(int64_t)n * D + d] = ghp;             // raw g_hat; fixed up below by the same thread
+            }
+            red[2 * u] = ghp * xp[u];
+            red[2 * u + 1] = xp[u] * xp[u];
+        }
+        wave_sum_rows<2 * kFsbUn>(red);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < kFsbUn; ++u)
+                if (n0 + u < Nb) { pw[n0 + u] = red[2 * u]; pw[N + M + n0 + u] = red[2 * u + 1]; }
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -757,10 +778,20 @@ __global__ __launch_bounds__(1024) void feature_sim_bwd_frame_kernel(
         corr[r] = cr;
     }
     __syncthreads();
-    for (int n = 0; n < N; ++n) {
-        float g = 0.0f;
-        if (n < Nb) g = gp_b[(int64_t)n * D + d] / norm_p[(int64_t)b * N + n] - xp_b[(int64_t)n * D + d] * corr[n];
-        gp_b[(int64_t)n * D + d] = g;
+    for (int n0 = 0; n0 < N; n0 += kFsbUn) {                 // the same batching for the fix-up pass
+        float gh[kFsbUn], xp[kFsbUn], nr[kFsbUn];
+#pragma unroll
+        for (int u = 0; u < kFsbUn; ++u) {
+            const int n = n0 + u < Nb ? n0 + u : Nb - 1;
+            gh[u] = gp_b[(int64_t)n * D + d];
+            xp[u] = xp_b[(int64_t)n * D + d];
+            nr[u] = norm_p[(int64_t)b * N + n];
+        }
+#pragma unroll
+        for (int u = 0; u < kFsbUn; ++u) {
+            const int n = n0 + u;
+            if (n < N) gp_b[(int64_t)n * D + d] = n < Nb ? gh[u] / nr[u] - xp[u] * corr[n] : 0.0f;
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -792,10 +823,11 @@ extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, con
     // a whole number of waves up to one workgroup; anything else: the block-per-row form
     const int nw = D / 64;
     const size_t frame_lds = sizeof(float) * ((size_t)M * N + (size_t)nw * 2 * (N + M) + (size_t)(N + M));
-    // (-1 = by batch size: ONE workgroup per frame is a 46 us chain when there is one frame -- 55 row workgroups finish in a
-    // fraction of that -- and 5x the row form's throughput once every CU has a frame: the crossover sits near 40 frames)
+    // (-1 = by batch size.  Measured at ONE frame, 50 x 5, D = 512: the per-row form 43 us, the per-frame form 46 us while its
+    // row loop was rolled (one L2 round trip per proposal row), with the rows batched eight at a time see profiles/r05; at 512
+    // frames the per-frame form is 5x the per-row form's throughput.  kFeatBwdRowsMaxB = 0: the per-frame form at every size)
     const int frame_mode = dmm::opt(DMM_OPT_FEAT_BWD_FRAME);
-    if ((frame_mode == 1 || (frame_mode < 0 && B > 32)) && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
+    if ((frame_mode == 1 || (frame_mode < 0 && B > dmm::kFeatBwdRowsMaxB)) && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
         frame_lds <= 60 * 1024) {
 #define DMM_FSB(MT_)                                                                                                     \
     hipLaunchKernelGGL((dmm::feature_sim_bwd_frame_kernel<MT_>), dim3(B), dim3(D), frame_lds, (hipStream_t)stream, dsim, \
