@@ -313,6 +313,6 @@ def test_two_devices_two_threads_like_nn_dataparallel():
     for k in range(2):
         for i, (a, b) in enumerate(zip(got[k], alone[k])):
             if i in (7, 8):                                       # gradients: float atomics across workgroups (arrival order)
-                assert float(np.abs(a - b).max()) <= 2e-6 * (float(np.abs(b).max()) or 1.0), (k, i)
+                assert float(np.abs(a - b).max()) <= 1e-5 * (float(np.abs(b).max()) or 1.0), (k, i)
             else:
                 assert np.array_equal(a, b), (k, i)
