@@ -283,13 +283,19 @@ def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
     from conftest import record_achieved
     pm, dout, Rb, nv, mv, want = _mix_bwd_case(B, N, M, H, W, seed=N * 31 + M, dtype=dtype, ragged=ragged)
     scale = float(want.abs().max()) or 1.0
-    for mode in (-1, 0):
-        with _lib.options(MIX_SHARED=mode):
+    for mode, lock in ((-1, 1), (-1, 0), (0, 1)):                     # union kernel, waves in lock step / free running; row kernel
+        with _lib.options(MIX_SHARED=mode, MIX_SHARED_LOCKSTEP=lock):
             got = ops.mask_mix_bwd(Rb, pm, dout, nv, mv).double()
+            if mode == -1 and M <= 32 and N <= 256:
+                # the forward union kernel under the same setting: bit for bit the row kernel's result
+                fwd = ops.mask_mix(Rb, pm, nv, mv, shared=True)
+                with _lib.options(MIX_SHARED=0):
+                    fwd_rows = ops.mask_mix(Rb, pm, nv, mv, shared=False)
+                assert torch.equal(fwd, fwd_rows), (mode, lock)
         assert bool((got[Rb == 0] == 0).all())
         err = float((got - want).abs().max()) / scale
-        assert err <= 2e-5, (mode, err)
-        if mode == -1:
+        assert err <= 2e-5, (mode, lock, err)
+        if mode == -1 and lock == 1:
             record_achieved(f"mix_bwd/{B}x{N}x{M}x{H}x{W}_{str(dtype)[6:]}/rel_err", err)
     fp = ops.FramePlanes([pm[b, :(int(nv[b]) if nv is not None else N)] for b in range(B)])
     t = ops.mask_mix_bwd(Rb, fp, dout, nv if nv is not None else None, mv).double()
