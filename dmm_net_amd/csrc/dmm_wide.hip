@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kWideSolverThreads) void relax_match_wide_kernel(
 // LDS: the iterate X (column / row sums) and the products X * C (cost norm) -- two M x Pp tables.  Same operations in the
 // same order as relax_match_wide_kernel (element-wise steps are order free; the sums are the same torder:: routines on the
 // same values), so the results stay bit identical.  Tables of more than 12288 entries keep the kernel above.
-// 512 threads per frame: 8 waves = 2 per SIMD = 256 VGPRs (1024 threads would cap at 128).  Measured (tools/wide_breakdown.py,
+// 512 threads per frame: 8 waves = 2 per SIMD = 256 VGPRs (1024 threads would cap at 128).  Measured (round 4, LABLOG;
 // one frame, 20 x 5): 50 x 40 solver 0.49 ms, 300 x 40 1.29 ms (L2-resident form: 0.95 / 2.5): the K = 24 instantiation still
 // spills ~150 registers inside the sweep (~100 registers of fixed cost from the inlined ATen-order sums + ~13 per element).
 // ---------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ Counterpart of ``dmm/modules/vision.py:6-38`` (torchvision ``ResNet`` subclasses
 The convolutions are plain ``torch.nn`` modules: on ROCm they run on MIOpen (the only MFMA work on the whole path
 -- the matching kernels are bandwidth / latency bound and never touch the matrix cores).  For inference
 ``fold_batchnorm`` + ``GraphedEncoder`` (bf16 autocast, NCHW) is the fast setting on MI355X with the MIOpen of this
-image (ResNet-50, 8 frames of 255x255: 3.6 ms eager channels_last bf16 -> 2.5 ms; ``tools/encoder_timing.py``).  torchvision is not a dependency: the body is
+image (ResNet-50, 8 frames of 255x255: 3.6 ms eager channels_last bf16 -> 2.5 ms; round 1, LABLOG).  torchvision is not a dependency: the body is
 written out here with torchvision's parameter names (``conv1, bn1, layer1..4.N.convK/bnK/downsample.0/1, fc``)
 so reference checkpoints (``encoder`` keys, ``dmm/utils/utils.py:57-111``) load with ``load_state_dict``.
 
@@ -280,7 +280,7 @@ class GraphedEncoder:
     removes the per-launch host cost.  The encoder must be in ``eval()`` mode (BatchNorm running statistics; nothing
     in the graph may depend on host state).  Outputs are views of the graph's static buffers: consume (or clone) them
     before the next call.  ``torch.backends.cudnn.benchmark = True`` before the first call lets MIOpen search its
-    solvers during the warm-up (ResNet-50, 8 frames: 36 s once, 2.21 -> 2.08 ms per replay; tools/encoder_find_mode.py).  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
+    solvers during the warm-up (ResNet-50, 8 frames: 36 s once, 2.21 -> 2.08 ms per replay; round 2, LABLOG).  ``autocast_dtype=torch.bfloat16`` captures the bf16 path of BASELINE config 3.
     """
 
     static_outputs = True      # outputs alias the graph's buffers (video.FrameLoop clones what it keeps across frames)
