@@ -50,6 +50,35 @@ def test_argument_validation_without_gpu():
     assert L.dmm_relax_solve_f32(one, 1, 3, 257, None, None, 1, 1, 0.1, one, one, None, one, None) == 2
 
 
+def test_training_entries_validate_their_arguments_without_gpu():
+    """(5d) / (5e) / (1e): workspace sizes are positive and grow with the batch, null pointers / negative sizes answer
+    DMM_ERR_BAD_ARG, tables outside the fast kernels' envelope answer DMM_ERR_UNSUPPORTED (the caller then takes the granular
+    entries) -- all before anything touches the device."""
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.load()
+    assert 0 < L.dmm_match_train_forward_workspace_bytes(1, 50, 5, 512) < L.dmm_match_train_forward_workspace_bytes(4, 50, 5, 512)
+    assert L.dmm_match_train_forward_workspace_bytes(0, 50, 5, 512) == 0
+    assert L.dmm_match_train_backward_workspace_bytes(1, 50, 5, 512, 10, 5) > 4 * (50 + 5) * 512
+    one = ctypes.c_void_p(8)
+    base = lambda B, N, M: (one, one, one, 0, one, one, one, B, N, M, 64, 512, 3200, 64, 320, 64, 320, 64, None, None, 0.3,
+                            10, 5, 0.1, 0, one, one, one, one, one, one, one, one, one, one, 1 << 30, None)
+    assert L.dmm_match_train_forward(*base(-1, 50, 5)) == 1
+    assert L.dmm_match_train_forward(*base(0, 50, 5)) == 0                       # nothing to do
+    assert L.dmm_match_train_forward(*base(1, 0, 5)) == 1
+    assert L.dmm_match_train_forward(*base(1, 50, 33)) == 2                      # more than 32 templates
+    assert L.dmm_match_train_forward(*base(1, 300, 5)) == 2                      # more than 256 solver columns
+    args = list(base(1, 50, 5))
+    args[0] = None
+    assert L.dmm_match_train_forward(*args) == 1
+    args = list(base(1, 50, 5))
+    args[28] = None                                                              # cost_loss missing although targets are given
+    assert L.dmm_match_train_forward(*args) == 1
+    assert L.dmm_matching_loss_f32(None, None, None, None, 2, 50, 5, None, None, None, None, None) == 1
+    assert L.dmm_matching_loss_f32(one, one, one, one, 2, 9000, 5, None, None, one, one, None) == 2
+    assert L.dmm_launch_count() >= 0
+
+
 def test_product_does_not_import_oracle():
     """The product package must never reach into oracle/ (CPU fallback would void parity)."""
     pkg = os.path.join(ROOT, "dmm_net_amd")

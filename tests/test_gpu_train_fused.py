@@ -95,7 +95,9 @@ def assert_same(a, b):
                                          (2, 30, 4, 20, 20, 96),       # D neither takes: normalise + cosine
                                          (2, 3, 5, 16, 16, 512),       # P <= O: the padded solver width
                                          (1, 1, 1, 9, 9, 64),          # one proposal, one template
-                                         (2, 130, 6, 20, 24, 512)])    # more than one wave of columns
+                                         (2, 130, 6, 20, 24, 512),     # more than one wave of columns
+                                         (2, 50, 10, 255, 255, 512),   # BASELINE configs[1]'s frame at full size
+                                         (1, 50, 5, 255, 448, 512)])   # the product's frame (bench.py --config dropin)
 def test_fused_training_call_equals_the_granular_chain_bit_for_bit(B, N, M, H, W, D):
     d = batch(B, N, M, H, W, D, seed=300 + N + M)
     with granular():
