@@ -154,3 +154,30 @@ def refined_planes(seed: int, O: int, H: int, W: int) -> np.ndarray:
     outs[:, : H // 2] = np.round(outs[:, : H // 2] * 4) / 4
     outs[:, :, : W // 3] *= np.float32(0.4)
     return outs
+
+
+# ---- seeded inputs of the matching-loss fixture G21 (tests/golden/gen_golden.py g21 and the tests regenerate them) ----------
+MATCH_LOSS_CASES = [(8, 3, 16, 16, "random"), (50, 10, 24, 24, "random"), (3, 5, 8, 8, "random"), (6, 4, 8, 8, "zeros"),
+                    (6, 4, 8, 8, "duplicates"), (1, 1, 4, 4, "random"), (40, 20, 12, 12, "random"), (5, 5, 6, 6, "one_target")]
+
+
+def match_loss_case(k: int):
+    """-> (proposals [N,H,W] fp32, targets [M,H,W] 0/1 fp32, similarity table [M,N]) of MATCH_LOSS_CASES[k]: inputs of
+    compute_matching_loss chosen for their ties (empty masks: every IoU 0; duplicate planes: tied columns and rows; one live
+    target plane)."""
+    N, M, H, W, kind = MATCH_LOSS_CASES[k]
+    rng = np.random.default_rng(2100 + k)
+    P = rng.random((N, H, W)).astype(np.float32)
+    Tg = (rng.random((M, H, W)) > 0.5).astype(np.float32)
+    if kind == "zeros":
+        P[:] = 0
+        Tg[:] = 0
+    elif kind == "duplicates":
+        base = (rng.random((H, W)) > 0.5).astype(np.float32)
+        P[:] = base
+        Tg[:] = base
+        Tg[2] = 0
+    elif kind == "one_target":
+        Tg[1:] = 0
+    sim = rng.standard_normal((M, N)).astype(np.float32)
+    return P, Tg, sim

@@ -35,6 +35,7 @@ are data only -- no reference source text is stored.  Groups follow SURVEY.md se
      IoU > thresh suppresses as in nms.cu, stable order for ties): duplicates, exact-threshold pairs, score ties.
   G16 encoder heads first hand: the reference's FeatureExtractorBase (base.py:18-69, plain torch.nn behind the stubs)
      + the head calls of model_encoder.py:136-146 on seeded body features, train and eval mode, all parameters.
+  G21 the tail of compute_matching_loss first hand on tie-heavy inputs (empty masks, duplicate planes, one live target).
   G14 algo 'hun' through the imported MatchModel (hungarian_matching with its hard-coded .cuda() patched to a
      no-op on this CPU-only box): outputs + gradients of cost_loss (the only differentiable term under 'hun').
 """
@@ -1110,8 +1111,30 @@ def g20():
     save("g20_wide_gradients", d)
 
 
+from dmm_net_amd.synth import MATCH_LOSS_CASES, match_loss_case  # noqa: E402  (seeded inputs shared with the tests)
+
+
+def g21():
+    """The tail of compute_matching_loss FIRST HAND (match_helper.py:30-49, imported): gt IoU table, the greedy one-hot of
+    relax_matching(-gt_iou, 0, 0, 0) and the mse, on inputs chosen for their ties -- pins the first-argmin rules of the
+    device's one-launch form (dmm_matching_loss_f32) against the reference itself, not only against the oracle."""
+    from dmm.utils.match_helper import compute_iou_binary_mask_2D, compute_matching_loss
+    d = {}
+    for k, (N, M, H, W, kind) in enumerate(MATCH_LOSS_CASES):
+        P, Tg, sim = match_loss_case(k)
+        loss = compute_matching_loss(T(P), T(Tg), T(sim), {})
+        pe = (T(P) > 0.5).view(1, N, -1).expand(M, -1, -1).contiguous().view(M * N, -1)
+        te = T(Tg).view(M, 1, -1).expand(-1, N, -1).contiguous().view(M * N, -1)
+        gt_iou = compute_iou_binary_mask_2D(pe, te).view(M, N)
+        gt = relax_matching(-gt_iou, max_iter=0, proj_iter=0, lr=0)[0]
+        d.update(flat(f"c{k}", dict(shape=np.array([N, M, H, W], np.int32), loss=np.float32(loss.item()),
+                                    gt_iou=gt_iou.numpy(), gt_matched=gt.numpy())))
+    d["n"] = np.int32(len(MATCH_LOSS_CASES))
+    save("g21_matching_loss", d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
-                             "g15", "g16", "g17", "g19", "g20"]     # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
+                             "g15", "g16", "g17", "g19", "g20", "g21"]   # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
     for w in which:
         globals()[w]()

@@ -324,3 +324,23 @@ def test_ragged_frames_get_the_similarity_in_the_order_of_their_own_proposal_cou
         want = oracle.cosine(fr.template_feature[:counts_m[b]], fr.proposed_feature[:counts_n[b]])
         assert np.array_equal(cos[b, :counts_m[b], :counts_n[b]], want), (b, counts_n[b])
         assert not cos[b, :, counts_n[b]:].any()
+
+
+def test_matching_loss_kernel_against_the_reference_fixture_g21():
+    """dmm_matching_loss_f32 against the reference's own compute_matching_loss tail (fixture G21, first hand): the one-hot
+    bit for bit -- empty masks (every argmin a tie), duplicate planes, one live target -- and the loss to the last ulps."""
+    from conftest import golden
+    g = golden("g21_matching_loss")
+    L = _lib.load()
+    for k in range(int(g["n"])):
+        P, Tg, sim = synth.match_loss_case(k)
+        N, M = P.shape[0], Tg.shape[0]
+        (gi, ap, at), (gi2, at2) = ops.iou_counts_dual(dev(P)[None], dev(Tg)[None], dev(Tg)[None])
+        gt = torch.empty((1, M, N), dtype=torch.float32, device=DEV)
+        loss = torch.empty((1,), dtype=torch.float32, device=DEV)
+        sim_d = dev(sim)
+        assert L.dmm_matching_loss_f32(gi2.data_ptr(), ap.data_ptr(), at2.data_ptr(), sim_d.data_ptr(), 1, N, M, None, None,
+                                       gt.data_ptr(), loss.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        assert np.array_equal(gt[0].cpu().numpy(), g[f"c{k}/gt_matched"]), k
+        want = float(g[f"c{k}/loss"])
+        assert abs(float(loss[0]) - want) <= 2e-7 * max(1.0, abs(want)), (k, float(loss[0]), want)

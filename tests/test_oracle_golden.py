@@ -336,3 +336,16 @@ def test_torch_restatement_for_the_cpu_baseline_agrees_with_the_oracle():
             assert np.abs(r["match_score"].numpy() - o["match_score"]).max() <= 1e-6
             assert np.abs(r["det_score"].numpy() - o["det_score"]).max() <= 1e-6
             assert np.abs(r["full_outmask"].numpy() - o["full_outmask"]).max() <= 1e-5
+
+
+def test_g21_matching_loss_tail_first_hand():
+    """The oracle's compute_matching_loss tail against the reference's own (G21: gt IoU, the greedy one-hot incl. its
+    first-argmin rules on empty masks / duplicate planes / one live target, and the mse), bit for bit."""
+    g = golden("g21_matching_loss")
+    for k in range(int(g["n"])):
+        P, Tg, sim = synth.match_loss_case(k)
+        assert list(g[f"c{k}/shape"]) == [P.shape[0], Tg.shape[0], P.shape[1], P.shape[2]]
+        loss, gi, go = oracle.matching_loss(P, Tg, sim)
+        assert np.array_equal(gi, g[f"c{k}/gt_iou"]), k
+        assert np.array_equal(go, g[f"c{k}/gt_matched"]), k
+        assert abs(loss - float(g[f"c{k}/loss"])) <= 1e-7 * max(1.0, abs(loss)), (k, loss, float(g[f"c{k}/loss"]))
