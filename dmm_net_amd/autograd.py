@@ -190,6 +190,29 @@ def frame_fused_ok(pm, tm) -> bool:
             and not pm.requires_grad and _lib.get_option("FORCE_WIDE") != 1)
 
 
+class _RaggedPadFn(torch.autograd.Function):
+    """Per-video blocks [P_b, D] -> [B, P_max, D] by ONE launch (``ops.ragged_pad``), differentiable: the gradient of a
+    block is the view ``g[b, :P_b]`` of the batch's gradient -- no kernel.  (The trainer's batching step used to be a
+    zero fill + one in-place copy per video, each with a CopySlices node whose backward is a clone + fill + copy: ~35
+    tensor-op kernels around the 10 of the layer itself for 4 videos, round-5 timeline of ``DMM_Model.forward``.)"""
+
+    @staticmethod
+    def forward(ctx, counts, P_max, *blocks):
+        ctx.rows = [int(b.shape[0]) for b in blocks]
+        return ops.ragged_pad(list(blocks), int(P_max), counts)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g[b, :p] for b, p in enumerate(ctx.rows))
+
+
+def ragged_pad(blocks, P_max, counts):
+    """``ops.ragged_pad`` with a gradient path to the blocks that ask for one."""
+    if torch.is_grad_enabled() and any(b.requires_grad for b in blocks):
+        return _RaggedPadFn.apply(counts, int(P_max), *blocks)
+    return ops.ragged_pad(list(blocks), int(P_max), counts)
+
+
 def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
                         proj_iter, lr, is_test, counts=None):
     """B frames through the layer with autograd.  ``tf`` is [B,O,D] or, for several template-feature entries,

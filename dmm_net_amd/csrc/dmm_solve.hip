@@ -111,15 +111,11 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
 constexpr int kMaxTapeOuter = 1024;
 
 template <int MT, int NG, bool EXACT>
-__global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
+__device__ __forceinline__ void relax_match_bwd_body(
     const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
     const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
-    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
-    __shared__ float red_buf[2 * NG * (MT + 1)];
-    __shared__ float xbuf[MT * 64 * NG];
-    __shared__ float rsbuf[MT + 1];
-    __shared__ int sweeps_s[kMaxTapeOuter];
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws, float *red_buf, float *xbuf, float *rsbuf, int *sweeps_s) {
     const int b = blockIdx.x;
     const int col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
@@ -253,6 +249,52 @@ __global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
         for (int i = 0; i < Mb; ++i) dsim_b[(int64_t)i * N + col] = 0.0f;
 }
 
+template <int MT, int NG, bool EXACT>
+__global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
+    const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
+    const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
+    __shared__ float red_buf[2 * NG * (MT + 1)];
+    __shared__ float xbuf[MT * 64 * NG];
+    __shared__ float rsbuf[MT + 1];
+    __shared__ int sweeps_s[kMaxTapeOuter];
+    relax_match_bwd_body<MT, NG, EXACT>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in, dsim_out,
+                                        tape_ws, red_buf, xbuf, rsbuf, sweeps_s);
+}
+
+// Ragged template counts (DMM_Model's batches carry m_valid; usually every video has all of its templates): like the
+// forward's relax_match_ragged_kernel, the one wave of a frame runs the EXACT-row-count body of ITS frame.  The guarded
+// MT = 8 instantiation carried 8 rows and a row guard on every element of every sweep, forward re-run and reverse walk:
+// 284 us for the backward of 4 videos x 5 templates at 10 x 5 against 57 us for one exact 5-row frame (round 5,
+// tools/dropin_trace.py model).
+template <int MTMAX>
+__global__ __launch_bounds__(64) void relax_match_bwd_ragged_kernel(
+    const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
+    const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
+    __shared__ float red_buf[2 * (MTMAX + 1)];
+    __shared__ float xbuf[MTMAX * 64];
+    __shared__ float rsbuf[MTMAX + 1];
+    __shared__ int sweeps_s[kMaxTapeOuter];
+    const int Mb = m_valid ? m_valid[blockIdx.x] : M;
+#define DMM_BODY(K)                                                                                                       \
+    case K:                                                                                                               \
+        if constexpr (K <= MTMAX)                                                                                         \
+            relax_match_bwd_body<K, 1, true>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in, \
+                                             dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s);                          \
+        break;
+    switch (Mb) {
+        DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
+        default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
+            relax_match_bwd_body<1, 1, false>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in,
+                                              dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s);
+            break;
+    }
+#undef DMM_BODY
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, const int32_t *area_p,
@@ -373,6 +415,11 @@ extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, i
     if (!workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
     const bool exact_ok = (m_valid == nullptr);
     uint2 *tape = (uint2 *)workspace;
+    if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
+        hipLaunchKernelGGL((dmm::relax_match_bwd_ragged_kernel<8>), dim3(B), dim3(64), 0, (hipStream_t)stream, sim, score_p, N, M,
+                           n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out, tape);
+        return dmm::check_launch();
+    }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                       \
     hipLaunchKernelGGL((dmm::relax_match_bwd_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
                        sim, score_p, N, M, n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out,  \

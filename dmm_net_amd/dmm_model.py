@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .autograd import match_layer_batched
+from .autograd import match_layer_batched, ragged_pad
 from .match_model import MatchModel
 
 
@@ -74,11 +74,12 @@ class DMM_Model(nn.Module):
                 "get {} {}".format(prop_m[b].shape[-2:], mask_last_occurence[b].shape[-2:])
             assert prop_feat[b].shape[0] == P, "get {} {}".format(P, prop_feat[b].shape[0])
         n_valid = _lib.small_to_device([int(p.shape[0]) for p in prop_m], torch.int32, dev)
-        if dev.type == "cuda" and not any(t.requires_grad for t in prop_feat):
-            # inference: the per-video blocks are stacked by one launch each (a zero fill + one copy per video before)
+        if dev.type == "cuda":
+            # the per-video blocks are stacked by one launch each (a zero fill + one copy per video before); with a
+            # gradient path for the feature rows (the scores carry none: the layer returns no score gradient)
             from . import ops
-            pf = ops.ragged_pad([f.float() for f in prop_feat], Pmax, n_valid)
-            sc = ops.ragged_pad([s_.float().reshape(-1, 1) for s_ in prop_score], Pmax, n_valid).view(B, Pmax)
+            pf = ragged_pad([f.float() for f in prop_feat], Pmax, n_valid)
+            sc = ops.ragged_pad([s_.detach().float().reshape(-1, 1) for s_ in prop_score], Pmax, n_valid).view(B, Pmax)
         else:
             pf = prop_feat[0].new_zeros((B, Pmax, D))
             sc = mask_last_occurence.new_zeros((B, Pmax))
@@ -221,5 +222,6 @@ class DMM_Model(nn.Module):
         else:
             full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                            n_tplt, targets, skip, row_scale)
-        match_loss = [prop_feat[b].sum() * 0 if skip[b] else loss[b] for b in range(B)]      # :121
+        per_video = loss.unbind(0) if torch.is_tensor(loss) else loss        # (one stack in backward, not B x zeros + copy)
+        match_loss = [prop_feat[b].sum() * 0 if skip[b] else per_video[b] for b in range(B)]      # :121
         return full, tplt_dict, match_loss, self._out_mask_last(full, mask_last_occurence, skip)
