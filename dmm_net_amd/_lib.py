@@ -282,6 +282,32 @@ def small_to_device(values, dtype, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def small_to_device_many(specs, device):
+    """Several short host lists in ONE pinned staging buffer and ONE copy: ``specs`` = [(values, torch dtype), ...] ->
+    one device tensor per entry (views of one allocation, each 8-byte aligned).  The per-video driver hands five such
+    tables to the layer per call (proposal / template counts, three pointer tables): five pinned allocations and five
+    copies were ~70 us of host time per call (round 5, ``tools/dropin_trace.py model cprofile``)."""
+    import numpy as np
+    import torch
+    np_of = {torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32}
+    parts, spans, off = [], [], 0
+    for values, dtype in specs:
+        a = np.asarray(values, dtype=np_of[dtype])
+        nbytes = a.size * a.itemsize
+        pad = (-nbytes) % 8
+        parts.append(a.view(np.uint8))
+        if pad:
+            parts.append(np.zeros(pad, dtype=np.uint8))
+        spans.append((off, nbytes, dtype))
+        off += nbytes + pad
+    host = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8))
+    if torch.device(device).type == "cuda":
+        buf = host.pin_memory().to(device, non_blocking=True)
+    else:
+        buf = host.to(device)
+    return [buf[o:o + n].view(dt) for (o, n, dt) in spans]
+
+
 _NULL_CTX = None
 
 

@@ -197,20 +197,20 @@ class _RaggedPadFn(torch.autograd.Function):
     tensor-op kernels around the 10 of the layer itself for 4 videos, round-5 timeline of ``DMM_Model.forward``.)"""
 
     @staticmethod
-    def forward(ctx, counts, P_max, *blocks):
+    def forward(ctx, counts, P_max, table, *blocks):
         ctx.rows = [int(b.shape[0]) for b in blocks]
-        return ops.ragged_pad(list(blocks), int(P_max), counts)
+        return ops.ragged_pad(list(blocks), int(P_max), counts, table)
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None) + tuple(g[b, :p] for b, p in enumerate(ctx.rows))
+        return (None, None, None) + tuple(g[b, :p] for b, p in enumerate(ctx.rows))
 
 
-def ragged_pad(blocks, P_max, counts):
-    """``ops.ragged_pad`` with a gradient path to the blocks that ask for one."""
+def ragged_pad(blocks, P_max, counts, table=None):
+    """``ops.ragged_pad`` with a gradient path to the blocks that ask for one (``table``: see there)."""
     if torch.is_grad_enabled() and any(b.requires_grad for b in blocks):
-        return _RaggedPadFn.apply(counts, int(P_max), *blocks)
-    return ops.ragged_pad(list(blocks), int(P_max), counts)
+        return _RaggedPadFn.apply(counts, int(P_max), table, *blocks)
+    return ops.ragged_pad(list(blocks), int(P_max), counts, table)
 
 
 def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=None, *, score_weight, max_iter,
@@ -219,6 +219,12 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
     [T,B,O,D].  Returns (full_outmask [B,O,H,W], match_score [B,O], det_score [B,O], cost_loss [B], iters [B])."""
     if tf.dim() == 3:
         tf = tf.unsqueeze(0)
+    if isinstance(pm, ops.FramePlanes):                      # the caller built the pointer table (DMM_Model: one upload)
+        tm = tm if tm.dtype == pm.dtype else tm.to(pm.dtype)
+        if targets is not None and targets.dtype != pm.dtype:
+            targets = targets.to(pm.dtype)
+        return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
+                                   float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
     if isinstance(pm, (list, tuple)):
         # one tensor per frame (DMM_Model's per-video proposal planes): matched in place through the pointer-table
         # entry points; only a mask gradient or mixed dtypes force the stacked copy

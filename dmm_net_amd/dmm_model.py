@@ -73,14 +73,30 @@ class DMM_Model(nn.Module):
             assert prop_m[b].shape[-2:] == mask_last_occurence[b].shape[-2:], \
                 "get {} {}".format(prop_m[b].shape[-2:], mask_last_occurence[b].shape[-2:])
             assert prop_feat[b].shape[0] == P, "get {} {}".format(P, prop_feat[b].shape[0])
-        n_valid = _lib.small_to_device([int(p.shape[0]) for p in prop_m], torch.int32, dev)
+        m_counts = [0 if skip[b] else n_tplt[b] for b in range(B)]
+        pm = list(prop_m)
         if dev.type == "cuda":
-            # the per-video blocks are stacked by one launch each (a zero fill + one copy per video before); with a
-            # gradient path for the feature rows (the scores carry none: the layer returns no score gradient)
+            # the per-video blocks are stacked by one launch each (a zero fill + one copy per video before), with a
+            # gradient path for the feature rows (the scores carry none: the layer returns no score gradient); the two
+            # count vectors and the three pointer tables of the call go up in ONE copy
             from . import ops
-            pf = ragged_pad([f.float() for f in prop_feat], Pmax, n_valid)
-            sc = ops.ragged_pad([s_.detach().float().reshape(-1, 1) for s_ in prop_score], Pmax, n_valid).view(B, Pmax)
+            pf_blocks, pf_addr = ops.ragged_blocks([f.float() for f in prop_feat])
+            sc_blocks, sc_addr = ops.ragged_blocks([s_.detach().float().reshape(-1, 1) for s_ in prop_score])
+            i32, i64 = torch.int32, torch.int64
+            specs = [([int(p.shape[0]) for p in prop_m], i32), (m_counts, i32), (pf_addr, i64), (sc_addr, i64)]
+            direct = not (any(t.requires_grad for t in pm) or len({t.dtype for t in pm}) > 1 or pm[0].dtype not in ops._DT)
+            if direct:                                # (else match_layer_batched stacks a copy, autograd.py)
+                pm = ops.FramePlanes(pm, table=None)
+                specs.append((pm.addresses(), i64))
+            up = _lib.small_to_device_many(specs, dev)
+            n_valid, m_valid = up[0], up[1]
+            if direct:
+                pm.table = up[4]
+            pf = ragged_pad(pf_blocks, Pmax, n_valid, up[2])
+            sc = ops.ragged_pad(sc_blocks, Pmax, n_valid, up[3]).view(B, Pmax)
         else:
+            n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
+            m_valid = torch.tensor(m_counts, dtype=torch.int32, device=dev)
             pf = prop_feat[0].new_zeros((B, Pmax, D))
             sc = mask_last_occurence.new_zeros((B, Pmax))
             for b in range(B):
@@ -89,14 +105,12 @@ class DMM_Model(nn.Module):
                 sc[b, :P] = prop_score[b]
         # the mask planes stay where they are: one tensor per video, handed to the kernels as a pointer table (the
         # round-1 driver copied them into a [B, Pmax, H, W] batch: 2 x 13 MB per video in front of a 15.6 MB cost pass)
-        pm = list(prop_m)
         tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
         if row_scale is not None:
             # valid templates that are NOT a prefix: the reference's OF_matrix = diag(valid)[:O] (dmm_model.py:151-156)
             # zeroes the feature rows -- and, transposed, the scattered output rows (:78-80) -- of slots i < O with
             # valid[i] == 0
             tf = tf * row_scale[:, :, None]
-        m_valid = _lib.small_to_device([0 if skip[b] else n_tplt[b] for b in range(B)], torch.int32, dev)
         counts = None
         if packed is not None and targets is None:
             # the proposals come with their 1-bit (mask > 0.5) planes (emitted by the paste kernel): the cost pass

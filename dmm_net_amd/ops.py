@@ -61,7 +61,9 @@ class FramePlanes:
     without being copied into a [B, Nmax, H, W] batch first.  Frame b has ``planes[b].shape[0]`` planes (ragged: pass
     ``n_valid``); all frames share H, W, dtype and the plane stride."""
 
-    def __init__(self, planes):
+    def __init__(self, planes, table="build"):
+        """``table``: "build" uploads the pointer table here; None defers it -- the caller uploads ``addresses()`` together
+        with its other small tables (``_lib.small_to_device_many``) and assigns ``.table``."""
         planes = list(planes)
         assert len(planes) > 0
         H, W = int(planes[0].shape[-2]), int(planes[0].shape[-1])
@@ -87,8 +89,11 @@ class FramePlanes:
         self.N = max(int(t.shape[0]) for t in fixed)
         self.counts = [int(t.shape[0]) for t in fixed]
         # one small H2D copy; frames without planes get a valid dummy address (never dereferenced: n_valid = 0)
-        any_ptr = next((t.data_ptr() for t in fixed if t.shape[0]), 0)
-        self.table = _lib.small_to_device([t.data_ptr() if t.shape[0] else any_ptr for t in fixed], torch.int64, self.device)
+        self.table = _lib.small_to_device(self.addresses(), torch.int64, self.device) if table == "build" else table
+
+    def addresses(self):
+        any_ptr = next((t.data_ptr() for t in self.planes if t.shape[0]), 0)
+        return [t.data_ptr() if t.shape[0] else any_ptr for t in self.planes]
 
     def n_valid(self) -> torch.Tensor:
         return _lib.small_to_device(self.counts, torch.int32, self.device)
@@ -149,11 +154,21 @@ def pack_words(HW: int) -> int:
     return 4 * ((HW + 255) // 256)
 
 
-def ragged_pad(blocks, P_max: int, counts: torch.Tensor) -> torch.Tensor:
+def ragged_blocks(blocks):
+    """-> (contiguous blocks, their addresses as the pointer table of ``ragged_pad`` wants them)."""
+    blocks = [b.contiguous() for b in blocks]
+    any_ptr = next((b.data_ptr() for b in blocks if b.shape[0]), 0)
+    return blocks, [b.data_ptr() if b.shape[0] else any_ptr for b in blocks]
+
+
+def ragged_pad(blocks, P_max: int, counts: torch.Tensor, table: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-video blocks [P_b, ...] (same trailing shape and dtype, 4-byte multiples per row) -> [B, P_max, ...] with
     zeros from row P_b on, in ONE launch (``dmm_ragged_pad``): the batching step of the per-video driver.
-    counts: [B] int32 on the device (= the n_valid the ragged kernels take anyway)."""
-    blocks = [b.contiguous() for b in blocks]
+    counts: [B] int32 on the device (= the n_valid the ragged kernels take anyway).  ``table`` (optional): the blocks'
+    addresses already on the device (``ragged_blocks`` + ``_lib.small_to_device_many``; the blocks must then be the
+    contiguous ones ``ragged_blocks`` returned)."""
+    if table is None:
+        blocks, addrs = ragged_blocks(blocks)
     first = blocks[0]
     _need_gpu(first, counts)
     tail = tuple(first.shape[1:])
@@ -163,8 +178,8 @@ def ragged_pad(blocks, P_max: int, counts: torch.Tensor) -> torch.Tensor:
     out = torch.empty((len(blocks), int(P_max)) + tail, dtype=first.dtype, device=first.device)
     if row_bytes % 4 != 0 or any(tuple(b.shape[1:]) != tail or b.dtype != first.dtype for b in blocks):
         raise ValueError("ragged_pad: blocks must share dtype and trailing shape, rows of a multiple of 4 bytes")
-    any_ptr = next((b.data_ptr() for b in blocks if b.shape[0]), 0)
-    table = _lib.small_to_device([b.data_ptr() if b.shape[0] else any_ptr for b in blocks], torch.int64, first.device)
+    if table is None:
+        table = _lib.small_to_device(addrs, torch.int64, first.device)
     with _lib.device_guard(first.device):
         rc = _lib.load().dmm_ragged_pad(_ptr(table), _ptr(counts), len(blocks), int(P_max), row_bytes, _ptr(out),
                                         _stream(first))
