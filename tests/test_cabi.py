@@ -157,3 +157,17 @@ def test_dispatch_options_go_through_the_abi_and_not_through_the_environment(mon
     for fn in os.listdir(_lib.CSRC):
         if fn.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(_lib.CSRC, fn)).read(), fn
+
+
+def test_small_tables_share_one_staging_buffer():
+    """``_lib.small_to_device_many``: several short host lists -> views of ONE buffer (one pinned copy on a GPU), each
+    8-byte aligned, dtypes and values kept."""
+    import torch
+    specs = [([3, 1, 2], torch.int32), ([], torch.int32), ([2 ** 40 + 8, 7], torch.int64), ([0.5, -2.0, 1e-8], torch.float32)]
+    got = _lib.small_to_device_many(specs, "cpu")
+    assert [t.dtype for t in got] == [s[1] for s in specs]
+    assert got[0].tolist() == [3, 1, 2] and got[1].numel() == 0 and got[2].tolist() == [2 ** 40 + 8, 7]
+    assert got[3].tolist() == torch.tensor([0.5, -2.0, 1e-8]).tolist()
+    base = got[0].untyped_storage().data_ptr()
+    assert all(t.untyped_storage().data_ptr() == base for t in got if t.numel())
+    assert all(t.data_ptr() % 8 == 0 for t in got if t.numel())

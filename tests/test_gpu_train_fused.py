@@ -344,3 +344,61 @@ def test_matching_loss_kernel_against_the_reference_fixture_g21():
         assert np.array_equal(gt[0].cpu().numpy(), g[f"c{k}/gt_matched"]), k
         want = float(g[f"c{k}/loss"])
         assert abs(float(loss[0]) - want) <= 2e-7 * max(1.0, abs(want)), (k, float(loss[0]), want)
+
+
+def test_ragged_solver_backward_runs_every_frame_in_its_own_row_count():
+    """``dmm_relax_match_bwd_f32`` with ``m_valid`` (DMM_Model's batches): each frame goes through the exact-row body of ITS
+    template count (``relax_match_bwd_ragged_kernel``) -- the gradient of a frame must equal, bit for bit, what the dense
+    launch gives for that frame alone with exactly its live rows and columns."""
+    B, N, M = 7, 50, 8
+    g = torch.Generator(device=DEV).manual_seed(77)
+    sim = torch.randn((B, M, N), generator=g, device=DEV) * 0.2
+    sc = torch.rand((B, N), generator=g, device=DEV)
+    Pp = ops.padded_width(N, M)
+    dRb = torch.rand((B, M, Pp), generator=g, device=DEV)
+    dms = torch.rand((B, M), generator=g, device=DEV)
+    dds = torch.rand((B, M), generator=g, device=DEV)
+    mv = [8, 5, 1, 0, 3, 2, 7]
+    nv = [50, 50, 37, 50, 2, 50, 9]
+    for is_test in (0, 1):
+        kb = dict(max_iter=10, proj_iter=5, lr=0.1, is_test=is_test)
+        got = ops.relax_match_bwd(sim, sc, dRb, dms, dds, n_valid=torch.tensor(nv, dtype=torch.int32, device=DEV),
+                                  m_valid=torch.tensor(mv, dtype=torch.int32, device=DEV), **kb)
+        for b in range(B):
+            m, n = mv[b], nv[b]
+            if m == 0:
+                assert float(got[b].abs().max()) == 0.0
+                continue
+            pp = ops.padded_width(n, m)
+            one = ops.relax_match_bwd(sim[b:b + 1, :m, :n].contiguous(), sc[b:b + 1, :n].contiguous(),
+                                      dRb[b:b + 1, :m, :pp].contiguous(), dms[b:b + 1, :m].contiguous(),
+                                      dds[b:b + 1, :m].contiguous(), **kb)
+            assert torch.equal(got[b, :m, :n], one[0]), (is_test, b, float((got[b, :m, :n] - one[0]).abs().max()))
+            assert float(got[b, m:].abs().max() if m < M else 0.0) == 0.0
+            assert float(got[b, :, n:].abs().max() if n < N else 0.0) == 0.0
+
+
+def test_ragged_pad_with_a_gradient_path():
+    """``autograd.ragged_pad``: the per-video blocks in one launch, zeros behind every block, and the gradient of a block =
+    its rows of the batch's gradient (what the zero-fill + per-video copy loop it replaces gives)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rows = [50, 0, 13, 50]
+    blocks = [torch.randn((r, 512), generator=g, device=DEV, requires_grad=True) for r in rows]
+    P = max(rows)
+    counts = torch.tensor(rows, dtype=torch.int32, device=DEV)
+    out = autograd.ragged_pad(blocks, P, counts)
+    assert out.requires_grad and out.shape == (4, P, 512)
+    ref = torch.zeros((4, P, 512), device=DEV)
+    for b, blk in enumerate(blocks):
+        ref[b, :rows[b]] = blk.detach()
+    assert torch.equal(out.detach(), ref)
+    w = torch.rand(out.shape, generator=g, device=DEV)
+    (out * w).sum().backward()
+    for b, blk in enumerate(blocks):
+        assert torch.equal(blk.grad, w[b, :rows[b]])
+    with torch.no_grad():
+        assert not autograd.ragged_pad(blocks, P, counts).requires_grad
+    # the table handed over by the caller (one upload for all of a call's small tables)
+    blks, addr = ops.ragged_blocks([b.detach() for b in blocks])
+    cnt, tab = _lib.small_to_device_many([(rows, torch.int32), (addr, torch.int64)], torch.device(DEV))
+    assert torch.equal(ops.ragged_pad(blks, P, cnt, tab), ref)
