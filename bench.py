@@ -1095,6 +1095,15 @@ def bench_dropin(R):
             x.grad = None
         out, _, ml, _ = m_tr(None, props, None, mask_last, tplt, valid, targets)
         (out.sum() + sum(ml)).backward()
+    # ... and for ONE video, the evaluator's batch (scripts/eval/*.sh: -batch_size=1)
+    m_ev1 = DMM_Model(cfgs(40), is_test=1, feature_extractor=lambda feats, pr: feats_p[0])
+    infos1 = {"extra_frame": [False], "valid": valid[:1]}
+
+    def call_inf1():
+        with torch.no_grad():
+            m_ev1.inference(infos1, props[:1], None, mask_last[:1], {0: tplt[0]})
+    cases["dmm_model_inference_1_video"] = dict(measure(call_inf1), what=f"DMM_Model.inference, 1 video x {P} proposals x {F} "
+                                                f"templates, {H}x{W}, 40 x 5 (the evaluator's batch, scripts/eval/eval.sh:6)")
     cases["dmm_model_inference_4_videos"] = dict(measure(call_inf, n=max(20, n_calls // 4)),
                                                  what=f"DMM_Model.inference, {B} videos x {P} proposals x {F} templates, {H}x{W}, "
                                                       "40 x 5 (dmm_model.py:48-86); ROI feature rows handed over")

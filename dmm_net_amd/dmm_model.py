@@ -128,6 +128,21 @@ class DMM_Model(nn.Module):
             full = full * row_scale[:, :, None, None]
         return full, loss
 
+    def _match_single(self, prop_feat, prop_m, prop_score, tplt_feat, mask_last_occurence, O, targets):
+        """ONE video (the evaluator's batch: scripts/eval/*.sh run ``-batch_size=1``) with its templates a prefix and none
+        skipped: the reference's own call, ``self.match_layer`` on the first O rows (dmm_model.py:75-77 / :130-132) --
+        three launches in the evaluator, one library call each way in the trainer; the ragged batch machinery (count
+        vectors, pointer tables, batching launches) is for B > 1.  Returns (full [1,F,H,W], [loss])."""
+        _, F, H, W = CHECK4D(mask_last_occurence)
+        full, _, _, _, loss = self.match_layer(prop_feat, prop_m, [tplt_feat.view(F, -1)[:O]], mask_last_occurence[0, :O],
+                                               prop_score, None if targets is None else targets[0][:O])
+        if O < F:                                                  # the slots behind the live templates stay zero (:78-80)
+            out = full.new_zeros((1, F, H, W))
+            out[0, :O] = full
+        else:
+            out = full.unsqueeze(0)
+        return out, [loss["cost_loss"]] if len(loss) > 0 else []
+
     @staticmethod
     def _valid_layout(tplt_valid_batch, n_tplt_hint=None):
         """-> (live templates per video, row_scale [B,F] or None).  ONE host sync for the whole batch.  The reference
@@ -216,8 +231,12 @@ class DMM_Model(nn.Module):
             packed = None
             if all("mask_packed" in p.fields() for p in proposals):
                 packed = [p.get_field("mask_packed") for p in proposals]
-            full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
-                                        tg, skip, row_scale, packed)
+            if B == 1 and packed is None and row_scale is None and not skip[0]:
+                full, _ = self._match_single(prop_feat[0], prop_m[0], prop_score[0], tplt_feat[0], mask_last_occurence,
+                                             n_tplt[0], tg)
+            else:
+                full, _ = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence, n_tplt,
+                                            tg, skip, row_scale, packed)
         return full, tplt_dict, [], self._out_mask_last(full, mask_last_occurence, skip, bool(infos.get("alias_ok")))
 
     # ---- dmm_model.py:88-142 -----------------------------------------------------------------------
@@ -233,6 +252,9 @@ class DMM_Model(nn.Module):
         if self.match_algo != "relax":
             full, loss = self._per_video(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                          tplt_valid_batch, n_tplt, targets, skip)
+        elif B == 1 and row_scale is None and not skip[0]:
+            full, loss = self._match_single(prop_feat[0], prop_m[0], prop_score[0], tplt_feat[0], mask_last_occurence,
+                                            n_tplt[0], targets)
         else:
             full, loss = self._match_batch(list(prop_feat), prop_m, prop_score, tplt_feat, mask_last_occurence,
                                            n_tplt, targets, skip, row_scale)

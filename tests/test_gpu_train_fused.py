@@ -402,3 +402,52 @@ def test_ragged_pad_with_a_gradient_path():
     blks, addr = ops.ragged_blocks([b.detach() for b in blocks])
     cnt, tab = _lib.small_to_device_many([(rows, torch.int32), (addr, torch.int64)], torch.device(DEV))
     assert torch.equal(ops.ragged_pad(blks, P, cnt, tab), ref)
+
+
+@pytest.mark.parametrize("O", [5, 3])
+def test_dmm_model_one_video_takes_the_frame_call_and_equals_the_batched_path(O):
+    """``DMM_Model`` with ONE video (the evaluator's batch size) calls ``MatchModel`` on the first O rows like the reference;
+    outputs, loss and gradients must equal the ragged batch path's (which G17 pins on the reference's own ``DMM_Model``)."""
+    from dmm_net_amd.dmm_model import DMM_Model
+    from dmm_net_amd.proposals import SimpleBoxList
+    P, F, H, W, D = 50, 5, 64, 72, 512
+    fr = synth.make_frame(P, F, H, W, D, seed=900 + O, kind="structured", with_targets=True)
+    bl = SimpleBoxList(torch.tensor([[0.0, 0.0, 10.0, 10.0]] * P, device=DEV), (W, H))
+    bl.add_field("mask", dev(fr.proposed_mask).unsqueeze(1))
+    bl.add_field("scores", dev(fr.proposal_score))
+    valid = torch.tensor([[1.0] * O + [0.0] * (F - O)], device=DEV)
+    mask_last = dev(fr.mask_last_occurence).unsqueeze(0)
+    targets = dev(fr.targets).unsqueeze(0)
+    tfeat = dev(fr.template_feature)
+
+    def run(single, is_test):
+        pf = dev(fr.proposed_feature).requires_grad_(not is_test)
+        dm = DMM_Model(cfg(10, 5), is_test=is_test, feature_extractor=lambda f, pr: pf)
+        tplt = {0: {"feat": [tfeat], "refine_input_feat": [()]}}
+        if is_test:
+            infos = {"extra_frame": [False], "valid": valid}
+            if single:
+                full, _, _, last = dm.inference(infos, [bl], None, mask_last, tplt)
+            else:
+                full, _ = dm._match_batch([pf], [bl.get_field("mask").squeeze(1)], [bl.get_field("scores")], [tfeat],
+                                          mask_last, [O], None, [False])
+                last = full
+            return full, last, None, None
+        if single:
+            full, _, ml, last = dm(None, [bl], None, mask_last, tplt, valid, targets)
+        else:
+            full, loss = dm._match_batch([pf], [bl.get_field("mask").squeeze(1)], [bl.get_field("scores")], [tfeat],
+                                         mask_last, [O], targets, [False])
+            ml, last = [loss[0]], full
+        (full.sum() * 0.01 + ml[0]).backward()
+        return full, last, ml[0], pf.grad
+
+    for is_test in (1, 0):
+        a, b_ = run(True, is_test), run(False, is_test)
+        assert a[0].shape == (1, F, H, W) and torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]), is_test
+        assert float(a[0][0, O:].abs().max() if O < F else 0.0) == 0.0
+        if not is_test:
+            la, lb = float(a[2].detach()), float(b_[2].detach())
+            assert abs(la - lb) <= 2e-7 * max(1.0, abs(lb))
+            scale = float(b_[3].abs().max())
+            assert float((a[3] - b_[3]).abs().max()) <= 1e-5 * scale
