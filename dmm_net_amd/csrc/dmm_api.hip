@@ -27,7 +27,7 @@ void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 static constexpr int kOptDefaults[DMM_OPT_COUNT] = {
     /* COST_KERNEL */ -1,      /* COST_TINY_FRAMES */ 8,   /* SOLVER_KERNEL */ -1,  /* FORCE_WIDE */ 0,
     /* COSINE_KERNEL */ 0,     /* COST_WGS */ 8192,        /* COST_SMALL_WGS */ 512, /* COST_TL_WGS */ 512,
-    /* COST_XCD */ 1,          /* MIX_XCD */ 1,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
+    /* COST_XCD */ 1,          /* MIX_XCD */ 3,            /* MIX_WGS */ 320000,    /* MIX_STEPQ */ 2,
     /* MIX_ALIGN */ 128,       /* MIX_NT */ 3,             /* SOLVER_HELPER_MAX */ 512, /* NMS_WAVE */ 1,
     /* COS_ROWS_MIN_N */ 65,   /* GEMM_TUNE */ 1,          /* PACK_VARIANT */ 4,    /* SMALL_FUSED */ 1,
     /* MIX_SHARED */ -1,       /* MIX_SHARED_STEPS */ 1,   /* FEAT_BWD_FRAME */ -1, /* MIX_SHARED_LOCKSTEP */ 1,
@@ -91,7 +91,8 @@ extern "C" int dmm_set_option(int option, int value) {
     switch (option) {                                            // ranges: a bad value must not reach a launch computation
         case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED: case DMM_OPT_FEAT_BWD_FRAME:
             if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
-        case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD: case DMM_OPT_MIX_XCD:
+        case DMM_OPT_MIX_XCD: if (value < 0 || value > 7) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD:
         case DMM_OPT_NMS_WAVE: case DMM_OPT_SMALL_FUSED: case DMM_OPT_MIX_SHARED_LOCKSTEP:
             if (value < 0 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_ALIGN: if (value != 16 && value != 32 && value != 64 && value != 128) return DMM_ERR_BAD_ARG; break;

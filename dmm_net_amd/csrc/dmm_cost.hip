@@ -182,34 +182,6 @@ __device__ __forceinline__ void process_chunk(const T *Pb, const T *Tb, const T 
     }
 }
 
-// Workgroups are dispatched round-robin over the 8 XCDs by linear id.  With the plain (range = blockIdx.x, frame =
-// blockIdx.y) mapping the chunk ranges of one frame land on different XCDs, so the 128-byte lines neighbouring ranges
-// share (plane rows are only 4-byte aligned) are fetched into several L2s.  Remapped, every complete group of 8 frames
-// gives each XCD ONE whole frame: measured +2 % on the cost launches (6.65 -> 6.79 TB/s at 512 frames).
-__device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &range) {
-    b = blockIdx.y;
-    range = blockIdx.x;
-    if (xcd_remap && (int)blockIdx.y < (int)(gridDim.y & ~7u)) {
-        const int splits = gridDim.x;
-        const int id = blockIdx.x + splits * blockIdx.y;
-        const int grp = id / (8 * splits), within = id - grp * 8 * splits;
-        b = grp * 8 + (within & 7);
-        range = within >> 3;
-    }
-}
-// the same for a workgroup that is number (bx, by) of a (gx, gy) sub-grid of its launch (the small-batch front kernel)
-__device__ __forceinline__ void xcd_frame_range(int xcd_remap, int &b, int &range, int bx, int by, int gx, int gy) {
-    b = by;
-    range = bx;
-    if (xcd_remap && by < (gy & ~7)) {
-        const int splits = gx;
-        const int id = bx + splits * by;
-        const int grp = id / (8 * splits), within = id - grp * 8 * splits;
-        b = grp * 8 + (within & 7);
-        range = within >> 3;
-    }
-}
-
 // grid = (splits, B); block = 256.  inter / area_* must be zero on entry (the launcher memsets).
 // Handles the tile [n0, n0 + 64*NG) x [m0, m0 + MT) of the (proposal, template) table.
 

@@ -427,13 +427,18 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
                                                                       const int32_t *__restrict__ n_valid,
                                                                       const int32_t *__restrict__ m_valid,
                                                                       TO *__restrict__ out, int64_t so_b, int64_t so_m,
-                                                                      int steps_per_wg, int lockstep) {
+                                                                      int steps_per_wg, int lockstep, int xcd_remap) {
     constexpr int E = 4;                                                  // pixels per lane and step (16 bytes of fp32)
     __shared__ __attribute__((aligned(16))) float w_c[DMM_MAX_PROPOSALS * MT];
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int wcnt_s[kMixThreads / 64];
-    const int b = blockIdx.y;
+    // DMM_OPT_MIX_XCD bit 1: every complete group of 8 frames gives each XCD one whole frame (dmm_common.h): the 128-byte
+    // lines that neighbouring 4 KiB steps of a plane share are asked for by ONE L2, a few dispatches apart.  50 x 10 train-mode
+    // supports, 512 frames: 1.364 -> 1.319 ms (0.706 -> 0.730 of 8 TB/s), traffic 1.041x -> 1.027x (tools/mix_bwd_probe.py).
+    // The backward (bit 2, off) takes four steps per workgroup -- its neighbours are its own: 1.264 -> 1.270 ms, same traffic
+    int b, range;
+    xcd_frame_range(xcd_remap, b, range);
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
     if (Nb <= 0) Mb = 0;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_shared_kernel(const floa
     const T *Pb = frame_base(masks_p, b, sp_b);
     TO *ob = out + (int64_t)b * so_b;
     const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
-    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_begin = range * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
     for (int s = s_begin; s < s_end; ++s) {
         const int x = (s * kMixThreads + threadIdx.x) * E;
@@ -517,7 +522,7 @@ static int mask_mix_shared_typed(const float *Rb, const T *masks_p, int B, int N
 #define DMM_MIXS_LAUNCH(MT_, NT_)                                                                                       \
     hipLaunchKernelGGL((mask_mix_shared_kernel<T, TO, MT_, NT_>), dim3(splits, B), dim3(kMixThreads), 0, stream, Rb,    \
                        masks_p, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, out, so_b, so_m, steps_per_wg,               \
-                       opt(DMM_OPT_MIX_SHARED_LOCKSTEP))
+                       opt(DMM_OPT_MIX_SHARED_LOCKSTEP), (opt(DMM_OPT_MIX_XCD) >> 1) & 1)
 #define DMM_MIXS_PICK(MT_)                       \
     do {                                         \
         if ((nt_mode & 3) == 3) DMM_MIXS_LAUNCH(MT_, 3); \
@@ -550,14 +555,15 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
                                                                           const int32_t *__restrict__ n_valid,
                                                                           const int32_t *__restrict__ m_valid,
                                                                           float *__restrict__ dRb, int steps_per_wg,
-                                                                          int lockstep) {
+                                                                          int lockstep, int xcd_remap) {
     constexpr int E = 4;
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int pbase_s[DMM_MAX_PROPOSALS + 1];                        // first slot of a union column
     __shared__ __attribute__((aligned(16))) float fold_s[kMixThreads / 64][kPairSlots][4];   // [wave][slot][16-lane row]
     __shared__ int wcnt_s[kMixThreads / 64];
-    const int b = blockIdx.y;
+    int b, range;
+    xcd_frame_range(xcd_remap, b, range);                                 // DMM_OPT_MIX_XCD bit 2; see mask_mix_shared_kernel
     int Nb = n_valid ? n_valid[b] : N;
     int Mb = m_valid ? m_valid[b] : M;
     if (Nb <= 0) Mb = 0;
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     const T *Pb = frame_base(masks_p, b, sp_b);
     const float *db = dout + (int64_t)b * M * HW;
     const int nsteps = (HW + kMixThreads * E - 1) / (kMixThreads * E);
-    const int s_begin = blockIdx.x * steps_per_wg;
+    const int s_begin = range * steps_per_wg;
     const int s_end = min(nsteps, s_begin + steps_per_wg);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
@@ -717,7 +723,8 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
 #define DMM_MIXB_LAUNCH(MT_)                                                                                        \
     hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads),                    \
                        sizeof(float) * (kMixThreads / 64) * (size_t)N * MT_, stream, Rb, masks_p, dout, N, M, Pp, HW, \
-                       sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg, opt(DMM_OPT_MIX_SHARED_LOCKSTEP))
+                       sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg, opt(DMM_OPT_MIX_SHARED_LOCKSTEP),               \
+                       (opt(DMM_OPT_MIX_XCD) >> 2) & 1)
     if (M <= 8) DMM_MIXB_LAUNCH(8);
     else if (M <= 16) DMM_MIXB_LAUNCH(16);
     else DMM_MIXB_LAUNCH(32);

@@ -90,7 +90,7 @@ typedef enum dmm_option {
     DMM_OPT_COST_SMALL_WGS = 6,     /*   sub-tiling threshold of small launches (512),                                     */
     DMM_OPT_COST_TL_WGS = 7,        /*   template lanes (512)                                                              */
     DMM_OPT_COST_XCD = 8,           /* XCD-aware workgroup -> (frame, range) mapping of the count kernels (1)              */
-    DMM_OPT_MIX_XCD = 9,            /*   ... of the mix kernel (1)                                                         */
+    DMM_OPT_MIX_XCD = 9,            /*   ... of the mix kernels, bits: 1 row kernel, 2 union kernel, 4 union backward (3)  */
     DMM_OPT_MIX_WGS = 10,           /* mix kernel: workgroup target (320000),                                              */
     DMM_OPT_MIX_STEPQ = 11,         /*   steps per workgroup quantum (2),                                                  */
     DMM_OPT_MIX_ALIGN = 12,         /*   store alignment in bytes: 16 / 32 / 64 / 128 (128),                               */

@@ -277,7 +277,8 @@ def _mix_bwd_case(B, N, M, H, W, seed, dtype=torch.float32, density=0.3, ragged=
     (2, 50, 10, 48, 52, torch.float16, False),
     (2, 33, 7, 48, 52, torch.bfloat16, True),
     (2, 65, 4, 24, 24, torch.float32, False), (2, 20, 17, 24, 24, torch.float32, False),
-    (2, 120, 32, 24, 24, torch.float32, False), (1, 240, 16, 16, 16, torch.float32, False)])   # the LDS gate's edge
+    (2, 120, 32, 24, 24, torch.float32, False), (1, 240, 16, 16, 16, torch.float32, False),    # the LDS gate's edge
+    (19, 50, 10, 40, 52, torch.float32, True)])        # two complete groups of 8 frames (XCD mapping) + 3, ragged
 def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
     """dmm_mask_mix_bwd (union kernel with the scalar-branch slot parking of round 5, and the row kernel it falls back to:
     option MIX_SHARED) against the float64 product on the support of Rb: inside the backward's bound (2e-5 of the largest
@@ -285,19 +286,21 @@ def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
     from conftest import record_achieved
     pm, dout, Rb, nv, mv, want = _mix_bwd_case(B, N, M, H, W, seed=N * 31 + M, dtype=dtype, ragged=ragged)
     scale = float(want.abs().max()) or 1.0
-    for mode, lock in ((-1, 1), (-1, 0), (0, 1)):                     # union kernel, waves in lock step / free running; row kernel
-        with _lib.options(MIX_SHARED=mode, MIX_SHARED_LOCKSTEP=lock):
+    # union kernel with the waves in lock step / free running, plain frame-major dispatch / one frame per XCD for the union
+    # kernels (MIX_XCD bits 2 and 4); the row kernel
+    for mode, lock, xcd in ((-1, 1, 3), (-1, 0, 7), (-1, 1, 1), (0, 1, 3)):
+        with _lib.options(MIX_SHARED=mode, MIX_SHARED_LOCKSTEP=lock, MIX_XCD=xcd):
             got = ops.mask_mix_bwd(Rb, pm, dout, nv, mv).double()
             if mode == -1 and M <= 32 and N <= 256:
                 # the forward union kernel under the same setting: bit for bit the row kernel's result
                 fwd = ops.mask_mix(Rb, pm, nv, mv, shared=True)
                 with _lib.options(MIX_SHARED=0):
                     fwd_rows = ops.mask_mix(Rb, pm, nv, mv, shared=False)
-                assert torch.equal(fwd, fwd_rows), (mode, lock)
+                assert torch.equal(fwd, fwd_rows), (mode, lock, xcd)
         assert bool((got[Rb == 0] == 0).all())
         err = float((got - want).abs().max()) / scale
-        assert err <= 2e-5, (mode, lock, err)
-        if mode == -1 and lock == 1:
+        assert err <= 2e-5, (mode, lock, xcd, err)
+        if mode == -1 and lock == 1 and xcd == 3:
             record_achieved(f"mix_bwd/{B}x{N}x{M}x{H}x{W}_{str(dtype)[6:]}/rel_err", err)
     fp = ops.FramePlanes([pm[b, :(int(nv[b]) if nv is not None else N)] for b in range(B)])
     t = ops.mask_mix_bwd(Rb, fp, dout, nv if nv is not None else None, mv).double()

@@ -24,6 +24,8 @@ ap.add_argument("--child", action="store_true")
 ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (the backward takes twice as many 4 KiB steps per workgroup)")
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--lockstep", type=int, default=-1, help="--pmc: pin MIX_SHARED_LOCKSTEP for the counter passes")
+ap.add_argument("--xcd", type=int, default=-1, help="pin MIX_XCD (1 = plain frame / step mapping of the union kernels, 3 = one "
+                                                    "whole frame per XCD); default: both, one after the other")
 args = ap.parse_args()
 
 PASSES = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES",
@@ -38,6 +40,8 @@ def run():
     from dmm_net_amd import _lib, ops
     if args.lockstep >= 0 and args.child:                            # counter passes of one setting: no A/B inside
         _lib.set_option("MIX_SHARED_LOCKSTEP", args.lockstep)
+    if args.xcd >= 0 and args.child:
+        _lib.set_option("MIX_XCD", args.xcd)
     dev = torch.device("cuda", 0)
     B, N, M, H, W = args.frames, 50, 10, 255, 255
     g = torch.Generator(device=dev).manual_seed(7)
@@ -64,12 +68,13 @@ def run():
     ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 10)                       # clocks up before the first figure
     for steps in [int(v) for v in args.steps.split(",")]:
         for lock in ((args.lockstep,) if args.lockstep >= 0 else (0, 1)):
-            with _lib.options(MIX_SHARED_STEPS=steps, MIX_SHARED_LOCKSTEP=lock):
-                t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
-                tf = ms(lambda: ops.mask_mix(Rb, pm, shared=True), args.reps)
-            for name, tt in (("bwd_union", t), ("fwd_union", tf)):
-                out["runs"][f"{name}_steps{steps}_lockstep{lock}"] = {
-                    "ms": round(tt, 4), "GBps": round(alg / tt / 1e6, 1), "frac_of_8TBps": round(alg / tt / 1e6 / 8000, 4)}
+            for xcd in ((args.xcd,) if args.xcd >= 0 else (1, 3, 1, 3)):
+                with _lib.options(MIX_SHARED_STEPS=steps, MIX_SHARED_LOCKSTEP=lock, MIX_XCD=xcd):
+                    t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
+                    tf = ms(lambda: ops.mask_mix(Rb, pm, shared=True), args.reps)
+                for name, tt in (("bwd_union", t), ("fwd_union", tf)):
+                    out["runs"].setdefault(f"{name}_steps{steps}_lockstep{lock}_xcd{xcd}", []).append(
+                        {"ms": round(tt, 4), "frac_of_8TBps": round(alg / tt / 1e6 / 8000, 4)})
     with _lib.options(MIX_SHARED=0):
         t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 3)
     out["runs"]["bwd_rows"] = {"ms": round(t, 4), "frac_of_8TBps": round(alg / t / 1e6 / 8000, 4)}
@@ -88,7 +93,8 @@ if args.pmc and not args.child:
         shutil.rmtree(d, ignore_errors=True)
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--",
                             sys.executable, os.path.abspath(__file__), "--child", "--frames", str(args.frames), "--reps", "3",
-                            "--steps", args.steps.split(",")[0], "--lockstep", str(args.lockstep)], cwd="/tmp", env=env,
+                            "--steps", args.steps.split(",")[0], "--lockstep", str(args.lockstep), "--xcd", str(args.xcd)],
+                           cwd="/tmp", env=env,
                            capture_output=True, text=True)
         if r.returncode != 0:
             print("pass failed:", ctrs, r.stderr[-400:])
