@@ -244,25 +244,11 @@ def self_launch(args):
 
 
 def bind_to_gpu_numa_node(index):
-    """Pin this process's host threads to the CPUs local to GPU ``index`` (its PCI device's ``local_cpulist`` in sysfs):
-    on an 8-GPU node the launch path of a rank then does not cross sockets.  Returns the NUMA node or None; every failure
-    (no sysfs entry, no permission, a container without the topology) is silent -- the bench runs unpinned."""
-    try:
-        pr = torch.cuda.get_device_properties(index)
-        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-        base = f"/sys/bus/pci/devices/{bdf}"
-        node = int(open(base + "/numa_node").read().strip())
-        cpus = set()
-        for part in open(base + "/local_cpulist").read().strip().split(","):
-            lo, _, hi = part.partition("-")
-            cpus.update(range(int(lo), int(hi or lo) + 1))
-        allowed = cpus & set(os.sched_getaffinity(0))
-        if node < 0 or not allowed:
-            return None
-        os.sched_setaffinity(0, allowed)
-        return node
-    except Exception:
-        return None
+    """Pin this process's host threads to the CPUs local to GPU ``index`` (``distributed.bind_host_threads_to_gpu``): on
+    an 8-GPU node the launch path of a rank then does not cross sockets.  Returns the NUMA node or None; every failure (no
+    sysfs entry, no permission, a container without the topology) is silent -- the bench runs unpinned."""
+    from dmm_net_amd.distributed import bind_host_threads_to_gpu
+    return bind_host_threads_to_gpu(index)[0]
 
 
 class Runner:
@@ -995,9 +981,16 @@ def bench_dropin(R):
     def measure(call, n=n_calls, reps=3):
         """median (and min / max) over ``reps`` repeats of n back-to-back calls: wall us per call (host clock, one sync at
         the end), device us per call (events around the same calls queued behind a blocker) and launches per call."""
+        import gc
         for _ in range(10):
             call()
         torch.cuda.synchronize(dev)
+        # like timeit: no cyclic garbage collection inside the timed loops (inside the default run this case follows five
+        # others in the same process -- a ResNet-101 training step among them -- and a generation-2 pass over everything
+        # they left tracked cost the 0.2 ms calls here 25-40 % of wall clock: 240 us against 190-205 standalone)
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         walls, devs = [], []
         l0 = L.dmm_launch_count()
         call()
@@ -1021,11 +1014,17 @@ def bench_dropin(R):
             b.record()
             torch.cuda.synchronize(dev)
             devs.append(a.elapsed_time(b) / n * 1e3)
+        if gc_was:
+            gc.enable()
         med = lambda v: sorted(v)[len(v) // 2]
         return {"wall_us": round(med(walls), 1), "wall_us_min_max": [round(min(walls), 1), round(max(walls), 1)],
                 "device_us": round(med(devs), 1), "library_launches": launches,
                 "wall_over_device": round(med(walls) / max(med(devs), 1e-9), 3), "calls": n, "repeats": reps}
 
+    # one process per GPU, its host threads next to that GPU -- what a trainer / evaluator process does at start-up
+    # (INTEGRATION.md); at N = 1 the mask is put back afterwards: the cpu_baseline leg uses every core
+    from dmm_net_amd.distributed import bind_host_threads_to_gpu
+    numa_node, unbind = bind_host_threads_to_gpu(dev.index) if world == 1 else (R.numa, lambda: None)
     cases = {}
     # (a) the evaluator's call: MatchModel(cfg, is_test=1).forward under no_grad, eval solver setting 40 x 5
     ev = MatchModel(cfgs(40), is_test=1)
@@ -1110,6 +1109,7 @@ def bench_dropin(R):
     cases["dmm_model_forward_backward_4_videos"] = dict(measure(call_fwd, n=max(20, n_calls // 4)),
                                                         what=f"DMM_Model.forward + backward, {B} videos, 10 x 5 "
                                                              "(dmm_model.py:88-142)")
+    unbind()
     head = cases["eval_forward_50x5"]
     out = {
         "metric": "calls/sec of the drop-in (MatchModel.forward as the evaluator calls it: 50 proposals x 5 templates, "
@@ -1121,6 +1121,8 @@ def bench_dropin(R):
                                "MatchModel call; 4 videos per DMM_Model call); wall = host clock around n back-to-back calls "
                                "+ one synchronize, device = HIP events around the same calls enqueued behind a blocker (the host "
                                "runs ahead: back-to-back device time); median of 3 repeats",
+                   "host_threads": (f"pinned to the CPUs of NUMA node {numa_node} (the GPU's)" if numa_node is not None
+                                    else "unpinned (GPU topology not visible)"),
                    "cases": cases},
     }
     return out
@@ -1142,6 +1144,7 @@ def compact(out):
     if "cases" in out["config"]:                                 # the drop-in: per-call wall / device / launches
         c["cases"] = {k: {kk: v[kk] for kk in ("wall_us", "device_us", "library_launches", "wall_over_device")}
                       for k, v in out["config"]["cases"].items()}
+        c["host_threads"] = out["config"].get("host_threads")
     if "by_batch" in out["config"]:                              # training form: per-kernel ms / fraction of the HBM peak
         c["by_batch"] = {b: {"fwd_bwd_ms": v["fwd_bwd_ms"], "selected_planes_per_frame": v["selected_planes_per_frame"],
                              "kernels": {k: ({"ms": e["ms"], "frac": e["frac"]} if "frac" in e else {"ms": e["ms"]})

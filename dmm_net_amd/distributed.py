@@ -44,6 +44,59 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     return dist.get_rank(), dist.get_world_size()
 
 
+def gpu_local_cpus(index: int):
+    """-> (NUMA node, set of CPUs local to GPU ``index``) from its PCI device's sysfs entry, or (None, None) when the
+    topology is not visible (a container without sysfs, node -1)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return (node, cpus) if node >= 0 and cpus else (None, None)
+    except Exception:
+        return None, None
+
+
+def bind_host_threads_to_gpu(index: int, all_threads: bool = True):
+    """Pin the host threads of this process to the CPUs local to GPU ``index`` -- call it once at the top of a trainer /
+    evaluator process (one process per GPU, scripts/train/train_101.sh:27-28).  Why it matters on a two-socket MI355X host:
+    a per-frame call of the layer is ~10 launches from the Python thread plus, in training, a hand-off to autograd's
+    device thread and back; with the two threads on different sockets the same call measured 237 us against 183 us
+    (``bench.py --config dropin``, round 5: unpinned runs were bimodal, pinned ones were not).
+    ``all_threads``: also re-pin the threads that already exist (autograd's worker is created at the first backward and keeps
+    the mask it was born with).  Returns (numa_node | None, restore) -- ``restore()`` puts the previous masks back; every
+    failure is silent (the process stays unpinned)."""
+    node, cpus = gpu_local_cpus(index)
+    if node is None:
+        return None, (lambda: None)
+    saved = {}
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")] if all_threads else [0]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            old = os.sched_getaffinity(tid)
+            allowed = cpus & old
+            if allowed:
+                os.sched_setaffinity(tid, allowed)
+                saved[tid] = old
+        except OSError:
+            pass                                     # a thread that ended meanwhile, or no permission
+
+    def restore():
+        for tid, old in saved.items():
+            try:
+                os.sched_setaffinity(tid, old)
+            except OSError:
+                pass
+    return (node if saved else None), restore
+
+
 class GradBucketer:
     """Bucketed mean all-reduce of ``param.grad`` over the default process group, gradients kept as VIEWS of the flat
     buckets (DDP's ``gradient_as_bucket_view``; the reference gets the mean from DDP, train.py:178-184, and repeats it

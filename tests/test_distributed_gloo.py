@@ -347,3 +347,14 @@ def test_gloo_world2_steady_mode_takes_the_host_read_off_the_step_and_heals():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
+
+
+def test_host_thread_pinning_is_silent_without_a_gpu_topology():
+    """``bind_host_threads_to_gpu``: no visible GPU / sysfs topology -> (None, no-op restore), masks untouched."""
+    import os
+    from dmm_net_amd.distributed import bind_host_threads_to_gpu
+    before = os.sched_getaffinity(0)
+    node, restore = bind_host_threads_to_gpu(0)
+    assert node is None
+    restore()
+    assert os.sched_getaffinity(0) == before

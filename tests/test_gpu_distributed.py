@@ -316,3 +316,33 @@ def test_two_devices_two_threads_like_nn_dataparallel():
                 assert float(np.abs(a - b).max()) <= 1e-5 * (float(np.abs(b).max()) or 1.0), (k, i)
             else:
                 assert np.array_equal(a, b), (k, i)
+
+
+def test_host_threads_pin_to_the_gpus_numa_node_and_back():
+    """``distributed.bind_host_threads_to_gpu``: every thread of the process lands on the CPUs local to the GPU (when the
+    box shows the topology) and ``restore()`` gives the old masks back."""
+    import os
+    import threading
+    from dmm_net_amd.distributed import bind_host_threads_to_gpu, gpu_local_cpus
+    node, cpus = gpu_local_cpus(0)
+    stop = threading.Event()
+    worker_tid = []
+    t = threading.Thread(target=lambda: (worker_tid.append(threading.get_native_id()), stop.wait(30)))
+    t.start()
+    while not worker_tid:
+        pass
+    before = {tid: os.sched_getaffinity(tid) for tid in (0, worker_tid[0])}
+    got, restore = bind_host_threads_to_gpu(0)
+    try:
+        if node is None:
+            assert got is None
+        else:
+            assert got == node
+            for tid in before:
+                assert os.sched_getaffinity(tid) <= cpus and os.sched_getaffinity(tid)
+    finally:
+        restore()
+        for tid, m in before.items():
+            assert os.sched_getaffinity(tid) == m
+        stop.set()
+        t.join()
