@@ -1053,6 +1053,11 @@ def bench_dropin(R):
               "iterations (dmm_model.py:130-132)")
     cases["train_fwd_bwd_50x5"] = dict(measure(call_train), what=what_b)
     assert pf.grad is not None and bool(torch.isfinite(pf.grad).all()) and float(pf.grad.abs().sum()) > 0
+    # the same call with autograd's backward on the CALLING thread (torch.autograd.set_multithreading_enabled(False), one line
+    # in a trainer that owns one GPU per process): no hand-off to the device thread and back per backward()
+    with torch.autograd.set_multithreading_enabled(False):
+        cases["train_fwd_bwd_50x5_autograd_on_calling_thread"] = dict(
+            measure(call_train), what=what_b + " -- under torch.autograd.set_multithreading_enabled(False)")
     old = autograd._FUSED_TRAIN
     autograd._FUSED_TRAIN = False                                # the pre-fusion chain, for the record
     try:
@@ -1060,7 +1065,9 @@ def bench_dropin(R):
                                                           "(12 library calls + tensor ops), what round 4 shipped")
     finally:
         autograd._FUSED_TRAIN = old
-    # (c) DMM_Model for 4 videos (all videos of the step through one ragged launch sequence)
+    # (c) DMM_Model for 4 videos (all videos of the step through one ragged launch sequence).  The valid-flags tensor is the
+    # same object call after call, as the reference passes it for the frames of a clip (trainer.py:113-121): its layout is
+    # read from the device once per clip, a frame step after the first has no host sync
     B, F, P = 4, 5, 50
 
     def boxes(n):
@@ -1106,6 +1113,10 @@ def bench_dropin(R):
     cases["dmm_model_inference_4_videos"] = dict(measure(call_inf, n=max(20, n_calls // 4)),
                                                  what=f"DMM_Model.inference, {B} videos x {P} proposals x {F} templates, {H}x{W}, "
                                                       "40 x 5 (dmm_model.py:48-86); ROI feature rows handed over")
+    with torch.autograd.set_multithreading_enabled(False):
+        cases["dmm_model_forward_backward_4_videos_autograd_on_calling_thread"] = dict(
+            measure(call_fwd, n=max(20, n_calls // 4)), what=f"DMM_Model.forward + backward, {B} videos, 10 x 5, under "
+                                                             "torch.autograd.set_multithreading_enabled(False)")
     cases["dmm_model_forward_backward_4_videos"] = dict(measure(call_fwd, n=max(20, n_calls // 4)),
                                                         what=f"DMM_Model.forward + backward, {B} videos, 10 x 5 "
                                                              "(dmm_model.py:88-142)")

@@ -22,6 +22,7 @@ Proposals are duck-typed like maskrcnn_benchmark ``BoxList``: ``len(p)``, ``p.ge
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable, List, Optional
 
 import torch
@@ -35,6 +36,9 @@ from .match_model import MatchModel
 def CHECK4D(t):
     assert len(t.shape) == 4, "get {} {}".format(t.shape, len(t.shape))
     return t.shape
+
+
+_VALID_CACHE = weakref.WeakKeyDictionary()          # DMM_Model instance -> (weakref of the clip's valid tensor, its version, layout)
 
 
 class DMM_Model(nn.Module):
@@ -143,6 +147,21 @@ class DMM_Model(nn.Module):
             out = full.unsqueeze(0)
         return out, [loss["cost_loss"]] if len(loss) > 0 else []
 
+    def _valid_layout_of_clip(self, tplt_valid_batch):
+        """``_valid_layout`` once per CLIP: the reference builds ``tplt_valid_batch`` when a clip starts and hands the same
+        tensor to every frame step (trainer.py:113-121, evaluator.py:114-126), so the answer for this very tensor object at
+        this very version (no in-place write since) is kept -- a frame step after the first costs no host sync.  The tensor
+        is held weakly; a new tensor, or the same one after any in-place edit, is read again."""
+        c = _VALID_CACHE.get(self)                                 # (outside the module's __dict__: deepcopy / pickle safe)
+        if c is not None and c[0]() is tplt_valid_batch and c[1] == tplt_valid_batch._version:
+            return c[2]
+        got = self._valid_layout(tplt_valid_batch)
+        try:
+            _VALID_CACHE[self] = (weakref.ref(tplt_valid_batch), tplt_valid_batch._version, got)
+        except TypeError:                                          # (an object that cannot be weakly referenced)
+            _VALID_CACHE.pop(self, None)
+        return got
+
     @staticmethod
     def _valid_layout(tplt_valid_batch, n_tplt_hint=None):
         """-> (live templates per video, row_scale [B,F] or None).  ONE host sync for the whole batch.  The reference
@@ -218,7 +237,7 @@ class DMM_Model(nn.Module):
         if infos.get("n_tplt"):
             n_tplt, row_scale = list(infos["n_tplt"]), infos.get("row_scale")
         else:
-            n_tplt, row_scale = self._valid_layout(tplt_valid_batch)
+            n_tplt, row_scale = self._valid_layout_of_clip(tplt_valid_batch)
         skip = [n_tplt[b] == 0 or bool(extra_frame[b]) for b in range(B)]
         tplt_feat = self._template_features(tplt_dict, B)
         tg = None
@@ -246,7 +265,7 @@ class DMM_Model(nn.Module):
         boxes_per_image = [len(box) for box in proposals]
         prop_feat = self.feature_extractor(backbone_feature, proposals).split(boxes_per_image, dim=0)
         prop_m, prop_score = self._proposal_fields(proposals)
-        n_tplt, row_scale = self._valid_layout(tplt_valid_batch)            # one host sync for the whole batch
+        n_tplt, row_scale = self._valid_layout_of_clip(tplt_valid_batch)   # one host sync per clip for the whole batch
         skip = [n_tplt[b] == 0 for b in range(B)]
         tplt_feat = self._template_features(tplt_dict, B)
         if self.match_algo != "relax":

@@ -47,3 +47,29 @@ def test_small_host_helpers_on_cpu():
     s = video._slice_batch(out, 2, 4)
     assert s["a"][0].tolist() == [[4, 5], [6, 7]] and s["a"][1].tolist() == [2, 3] and s["b"][0].tolist() == [[2], [3]]
     assert isinstance(s["a"], tuple) and isinstance(s["b"], list) and s["c"] == "tag"
+
+
+def test_valid_layout_is_read_once_per_clip_tensor():
+    """``DMM_Model._valid_layout_of_clip``: the reference hands the SAME ``tplt_valid_batch`` tensor to every frame step of a
+    clip (trainer.py:113-121) -- its layout (live templates per video, non-prefix scale) is read from the device once per
+    tensor object and version; an in-place edit or another tensor is read again; nothing ends up in the module's __dict__
+    (deepcopy / pickle of the model keep working)."""
+    import copy
+    import pickle
+    import torch
+    from dmm_net_amd import dmm_model
+    cfg = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
+           "score_weight": 0.3}
+    m = dmm_model.DMM_Model(cfg, 0)
+    v = torch.tensor([[1., 1., 0.], [1., 0., 0.]])
+    a = m._valid_layout_of_clip(v)
+    assert a[0] == [2, 1] and a[1] is None and m._valid_layout_of_clip(v) is a
+    v[1, 1] = 1                                   # in-place edit: version moves, the flags are read again
+    assert m._valid_layout_of_clip(v)[0] == [2, 2]
+    w = torch.tensor([[1., 0., 1.], [0., 0., 0.]])  # another clip, templates not a prefix
+    n_tplt, scale = m._valid_layout_of_clip(w)
+    assert n_tplt == [2, 0] and scale.tolist() == [[1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    assert m._valid_layout_of_clip(v)[0] == [2, 2]  # (one entry per model: v is read again, correctly)
+    copy.deepcopy(m)
+    pickle.dumps(m)
+    assert not any(k.startswith("_valid") for k in m.__dict__)
