@@ -32,7 +32,7 @@ SYMBOLS = (
     "dmm_workspace_bytes_packed", "dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32",
     "dmm_paste_kept_f32", "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32", "dmm_roialign4_mean_nhwc_fwd",
     "dmm_conv1x1_bf16", "dmm_im2col3x3_bf16", "dmm_bias_relu_maxpool_bf16", "dmm_relax_any_scratch_bytes", "dmm_relax_match_any_f32", "dmm_relax_match_f16s", "dmm_match_solve_packed", "dmm_step_finish_f32",
-    "dmm_matching_loss_f32", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
+    "dmm_matching_loss_f32", "dmm_match_train_tape_bytes", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
     "dmm_match_train_backward_workspace_bytes", "dmm_match_train_backward",
 )
 
@@ -179,15 +179,17 @@ def load():
     L.dmm_matching_loss_f32.restype = c_int
     L.dmm_match_train_forward_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     L.dmm_match_train_forward_workspace_bytes.restype = sz
+    L.dmm_match_train_tape_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    L.dmm_match_train_tape_bytes.restype = sz
     L.dmm_match_train_forward.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64,
                                           c_i64, c_i64, c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp,
-                                          vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+                                          vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, ctypes.POINTER(c_int), vp]
     L.dmm_match_train_forward.restype = c_int
     L.dmm_match_train_backward_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
     L.dmm_match_train_backward_workspace_bytes.restype = sz
     L.dmm_match_train_backward.argtypes = [vp, c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int,
                                            c_int, c_i64, c_i64, vp, vp, c_float, c_int, c_int, c_float, c_int, vp, vp, vp,
-                                           sz, vp]
+                                           sz, vp, vp, c_int, vp]
     L.dmm_match_train_backward.restype = c_int
     for f in ("dmm_match_forward_packed", "dmm_proposal_boxes_f32", "dmm_nms_slots_f32", "dmm_paste_kept_f32",
               "dmm_step_select_i32", "dmm_step_advance", "dmm_commit_masks_f32"):

@@ -75,12 +75,13 @@ class _MatchLayerFn(torch.autograd.Function):
             got = ops.match_train_forward(pm, tm, targets, pf_c, tf_c, sc_c, n_valid, m_valid, score_weight=score_weight,
                                           max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
             if got is not None:
-                full, ms, ds, loss, iters, saved = got
+                full, ms, ds, loss, iters, saved, ctx.taped = got
                 ctx.fused = True
                 ctx.frame_planes = pm if isinstance(pm, ops.FramePlanes) else None
                 empty = _EMPTY
                 ctx.save_for_backward(pf_c, tf_c, sc_c, saved, empty if ctx.frame_planes is not None else pm,
-                                      n_valid if n_valid is not None else empty, m_valid if m_valid is not None else empty)
+                                      n_valid if n_valid is not None else empty, m_valid if m_valid is not None else empty,
+                                      iters)
                 ctx.has_targets = targets is not None
                 ctx.ragged = (n_valid is not None, m_valid is not None)
                 ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
@@ -135,12 +136,13 @@ class _MatchLayerFn(torch.autograd.Function):
             need_pf, need_tf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
             if not (need_pf or need_tf):
                 return (None,) * 14
-            pf, tf, sc, saved, pm, n_valid, m_valid = ctx.saved_tensors
+            pf, tf, sc, saved, pm, n_valid, m_valid, iters = ctx.saved_tensors
             score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
             g_t, g_p = ops.match_train_backward(
                 ctx.frame_planes if ctx.frame_planes is not None else pm, pf, tf, sc, saved, ctx.has_targets, d_full, d_ms,
                 d_ds, d_loss, n_valid if ctx.ragged[0] else None, m_valid if ctx.ragged[1] else None, ctx.n_tplt,
-                score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+                score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test, iters=iters,
+                taped=ctx.taped)
             return (g_p if need_pf else None, g_t.unsqueeze(0) if need_tf else None) + (None,) * 12
         from .backward import match_layer_backward
         return match_layer_backward(ctx, d_full, d_ms, d_ds, d_loss)
@@ -160,8 +162,8 @@ class _MatchFrameFn(torch.autograd.Function):
                                       max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test, one_frame=True)
         if got is None:
             raise _lib.DmmError("dmm_match_train_forward refused a shape frame_fused_ok() accepted")
-        full, ms, ds, loss, iters, saved = got
-        ctx.save_for_backward(pf_c, tf_c, sc_c, saved, pm)
+        full, ms, ds, loss, iters, saved, ctx.taped = got
+        ctx.save_for_backward(pf_c, tf_c, sc_c, saved, pm, iters)
         ctx.has_targets = targets is not None
         ctx.cfg = (score_weight, max_iter, proj_iter, lr, is_test)
         ctx.n_tplt = tm.shape[0]
@@ -174,11 +176,11 @@ class _MatchFrameFn(torch.autograd.Function):
         need_pf, need_tf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_pf or need_tf):
             return (None,) * 11
-        pf, tf, sc, saved, pm = ctx.saved_tensors
+        pf, tf, sc, saved, pm, iters = ctx.saved_tensors
         score_weight, max_iter, proj_iter, lr, is_test = ctx.cfg
         g_t, g_p = ops.match_train_backward(pm, pf, tf, sc, saved, ctx.has_targets, d_full, d_ms, d_ds, d_loss, None, None,
                                             ctx.n_tplt, score_weight=score_weight, max_iter=max_iter, proj_iter=proj_iter,
-                                            lr=lr, is_test=is_test, one_frame=True)
+                                            lr=lr, is_test=is_test, one_frame=True, iters=iters, taped=ctx.taped)
         return (g_p if need_pf else None, g_t if need_tf else None) + (None,) * 9
 
 

@@ -35,7 +35,14 @@ int relax_match_launch(const float *cos_in, const int32_t *inter, const int32_t 
                        const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
                        float score_weight, int max_iter, int proj_iter, float lr, int is_test, float *sim_out, float *R_out,
                        float *Rb_out, float *match_score, float *det_score, int32_t *iters_out, float *X_final,
-                       int clear_tables, int *cleared, dmm_stream_t stream);
+                       int clear_tables, int *cleared, dmm_stream_t stream, void *tape = nullptr, int *taped = nullptr);
+// the training call's solver tape (dmm_solve.hip): bytes (0 = not taped), and the backward that walks it
+size_t relax_tape_bytes(int B, int N, int M, int max_iter, int proj_iter);
+int relax_match_bwd_launch(const float *sim, const float *score_p, int B, int N, int M, const int32_t *n_valid,
+                           const int32_t *m_valid, int max_iter, int proj_iter, float lr, int is_test, const float *dRb,
+                           const float *d_match_score, const float *d_det_score, float *dsim_out, void *workspace,
+                           size_t workspace_bytes, const void *fwd_tape, const float *R_saved, const int32_t *iters_saved,
+                           dmm_stream_t stream);
 
 // General forms for tables outside the compiled envelope (dmm_wide.hip): any N, M; the solver keeps its state in
 // `scratch` (B x wide_scratch_floats(M, max(N, M + 1)) floats).

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final) {
+    float *__restrict__ X_final, uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
     __shared__ float red_buf[2 * NG * (MT + 1)];
     __shared__ float xbuf[MT * 64 * NG];
     __shared__ float rsbuf[MT + 1];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 
     if (NG == 1 && solver_helper_entry(xbuf, hs)) return;       // 128-thread workgroups: wave 1 is the norm helper
     relax_match_body<MT, NG, EXACT>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                     is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, red_buf,
-                                    xbuf, rsbuf, hs);
+                                    xbuf, rsbuf, hs, tape_bits, tape_sweeps);
     if (NG == 1) solver_helper_stop(hs);                        // (paths that never reached the solver)
 }
 
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final) {
+    float *__restrict__ X_final, uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
     __shared__ float red_buf[2 * (MTMAX + 1)];
     __shared__ float xbuf[MTMAX * 64];
     __shared__ float rsbuf[MTMAX + 1];
@@ -83,14 +83,14 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
         if constexpr (K <= MTMAX)                                                                                       \
             relax_match_body<K, 1, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, \
                                          prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,       \
-                                         X_final, red_buf, xbuf, rsbuf, hs);                                            \
+                                         X_final, red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);                    \
         break;
     switch (Mb) {
         DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
         default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
             relax_match_body<1, 1, false>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                           is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final,
-                                          red_buf, xbuf, rsbuf, hs);
+                                          red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);
             break;
     }
 #undef DMM_BODY
@@ -115,7 +115,11 @@ __device__ __forceinline__ void relax_match_bwd_body(
     const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
     const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
-    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws, float *red_buf, float *xbuf, float *rsbuf, int *sweeps_s) {
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws, float *red_buf, float *xbuf, float *rsbuf, int *sweeps_s,
+    const float *__restrict__ R_saved, const int32_t *__restrict__ iters_saved) {
+    // R_saved != null (one-wave kernels; dmm_match_train_backward): the forward kept its tape -- tape_ws holds the sweep
+    // records AND, behind them, the sweep counts ([B][max_iter]); R and the iteration counts are the forward's outputs.
+    // Step 1 (the re-run) is skipped.
     const int b = blockIdx.x;
     const int col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
@@ -139,7 +143,19 @@ __device__ __forceinline__ void relax_match_bwd_body(
     }
     float X[MT], acc[MT];
     RelaxTape tape{tape_ws + (size_t)b * prm.max_iter * prm.proj_iter * (64 * NG), sweeps_s};
-    const int iters = relax_core<MT, NG, EXACT, true>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape);
+    int iters;
+    const bool from_tape = NG == 1 && R_saved != nullptr;
+    if (from_tape) {
+        iters = iters_saved[b];
+        const int *sweeps_g = (const int *)(tape_ws + (size_t)gridDim.x * prm.max_iter * prm.proj_iter * 64) + (size_t)b * prm.max_iter;
+        for (int i = threadIdx.x; i < iters; i += 64 * NG) sweeps_s[i] = sweeps_g[i];
+        const int PpR = N > M ? N : M + 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            acc[i] = (DMM_ROW(i) && livec) ? R_saved[(int64_t)b * M * PpR + (int64_t)i * PpR + col] : 0.0f;
+    } else {
+        iters = relax_core<MT, NG, EXACT, true>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape);
+    }
     __syncthreads();                                                   // sweeps_s + tape visible to the block
 
     // ---- epilogue adjoints -> dR (per X_list entry: g = dR / len) and the direct d(sim_pad) term ----
@@ -149,7 +165,7 @@ __device__ __forceinline__ void relax_match_bwd_body(
     int cand[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        r[i] = acc[i] / flen;
+        r[i] = from_tape ? acc[i] : acc[i] / flen;                     // (the forward's R is this very quotient)
         rmax[i] = (livec && DMM_ROW(i)) ? r[i] : -__builtin_inff();
         const float rc = r[i] < 0.0f ? 0.0f : (r[i] > 1.0f ? 1.0f : r[i]);
         v[i] = (livec && DMM_ROW(i)) ? rc * (-C[i]) : -__builtin_inff();
@@ -254,13 +270,14 @@ __global__ __launch_bounds__(64 * NG) void relax_match_bwd_kernel(
     const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
     const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
-    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws, const float *__restrict__ R_saved,
+    const int32_t *__restrict__ iters_saved) {
     __shared__ float red_buf[2 * NG * (MT + 1)];
     __shared__ float xbuf[MT * 64 * NG];
     __shared__ float rsbuf[MT + 1];
     __shared__ int sweeps_s[kMaxTapeOuter];
     relax_match_bwd_body<MT, NG, EXACT>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in, dsim_out,
-                                        tape_ws, red_buf, xbuf, rsbuf, sweeps_s);
+                                        tape_ws, red_buf, xbuf, rsbuf, sweeps_s, R_saved, iters_saved);
 }
 
 // Ragged template counts (DMM_Model's batches carry m_valid; usually every video has all of its templates): like the
@@ -273,7 +290,8 @@ __global__ __launch_bounds__(64) void relax_match_bwd_ragged_kernel(
     const float *__restrict__ sim_in, const float *__restrict__ score_p, int N, int M,
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, RelaxParams prm, int is_test,
     const float *__restrict__ dRb_in, const float *__restrict__ dms_in, const float *__restrict__ dds_in,
-    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws) {
+    float *__restrict__ dsim_out, uint2 *__restrict__ tape_ws, const float *__restrict__ R_saved,
+    const int32_t *__restrict__ iters_saved) {
     __shared__ float red_buf[2 * (MTMAX + 1)];
     __shared__ float xbuf[MTMAX * 64];
     __shared__ float rsbuf[MTMAX + 1];
@@ -283,13 +301,13 @@ __global__ __launch_bounds__(64) void relax_match_bwd_ragged_kernel(
     case K:                                                                                                               \
         if constexpr (K <= MTMAX)                                                                                         \
             relax_match_bwd_body<K, 1, true>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in, \
-                                             dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s);                          \
+                                             dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s, R_saved, iters_saved);    \
         break;
     switch (Mb) {
         DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
         default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
             relax_match_bwd_body<1, 1, false>(sim_in, score_p, N, M, n_valid, m_valid, prm, is_test, dRb_in, dms_in, dds_in,
-                                              dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s);
+                                              dsim_out, tape_ws, red_buf, xbuf, rsbuf, sweeps_s, R_saved, iters_saved);
             break;
     }
 #undef DMM_BODY
@@ -308,6 +326,15 @@ extern "C" int dmm_relax_match_f32(const float *cos_in, const int32_t *inter, co
                                    X_final, 0, nullptr, stream);
 }
 
+// Bytes of the tape dmm_match_train_forward keeps for dmm_match_train_backward: per frame max_iter * proj_iter sweep records of
+// 64 x 8 bytes + max_iter sweep counts; 0 = this table is not taped (wider than one wave: the backward re-runs the solver).
+size_t dmm::relax_tape_bytes(int B, int N, int M, int max_iter, int proj_iter) {
+    if (B <= 0 || N <= 0 || M <= 0 || max_iter <= 0 || proj_iter <= 0) return 0;
+    const int Pp = N > M ? N : M + 1;
+    if (M > DMM_MAX_TEMPLATES || Pp > 64 || max_iter > dmm::kMaxTapeOuter || dmm::opt(DMM_OPT_FORCE_WIDE) == 1) return 0;
+    return (size_t)B * ((size_t)max_iter * proj_iter * 64 * sizeof(uint2) + (size_t)max_iter * sizeof(int));
+}
+
 // dmm_relax_match_f32 proper.  clear_tables (dmm_match_forward_ws only; the tables are then its workspace, not the
 // caller's): ask the kernel to zero inter / area_p / area_t once it has read them; *cleared says whether the kernel that
 // was launched does that (the thread-per-column kernels on dense frames do, the other mappings do not).
@@ -315,8 +342,9 @@ int dmm::relax_match_launch(const float *cos_in, const int32_t *inter, const int
                             const float *score_p, int B, int N, int M, const int32_t *n_valid, const int32_t *m_valid,
                             float score_weight, int max_iter, int proj_iter, float lr, int is_test, float *sim_out,
                             float *R_out, float *Rb_out, float *match_score, float *det_score, int32_t *iters_out,
-                            float *X_final, int clear_tables, int *cleared, dmm_stream_t stream) {
+                            float *X_final, int clear_tables, int *cleared, dmm_stream_t stream, void *tape, int *taped) {
     if (cleared) *cleared = 0;
+    if (taped) *taped = 0;
     is_test = is_test != 0;                       // the upper bits of the kernels' argument are the library's own
     if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
@@ -333,16 +361,24 @@ int dmm::relax_match_launch(const float *cos_in, const int32_t *inter, const int
                                           w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,
                                           iters_out, X_final, (hipStream_t)stream);
     const bool exact_ok = (m_valid == nullptr);   // every frame has exactly M templates
+    // the tape (dmm_match_train_forward): the one-wave kernels write it; wider tables do not (relax_tape_bytes = 0)
+    uint2 *tape_bits = nullptr;
+    int *tape_sweeps = nullptr;
+    if (tape && taped && dmm::relax_tape_bytes(B, N, M, max_iter, proj_iter) > 0) {
+        tape_bits = (uint2 *)tape;
+        tape_sweeps = (int *)(tape_bits + (size_t)B * max_iter * proj_iter * 64);
+        *taped = 1;
+    }
     if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
         hipLaunchKernelGGL((dmm::relax_match_ragged_kernel<8>), dim3(B), dim3(dmm::solver_block(1, B)), 0, (hipStream_t)stream, cos_in, inter,
                            area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out,
-                           Rb_out, match_score, det_score, iters_out, X_final);
+                           Rb_out, match_score, det_score, iters_out, X_final, tape_bits, tape_sweeps);
         return dmm::check_launch();
     }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                    \
     hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream,   \
                        cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, \
-                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
+                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, tape_bits, tape_sweeps)
     if (clear_tables && cleared && !n_valid && !m_valid) {
         is_test |= dmm::kRelaxClearTables;
         *cleared = 1;
@@ -398,11 +434,25 @@ extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, i
                                        float lr, int is_test, const float *dRb, const float *d_match_score,
                                        const float *d_det_score, float *dsim_out, void *workspace,
                                        size_t workspace_bytes, dmm_stream_t stream) {
+    return dmm::relax_match_bwd_launch(sim, score_p, B, N, M, n_valid, m_valid, max_iter, proj_iter, lr, is_test, dRb,
+                                       d_match_score, d_det_score, dsim_out, workspace, workspace_bytes, nullptr, nullptr,
+                                       nullptr, stream);
+}
+
+// dmm_relax_match_bwd_f32 proper.  fwd_tape / R_saved / iters_saved (dmm_match_train_backward, all three or none): the tape
+// the forward's one-wave kernel kept (relax_tape_bytes > 0 and `taped` returned 1), its R and its iteration counts -- the
+// kernel then walks that tape instead of re-running the solver into `workspace`.
+int dmm::relax_match_bwd_launch(const float *sim, const float *score_p, int B, int N, int M, const int32_t *n_valid,
+                                const int32_t *m_valid, int max_iter, int proj_iter, float lr, int is_test,
+                                const float *dRb, const float *d_match_score, const float *d_det_score, float *dsim_out,
+                                void *workspace, size_t workspace_bytes, const void *fwd_tape, const float *R_saved,
+                                const int32_t *iters_saved, dmm_stream_t stream) {
     if (B < 0 || N < 0 || M < 0 || max_iter < 0 || proj_iter < 0) return DMM_ERR_BAD_ARG;
     if (B == 0 || M == 0) return DMM_OK;
     if (N == 0 || !sim || !score_p || !dsim_out) return DMM_ERR_BAD_ARG;
     const int Pp = N > M ? N : M + 1;
-    if (workspace_bytes < dmm_relax_bwd_workspace_bytes(B, N, M, max_iter, proj_iter)) return DMM_ERR_WORKSPACE;
+    const bool from_tape = fwd_tape && R_saved && iters_saved && dmm::relax_tape_bytes(B, N, M, max_iter, proj_iter) > 0;
+    if (!from_tape && workspace_bytes < dmm_relax_bwd_workspace_bytes(B, N, M, max_iter, proj_iter)) return DMM_ERR_WORKSPACE;
     const dmm::RelaxParams prm{max_iter, proj_iter, lr};
     if (M > DMM_MAX_TEMPLATES || Pp > DMM_MAX_PROPOSALS || max_iter > dmm::kMaxTapeOuter ||
         dmm::opt(DMM_OPT_FORCE_WIDE) == 1) {
@@ -412,18 +462,20 @@ extern "C" int dmm_relax_match_bwd_f32(const float *sim, const float *score_p, i
         return dmm::launch_relax_match_bwd_wide(sim, score_p, B, N, M, n_valid, m_valid, prm, is_test, dRb, d_match_score,
                                                 d_det_score, dsim_out, workspace, (hipStream_t)stream);
     }
-    if (!workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
+    if (!from_tape && !workspace && max_iter * proj_iter > 0) return DMM_ERR_BAD_ARG;
     const bool exact_ok = (m_valid == nullptr);
-    uint2 *tape = (uint2 *)workspace;
+    uint2 *tape = from_tape ? (uint2 *)const_cast<void *>(fwd_tape) : (uint2 *)workspace;
+    const float *Rs = from_tape ? R_saved : nullptr;
+    const int32_t *its = from_tape ? iters_saved : nullptr;
     if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
         hipLaunchKernelGGL((dmm::relax_match_bwd_ragged_kernel<8>), dim3(B), dim3(64), 0, (hipStream_t)stream, sim, score_p, N, M,
-                           n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out, tape);
+                           n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out, tape, Rs, its);
         return dmm::check_launch();
     }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                       \
     hipLaunchKernelGGL((dmm::relax_match_bwd_kernel<MT_, NG_, EX_>), dim3(B), dim3(64 * NG_), 0, (hipStream_t)stream,   \
                        sim, score_p, N, M, n_valid, m_valid, prm, is_test, dRb, d_match_score, d_det_score, dsim_out,  \
-                       tape)
+                       tape, Rs, its)
     DMM_DISPATCH_SOLVER(M, Pp, exact_ok, DMM_CALL);
 #undef DMM_CALL
     return dmm::check_launch();

@@ -532,11 +532,20 @@ __device__ __forceinline__ void row_steps_wave(const float *rowbuf, int n, int m
 // element-wise work around them): 10 x 50 at 20 x 5 64.5 -> 58.3 us, 5 x 50 50.5 -> 44.7 us with the width class fixed.
 // So the core is compiled for the model's width classes (4, 5, 6: 32..55 columns -- the evaluator keeps up to 50 proposals
 // per frame, 30..50 after NMS) and once more for any width.
-template <int MT, bool EXACT, int VSC = -1>
+// Tape (for the backward): per executed sweep and thread one uint2 {relu bits (bit i <=> row i passed the relu),
+// column-over flag}; per outer iteration the number of executed sweeps.
+struct RelaxTape {
+    uint2 *bits;        // global [max_iter * proj_iter][64 * NG]
+    int *sweeps;        // [max_iter] (LDS in the backward's re-run)
+};
+
+template <int MT, bool EXACT, int VSC = -1, bool TAPE = false>
 __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                              float *xbuf, float *rsbuf, int *hs, float (&X)[MT], float (&acc)[MT],
-                                             float *cost_out, float *rowbuf /* LDS, MT * kRowStride + 8 floats, 16-byte aligned */) {
+                                             float *cost_out, float *rowbuf /* LDS, MT * kRowStride + 8 floats, 16-byte aligned */,
+                                             RelaxTape tape = RelaxTape{nullptr, nullptr}) {
     constexpr int MP = (MT + 1) / 2;                   // row pairs; an odd MT leaves a dummy slot that stays zero
+    int tape_pos = 0;
     const int n = EXACT ? MT : n_rt;
     const bool with_helper = blockDim.x > 64;          // wave 1 computes the cost norms (norm_helper_wave)
     if (with_helper && threadIdx.x == 0) hs[3] = n * m;
@@ -623,10 +632,12 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
         // the wave for the whole compare -> scalar -> branch latency, ~0.1 us per sweep); when sweep j turns out to have
         // moved nothing, the relu step of sweep j + 1 -- all that was done since: it only touches X and P0 -- is undone.
         unsigned long long moved_prev = ~0ull;
+        int sweeps_done = 0;
         // one sweep; true = the sweep before it moved nothing (stop).  Called twice per trip of the loop below: X and
         // X_start trade registers from one sweep to the next, and a rolled loop paid for that with 20 v_mov per sweep.
         auto sweep = [&]() -> bool {
             f32x2 Xs[MP], P0s[MP];
+            unsigned relu_bits = 0;
             // {X >= 0} (:74-76) then X = Y + P1 (:78)
 #pragma unroll
             for (int k = 0; k < MP; ++k) {
@@ -634,6 +645,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
                 P0s[k] = P0[k];
                 const f32x2 x = Xp[k] + P0[k];
                 const f32x2 y = f32x2{__builtin_fmaxf(x.x, 0.0f), __builtin_fmaxf(x.y, 0.0f)};
+                if (TAPE) relu_bits |= (x.x > 0.0f ? 1u << (2 * k) : 0u) | (x.y > 0.0f ? 2u << (2 * k) : 0u);
                 P0[k] = x - y;
                 Xp[k] = y + P1[k];
             }
@@ -671,6 +683,11 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             }
             // {column sums <= 1}: project_col (:21-34, :79-80); then X = Y + P2 (:82)
             const bool over = cs > 1.0f;                       // mask = (X_col_sum <= 1)
+            if (TAPE) {                                        // (a sweep undone above was never taped)
+                tape.bits[(size_t)tape_pos * 64 + threadIdx.x] = make_uint2(relu_bits, over ? 1u : 0u);
+                ++tape_pos;
+                ++sweeps_done;
+            }
             float tc = div_by_const(cs - 1.0f, fn, rcp_n);
             tc = over ? tc : 0.0f;                             // x - 0 = x: the reference's `Y = X` branch, exactly
 #pragma unroll
@@ -721,6 +738,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
             while (hs_load(&hs[1]) != it + 1) {}
             cost = __int_as_float(hs[2]);
         }
+        if (TAPE && threadIdx.x == 0) tape.sweeps[it] = sweeps_done;
         if (cost_out && threadIdx.x == 0) cost_out[it + 1] = cost;
         if (cost_prev == cost) break;                           // :96-98
         cost_prev = cost;
@@ -743,13 +761,6 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
 // EXACT: n == MT at compile time (all row guards fold away).
 // xbuf: LDS [MT * 64 * NG] floats, rsbuf: LDS [MT + 1] floats.
 // ---------------------------------------------------------------------------------------------
-// Tape (backward only): per executed sweep and thread one uint2 {relu bits (bit i <=> row i passed the relu),
-// column-over flag}; per outer iteration the number of executed sweeps.
-struct RelaxTape {
-    uint2 *bits;        // global [max_iter * proj_iter][64 * NG]
-    int *sweeps;        // LDS [max_iter]
-};
-
 template <int MT, int NG, bool EXACT, bool TAPE = false>
 __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                           BlockRed<MT, NG> &red, float *xbuf, float *rsbuf, float (&X)[MT],
@@ -759,6 +770,11 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
     if constexpr (NG == 1 && !TAPE) {                  // forward, one wave per frame: the latency form
         (void)red;
         __shared__ __attribute__((aligned(16))) float rowbuf_w1[MT * kRowStride + 8];   // one buffer for all the variants
+        // the training forward tapes its sweeps for the backward (dmm_match_train_forward; one width-generic instantiation):
+        // the backward then skips its re-run of the solver.  (TAPE = true -- the backward's own re-run when no tape was
+        // kept -- stays on the form below: without the helper wave it is the faster one, 48.3 vs 50.9 us at 5 x 50, 10 x 5)
+        if (tape.bits)
+            return relax_core_w1<MT, EXACT, -1, true>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1, tape);
         switch (m >> 3) {                              // the evaluator's frames: 50 proposals, 32..55 columns after NMS
             case 4: return relax_core_w1<MT, EXACT, 4>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
             case 5: return relax_core_w1<MT, EXACT, 5>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
@@ -1105,7 +1121,10 @@ __device__ __forceinline__ void relax_match_body(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf, int *hs) {
+    float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf, int *hs,
+    uint2 *__restrict__ tape_bits = nullptr, int *__restrict__ tape_sweeps = nullptr) {
+    // tape_bits / tape_sweeps (one-wave kernels only; dmm_match_train_forward): [B][max_iter * proj_iter][64] sweep records and
+    // [B][max_iter] executed-sweep counts for dmm_relax_match_bwd's taped form
     const int b = blockIdx.x;
     const int col = threadIdx.x;
     BlockRed<MT, NG> red(red_buf, threadIdx.x >> 6);
@@ -1186,8 +1205,10 @@ __device__ __forceinline__ void relax_match_body(
                 if (DMM_ROW(i) && col < PpS) X_b[(int64_t)i * PpS + col] = livec ? X[i] : 0.0f;
         }
     } else {
-        iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
-                                          RelaxTape{nullptr, nullptr}, hs);
+        RelaxTape tape{nullptr, nullptr};
+        if (NG == 1 && tape_bits)
+            tape = RelaxTape{tape_bits + (size_t)b * prm.max_iter * prm.proj_iter * 64, tape_sweeps + (size_t)b * prm.max_iter};
+        iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape, hs);
     }
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
 

@@ -644,8 +644,10 @@ def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_va
     batch axis, as the reference's trainer hands them over (masks_p [N,H,W], masks_t / targets [M,H,W], feat_p [N,D],
     feat_t [M,D], score_p [N]) and so are the results -- no unsqueeze / select views around the call.  Returns None when the
     shape is outside the entry's envelope (the caller then runs the granular ops), else
-    (full [B,M,H,W], match_score [B,M], det_score [B,M], cost_loss [B] | None, iters [B], saved) with ``saved`` = the flat
-    fp32 block cos | sim | Rb | gt that ``match_train_backward`` reads."""
+    (full [B,M,H,W], match_score [B,M], det_score [B,M], cost_loss [B] | None, iters [B], saved, taped) with ``saved`` = the
+    flat fp32 block cos | sim | Rb | gt (| the solver's tape, 256-byte aligned) that ``match_train_backward`` reads and
+    ``taped`` = whether the forward's solver kernel kept its tape there (tables of <= 64 solver columns: the backward then
+    does not re-run the solver)."""
     fp = masks_p if isinstance(masks_p, FramePlanes) else None
     if one_frame:
         masks_p, sp_n = _planes3(masks_p)
@@ -694,27 +696,43 @@ def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_va
     loss = torch.empty(lead, **f32) if targets is not None else None
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     n_cs, n_rb = B * M * N, B * M * Pp
-    saved = torch.empty((3 * n_cs + n_rb,), **f32)
+    tape_off, tape_bytes = _train_tape_layout(L, B, N, M, max_iter, proj_iter)
+    saved = torch.empty((tape_off // 4 + tape_bytes // 4,), **f32)
     sp = saved.data_ptr()
+    taped = ctypes.c_int(0)
     with _lib.device_guard(dev):
         rc = L.dmm_match_train_forward(p_ptr, masks_t.data_ptr(), g_ptr, _DT[dt], feat_p.data_ptr(), feat_t.data_ptr(),
                                        score_p.data_ptr(), B, N, M, H * W, D, sp_b, sp_n, st_b, st_m, sg_b, sg_m,
                                        _ptr(n_valid), _ptr(m_valid), score_weight, max_iter, proj_iter, lr, is_test,
                                        full.data_ptr(), ms.data_ptr(), ds.data_ptr(), _ptr(loss), iters.data_ptr(), sp,
                                        sp + 4 * n_cs, sp + 8 * n_cs, (sp + 8 * n_cs + 4 * n_rb) if targets is not None else None,
-                                       ws.data_ptr(), ws.numel(), stream)
+                                       ws.data_ptr(), ws.numel(), (sp + tape_off) if tape_bytes else None, tape_bytes,
+                                       ctypes.byref(taped), stream)
     if rc == 2:                                               # DMM_ERR_UNSUPPORTED: nothing was launched
         return None
     if rc:
         _lib.check(rc, "dmm_match_train_forward")
-    return full, ms, ds, loss, iters, saved
+    return full, ms, ds, loss, iters, saved, int(taped.value)
+
+
+def _train_tape_layout(L, B, N, M, max_iter, proj_iter):
+    """-> (byte offset of the solver's tape inside the training call's saved block, its size; 0 = not taped)."""
+    k = ("tt", B, N, M, max_iter, proj_iter)
+    got = _WS_NEED.get(k)
+    if got is None:
+        n_cs, n_rb = B * M * N, B * M * padded_width(N, M)
+        off = -(-(4 * (3 * n_cs + n_rb)) // 256) * 256
+        got = _WS_NEED[k] = (off, int(L.dmm_match_train_tape_bytes(B, N, M, int(max_iter), int(proj_iter))))
+    return got
 
 
 def match_train_backward(masks_p, feat_p, feat_t, score_p, saved, has_loss, d_full, d_ms, d_ds, d_loss, n_valid, m_valid,
-                         M, *, score_weight, max_iter, proj_iter, lr, is_test, one_frame=False):
+                         M, *, score_weight, max_iter, proj_iter, lr, is_test, one_frame=False, iters=None, taped=0):
     """-> (g_feat_t [B,M,D], g_feat_p [B,N,D]): the whole backward of ``match_train_forward`` as ONE C-ABI call
     (``dmm_match_train_backward``, (5e)): normalise both feature sets -> mix backward -> taped solver backward ->
-    feature-similarity backward.  ``saved`` is the forward's block; d_* may be None.  ``one_frame``: as in the forward."""
+    feature-similarity backward.  ``saved`` is the forward's block; d_* may be None.  ``one_frame``: as in the forward.
+    ``iters`` / ``taped``: the forward's iteration counts and its ``taped`` flag -- with them the solver's backward walks the
+    tape inside ``saved`` instead of re-running the solver."""
     fp = masks_p if isinstance(masks_p, FramePlanes) else None
     if one_frame:
         masks_p, sp_n = _planes3(masks_p)
@@ -743,13 +761,16 @@ def match_train_backward(masks_p, feat_p, feat_t, score_p, saved, has_loss, d_fu
     use_loss = has_loss and d_loss is not None
     g_t, g_p = torch.empty_like(feat_t), torch.empty_like(feat_p)
     sp = saved.data_ptr()
+    tape_off, tape_bytes = _train_tape_layout(L, B, N, M, max_iter, proj_iter)
+    walk = bool(taped) and iters is not None and tape_bytes > 0 and saved.numel() * 4 >= tape_off + tape_bytes
     with _lib.device_guard(dev):
         rc = L.dmm_match_train_backward(p_ptr, _DT[dt], feat_p.data_ptr(), feat_t.data_ptr(), score_p.data_ptr(),
                                         sp if use_loss else None, sp + 4 * n_cs, sp + 8 * n_cs,
                                         (sp + 8 * n_cs + 4 * n_rb) if use_loss else None, _ptr(d_full), _ptr(d_ms),
                                         _ptr(d_ds), _ptr(d_loss) if use_loss else None, B, N, M, H * W, D, sp_b, sp_n,
                                         _ptr(n_valid), _ptr(m_valid), score_weight, max_iter, proj_iter, lr, is_test,
-                                        g_t.data_ptr(), g_p.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                                        g_t.data_ptr(), g_p.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        (sp + tape_off) if walk else None, _ptr(iters) if walk else None, int(walk), stream)
     if rc:
         _lib.check(rc, "dmm_match_train_backward")
     return g_t, g_p

@@ -441,7 +441,14 @@ DMM_API int dmm_matching_loss_f32(const int32_t *inter2 /*[B,M,N]*/, const int32
  *   = (2) on both feature sets (one launch; the forward keeps no normalised rows) -> (4b) -> (3b) -> (2d).  Any of d_full
  *   [B,M,HW], d_match_score, d_det_score [B,M] may be NULL (no gradient from that output); gt / d_loss / cos NULL together
  *   (no loss term).  Any N, M.  workspace >= dmm_match_train_backward_workspace_bytes(B, N, M, D, max_iter, proj_iter).
+ * The solver's TAPE (optional, both entries): the reference's autograd keeps every intermediate of relax_matching
+ *   (relax_match.py:68-98) for its backward; (3b) alone re-runs the solver to rebuild what it needs.  Given a caller block
+ *   `tape` of dmm_match_train_tape_bytes(B, N, M, max_iter, proj_iter) bytes (0 = this table is not taped: wider than 64 solver
+ *   columns) and iters_out != NULL, the forward's solver kernel records it there (R, and per projection sweep and column 8
+ *   bytes of gate bits) and sets *taped = 1; handed back with that flag and the forward's iters, the backward walks the
+ *   records instead of re-running the solver (same gradient: the same gates).  tape == NULL / taped == 0: as before.
  * ------------------------------------------------------------------------------------------- */
+DMM_API size_t dmm_match_train_tape_bytes(int B, int N, int M, int max_iter, int proj_iter);
 DMM_API size_t dmm_match_train_forward_workspace_bytes(int B, int N, int M, int D);
 DMM_API int dmm_match_train_forward(const void *masks_p, const void *masks_t, const void *targets, int mask_dtype,
                                     const float *feat_p, const float *feat_t, const float *score_p, int B, int N, int M,
@@ -450,7 +457,8 @@ DMM_API int dmm_match_train_forward(const void *masks_p, const void *masks_t, co
                                     int max_iter, int proj_iter, float lr, int is_test, float *full_outmask,
                                     float *match_score, float *det_score, float *cost_loss, int32_t *iters_out,
                                     float *cos_out, float *sim_out, float *Rb_out, float *gt_out, void *workspace,
-                                    size_t workspace_bytes, dmm_stream_t stream);
+                                    size_t workspace_bytes, void *tape, size_t tape_bytes, int *taped /* host, may be NULL */,
+                                    dmm_stream_t stream);
 DMM_API size_t dmm_match_train_backward_workspace_bytes(int B, int N, int M, int D, int max_iter, int proj_iter);
 DMM_API int dmm_match_train_backward(const void *masks_p, int mask_dtype, const float *feat_p, const float *feat_t,
                                      const float *score_p, const float *cos, const float *sim, const float *Rb,
@@ -459,7 +467,8 @@ DMM_API int dmm_match_train_backward(const void *masks_p, int mask_dtype, const 
                                      int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
                                      float score_weight, int max_iter, int proj_iter, float lr, int is_test,
                                      float *g_feat_t /*[B,M,D]*/, float *g_feat_p /*[B,N,D]*/, void *workspace,
-                                     size_t workspace_bytes, dmm_stream_t stream);
+                                     size_t workspace_bytes, const void *tape, const int32_t *iters /*[B], the forward's*/,
+                                     int taped, dmm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) Fused 4-level ROIAlign + spatial mean: the reference's ROI feature extractor

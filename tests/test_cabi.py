@@ -60,9 +60,13 @@ def test_training_entries_validate_their_arguments_without_gpu():
     assert 0 < L.dmm_match_train_forward_workspace_bytes(1, 50, 5, 512) < L.dmm_match_train_forward_workspace_bytes(4, 50, 5, 512)
     assert L.dmm_match_train_forward_workspace_bytes(0, 50, 5, 512) == 0
     assert L.dmm_match_train_backward_workspace_bytes(1, 50, 5, 512, 10, 5) > 4 * (50 + 5) * 512
+    # the solver's tape: R + 10 x 5 sweep records of 64 x 8 bytes + 10 sweep counts per frame; none for tables wider than a wave
+    assert L.dmm_match_train_tape_bytes(1, 50, 5, 10, 5) >= 4 * 5 * 50 + 50 * 512 + 40
+    assert L.dmm_match_train_tape_bytes(4, 50, 5, 10, 5) > 3 * L.dmm_match_train_tape_bytes(1, 50, 5, 10, 5)
+    assert L.dmm_match_train_tape_bytes(1, 200, 20, 10, 5) == 0 and L.dmm_match_train_tape_bytes(1, 50, 5, 0, 5) == 0
     one = ctypes.c_void_p(8)
     base = lambda B, N, M: (one, one, one, 0, one, one, one, B, N, M, 64, 512, 3200, 64, 320, 64, 320, 64, None, None, 0.3,
-                            10, 5, 0.1, 0, one, one, one, one, one, one, one, one, one, one, 1 << 30, None)
+                            10, 5, 0.1, 0, one, one, one, one, one, one, one, one, one, one, 1 << 30, None, 0, None, None)
     assert L.dmm_match_train_forward(*base(-1, 50, 5)) == 1
     assert L.dmm_match_train_forward(*base(0, 50, 5)) == 0                       # nothing to do
     assert L.dmm_match_train_forward(*base(1, 0, 5)) == 1

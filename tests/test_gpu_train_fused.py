@@ -454,3 +454,35 @@ def test_dmm_model_one_video_takes_the_frame_call_and_equals_the_batched_path(O)
             assert abs(la - lb) <= 2e-7 * max(1.0, abs(lb))
             scale = float(b_[3].abs().max())
             assert float((a[3] - b_[3]).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("B,N,M,ragged", [(1, 50, 5, False), (3, 50, 10, False), (5, 40, 8, True), (2, 3, 5, False),
+                                          (2, 64, 16, False)])
+def test_backward_from_the_forwards_tape_equals_the_rerun_bit_for_bit(B, N, M, ragged):
+    """The training forward keeps the solver's tape (gate bits per sweep, sweep counts, R); the backward that walks it must
+    give exactly what the backward that re-runs the solver gives -- same gates, same arithmetic.  Tables wider than one
+    wave are not taped (``taped`` = 0) and always re-run."""
+    H, W, D = 24, 28, 512
+    d = batch(B, N, M, H, W, D, seed=300 + N + M)
+    nv = mv = None
+    if ragged:
+        nv = torch.tensor([N, N - 7, 1, N, 9][:B], dtype=torch.int32, device=DEV)
+        mv = torch.tensor([M, 3, 1, 0, M - 1][:B], dtype=torch.int32, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for is_test in (0, 1):
+        kw = dict(score_weight=0.3, max_iter=10, proj_iter=5, lr=0.1, is_test=is_test)
+        got = ops.match_train_forward(d["pm"], d["tm"], d["tg"], d["pf"], d["tf"], d["sc"], nv, mv, **kw)
+        full, ms, ds, loss, iters, saved, taped = got
+        assert taped == 1
+        d_full = torch.rand(full.shape, generator=g, device=DEV)
+        d_ms = torch.rand(ms.shape, generator=g, device=DEV)
+        d_ds = torch.rand(ds.shape, generator=g, device=DEV)
+        d_loss = torch.rand(loss.shape, generator=g, device=DEV)
+        args = (d["pm"], d["pf"], d["tf"], d["sc"], saved, True, d_full, d_ms, d_ds, d_loss, nv, mv, M)
+        walked = ops.match_train_backward(*args, iters=iters, taped=taped, **kw)
+        rerun = ops.match_train_backward(*args, **kw)
+        assert torch.equal(walked[0], rerun[0]) and torch.equal(walked[1], rerun[1]), (is_test, B, N, M)
+        assert float(rerun[1].abs().max()) > 0
+    wide = batch(1, 100, 5, 16, 16, D, seed=5)
+    assert ops.match_train_forward(wide["pm"], wide["tm"], wide["tg"], wide["pf"], wide["tf"], wide["sc"], None, None,
+                                   score_weight=0.3, max_iter=10, proj_iter=5, lr=0.1, is_test=0)[6] == 0
