@@ -920,7 +920,10 @@ def bench_train(R, Bs=(64, 512)):
         per_B[str(B)] = {"fwd_bwd_ms": round(elapsed / steps * 1e3, 4), "frames_per_s": round(B * steps / elapsed, 1),
                          "steps": steps, "selected_planes_per_frame": round(n_union / B, 2),
                          "selected_row_plane_pairs_per_frame": round(nnz / B, 2),
-                         "kernel_sum_ms": round(sum(t.values()), 4), "kernels": kern}
+                         "kernel_sum_ms": round(sum(t.values()), 4), "kernels": kern,
+                         "note": "fwd_bwd_ms = the fused training entries (the forward keeps the solver's tape, the backward "
+                                 "walks it); the per-kernel rows time the granular entries one by one -- their "
+                                 "relax_match_bwd re-runs the solver first (about half of its time)"}
         del pm, tm, tg, dfull
         torch.cuda.empty_cache()
     big = per_B[max(per_B, key=int)]
