@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final, uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
+    float *__restrict__ X_final) {
     __shared__ float red_buf[2 * NG * (MT + 1)];
     __shared__ float xbuf[MT * 64 * NG];
     __shared__ float rsbuf[MT + 1];
@@ -57,8 +57,30 @@ __global__ __launch_bounds__(NG == 1 ? 128 : 64 * NG, (NG == 4 && MT <= 20) ? 2 
     if (NG == 1 && solver_helper_entry(xbuf, hs)) return;       // 128-thread workgroups: wave 1 is the norm helper
     relax_match_body<MT, NG, EXACT>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                     is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, red_buf,
-                                    xbuf, rsbuf, hs, tape_bits, tape_sweeps);
+                                    xbuf, rsbuf, hs);
     if (NG == 1) solver_helper_stop(hs);                        // (paths that never reached the solver)
+}
+
+// The same kernel for the TRAINING forward (dmm_match_train_forward): one wave per frame, and the solver records its sweeps
+// (gate bits per column and sweep, executed sweeps per outer iteration) for the backward.  Kernels of their own so that the
+// evaluator's solve stays the code it was.
+template <int MT, bool EXACT>
+__global__ __launch_bounds__(128) void relax_match_taped_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
+    __shared__ float red_buf[2 * (MT + 1)];
+    __shared__ float xbuf[MT * 64];
+    __shared__ float rsbuf[MT + 1];
+    __shared__ int hs[4];
+    if (solver_helper_entry(xbuf, hs)) return;
+    relax_match_body<MT, 1, EXACT, false, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou,
+                                                prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,
+                                                nullptr, red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);
+    solver_helper_stop(hs);
 }
 
 // Ragged batches of small problems (the product: up to maxseqlen = 5 templates per video, a different count per video):
@@ -71,7 +93,7 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
     const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
     RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
-    float *__restrict__ X_final, uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
+    float *__restrict__ X_final) {
     __shared__ float red_buf[2 * (MTMAX + 1)];
     __shared__ float xbuf[MTMAX * 64];
     __shared__ float rsbuf[MTMAX + 1];
@@ -83,14 +105,48 @@ __global__ __launch_bounds__(128) void relax_match_ragged_kernel(
         if constexpr (K <= MTMAX)                                                                                       \
             relax_match_body<K, 1, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, \
                                          prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out,       \
-                                         X_final, red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);                    \
+                                         X_final, red_buf, xbuf, rsbuf, hs);                                            \
         break;
     switch (Mb) {
         DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
         default:                                            // 1 template, and dead frames (Mb <= 0: zeros)
             relax_match_body<1, 1, false>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm,
                                           is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final,
-                                          red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);
+                                          red_buf, xbuf, rsbuf, hs);
+            break;
+    }
+#undef DMM_BODY
+    solver_helper_stop(hs);
+}
+
+// ... and its taped twin for the training forward (see relax_match_taped_kernel)
+template <int MTMAX>
+__global__ __launch_bounds__(128) void relax_match_ragged_taped_kernel(
+    const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
+    const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
+    const int32_t *__restrict__ n_valid, const int32_t *__restrict__ m_valid, float w_feat, float w_iou,
+    RelaxParams prm, int is_test, float *__restrict__ sim_out, float *__restrict__ R_out, float *__restrict__ Rb_out,
+    float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
+    uint2 *__restrict__ tape_bits, int *__restrict__ tape_sweeps) {
+    __shared__ float red_buf[2 * (MTMAX + 1)];
+    __shared__ float xbuf[MTMAX * 64];
+    __shared__ float rsbuf[MTMAX + 1];
+    __shared__ int hs[4];
+    if (solver_helper_entry(xbuf, hs)) return;
+    const int Mb = m_valid ? m_valid[blockIdx.x] : M;
+#define DMM_BODY(K)                                                                                                     \
+    case K:                                                                                                             \
+        if constexpr (K <= MTMAX)                                                                                       \
+            relax_match_body<K, 1, true, false, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, \
+                                                      w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,   \
+                                                      iters_out, nullptr, red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps); \
+        break;
+    switch (Mb) {
+        DMM_BODY(2) DMM_BODY(3) DMM_BODY(4) DMM_BODY(5) DMM_BODY(6) DMM_BODY(7) DMM_BODY(8)
+        default:
+            relax_match_body<1, 1, false, false, true>(cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat,
+                                                       w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,
+                                                       iters_out, nullptr, red_buf, xbuf, rsbuf, hs, tape_bits, tape_sweeps);
             break;
     }
 #undef DMM_BODY
@@ -361,24 +417,44 @@ int dmm::relax_match_launch(const float *cos_in, const int32_t *inter, const int
                                           w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score,
                                           iters_out, X_final, (hipStream_t)stream);
     const bool exact_ok = (m_valid == nullptr);   // every frame has exactly M templates
-    // the tape (dmm_match_train_forward): the one-wave kernels write it; wider tables do not (relax_tape_bytes = 0)
-    uint2 *tape_bits = nullptr;
-    int *tape_sweeps = nullptr;
-    if (tape && taped && dmm::relax_tape_bytes(B, N, M, max_iter, proj_iter) > 0) {
-        tape_bits = (uint2 *)tape;
-        tape_sweeps = (int *)(tape_bits + (size_t)B * max_iter * proj_iter * 64);
+    // the tape (dmm_match_train_forward): the taped one-wave kernels write it -- dense batches of <= 16 templates, ragged
+    // ones of <= 8; anything else is not taped (the backward re-runs the solver)
+    if (tape && taped && !X_final && dmm::relax_tape_bytes(B, N, M, max_iter, proj_iter) > 0 && (exact_ok ? M <= 16 : M <= 8)) {
+        uint2 *tape_bits = (uint2 *)tape;
+        int *tape_sweeps = (int *)(tape_bits + (size_t)B * max_iter * proj_iter * 64);
         *taped = 1;
+#define DMM_TAPED(MT_)                                                                                                   \
+    hipLaunchKernelGGL((dmm::relax_match_taped_kernel<MT_, true>), dim3(B), dim3(dmm::solver_block(1, B)), 0,            \
+                       (hipStream_t)stream, cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, \
+                       prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, tape_bits, tape_sweeps)
+        if (!exact_ok) {
+            hipLaunchKernelGGL((dmm::relax_match_ragged_taped_kernel<8>), dim3(B), dim3(dmm::solver_block(1, B)), 0,
+                               (hipStream_t)stream, cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat,
+                               w_iou, prm, is_test, sim_out, R_out, Rb_out, match_score, det_score, iters_out, tape_bits,
+                               tape_sweeps);
+        } else {
+            switch (M) {
+                case 1: DMM_TAPED(1); break;   case 2: DMM_TAPED(2); break;   case 3: DMM_TAPED(3); break;
+                case 4: DMM_TAPED(4); break;   case 5: DMM_TAPED(5); break;   case 6: DMM_TAPED(6); break;
+                case 7: DMM_TAPED(7); break;   case 8: DMM_TAPED(8); break;   case 9: DMM_TAPED(9); break;
+                case 10: DMM_TAPED(10); break; case 11: DMM_TAPED(11); break; case 12: DMM_TAPED(12); break;
+                case 13: DMM_TAPED(13); break; case 14: DMM_TAPED(14); break; case 15: DMM_TAPED(15); break;
+                default: DMM_TAPED(16); break;
+            }
+        }
+#undef DMM_TAPED
+        return dmm::check_launch();
     }
     if (!exact_ok && M <= 8 && Pp <= 64) {        // ragged template counts, one wave per frame: per-frame exact bodies
         hipLaunchKernelGGL((dmm::relax_match_ragged_kernel<8>), dim3(B), dim3(dmm::solver_block(1, B)), 0, (hipStream_t)stream, cos_in, inter,
                            area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, sim_out, R_out,
-                           Rb_out, match_score, det_score, iters_out, X_final, tape_bits, tape_sweeps);
+                           Rb_out, match_score, det_score, iters_out, X_final);
         return dmm::check_launch();
     }
 #define DMM_CALL(MT_, NG_, EX_)                                                                                    \
     hipLaunchKernelGGL((dmm::relax_match_kernel<MT_, NG_, EX_>), dim3(B), dim3(dmm::solver_block(NG_, B)), 0, (hipStream_t)stream,   \
                        cos_in, inter, area_p, area_t, score_p, N, M, n_valid, m_valid, w_feat, w_iou, prm, is_test, \
-                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final, tape_bits, tape_sweeps)
+                       sim_out, R_out, Rb_out, match_score, det_score, iters_out, X_final)
     if (clear_tables && cleared && !n_valid && !m_valid) {
         is_test |= dmm::kRelaxClearTables;
         *cleared = 1;

@@ -761,7 +761,7 @@ __device__ __forceinline__ int relax_core_w1(const float (&C)[MT], int n_rt, int
 // EXACT: n == MT at compile time (all row guards fold away).
 // xbuf: LDS [MT * 64 * NG] floats, rsbuf: LDS [MT + 1] floats.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NG, bool EXACT, bool TAPE = false>
+template <int MT, int NG, bool EXACT, bool TAPE = false, bool W1TAPE = false>
 __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m, int col, const RelaxParams prm,
                                           BlockRed<MT, NG> &red, float *xbuf, float *rsbuf, float (&X)[MT],
                                           float (&acc)[MT], float *cost_out /* global [max_iter+1] or null */,
@@ -770,11 +770,15 @@ __device__ __forceinline__ int relax_core(const float (&C)[MT], int n_rt, int m,
     if constexpr (NG == 1 && !TAPE) {                  // forward, one wave per frame: the latency form
         (void)red;
         __shared__ __attribute__((aligned(16))) float rowbuf_w1[MT * kRowStride + 8];   // one buffer for all the variants
-        // the training forward tapes its sweeps for the backward (dmm_match_train_forward; one width-generic instantiation):
-        // the backward then skips its re-run of the solver.  (TAPE = true -- the backward's own re-run when no tape was
-        // kept -- stays on the form below: without the helper wave it is the faster one, 48.3 vs 50.9 us at 5 x 50, 10 x 5)
-        if (tape.bits)
+        // W1TAPE (the kernels of dmm_match_train_forward; kernels of their own: folded into the untaped ones as a run-time
+        // choice the evaluator's solve measured 0.9 us slower, 78.5 vs 77.6 us at 5 x 50, 40 x 5): the training forward tapes
+        // its sweeps for the backward, which then skips its re-run of the solver.  (TAPE = true -- the backward's own re-run
+        // when no tape was kept -- stays on the form below: without the helper wave it is the faster one, 48.3 vs 50.9 us)
+        if constexpr (W1TAPE) {
+            if ((m >> 3) == 6)                         // 48..55 columns: the model's 50 proposals
+                return relax_core_w1<MT, EXACT, 6, true>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1, tape);
             return relax_core_w1<MT, EXACT, -1, true>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1, tape);
+        }
         switch (m >> 3) {                              // the evaluator's frames: 50 proposals, 32..55 columns after NMS
             case 4: return relax_core_w1<MT, EXACT, 4>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
             case 5: return relax_core_w1<MT, EXACT, 5>(C, n_rt, m, col, prm, xbuf, rsbuf, hs, X, acc, cost_out, rowbuf_w1);
@@ -1114,7 +1118,7 @@ __device__ __forceinline__ int relax_core_h(const float (&C)[MT], int n, int m, 
 // relax_match_launch for the kernels built on relax_match_body)
 constexpr int kRelaxClearTables = 2;
 
-template <int MT, int NG, bool EXACT, bool HALF = false>
+template <int MT, int NG, bool EXACT, bool HALF = false, bool W1TAPE = false>
 __device__ __forceinline__ void relax_match_body(
     const float *__restrict__ cos_in, const int32_t *__restrict__ inter, const int32_t *__restrict__ area_p,
     const int32_t *__restrict__ area_t, const float *__restrict__ score_p, int N, int M,
@@ -1123,7 +1127,7 @@ __device__ __forceinline__ void relax_match_body(
     float *__restrict__ match_score, float *__restrict__ det_score, int32_t *__restrict__ iters_out,
     float *__restrict__ X_final, float *red_buf, float *xbuf, float *rsbuf, int *hs,
     uint2 *__restrict__ tape_bits = nullptr, int *__restrict__ tape_sweeps = nullptr) {
-    // tape_bits / tape_sweeps (one-wave kernels only; dmm_match_train_forward): [B][max_iter * proj_iter][64] sweep records and
+    // tape_bits / tape_sweeps (W1TAPE kernels only; dmm_match_train_forward): [B][max_iter * proj_iter][64] sweep records and
     // [B][max_iter] executed-sweep counts for dmm_relax_match_bwd's taped form
     const int b = blockIdx.x;
     const int col = threadIdx.x;
@@ -1205,10 +1209,14 @@ __device__ __forceinline__ void relax_match_body(
                 if (DMM_ROW(i) && col < PpS) X_b[(int64_t)i * PpS + col] = livec ? X[i] : 0.0f;
         }
     } else {
-        RelaxTape tape{nullptr, nullptr};
-        if (NG == 1 && tape_bits)
-            tape = RelaxTape{tape_bits + (size_t)b * prm.max_iter * prm.proj_iter * 64, tape_sweeps + (size_t)b * prm.max_iter};
-        iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape, hs);
+        if constexpr (W1TAPE && NG == 1) {
+            const RelaxTape tape{tape_bits + (size_t)b * prm.max_iter * prm.proj_iter * 64,
+                                 tape_sweeps + (size_t)b * prm.max_iter};
+            iters = relax_core<MT, NG, EXACT, false, true>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr, tape, hs);
+        } else {
+            iters = relax_core<MT, NG, EXACT>(C, Mb, Pp, col, prm, red, xbuf, rsbuf, X, acc, nullptr,
+                                              RelaxTape{nullptr, nullptr}, hs);
+        }
     }
     if (iters_out && threadIdx.x == 0) iters_out[b] = iters;
 
