@@ -89,7 +89,8 @@ extern "C" int dmm_abi_version(void) { return DMM_ABI_VERSION; }
 extern "C" int dmm_set_option(int option, int value) {
     if (option < 0 || option >= DMM_OPT_COUNT) return DMM_ERR_BAD_ARG;
     switch (option) {                                            // ranges: a bad value must not reach a launch computation
-        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED: case DMM_OPT_FEAT_BWD_FRAME:
+        case DMM_OPT_FEAT_BWD_FRAME: if (value < -1 || value > 2) return DMM_ERR_BAD_ARG; break;
+        case DMM_OPT_COST_KERNEL: case DMM_OPT_SOLVER_KERNEL: case DMM_OPT_MIX_SHARED:
             if (value < -1 || value > 1) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_MIX_XCD: if (value < 0 || value > 7) return DMM_ERR_BAD_ARG; break;
         case DMM_OPT_FORCE_WIDE: case DMM_OPT_COSINE_KERNEL: case DMM_OPT_COST_XCD:

@@ -483,6 +483,11 @@ extern "C" int dmm_feature_normalize_f32(const float *in, int64_t rows, int D, f
 }
 
 namespace dmm {
+// one wave per gradient row up to this many frames (feature_sim_bwd_wave_rows_kernel).  us per call, per-frame kernel vs wave
+// rows (D = 512; ~10 us of each figure is the host's): 50 x 5: B = 1 31 / 14, 64 33 / 14, 256 41 / 33, 512 56 / 61; 50 x 10:
+// 46 / 14, 48 / 17, 58 / 49, 71 / 90; 200 x 20: 290 / 14, 311 / 60, 340 / 244, 413 / 482 -- every wave re-reads the rows it
+// combines (L2), so the per-frame kernel's one pass wins once the chip is full
+constexpr int kFeatBwdWaveMaxB = 256;
 constexpr int kFeatBwdRowsMaxB = 0;      // the per-row form up to this many frames (0: never -- see dmm_feature_sim_bwd_f32)
 // dmm_feature_normalize_f32 on two row sets with one launch (same kernel body: bit identical)
 int feature_normalize2_launch(const float *in_a, int64_t rows_a, float *out_a, float *norms_a, const float *in_b,
@@ -803,6 +808,147 @@ __global__ __launch_bounds__(1024) void feature_sim_bwd_frame_kernel(
     }
 }
 
+
+// The same backward for a HANDFUL of frames (the trainer's per-frame call, DMM_Model's 4 videos): ONE WAVE PER GRADIENT ROW.
+// The per-frame kernel above walks its proposal rows in batches through three block-wide phases -- with one frame in flight
+// that is ~14 dependent L2 round trips, 31 us for 50 x 5 rows of 512 features.  Here a proposal row is one wave (lane = 8
+// neighbouring features of D = 512): its <= 32 coefficients sit in the lanes, the template rows it needs are all loaded at once,
+// the two row sums are wave sums -- one round trip and no barrier; a template row (N terms) takes the eight waves of a
+// workgroup, each summing every eighth proposal row, folded through LDS in a fixed order.  grid = (ceil(N / 8) + M, B).
+// Same formulas as the kernels above; the summation order differs (inside the backward's 2e-5 bound).
+template <int VEC>                                         // D == 64 * VEC
+__global__ __launch_bounds__(512) void feature_sim_bwd_wave_rows_kernel(
+    const float *__restrict__ dsim, const float *__restrict__ cosv, const float *__restrict__ gt,
+    const float *__restrict__ d_loss, float w_feat, const float *__restrict__ feat_t, const float *__restrict__ feat_p,
+    const float *__restrict__ featn_t, const float *__restrict__ featn_p, const float *__restrict__ norm_t,
+    const float *__restrict__ norm_p, int N, int M, const int32_t *__restrict__ n_valid,
+    const int32_t *__restrict__ m_valid, float *__restrict__ g_t, float *__restrict__ g_p) {
+    constexpr int D = 64 * VEC, kRows = 8;
+    __shared__ __attribute__((aligned(16))) float part[8][D];
+    __shared__ float red_s[2][8];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Nb = n_valid ? n_valid[b] : N, Mb = m_valid ? m_valid[b] : M;
+    const bool dead = Nb <= 0 || Mb <= 0;
+    const float lscale = (!dead && gt && d_loss) ? 2.0f * d_loss[b] / (float)(Nb * Mb) : 0.0f;
+    auto coef_at = [&](int m, int n) -> float {
+        const int64_t idx = ((int64_t)b * M + m) * N + n;
+        float c = dsim[idx] * w_feat;
+        if (gt && d_loss) c += (cosv[idx] - gt[idx]) * lscale;
+        return c;
+    };
+    auto load_row = [&](const float *row, float (&v)[VEC]) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const float4u t = *reinterpret_cast<const float4u *>(row + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    };
+    auto store_row = [&](float *row, const float (&v)[VEC]) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            float4u t;
+            t.x = v[4 * q]; t.y = v[4 * q + 1]; t.z = v[4 * q + 2]; t.w = v[4 * q + 3];
+            *reinterpret_cast<float4u *>(row + 4 * q) = t;
+        }
+    };
+    const int pblocks = (N + 7) / 8;
+    if ((int)blockIdx.x < pblocks) {
+        // ---- a proposal row per wave: g_hat = sum_m coef[m, n] * tn[m];  g = g_hat / c - x * (g_hat . x) / (c^2 * |x|) ----
+        const int n = blockIdx.x * 8 + wave;
+        if (n >= N) return;
+        float *out = g_p + ((int64_t)b * N + n) * D + lane * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        if (dead || n >= Nb) { store_row(out, acc); return; }
+        const float cl = lane < Mb ? coef_at(lane, n) : 0.0f;              // lane m holds coef[m, n] (M <= 64)
+        float x[VEC];
+        load_row(feat_p + ((int64_t)b * N + n) * D + lane * VEC, x);
+        const float *tn_b = featn_t + (int64_t)b * M * D + lane * VEC;
+        for (int m0 = 0; m0 < Mb; m0 += kRows) {
+            float t[kRows][VEC];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) load_row(tn_b + (int64_t)(m0 + u < Mb ? m0 + u : Mb - 1) * D, t[u]);
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                const float c = m0 + u < Mb ? __shfl(cl, m0 + u) : 0.0f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(c, t[u][k], acc[k]);
+            }
+        }
+        float pd = 0.0f, pq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { pd = __builtin_fmaf(acc[k], x[k], pd); pq = __builtin_fmaf(x[k], x[k], pq); }
+        const float dot = wave_sum(pd), nn = wave_sum(pq);
+        const float c = norm_p[(int64_t)b * N + n], nrm = __builtin_sqrtf(nn);
+        const float cr = nrm > 0.0f ? dot / (c * c * (nrm > 1e-30f ? nrm : 1e-30f)) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / c - x[k] * cr;
+        store_row(out, acc);
+        return;
+    }
+    // ---- a template row per workgroup: wave w sums the proposal rows w, w + 8, ...; fixed-order fold; same fix-up ----
+    const int m = blockIdx.x - pblocks;
+    float *out_row = g_t + ((int64_t)b * M + m) * D;
+    if (dead || m >= Mb) {
+        for (int d = threadIdx.x; d < D; d += 512) out_row[d] = 0.0f;
+        return;
+    }
+    {
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        const int cnt = Nb > wave ? (Nb - wave + 7) / 8 : 0;              // rows of this wave: n = wave + 8 j, j < cnt (<= 64)
+        const float cl = lane < cnt ? coef_at(m, wave + 8 * lane) : 0.0f; // lane j holds coef[m, wave + 8 j]
+        const float *pn_b = featn_p + (int64_t)b * N * D + lane * VEC;
+        for (int j0 = 0; j0 < cnt; j0 += kRows) {
+            float t[kRows][VEC];
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                const int j = j0 + u < cnt ? j0 + u : cnt - 1;
+                load_row(pn_b + (int64_t)(wave + 8 * j) * D, t[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kRows; ++u) {
+                const float c = j0 + u < cnt ? __shfl(cl, j0 + u) : 0.0f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(c, t[u][k], acc[k]);
+            }
+        }
+        store_row(&part[wave][lane * VEC], acc);
+    }
+    __syncthreads();
+    constexpr int PER = (D + 511) / 512;
+    float g[PER], xt[PER];
+    float pd = 0.0f, pq = 0.0f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int d = threadIdx.x + 512 * q;
+        g[q] = 0.0f; xt[q] = 0.0f;
+        if (d < D) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) g[q] += part[w][d];
+            xt[q] = feat_t[((int64_t)b * M + m) * D + d];
+            pd = __builtin_fmaf(g[q], xt[q], pd);
+            pq = __builtin_fmaf(xt[q], xt[q], pq);
+        }
+    }
+    pd = wave_sum(pd);
+    pq = wave_sum(pq);
+    if (lane == 0) { red_s[0][wave] = pd; red_s[1][wave] = pq; }
+    __syncthreads();
+    float dot = 0.0f, nn = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { dot += red_s[0][w]; nn += red_s[1][w]; }
+    const float c = norm_t[(int64_t)b * M + m], nrm = __builtin_sqrtf(nn);
+    const float cr = nrm > 0.0f ? dot / (c * c * (nrm > 1e-30f ? nrm : 1e-30f)) : 0.0f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int d = threadIdx.x + 512 * q;
+        if (d < D) out_row[d] = g[q] / c - xt[q] * cr;
+    }
+}
+
 }  // namespace dmm
 
 extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, const float *gt, const float *d_loss,
@@ -827,6 +973,19 @@ extern "C" int dmm_feature_sim_bwd_f32(const float *dsim, const float *cosv, con
     // row loop was rolled (one L2 round trip per proposal row), with the rows batched eight at a time see profiles/r05; at 512
     // frames the per-frame form is 5x the per-row form's throughput.  kFeatBwdRowsMaxB = 0: the per-frame form at every size)
     const int frame_mode = dmm::opt(DMM_OPT_FEAT_BWD_FRAME);
+    // a handful of frames: one wave per gradient row (2 = always, -1 = up to kFeatBwdWaveMaxB frames)
+    if ((frame_mode == 2 || (frame_mode < 0 && B <= dmm::kFeatBwdWaveMaxB)) && N > 0 && M > 0 && M <= 64 && N <= 512 &&
+        (D == 256 || D == 512 || D == 1024)) {
+#define DMM_FSW(VEC_)                                                                                                    \
+    hipLaunchKernelGGL((dmm::feature_sim_bwd_wave_rows_kernel<VEC_>), dim3((N + 7) / 8 + M, B), dim3(512), 0,            \
+                       (hipStream_t)stream, dsim, cosv, gt, d_loss, w_feat, feat_t, feat_p, featn_t, featn_p, norm_t,    \
+                       norm_p, N, M, n_valid, m_valid, g_feat_t, g_feat_p)
+        if (D == 256) DMM_FSW(4);
+        else if (D == 512) DMM_FSW(8);
+        else DMM_FSW(16);
+#undef DMM_FSW
+        return dmm::check_launch();
+    }
     if ((frame_mode == 1 || (frame_mode < 0 && B > dmm::kFeatBwdRowsMaxB)) && N > 0 && M > 0 && M <= 32 && D % 64 == 0 && D <= 1024 &&
         frame_lds <= 60 * 1024) {
 #define DMM_FSB(MT_)                                                                                                     \

@@ -105,8 +105,8 @@ typedef enum dmm_option {
     DMM_OPT_MIX_SHARED = 20,        /* mix / mix backward: -1 by entry point (default: dmm_mask_mix_shared_* and the backward
                                        stream the union of the rows' planes once), 0 row kernels always, 1 union kernels always */
     DMM_OPT_MIX_SHARED_STEPS = 21,  /* union kernels: 4 KiB steps of every plane per workgroup (1)                         */
-    DMM_OPT_FEAT_BWD_FRAME = 22,    /* dmm_feature_sim_bwd_f32: -1 by batch size (default: per feature row up to 32 frames, per frame
-                                       beyond), 1 one workgroup per frame, 0 one per feature row                              */
+    DMM_OPT_FEAT_BWD_FRAME = 22,    /* dmm_feature_sim_bwd_f32: -1 by batch size (default: one WAVE per feature row up to 256 frames,
+                                       one workgroup per frame beyond), 2 / 1 / 0: wave per row / per frame / workgroup per row  */
     DMM_OPT_MIX_SHARED_LOCKSTEP = 23, /* union kernels: 1 = one workgroup barrier per group of 8 planes keeps the four waves (four
                                        neighbouring 1 KiB pieces of every plane) in step (default: the lines the pieces share are
                                        then asked for at the same time, -2 % traffic), 0 = free-running waves                  */

@@ -1427,12 +1427,13 @@ def test_shared_plane_mix_equals_the_row_kernel_bit_for_bit(N, M, H, W):
         record_achieved("mix_shared/bwd_rel_err_50x10", float((dunion[:, :, :N].double() - dref).abs().max()) / scale)
 
 
-@pytest.mark.parametrize("B,N,M,D", [(3, 50, 10, 512), (2, 200, 20, 256), (4, 7, 32, 64), (2, 256, 1, 1024), (1, 3, 5, 128)])
+@pytest.mark.parametrize("B,N,M,D", [(3, 50, 10, 512), (2, 200, 20, 256), (4, 7, 32, 64), (2, 256, 1, 1024), (1, 3, 5, 128),
+                                     (1, 50, 5, 512), (4, 61, 33, 512)])
 def test_frame_form_of_the_feature_backward_agrees_with_the_row_form(B, N, M, D):
-    """dmm_feature_sim_bwd_f32 has two kernels (option FEAT_BWD_FRAME): one workgroup per feature row (rounds 2-3) and one per
-    FRAME with thread = feature column.  Both accumulate g_hat in the same order; the two per-row reductions of the
-    normalisation's backward differ in order: agreement within 2e-5 of the largest entry, with and without the matching-loss
-    term, ragged batches, dead frames, zero feature rows."""
+    """dmm_feature_sim_bwd_f32 has three kernels (option FEAT_BWD_FRAME): one workgroup per feature row (rounds 2-3), one per
+    FRAME with thread = feature column, and -- a handful of frames, D in {256, 512, 1024} -- one WAVE per feature row.  The
+    sums differ in order: agreement within 2e-5 of the largest entry, with and without the matching-loss term, ragged
+    batches, dead frames, zero feature rows."""
     g = torch.Generator(device=DEV).manual_seed(40 + N + M)
     tf = torch.randn((B, M, D), generator=g, device=DEV)
     pf = torch.relu(torch.randn((B, N, D), generator=g, device=DEV))
@@ -1455,7 +1456,9 @@ def test_frame_form_of_the_feature_backward_agrees_with_the_row_form(B, N, M, D)
                 rt, rp = ops.feature_sim_bwd(*args)
             with _lib.options(FEAT_BWD_FRAME=1):
                 ft, fp = ops.feature_sim_bwd(*args)
-            for a, b_ in ((rt, ft), (rp, fp)):
+            with _lib.options(FEAT_BWD_FRAME=2):                           # (outside its envelope: the by-shape choice)
+                wt, wp = ops.feature_sim_bwd(*args)
+            for a, b_ in ((rt, ft), (rp, fp), (rt, wt), (rp, wp)):
                 scale = max(float(a.abs().max()), 1e-12)
                 assert bool(torch.isfinite(b_).all())
                 assert float((a - b_).abs().max()) <= 2e-5 * scale, (ragged, loss, float((a - b_).abs().max()), scale)
