@@ -50,7 +50,15 @@ __global__ __launch_bounds__(256) void feature_normalize2_kernel(const float *__
                                                                  float *__restrict__ out_a, float *__restrict__ norms_a,
                                                                  const float *__restrict__ in_b, int64_t rows_b,
                                                                  float *__restrict__ out_b, float *__restrict__ norms_b,
-                                                                 int D, int blocks_a) {
+                                                                 int D, int blocks_a, uint32_t *__restrict__ zero_ptr,
+                                                                 int64_t zero_words) {
+    // zero_ptr / zero_words: an unrelated table the launch clears on the side (dmm_match_train_backward: dRb, which the mix
+    // backward behind it accumulates into -- saves the clearing launch in front of that kernel)
+    if (zero_ptr) {
+        const int64_t per = (zero_words + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per;
+        const int64_t hi = lo + per < zero_words ? lo + per : zero_words;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) zero_ptr[i] = 0u;
+    }
     if ((int)blockIdx.x < blocks_a) feature_normalize_rows(in_a, rows_a, D, out_a, norms_a, blockIdx.x);
     else feature_normalize_rows(in_b, rows_b, D, out_b, norms_b, (int64_t)blockIdx.x - blocks_a);
 }
@@ -491,12 +499,13 @@ constexpr int kFeatBwdWaveMaxB = 256;
 constexpr int kFeatBwdRowsMaxB = 0;      // the per-row form up to this many frames (0: never -- see dmm_feature_sim_bwd_f32)
 // dmm_feature_normalize_f32 on two row sets with one launch (same kernel body: bit identical)
 int feature_normalize2_launch(const float *in_a, int64_t rows_a, float *out_a, float *norms_a, const float *in_b,
-                              int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream) {
+                              int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream, void *zero_ptr,
+                              size_t zero_bytes) {
     if (rows_a <= 0 || rows_b <= 0 || D <= 0 || !in_a || !in_b || !out_a || !out_b) return DMM_ERR_BAD_ARG;
     const int64_t ba = (rows_a + 31) / 32, bb = (rows_b + 31) / 32;
     if (ba + bb > 0x7fffffffLL) return DMM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(feature_normalize2_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, stream, in_a, rows_a, out_a,
-                       norms_a, in_b, rows_b, out_b, norms_b, D, (int)ba);
+                       norms_a, in_b, rows_b, out_b, norms_b, D, (int)ba, (uint32_t *)zero_ptr, (int64_t)(zero_bytes / 4));
     return check_launch();
 }
 }  // namespace dmm

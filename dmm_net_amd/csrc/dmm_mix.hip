@@ -15,6 +15,7 @@
 namespace dmm {
 
 constexpr int kMixThreads = 256;
+static thread_local bool g_drb_prezeroed = false;     // set (per thread, for one call) by mask_mix_bwd_prezeroed: dRb is zero already
 static thread_local bool g_mix_shared_call = false;   // set by dmm_mask_mix_shared_* around the common entry point
 
 // ---------------------------------------------------------------------------------------------
@@ -324,7 +325,7 @@ template <typename T>
 static int mask_mix_bwd_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
                               int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
                               hipStream_t stream) {
-    DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
+    if (!g_drb_prezeroed) DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
     int splits = (8192 + B * M - 1) / (B * M);
     if (splits > nsteps) splits = nsteps;
@@ -709,7 +710,7 @@ template <typename T>
 static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp,
                                      int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
                                      float *dRb, hipStream_t stream) {
-    DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
+    if (!g_drb_prezeroed) DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));
     const int nsteps = (HW + kMixThreads * 4 - 1) / (kMixThreads * 4);
     // four steps per workgroup (the forward: one): every workgroup clears and folds its LDS slabs and ends with one atomic per
     // pair -- measured at B = 512, 50 x 10 with the waves in lock step: 1.281 / 1.268 ms at 2 / 4 steps (free running: 1.293 /
@@ -796,7 +797,7 @@ template <typename T>
 static int mask_mix_bwd_wide_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp, int HW,
                                    int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
                                    hipStream_t stream) {
-    if (Pp > N) DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));   // the padded columns
+    if (Pp > N && !g_drb_prezeroed) DMM_HIP_TRY(zero_async(dRb, sizeof(float) * (size_t)B * M * Pp, stream));   // the padded columns
     hipLaunchKernelGGL((mask_mix_bwd_wide_kernel<T>), dim3(N, M, B), dim3(256), 0, stream, Rb, masks_p, dout, N, M, Pp, HW,
                        sp_b, sp_n, n_valid, m_valid, dRb);
     return check_launch();
@@ -996,3 +997,15 @@ extern "C" int dmm_mask_mix_bwd_frames(const float *Rb, const void *const *masks
     return dmm_mask_mix_bwd(Rb, (const void *)masks_p_frames, dtype, dout, B, N, M, Pp, HW, dmm::kFrameTable, sp_n,
                             n_valid, m_valid, dRb, stream);
 }
+
+// dmm_mask_mix_bwd for a caller that cleared dRb itself (dmm_match_train_backward: by the launch in front)
+namespace dmm {
+int mask_mix_bwd_prezeroed(const float *Rb, const void *masks_p, int dtype, const float *dout, int B, int N, int M, int Pp,
+                           int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
+                           dmm_stream_t stream) {
+    g_drb_prezeroed = true;
+    const int rc = dmm_mask_mix_bwd(Rb, masks_p, dtype, dout, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, dRb, stream);
+    g_drb_prezeroed = false;
+    return rc;
+}
+}  // namespace dmm

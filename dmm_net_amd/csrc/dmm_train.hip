@@ -29,7 +29,11 @@ int iou_counts_dual_prezeroed(const void *masks_p, const void *masks_t, const vo
                               const int32_t *n_valid, const int32_t *m_valid, int32_t *inter, int32_t *area_p,
                               int32_t *area_t, int32_t *inter2, int32_t *area_t2, dmm_stream_t stream);
 int feature_normalize2_launch(const float *in_a, int64_t rows_a, float *out_a, float *norms_a, const float *in_b,
-                              int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream);
+                              int64_t rows_b, float *out_b, float *norms_b, int D, hipStream_t stream, void *zero_ptr = nullptr,
+                              size_t zero_bytes = 0);
+int mask_mix_bwd_prezeroed(const float *Rb, const void *masks_p, int dtype, const float *dout, int B, int N, int M, int Pp,
+                           int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid, float *dRb,
+                           dmm_stream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------------
 // compute_matching_loss after the counts (dmm/utils/match_helper.py:43-48):
@@ -336,12 +340,15 @@ extern "C" int dmm_match_train_backward(const void *masks_p, int mask_dtype, con
     dmm::TrainBwdWs w = dmm::carve_train_bwd(workspace, B, N, M, D, max_iter, proj_iter);
     if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    // (the normalising launch also clears dRb for the mix backward behind it: one launch less in a one-frame call)
     int rc = dmm::feature_normalize2_launch(feat_p, (int64_t)B * N, w.featn_p, w.norm_p, feat_t, (int64_t)B * M, w.featn_t,
-                                            w.norm_t, D, s);
+                                            w.norm_t, D, s, d_full ? (void *)w.dRb : nullptr,
+                                            sizeof(float) * (size_t)B * M * Pp);
     if (rc != DMM_OK) return rc;
     const float *dRb = nullptr;
     if (d_full) {
-        rc = dmm_mask_mix_bwd(Rb, masks_p, mask_dtype, d_full, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, w.dRb, stream);
+        rc = dmm::mask_mix_bwd_prezeroed(Rb, masks_p, mask_dtype, d_full, B, N, M, Pp, HW, sp_b, sp_n, n_valid, m_valid, w.dRb,
+                                         stream);
         if (rc != DMM_OK) return rc;
         dRb = w.dRb;
     }
