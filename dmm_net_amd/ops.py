@@ -722,8 +722,14 @@ def _train_tape_layout(L, B, N, M, max_iter, proj_iter):
     if got is None:
         n_cs, n_rb = B * M * N, B * M * padded_width(N, M)
         off = -(-(4 * (3 * n_cs + n_rb)) // 256) * 256
-        got = _WS_NEED[k] = (off, int(L.dmm_match_train_tape_bytes(B, N, M, int(max_iter), int(proj_iter))))
+        nbytes = int(L.dmm_match_train_tape_bytes(B, N, M, int(max_iter), int(proj_iter)))
+        # the tape is sized for max_iter x proj_iter sweeps whatever the solver executes (the shipped default 400 x 50 is
+        # 10 MB per frame, held until the backward): past _TAPE_MAX_BYTES per call the backward re-runs the solver instead
+        got = _WS_NEED[k] = (off, nbytes if nbytes <= _TAPE_MAX_BYTES else 0)
     return got
+
+
+_TAPE_MAX_BYTES = 256 << 20
 
 
 def match_train_backward(masks_p, feat_p, feat_t, score_p, saved, has_loss, d_full, d_ms, d_ds, d_loss, n_valid, m_valid,
