@@ -73,3 +73,28 @@ def test_valid_layout_is_read_once_per_clip_tensor():
     copy.deepcopy(m)
     pickle.dumps(m)
     assert not any(k.startswith("_valid") for k in m.__dict__)
+
+
+def test_bench_compacts_the_other_workloads_lines():
+    """``bench.compact``: what the default line's ``other_configs`` keeps of a workload's own line -- the drop-in's cases
+    (wall / device / launches per call, where the host threads sat) and the training form's per-kernel rows."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    drop = {"metric": "m", "value": 9.0, "unit": "calls/s", "ms_per_step": 0.1, "steps": 3,
+            "config": {"workload": "w", "host_threads": "pinned to the CPUs of NUMA node 1 (the GPU's)",
+                       "cases": {"eval_forward_50x5": {"wall_us": 100.0, "device_us": 102.0, "library_launches": 3,
+                                                       "wall_over_device": 0.98, "what": "...", "calls": 200}}}}
+    c = bench.compact(drop)
+    assert c["cases"] == {"eval_forward_50x5": {"wall_us": 100.0, "device_us": 102.0, "library_launches": 3,
+                                                "wall_over_device": 0.98}}
+    assert c["host_threads"].startswith("pinned") and c["workload"] == "w" and "roofline" not in c
+    train = {"metric": "m", "value": 1.0, "unit": "frames/s", "ms_per_step": 4.4, "steps": 10,
+             "roofline": {"bound": "hbm", "kernel": "k", "achieved": 6.4e3, "peak": 8e3, "unit": "GB/s", "frac": 0.8, "traffic": 1},
+             "config": {"workload": "t", "by_batch": {"64": {"fwd_bwd_ms": 0.73, "selected_planes_per_frame": 47.8,
+                                                              "kernels": {"mask_mix_bwd": {"ms": 0.175, "frac": 0.686, "bound": "hbm"},
+                                                                          "relax_match_bwd": {"ms": 0.157}}, "note": "..."}}}}
+    c = bench.compact(train)
+    assert c["roofline"] == {"bound": "hbm", "kernel": "k", "achieved": 6.4e3, "peak": 8e3, "unit": "GB/s", "frac": 0.8}
+    assert c["by_batch"]["64"]["kernels"] == {"mask_mix_bwd": {"ms": 0.175, "frac": 0.686}, "relax_match_bwd": {"ms": 0.157}}
