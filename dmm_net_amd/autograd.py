@@ -73,7 +73,8 @@ class _MatchLayerFn(torch.autograd.Function):
             # host bound otherwise (bench.py --config dropin)
             pf_c, tf_c, sc_c = pf.contiguous(), tf[0].contiguous(), sc.contiguous()
             got = ops.match_train_forward(pm, tm, targets, pf_c, tf_c, sc_c, n_valid, m_valid, score_weight=score_weight,
-                                          max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test)
+                                          max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test,
+                                          want_tape=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
             if got is not None:
                 full, ms, ds, loss, iters, saved, ctx.taped = got
                 ctx.fused = True
@@ -159,7 +160,8 @@ class _MatchFrameFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         pf_c, tf_c, sc_c = pf.contiguous(), tf.contiguous(), sc.contiguous()
         got = ops.match_train_forward(pm, tm, targets, pf_c, tf_c, sc_c, None, None, score_weight=score_weight,
-                                      max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test, one_frame=True)
+                                      max_iter=max_iter, proj_iter=proj_iter, lr=lr, is_test=is_test, one_frame=True,
+                                      want_tape=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         if got is None:
             raise _lib.DmmError("dmm_match_train_forward refused a shape frame_fused_ok() accepted")
         full, ms, ds, loss, iters, saved, ctx.taped = got

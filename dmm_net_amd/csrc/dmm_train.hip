@@ -244,13 +244,12 @@ extern "C" int dmm_match_train_forward(const void *masks_p, const void *masks_t,
     if (workspace_bytes < w.bytes) return DMM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const bool dense = !n_valid && !m_valid;
-    const bool table = sp_b == DMM_FRAME_TABLE;
     // one pass over the proposal planes for both IoU tables while both template sets fit one tile (<= 16 rows each)
     const bool dual = targets && M <= 16;
     const bool force_tile = dmm::opt(DMM_OPT_COSINE_KERNEL) == 1;
     int rc = DMM_ERR_UNSUPPORTED;
     bool counted = false;
-    if (dense && !table && !force_tile && (dual || !targets)) {
+    if (dense && !force_tile && (dual || !targets)) {      // (proposal planes behind a pointer table included: frame_base)
         // a handful of dense frames: similarity and counts beside each other in ONE launch (behind one clearing launch)
         rc = dmm::front_small_launch(masks_p, masks_t, dual ? targets : nullptr, mask_dtype, feat_t, feat_p, B, N, M, HW, D,
                                      sp_b, sp_n, st_b, st_m, sg_b, sg_m, cos_out, w.inter, w.area_p, w.area_t,

@@ -124,6 +124,10 @@ class DMM_Model(nn.Module):
             pk = ops.ragged_pad(list(packed), Pmax, n_valid)
             counts = ops.iou_counts_packed(pk, ops.pack_masks(mask_last_occurence.float()), H * W, n_valid, m_valid)
         cfg = self.match_layer
+        if counts is None and all(int(p.shape[0]) == Pmax for p in prop_m) and all(c == F for c in m_counts):
+            # every video has all of its proposals and templates (the usual training batch): a DENSE batch -- the layer then
+            # takes the exact-row kernels and, for a handful of videos, the one-launch similarity + counts kernel
+            n_valid = m_valid = None
         full, ms, ds, loss, _ = match_layer_batched(
             pf, pm, tf, mask_last_occurence, sc, targets, n_valid, m_valid, score_weight=cfg.cfgs["score_weight"],
             max_iter=cfg.max_iter, proj_iter=cfg.proj_iter, lr=cfg.relax_lr, is_test=int(bool(cfg.is_test)),

@@ -637,7 +637,7 @@ def _planes3(t: torch.Tensor):
 
 
 def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_valid, m_valid, *, score_weight, max_iter,
-                        proj_iter, lr, is_test, one_frame=False):
+                        proj_iter, lr, is_test, one_frame=False, want_tape=True):
     """The training call of B frames as ONE C-ABI call (``dmm_match_train_forward``, include/dmm_match.h (5d)): feature
     similarity -> counts against templates AND targets -> solver -> mix -> matching loss.  masks_p: [B,N,H,W] tensor or
     ``FramePlanes``; targets [B,M,H,W] of the masks' dtype or None.  ``one_frame``: the tensors are ONE frame without the
@@ -647,7 +647,7 @@ def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_va
     (full [B,M,H,W], match_score [B,M], det_score [B,M], cost_loss [B] | None, iters [B], saved, taped) with ``saved`` = the
     flat fp32 block cos | sim | Rb | gt (| the solver's tape, 256-byte aligned) that ``match_train_backward`` reads and
     ``taped`` = whether the forward's solver kernel kept its tape there (tables of <= 64 solver columns: the backward then
-    does not re-run the solver)."""
+    does not re-run the solver).  ``want_tape=False`` (no gradient will be asked for): the untaped solver kernels."""
     fp = masks_p if isinstance(masks_p, FramePlanes) else None
     if one_frame:
         masks_p, sp_n = _planes3(masks_p)
@@ -697,6 +697,8 @@ def match_train_forward(masks_p, masks_t, targets, feat_p, feat_t, score_p, n_va
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     n_cs, n_rb = B * M * N, B * M * Pp
     tape_off, tape_bytes = _train_tape_layout(L, B, N, M, max_iter, proj_iter)
+    if not want_tape:
+        tape_bytes = 0
     saved = torch.empty((tape_off // 4 + tape_bytes // 4,), **f32)
     sp = saved.data_ptr()
     taped = ctypes.c_int(0)
