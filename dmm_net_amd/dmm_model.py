@@ -84,7 +84,14 @@ class DMM_Model(nn.Module):
             # gradient path for the feature rows (the scores carry none: the layer returns no score gradient); the two
             # count vectors and the three pointer tables of the call go up in ONE copy
             from . import ops
-            pf_blocks, pf_addr = ops.ragged_blocks([f.float() for f in prop_feat])
+            # the feature rows of a batch of equal proposal counts are usually the row ranges of ONE tensor (the ROI
+            # extractor's [sum P, D] output, split per video, dmm_model.py:53-54 / :106): then the batch IS that tensor,
+            # viewed -- no launch, and the gradient goes straight to it
+            pf = self._rows_of_one_tensor(prop_feat, B, Pmax, D)
+            if pf is None:
+                pf_blocks, pf_addr = ops.ragged_blocks([f.float() for f in prop_feat])
+            else:
+                pf_addr = []
             sc_blocks, sc_addr = ops.ragged_blocks([s_.detach().float().reshape(-1, 1) for s_ in prop_score])
             i32, i64 = torch.int32, torch.int64
             specs = [([int(p.shape[0]) for p in prop_m], i32), (m_counts, i32), (pf_addr, i64), (sc_addr, i64)]
@@ -96,7 +103,8 @@ class DMM_Model(nn.Module):
             n_valid, m_valid = up[0], up[1]
             if direct:
                 pm.table = up[4]
-            pf = ragged_pad(pf_blocks, Pmax, n_valid, up[2])
+            if pf is None:
+                pf = ragged_pad(pf_blocks, Pmax, n_valid, up[2])
             sc = ops.ragged_pad(sc_blocks, Pmax, n_valid, up[3]).view(B, Pmax)
         else:
             n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
@@ -135,6 +143,21 @@ class DMM_Model(nn.Module):
         if row_scale is not None:
             full = full * row_scale[:, :, None, None]
         return full, loss
+
+    @staticmethod
+    def _rows_of_one_tensor(blocks, B, P, D):
+        """[B, P, D] view of the tensor the per-video blocks are consecutive row ranges of, or None: every block a
+        contiguous fp32 [P, D] view of the SAME base (what ``.split`` of a contiguous [B * P, D] tensor gives), in order,
+        covering it."""
+        base = getattr(blocks[0], "_base", None)
+        if base is None or base.dim() != 2 or base.dtype != torch.float32 or tuple(base.shape) != (B * P, D) \
+                or not base.is_contiguous():
+            return None
+        p0, step = base.data_ptr(), P * D * 4
+        for b, f in enumerate(blocks):
+            if f._base is not base or tuple(f.shape) != (P, D) or not f.is_contiguous() or f.data_ptr() != p0 + b * step:
+                return None
+        return base.view(B, P, D)
 
     def _match_single(self, prop_feat, prop_m, prop_score, tplt_feat, mask_last_occurence, O, targets):
         """ONE video (the evaluator's batch: scripts/eval/*.sh run ``-batch_size=1``) with its templates a prefix and none
