@@ -9,7 +9,8 @@ def use_shipped_miopen_db(develop: bool = False, enable: bool = True):
     MIOPEN_USER_DB_PATH points there.  MIOpen's OWN variable, MIOPEN_USER_DB_PATH, always wins when the caller has set it;
     this package reads no variable of its own: ``use_shipped_miopen_db(enable=False)`` (before the first convolution) takes
     the shipped db out again, ``develop=True`` points MIOpen at the tracked directory itself -- only to refresh what is
-    shipped (tools/).  Must run before the first convolution."""
+    shipped (tools/).  Must run before the first convolution: the encoders (``FeatureEncoder``, ``FastEncoder``) call it from
+    their constructors; importing the package does not."""
     import os
     import shutil
     global _DB_SET_BY_US
@@ -49,4 +50,6 @@ def use_shipped_miopen_db(develop: bool = False, enable: bool = True):
 
 
 _DB_SET_BY_US = None
-use_shipped_miopen_db()
+# (NOT called at import: importing the package -- e.g. only ``dmm_net_amd.match_model`` for the one-line swap -- leaves the
+# environment and ~/.cache alone.  The encoders call it when they are constructed: ``FeatureEncoder.__init__`` /
+# ``FastEncoder.__init__``, before the process's first convolution of theirs.)

@@ -34,6 +34,8 @@ SYMBOLS = (
     "dmm_conv1x1_bf16", "dmm_im2col3x3_bf16", "dmm_bias_relu_maxpool_bf16", "dmm_relax_any_scratch_bytes", "dmm_relax_match_any_f32", "dmm_relax_match_f16s", "dmm_match_solve_packed", "dmm_step_finish_f32",
     "dmm_matching_loss_f32", "dmm_match_train_tape_bytes", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
     "dmm_match_train_backward_workspace_bytes", "dmm_match_train_backward",
+    "dmm_bn_stats_bf16", "dmm_bn_apply_bf16", "dmm_bn_bwd_reduce_bf16", "dmm_bn_bwd_dx_bf16",
+    "dmm_graph_nodes_to_kernels",
 )
 
 _lib = None
@@ -141,6 +143,14 @@ def load():
                                c_i64, vp]
     L.dmm_bias_act_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp]
     L.dmm_bias_act_bf16.restype = c_int
+    L.dmm_bn_stats_bf16.argtypes = [vp, c_i64, c_int, vp, vp]
+    L.dmm_bn_apply_bf16.argtypes = [vp, vp, c_i64, c_int, vp, vp, vp, vp, vp, c_float, c_float, c_int, vp, vp, vp]
+    L.dmm_bn_bwd_reduce_bf16.argtypes = [vp, vp, vp, c_i64, c_int, vp, c_int, vp, vp]
+    L.dmm_bn_bwd_dx_bf16.argtypes = [vp, vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
+    L.dmm_graph_nodes_to_kernels.argtypes = [vp, c_int, vp, vp, vp]
+    for f in ("dmm_bn_stats_bf16", "dmm_bn_apply_bf16", "dmm_bn_bwd_reduce_bf16", "dmm_bn_bwd_dx_bf16",
+              "dmm_graph_nodes_to_kernels"):
+        getattr(L, f).restype = c_int
     L.dmm_mask_mix_to.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_int, c_i64,
                                   c_i64, vp]
     L.dmm_mask_mix_to.restype = c_int
@@ -200,7 +210,7 @@ def load():
               "dmm_roialign4_mean_bwd", "dmm_mask_mix_bwd", "dmm_paste_masks_f32", "dmm_nms_f32", "dmm_pack_masks",
               "dmm_mask_boxes_f32", "dmm_merge_labels_f32", "dmm_ragged_pad"):
         getattr(L, f).restype = c_int
-    if L.dmm_abi_version() != 1:
+    if L.dmm_abi_version() != 2:
         raise DmmError("libdmm_match.so ABI version mismatch")
     # libdmm_match.so needs libhipblaslt.so.1 / libamdhip64.so.7 by SONAME; torch (imported above) has already mapped its
     # bundled copies under the same sonames, so the loader binds to those -- ONE HIP runtime and ONE hipBLASLt per process.

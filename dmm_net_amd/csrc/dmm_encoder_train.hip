@@ -1,0 +1,358 @@
+// dmm_encoder_train.hip -- training-mode BatchNorm (+ residual) (+ ReLU) of the encoder on gfx950, channels-last bf16.
+//
+// Reference: the conv -> BatchNorm -> ReLU stacks the trainer differentiates through: dmm/modules/base.py:43-54 (prop heads),
+// model_encoder.py:137-146 (skip projections + bn), the torchvision Bottleneck / BasicBlock bodies reached through
+// dmm/modules/vision.py:6-38 (out = relu(bn3(conv3(x)) + identity)), under train.py:296-307 (forward, loss.backward()).
+// The stock path issues per layer and direction three MIOpen BatchNorm kernels + an add + a clamp (684 BatchNorm and 427
+// elementwise launches of the ~2 100 of one ResNet-101 step at 12 x 255 x 448; 6.75 of 17.6 ms of device time,
+// profiles/r06_cfg4_kernel_stats_autocast_nhwc.csv).  Here it is TWO launches each way:
+//
+//   forward    bn_stats:       per-channel sum(x), sum(x^2)                                 (reads x)
+//              bn_apply:       y = act(x * scale + shift (+ residual)); running statistics  (reads x (+ residual), writes y)
+//   backward   bn_bwd_reduce:  sum(g), sum(g * xhat),  g = dy * [y > 0]                      (reads dy, x (, y))
+//              bn_bwd_dx:      dx = w * invstd * (g - mean(g) - xhat * mean(g * xhat));      (reads dy, x (, y), writes dx
+//                              g itself = the residual branch's gradient; dweight, dbias       (+ dres))
+//
+// Layout: x [rows, C] bf16 (a channels-last activation viewed 2-D), C % 8 == 0 and C / 8 a divisor of 256 (every width of
+// the ResNets and heads: 32 .. 2048).  One thread = 8 consecutive channels (one 16-byte load) of every (256 / (C/8))-th row
+// of its workgroup's row range; fp32 arithmetic, one rounding.  Per-channel sums: per-thread fp32 accumulators -> one LDS
+// fold per workgroup -> one global fp32 atomic per (workgroup, channel, statistic) into a [2, C] buffer the caller zeroed.
+// (Atomic arrival order is free: the statistics of two runs may differ in their last bits, as MIOpen's do.)
+// var = E[x^2] - mean^2 in fp32, clamped at 0: inputs carry 8 significant bits and post-convolution activations have
+// |mean| / std of order 1, so the cancellation costs nothing a bf16 activation could show.
+//
+// Roofline: HBM / L2 streaming (3-4 passes forward, 5-7 backward over tensors of 1.4 .. 44 MB); the small ones are launch
+// bound, which is why the whole step replays from HIP graphs (dmm_net_amd/train_encoder.py).
+#include "dmm_common.h"
+
+namespace dmm {
+
+typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bf16_round(float v) {
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void unpack8(const u32x4t v, float *f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = __uint_as_float(v[k] << 16);
+        f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ u32x4t pack8(const float *f) {
+    u32x4t o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = bf16_round(f[2 * k]) | (bf16_round(f[2 * k + 1]) << 16);
+    return o;
+}
+
+__device__ __forceinline__ void load8f(const float *p, float *f) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// fold the 16 per-thread partials (two statistics x 8 channels) of the threads that share a channel group, then one
+// atomic per (channel, statistic) of the workgroup.  red: [256][16] floats.
+__device__ __forceinline__ void fold_and_add(const float *acc16, float *red, int c8, int C, float *__restrict__ out2C) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[t * 16 + k] = acc16[k];
+    __syncthreads();
+    const int rpp = 256 / c8;                            // threads (rows per pass) per channel group
+    for (int j = t; j < 16 * c8; j += 256) {             // j = cg * 16 + k
+        float s = 0.0f;
+        for (int r = 0; r < rpp; ++r) s += red[(r * c8) * 16 + j];
+        const int cg = j >> 4, k = j & 15;
+        unsafeAtomicAdd(&out2C[(k >> 3) * C + cg * 8 + (k & 7)], s);
+    }
+}
+
+// rows of workgroup g: [g * per, min(rows, (g + 1) * per)), per a multiple of the rows one pass covers
+__device__ __forceinline__ void row_range(int64_t rows, int rpp, int64_t &r0, int64_t &r1) {
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    per = (per + rpp - 1) / rpp * rpp;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < rows ? r0 + per : rows;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__restrict__ x, int64_t rows, int c8,
+                                                            float *__restrict__ stats) {
+    __shared__ float red[256 * 16];
+    const int cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    int64_t r0, r1;
+    row_range(rows, rpp, r0, r1);
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x);
+    int64_t r = r0 + ro;
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {             // four loads in flight
+        u32x4t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xp[(r + u * rpp) * c8 + cg];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[k] += f[k];
+                acc[8 + k] = __builtin_fmaf(f[k], f[k], acc[8 + k]);
+            }
+        }
+    }
+    for (; r < r1; r += rpp) {
+        float f[8];
+        unpack8(xp[r * c8 + cg], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc[k] += f[k];
+            acc[8 + k] = __builtin_fmaf(f[k], f[k], acc[8 + k]);
+        }
+    }
+    fold_and_add(acc, red, c8, c8 * 8, stats);
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ res,
+                                                            int64_t rows, int c8, const float *__restrict__ stats,
+                                                            const float *__restrict__ weight, const float *__restrict__ bias,
+                                                            float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                            float momentum, float eps, uint16_t *__restrict__ y,
+                                                            float *__restrict__ saved) {
+    const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    float s[8], q[8], w[8], b[8], scale[8], shift[8];
+    load8f(stats + cg * 8, s);
+    load8f(stats + C + cg * 8, q);
+    load8f(weight + cg * 8, w);
+    load8f(bias + cg * 8, b);
+    const float inv_n = 1.0f / (float)rows;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float mean = s[k] * inv_n;
+        float var = __builtin_fmaf(-mean, mean, q[k] * inv_n);
+        var = var > 0.0f ? var : 0.0f;
+        const float invstd = 1.0f / __builtin_sqrtf(var + eps);
+        scale[k] = w[k] * invstd;
+        shift[k] = __builtin_fmaf(-mean, scale[k], b[k]);
+        if (blockIdx.x == 0 && ro == 0) {
+            const int c = cg * 8 + k;
+            saved[c] = mean;
+            saved[C + c] = invstd;
+            if (running_mean) {                           // torch: running = (1 - m) * running + m * batch, unbiased variance
+                const float unb = rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
+                running_mean[c] = __builtin_fmaf(momentum, mean - running_mean[c], running_mean[c]);
+                running_var[c] = __builtin_fmaf(momentum, unb - running_var[c], running_var[c]);
+            }
+        }
+    }
+    int64_t r0, r1;
+    row_range(rows, rpp, r0, r1);
+    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x), *rp = reinterpret_cast<const u32x4t *>(res);
+    u32x4t *yp = reinterpret_cast<u32x4t *>(y);
+    for (int64_t r = r0 + ro; r < r1; r += rpp) {
+        const int64_t i = r * c8 + cg;
+        float f[8], g[8];
+        unpack8(xp[i], f);
+        if (RES) unpack8(rp[i], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = __builtin_fmaf(f[k], scale[k], shift[k]);
+            if (RES) v += g[k];
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            f[k] = v;
+        }
+        yp[i] = pack8(f);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                                 const uint16_t *__restrict__ y, int64_t rows, int c8,
+                                                                 const float *__restrict__ saved, float *__restrict__ sums) {
+    __shared__ float red[256 * 16];
+    const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    float mean[8], invstd[8];
+    load8f(saved + cg * 8, mean);
+    load8f(saved + C + cg * 8, invstd);
+    int64_t r0, r1;
+    row_range(rows, rpp, r0, r1);
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
+                 *yp = reinterpret_cast<const u32x4t *>(y);
+    int64_t r = r0 + ro;
+    for (; r + rpp < r1; r += 2 * rpp) {                 // two rows (4-6 loads) in flight
+        u32x4t vd[2], vx[2], vy[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = (r + u * rpp) * c8 + cg;
+            vd[u] = dp[i];
+            vx[u] = xp[i];
+            if (RELU) vy[u] = yp[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float g[8], f[8], o[8];
+            unpack8(vd[u], g);
+            unpack8(vx[u], f);
+            if (RELU) unpack8(vy[u], o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+                acc[k] += gk;
+                acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
+            }
+        }
+    }
+    for (; r < r1; r += rpp) {
+        const int64_t i = r * c8 + cg;
+        float g[8], f[8], o[8];
+        unpack8(dp[i], g);
+        unpack8(xp[i], f);
+        if (RELU) unpack8(yp[i], o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+            acc[k] += gk;
+            acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
+        }
+    }
+    fold_and_add(acc, red, c8, C, sums);
+}
+
+template <bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                             const uint16_t *__restrict__ y, int64_t rows, int c8,
+                                                             const float *__restrict__ saved, const float *__restrict__ weight,
+                                                             const float *__restrict__ sums, uint16_t *__restrict__ dx,
+                                                             uint16_t *__restrict__ dres, float *__restrict__ dweight,
+                                                             float *__restrict__ dbias) {
+    const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    float mean[8], invstd[8], w[8], sg[8], sgx[8], a[8], mg[8], mgx[8];
+    load8f(saved + cg * 8, mean);
+    load8f(saved + C + cg * 8, invstd);
+    load8f(weight + cg * 8, w);
+    load8f(sums + cg * 8, sg);
+    load8f(sums + C + cg * 8, sgx);
+    const float inv_n = 1.0f / (float)rows;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = w[k] * invstd[k];
+        mg[k] = sg[k] * inv_n;
+        mgx[k] = sgx[k] * inv_n;
+        if (blockIdx.x == 0 && ro == 0) {
+            dweight[cg * 8 + k] = sgx[k];
+            dbias[cg * 8 + k] = sg[k];
+        }
+    }
+    int64_t r0, r1;
+    row_range(rows, rpp, r0, r1);
+    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
+                 *yp = reinterpret_cast<const u32x4t *>(y);
+    u32x4t *op = reinterpret_cast<u32x4t *>(dx), *rp = reinterpret_cast<u32x4t *>(dres);
+    for (int64_t r = r0 + ro; r < r1; r += rpp) {
+        const int64_t i = r * c8 + cg;
+        float g[8], f[8], o[8];
+        unpack8(dp[i], g);
+        unpack8(xp[i], f);
+        if (RELU) unpack8(yp[i], o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+            g[k] = gk;
+            const float xhat = (f[k] - mean[k]) * invstd[k];
+            f[k] = a[k] * ((gk - mg[k]) - xhat * mgx[k]);
+        }
+        op[i] = pack8(f);
+        if (DRES) rp[i] = pack8(g);                      // (g = dy under the mask: exact in bf16)
+    }
+}
+
+static inline bool bn_shape_ok(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0 || (C & 7)) return false;
+    const int c8 = C / 8;
+    return c8 <= 256 && 256 % c8 == 0;
+}
+
+// workgroups: every thread gets >= `min_iters` rows where the tensor allows, at most `cap` workgroups
+static inline unsigned bn_grid(int64_t rows, int c8, int min_iters, int cap) {
+    const int rpp = 256 / c8;
+    int64_t g = (rows + (int64_t)rpp * min_iters - 1) / ((int64_t)rpp * min_iters);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace dmm
+
+extern "C" int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stats, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (rows == 0) return DMM_OK;
+    if (!x || !stats) return DMM_ERR_BAD_ARG;
+    if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
+    const int c8 = C / 8;
+    hipLaunchKernelGGL(dmm::bn_stats_bf16_kernel, dim3(dmm::bn_grid(rows, c8, 16, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)x, rows, c8, stats);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t rows, int C, const float *stats,
+                                 const float *weight, const float *bias, float *running_mean, float *running_var,
+                                 float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (rows == 0) return DMM_OK;
+    if (!x || !stats || !weight || !bias || !y || !saved || (!running_mean) != (!running_var)) return DMM_ERR_BAD_ARG;
+    if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
+    const int c8 = C / 8;
+    const dim3 grid(dmm::bn_grid(rows, c8, 8, 2048));
+#define DMM_BNA(RES_, RELU_)                                                                                             \
+    hipLaunchKernelGGL((dmm::bn_apply_bf16_kernel<RES_, RELU_>), grid, dim3(256), 0, (hipStream_t)stream,                \
+                       (const uint16_t *)x, (const uint16_t *)residual, rows, c8, stats, weight, bias, running_mean,     \
+                       running_var, momentum, eps, (uint16_t *)y, saved)
+    if (residual) { if (relu) DMM_BNA(true, true); else DMM_BNA(true, false); }
+    else { if (relu) DMM_BNA(false, true); else DMM_BNA(false, false); }
+#undef DMM_BNA
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                                      int relu, float *sums, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (rows == 0) return DMM_OK;
+    if (!dy || !x || !saved || !sums || (relu && !y)) return DMM_ERR_BAD_ARG;
+    if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
+    const int c8 = C / 8;
+    const dim3 grid(dmm::bn_grid(rows, c8, 16, 1024));
+    if (relu)
+        hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, sums);
+    else
+        hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, sums);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                                  const float *weight, const float *sums, int relu, void *dx, void *dres, float *dweight,
+                                  float *dbias, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (rows == 0) return DMM_OK;
+    if (!dy || !x || !saved || !weight || !sums || !dx || !dweight || !dbias || (relu && !y)) return DMM_ERR_BAD_ARG;
+    if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
+    const int c8 = C / 8;
+    const dim3 grid(dmm::bn_grid(rows, c8, 8, 2048));
+#define DMM_BND(RELU_, DRES_)                                                                                            \
+    hipLaunchKernelGGL((dmm::bn_bwd_dx_bf16_kernel<RELU_, DRES_>), grid, dim3(256), 0, (hipStream_t)stream,              \
+                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, sums,    \
+                       (uint16_t *)dx, (uint16_t *)dres, dweight, dbias)
+    if (relu) { if (dres) DMM_BND(true, true); else DMM_BND(true, false); }
+    else { if (dres) DMM_BND(false, true); else DMM_BND(false, false); }
+#undef DMM_BND
+    return dmm::check_launch();
+}

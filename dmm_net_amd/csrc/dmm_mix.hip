@@ -561,7 +561,12 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     __shared__ int col_s[DMM_MAX_PROPOSALS];
     __shared__ __attribute__((aligned(16))) unsigned rowmask_s[DMM_MAX_PROPOSALS];
     __shared__ int pbase_s[DMM_MAX_PROPOSALS + 1];                        // first slot of a union column
-    __shared__ __attribute__((aligned(16))) float fold_s[kMixThreads / 64][kPairSlots][4];   // [wave][slot][16-lane row]
+    // ONE dynamic block serves both forms (they are mutually exclusive: pairs <= kPairSlots or not): the slot slabs
+    // [wave][slot][16-lane row] = 16 KB, or the dense per-wave tables 4 * N * MT floats.  The launcher sizes it as the
+    // larger of the two, so a workgroup's LDS is that + ~3.1 KB of static tables: under 64 KB for everything the gate in
+    // mask_mix_bwd admits (as two separate arrays the worst case was ~75 KB).
+    extern __shared__ __attribute__((aligned(16))) float dyn_s[];
+    float (*fold_s)[kPairSlots][4] = reinterpret_cast<float (*)[kPairSlots][4]>(dyn_s);
     __shared__ int wcnt_s[kMixThreads / 64];
     int b, range;
     xcd_frame_range(xcd_remap, b, range);                                 // DMM_OPT_MIX_XCD bit 2; see mask_mix_shared_kernel
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
         // a dense support (more pairs than slots): pair sums in LDS, one table PER WAVE ([wave][union column][row], dynamic
         // LDS: 4 * N * MT floats) -- lane 0 of a wave adds to its own table in program order, the tables are folded in a
         // fixed order.  One LDS round trip per pair: slower, and only here.
-        extern __shared__ float acc_s[];
+        float *acc_s = dyn_s;
         const int tbl = N * MT;
         for (int i = threadIdx.x; i < (kMixThreads / 64) * tbl; i += kMixThreads) acc_s[i] = 0.0f;
         __syncthreads();
@@ -706,6 +711,13 @@ __global__ __launch_bounds__(kMixThreads) void mask_mix_bwd_shared_kernel(const 
     }
 }
 
+// dynamic LDS of mask_mix_bwd_shared_kernel: the slot slabs or the dense per-wave tables, whichever is larger
+static inline size_t mix_bwd_dynamic_lds(int N, int mt) {
+    const size_t slabs = sizeof(float) * (kMixThreads / 64) * kPairSlots * 4;
+    const size_t dense = sizeof(float) * (kMixThreads / 64) * (size_t)N * mt;
+    return dense > slabs ? dense : slabs;
+}
+
 template <typename T>
 static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const float *dout, int B, int N, int M, int Pp,
                                      int HW, int64_t sp_b, int64_t sp_n, const int32_t *n_valid, const int32_t *m_valid,
@@ -723,7 +735,7 @@ static int mask_mix_bwd_shared_typed(const float *Rb, const T *masks_p, const fl
     const int splits = (nsteps + steps_per_wg - 1) / steps_per_wg;
 #define DMM_MIXB_LAUNCH(MT_)                                                                                        \
     hipLaunchKernelGGL((mask_mix_bwd_shared_kernel<T, MT_>), dim3(splits, B), dim3(kMixThreads),                    \
-                       sizeof(float) * (kMixThreads / 64) * (size_t)N * MT_, stream, Rb, masks_p, dout, N, M, Pp, HW, \
+                       mix_bwd_dynamic_lds(N, MT_), stream, Rb, masks_p, dout, N, M, Pp, HW,                         \
                        sp_b, sp_n, n_valid, m_valid, dRb, steps_per_wg, opt(DMM_OPT_MIX_SHARED_LOCKSTEP),               \
                        (opt(DMM_OPT_MIX_XCD) >> 2) & 1)
     if (M <= 8) DMM_MIXB_LAUNCH(8);
@@ -951,8 +963,9 @@ extern "C" int dmm_mask_mix_bwd(const float *Rb, const void *masks_p, int dtype,
     // default: planes of the union streamed once -- while the four per-wave pair tables fit the default dynamic-LDS limit
     // (4 * N * MT floats: everything up to 112 proposals x 32 rows or 224 x 16); wider tables keep the row kernel
     const int mt = M <= 8 ? 8 : (M <= 16 ? 16 : 32);
-    // the union kernel's four per-wave pair tables (dynamic LDS) sit beside ~7.2 KB of static LDS: 4 * N * mt
-    // floats <= 56 KB keeps the total under the 64 KB a launch gets without an attribute (wider tables: the row kernel)
+    // The union kernel's four per-wave pair tables share ONE dynamic block with its slot slabs (mix_bwd_dynamic_lds: the
+    // larger of the two) beside ~3.1 KB of static tables: 4 * N * mt floats <= 56 KB keeps the workgroup under the 64 KB a
+    // launch gets without an attribute (wider tables: the row kernel).  Edge cases 112 x 32 and 224 x 16 are in the tests.
     if (dmm::opt(DMM_OPT_MIX_SHARED) != 0 && sizeof(float) * 4 * (size_t)N * mt <= 56 * 1024) {
         switch (dtype) {
             case DMM_F32:

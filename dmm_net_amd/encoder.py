@@ -187,6 +187,8 @@ class FeatureEncoder(nn.Module):
 
     def __init__(self, base_model: str = "resnet50", hidden_size: int = 128, kernel_size: int = 3):
         super().__init__()
+        from . import use_shipped_miopen_db
+        use_shipped_miopen_db()              # here, not at import: only a process that builds an encoder gets the find-db
         dims = get_skip_dims(base_model)
         hid, ker = int(hidden_size), int(kernel_size)
         pad = 0 if ker == 1 else 1
@@ -477,6 +479,8 @@ class FastEncoder(nn.Module):
 
     def __init__(self, encoder: "FeatureEncoder", dtype=torch.bfloat16):
         super().__init__()
+        from . import use_shipped_miopen_db
+        use_shipped_miopen_db()
         assert not encoder.training, "FastEncoder is an inference form: eval() first"
         if not isinstance(encoder.base, ResNetBody):
             raise NotImplementedError("FastEncoder is the bf16 channels-last form of the ResNet bodies (resnet34 / 50 / "

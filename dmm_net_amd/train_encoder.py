@@ -1,0 +1,397 @@
+"""bf16 channels-last TRAINING form of the encoder (reference a10 as the trainer runs it; BASELINE configs[3]).
+
+Counterpart of ``dmm/modules/model_encoder.py:86-162`` + ``base.py:18-69`` + ``vision.py:6-38`` under
+``train.py:296-307`` (forward, ``loss.backward()``, optimiser step).  Same parameters as ``FeatureEncoder`` -- the fp32
+``nn.Parameter`` objects of the wrapped encoder stay the masters the optimiser, the checkpoints and
+``distributed.GradBucketer`` see -- evaluated the way that is fast on MI355X:
+
+* **whole forward / backward as HIP-graph replays.**  At the trainer's batch (12 frames of 255 x 448) a ResNet-101 step is
+  ~2 100 launches of 5-50 us kernels: the stock step is HOST bound (device kernel time 17.6 ms inside a 24.4 ms step under
+  bf16 autocast, ``profiles/r06_cfg4_*``).  The encoder is cut into a few SEGMENTS (stem + layer1 + layer2 | layer3 | layer4 |
+  heads); each segment's forward and its backward (``torch.autograd.grad`` over the segment) are captured once per input
+  shape and replayed.  Segment k+1 reads segment k's static output in place; backward replays run last segment first and
+  after each one that segment's parameter gradients are handed over -- so a gradient all-reduce (``GradBucketer`` hooks)
+  starts under the backward of the segments still to run.
+* **bf16 activations, channels-last, end to end; fp32 master weights.**  Weights are cast inside the graphs (differentiable
+  cast: the backward graph ends in fp32 gradients for the masters); BatchNorm runs on bf16 activations with fp32 parameters
+  and statistics.  No autocast (its per-call weight casts and cache are what ``make_graphed_callables`` has to switch off).
+* **1x1 convolutions are matrix products** of the [B*H*W, Cin] activation matrix (2/3 of a bottleneck): forward, data
+  gradient and weight gradient go to hipBLASLt as plain GEMMs instead of MIOpen's implicit-GEMM kernels and their
+  zero / cast helper launches.
+* **BatchNorm (+ residual) (+ ReLU) as two launches each way** (``dmm_bn_*`` in ``csrc/dmm_encoder_train.hip``) where the
+  stock path issues 5-6 (three MIOpen BatchNorm kernels + add + clamp; backward likewise).
+
+Gradient hand-over.  Parameter gradients are NOT returned through autograd (350 inputs to one Function): after a segment's
+backward replay every parameter of the segment gets ``p.grad`` (the graph's static gradient buffer itself when ``p.grad is
+None``, else accumulated into the existing tensor) and its post-accumulate-grad hooks are called, exactly what autograd's
+AccumulateGrad does -- ``GradBucketer(overlap=True)`` and plain optimisers work unchanged.  As with DDP's bucket views, a
+gradient aliases a static buffer until the next backward: do not hold on to it across steps.
+
+Not supported: double backward, ``retain_graph`` replays of the same forward, forward hooks on the wrapped modules.
+Off the GPU (or with ``graphs=False``) the same segment functions run eagerly under autograd -- that is what the CPU
+tests compare with the fp32 ``FeatureEncoder``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .encoder import Bottleneck, FeatureEncoder, ResNetBody
+from .graphs import SafeGraph
+
+_CL = torch.channels_last
+
+
+# ---- BatchNorm (+ residual) (+ ReLU), training mode, bf16 NHWC: two launches each way -------------------------------
+class _BNActFn(torch.autograd.Function):
+    """y = act(BN_train(x) (+ residual)) on a channels-last bf16 activation; statistics, scale and shift in fp32.
+    forward = ``dmm_bn_stats_bf16`` (per-channel sum / sum of squares) + ``dmm_bn_apply_bf16`` (normalise, residual, ReLU,
+    running statistics); backward = ``dmm_bn_bwd_reduce_bf16`` (sum g, sum g*xhat with g = dy * [y > 0]) +
+    ``dmm_bn_bwd_dx_bf16`` (dx, and g as the residual branch's gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual):
+        from . import _lib
+        L = _lib.load()
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        R = B * H * W
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x, memory_format=_CL)
+        saved = torch.empty((2, C), dtype=torch.float32, device=x.device)          # mean, invstd
+        res = None
+        if residual is not None:
+            assert residual.shape == x.shape and residual.dtype == x.dtype
+            res = residual.contiguous(memory_format=_CL)
+        with _lib.device_guard(x.device):
+            _lib.check(L.dmm_bn_stats_bf16(x.data_ptr(), R, C, stats.data_ptr(), stream), "dmm_bn_stats_bf16")
+            _lib.check(L.dmm_bn_apply_bf16(x.data_ptr(), None if res is None else res.data_ptr(), R, C, stats.data_ptr(),
+                                           weight.data_ptr(), bias.data_ptr(),
+                                           None if running_mean is None else running_mean.data_ptr(),
+                                           None if running_var is None else running_var.data_ptr(), float(momentum),
+                                           float(eps), int(relu), y.data_ptr(), saved.data_ptr(), stream),
+                       "dmm_bn_apply_bf16")
+        ctx.save_for_backward(x, y, weight, saved)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from . import _lib
+        L = _lib.load()
+        x, y, weight, saved = ctx.saved_tensors
+        B, C, H, W = x.shape
+        R = B * H * W
+        dy = dy.contiguous(memory_format=_CL)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x, memory_format=_CL)
+        dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
+        dw = torch.empty((C,), dtype=torch.float32, device=x.device)
+        db = torch.empty((C,), dtype=torch.float32, device=x.device)
+        with _lib.device_guard(x.device):
+            _lib.check(L.dmm_bn_bwd_reduce_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
+                                                int(ctx.relu), sums.data_ptr(), stream), "dmm_bn_bwd_reduce_bf16")
+            _lib.check(L.dmm_bn_bwd_dx_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
+                                            weight.data_ptr(), sums.data_ptr(), int(ctx.relu), dx.data_ptr(),
+                                            None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                            stream), "dmm_bn_bwd_dx_bf16")
+        return dx, dw, db, None, None, None, None, None, dres
+
+
+def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True):
+    """BatchNorm2d module ``bn`` (its fp32 parameters and running statistics) on a bf16 channels-last activation,
+    followed by the optional residual add and ReLU.  ``fused`` and training and on the device: the two-launch HIP form."""
+    if (fused and bn.training and x.is_cuda and x.dtype == torch.bfloat16 and bn.affine and bn.track_running_stats
+            and x.shape[1] % 8 == 0 and bn.momentum is not None):
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+        return _BNActFn.apply(x.contiguous(memory_format=_CL), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              bn.momentum, bn.eps, relu, residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+# ---- convolutions ----------------------------------------------------------------------------------------------------
+def _conv(x, m: nn.Conv2d, dtype, linear_1x1: bool = True):
+    """Convolution ``m`` (fp32 master weight, cast here -- differentiably -- to the compute dtype) on a channels-last
+    activation.  A 1x1 convolution is the product of the activation matrix with W^T: ``F.linear`` on the NHWC view
+    (hipBLASLt forward, data gradient and weight gradient); stride 2 = a row subsample first."""
+    b = None if m.bias is None else m.bias.to(dtype)
+    if linear_1x1 and m.kernel_size == (1, 1) and m.groups == 1 and m.padding == (0, 0) and m.dilation == (1, 1):
+        if m.stride != (1, 1):
+            x = x[:, :, ::m.stride[0], ::m.stride[1]].contiguous(memory_format=_CL)
+        w = m.weight.view(m.out_channels, m.in_channels).to(dtype)
+        return F.linear(x.permute(0, 2, 3, 1), w, b).permute(0, 3, 1, 2)
+    w = m.weight.to(dtype=dtype, memory_format=_CL)
+    return F.conv2d(x, w, b, m.stride, m.padding, m.dilation, m.groups)
+
+
+class TrainEncoder(nn.Module):
+    """``TrainEncoder(FeatureEncoder(...))``: same ``forward(img) -> feature dict`` (model_encoder.py:157-160), same
+    parameters (``self.src`` is the wrapped encoder: build the optimiser / save checkpoints from it as before), training
+    mode, bf16 channels-last, HIP-graph replays.  ``backbone_feature`` comes back as fp32 NCHW (what the ROI feature
+    kernel's backward takes); ``refine_input_feat`` / ``body_feature`` as bf16 channels-last.
+
+    ``skips_need_grad``: the decoder's inputs (``refine_input_feat``: ``sk_k`` + ``bn_k``) take part in the backward.  A
+    trainer with the refine decoder leaves it on; a step that never sends a gradient there (bench.py's config 4: no decoder)
+    switches it off so that the backward graph does not run those four convolutions on zeros."""
+
+    SEGMENTS = ("front", "layer3", "layer4", "heads")
+
+    def __init__(self, encoder: FeatureEncoder, dtype=torch.bfloat16, graphs: bool = True, linear_1x1: bool = True,
+                 fused_bn: bool = True, skips_need_grad: bool = True, miopen_find: bool = False, warmup: int = 2):
+        super().__init__()
+        if not isinstance(encoder.base, ResNetBody):
+            raise NotImplementedError("TrainEncoder is the bf16 channels-last training form of the ResNet bodies")
+        self.src = encoder
+        self.dtype, self.graphs, self.linear_1x1, self.fused_bn = dtype, bool(graphs), bool(linear_1x1), bool(fused_bn)
+        self.skips_need_grad, self.miopen_find, self.warmup = bool(skips_need_grad), bool(miopen_find), int(warmup)
+        self.__dict__["_plans"] = {}             # (shape, device) -> _Plan; not module state
+
+    # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
+    def _cbr(self, x, conv, bn, relu, residual=None):
+        return _bn_act(_conv(x, conv, self.dtype, self.linear_1x1), bn, relu, residual, self.fused_bn)
+
+    def _block(self, x, blk):
+        idt = x if blk.downsample is None else self._cbr(x, blk.downsample[0], blk.downsample[1], False)
+        if isinstance(blk, Bottleneck):
+            out = self._cbr(x, blk.conv1, blk.bn1, True)
+            out = self._cbr(out, blk.conv2, blk.bn2, True)
+            return self._cbr(out, blk.conv3, blk.bn3, True, idt)
+        out = self._cbr(x, blk.conv1, blk.bn1, True)
+        return self._cbr(out, blk.conv2, blk.bn2, True, idt)
+
+    def _layer(self, x, layer):
+        for blk in layer:
+            x = self._block(x, blk)
+        return x
+
+    def _seg_front(self, img):
+        body = self.src.base
+        x = img.to(self.dtype).contiguous(memory_format=_CL)
+        x = self._cbr(x, body.conv1, body.bn1, True)
+        x = body.maxpool(x)
+        x2 = self._layer(x, body.layer1)
+        x3 = self._layer(x2, body.layer2)
+        return x2, x3
+
+    def _seg_layer3(self, x3):
+        return (self._layer(x3, self.src.base.layer3),)
+
+    def _seg_layer4(self, x4):
+        return (self._layer(x4, self.src.base.layer4),)
+
+    def _head(self, x, head):
+        out = self._cbr(x, head[0], head[1], True)                       # base.py:43-54: conv -> BN -> ReLU -> conv -> BN
+        return self._cbr(out, head[3], head[4], False)
+
+    def _seg_heads(self, x2, x3, x4, x5):
+        s = self.src
+        props = [self._head(x, getattr(s, f"prop{k}")) for k, x in ((2, x2), (3, x3), (4, x4), (5, x5))]
+        with (torch.enable_grad() if self.skips_need_grad else torch.no_grad()):
+            skips = [self._cbr(x, getattr(s, f"sk{k}"), getattr(s, f"bn{k}"), False)
+                     for k, x in ((5, x5), (4, x4), (3, x3), (2, x2))]
+        # the ROI feature kernel (forward and backward) works on fp32 NCHW levels
+        return tuple(p.float().contiguous() for p in props) + tuple(skips)
+
+    def _seg_params(self) -> Dict[str, List[nn.Parameter]]:
+        s, body = self.src, self.src.base
+        P = lambda *mods: [p for m in mods for p in m.parameters() if p.requires_grad]
+        heads = P(s.prop2, s.prop3, s.prop4, s.prop5)
+        if self.skips_need_grad:
+            heads += P(s.sk2, s.sk3, s.sk4, s.sk5, s.bn2, s.bn3, s.bn4, s.bn5)
+        return {"front": P(body.conv1, body.bn1, body.layer1, body.layer2), "layer3": P(body.layer3),
+                "layer4": P(body.layer4), "heads": heads}
+
+    @staticmethod
+    def _pack(outs_front, x4, x5, heads):
+        x2, x3 = outs_front
+        return {"backbone_feature": tuple(heads[:4]), "refine_input_feat": tuple(heads[4:]),
+                "body_feature": (x2, x3, x4, x5)}
+
+    def _eager(self, img):
+        front = self._seg_front(img)
+        (x4,) = self._seg_layer3(front[1])
+        (x5,) = self._seg_layer4(x4)
+        return self._pack(front, x4, x5, self._seg_heads(front[0], front[1], x4, x5))
+
+    # ---- entry ---------------------------------------------------------------------------------------------------------
+    def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
+        assert img.dim() == 4 and img.shape[1] == 3, img.shape           # model_encoder.py:91-92
+        if not (self.graphs and img.is_cuda and self.training and torch.is_grad_enabled()):
+            return self._eager(img)
+        key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _Plan(self, img)
+        return plan.run(img)
+
+
+class _Plan:
+    """The captured graphs of one input shape: forward graphs front -> layer3 -> layer4 -> heads (each reads its
+    predecessor's static outputs in place), backward graphs in the reverse order (each reads its successors' static input
+    gradients in place), all in one memory pool and captured in the order they replay."""
+
+    def __init__(self, enc: TrainEncoder, img: torch.Tensor):
+        self.enc = enc
+        dev = img.device
+        fns = {"front": enc._seg_front, "layer3": enc._seg_layer3, "layer4": enc._seg_layer4, "heads": enc._seg_heads}
+        self.params = enc._seg_params()
+        self.static_img = img.detach().clone()
+        pool = torch.cuda.graph_pool_handle()
+        # ---- warm-up (eager, off the capture): MIOpen / hipBLASLt pick their kernels, the allocator reaches its size;
+        # BatchNorm's running statistics are put back afterwards (the warm-up and the captures are not training steps)
+        bns = [m for m in enc.src.modules() if isinstance(m, nn.BatchNorm2d)]
+        keep = [(m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for m in bns]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        old = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = old or enc.miopen_find
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(enc.warmup, 1)):
+                    out = enc._eager(self.static_img)
+                    leaves = [t for t in out["backbone_feature"] + out["refine_input_feat"] if t.requires_grad]
+                    torch.autograd.grad(leaves, [p for ps in self.params.values() for p in ps],
+                                        [torch.zeros_like(t) for t in leaves], allow_unused=True)
+                    del out, leaves
+        finally:
+            torch.backends.cudnn.benchmark = old
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # ---- forward captures, in replay order; a segment's inputs are DETACHED views of its predecessor's outputs that
+        # require grad, so that every segment owns a separate autograd graph
+        self.fwd, self.bwd, self.ins, self.outs = {}, {}, {}, {}
+
+        def leaf(t):
+            return t.detach().requires_grad_(True)
+        def capture(name, *inputs):
+            g = SafeGraph()
+            with g.capture(pool=pool):
+                outs = fns[name](*inputs)
+            self.fwd[name], self.ins[name], self.outs[name] = g, inputs, outs
+            return outs
+        x2, x3 = capture("front", self.static_img)
+        i3 = leaf(x3)
+        (x4,) = capture("layer3", i3)
+        i4 = leaf(x4)
+        (x5,) = capture("layer4", i4)
+        h2, h3, h4, h5 = leaf(x2), leaf(x3), leaf(x4), leaf(x5)
+        heads = capture("heads", h2, h3, h4, h5)
+        # ---- backward captures, reverse order.  Gradients that arrive from outside: one static buffer per head output that
+        # requires grad.  Gradients between segments: the tensors autograd.grad returned in the successor's capture.
+        self.gout = [torch.zeros_like(o) if o.requires_grad else None for o in heads]
+        self.pgrads = {}
+
+        def capture_bwd(name, outs, gouts, inputs):
+            ps = self.params[name]
+            wrt = [t for t in inputs if t.requires_grad] + ps
+            g = SafeGraph()
+            with g.capture(pool=pool):
+                grads = torch.autograd.grad(outs, wrt, gouts, allow_unused=True)
+            self.bwd[name] = g
+            n_in = len(wrt) - len(ps)
+            self.pgrads[name] = list(grads[n_in:])
+            return grads[:n_in]
+        ho = [o for o in heads if o.requires_grad]
+        g2, g3h, g4h, g5h = capture_bwd("heads", ho, [g for g in self.gout if g is not None], (h2, h3, h4, h5))
+        (g4,) = capture_bwd("layer4", [x5], [g5h], (i4,))
+        # x4 feeds layer4 AND the heads: its gradient is the sum of the two static buffers (one add, captured with layer3's
+        # backward); likewise x3 (layer3 + heads) and x2 (heads only) for the front segment
+        wrt3 = [i3] + self.params["layer3"]
+        gb = SafeGraph()
+        with gb.capture(pool=pool):
+            grads = torch.autograd.grad([x4], wrt3, [g4 + g4h], allow_unused=True)
+        self.bwd["layer3"], self.pgrads["layer3"] = gb, list(grads[1:])
+        g3 = grads[0]
+        gf = SafeGraph()
+        with gf.capture(pool=pool):
+            grads = torch.autograd.grad([x2, x3], self.params["front"], [g2, g3 + g3h], allow_unused=True)
+        self.bwd["front"], self.pgrads["front"] = gf, list(grads)
+        self.result = TrainEncoder._pack((x2, x3), x4, x5, heads)
+        self.heads = heads
+        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+        # what the rewrite found: {segment: (memset nodes, memcpy nodes) turned into kernel nodes} per direction
+        self.rewritten = {"fwd": {k: g.rewritten for k, g in self.fwd.items()}, "bwd": {k: g.rewritten for k, g in self.bwd.items()}}
+        for (rm, rv, nb), m in zip(keep, bns):
+            with torch.no_grad():
+                m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
+
+    def run(self, img):
+        self.static_img.copy_(img)
+        for name in TrainEncoder.SEGMENTS:
+            self.fwd[name].replay()
+        outs = _PlanFn.apply(self, self.anchor)
+        # (the body's own levels are handed out detached: inside the graphs they are inputs of the heads, not autograd leaves
+        # of the caller)
+        return {"backbone_feature": tuple(outs[:4]), "refine_input_feat": tuple(outs[4:]),
+                "body_feature": tuple(t.detach() for t in self.result["body_feature"])}
+
+    def backward(self, grads: Sequence[Optional[torch.Tensor]]):
+        k = 0
+        for g, o in zip(self.gout, self.heads):
+            if g is None:
+                continue
+            gi = grads[k] if k < len(grads) else None
+            if gi is None:
+                g.zero_()
+            elif gi.data_ptr() != g.data_ptr():
+                g.copy_(gi)
+            k += 1
+        for name in reversed(TrainEncoder.SEGMENTS):
+            # gradient accumulation (a second backward before zero_grad): a gradient that still IS this graph's static
+            # buffer would be overwritten by the replay -- it moves into its own tensor first (the usual flow, gradients
+            # set to None or re-pointed at bucket views between steps, never takes this path)
+            for p, g in zip(self.params[name], self.pgrads[name]):
+                if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                    p.grad = p.grad.clone()
+            self.bwd[name].replay()
+            _deliver(self.params[name], self.pgrads[name])
+
+
+def _deliver(params, grads):
+    """What autograd's AccumulateGrad does for a leaf, then its post-accumulate-grad hooks (GradBucketer's among them)."""
+    acc_dst, acc_src = [], []
+    for p, g in zip(params, grads):
+        if g is None:
+            continue
+        if p.grad is None:
+            p.grad = g.detach()
+        else:
+            acc_dst.append(p.grad), acc_src.append(g)
+    if acc_dst:
+        torch._foreach_add_(acc_dst, acc_src)
+    for p, g in zip(params, grads):
+        hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+        if g is not None and hooks:
+            for h in list(hooks.values()):
+                h(p)
+
+
+class _PlanFn(torch.autograd.Function):
+    """The graphed encoder as one autograd node (``anchor``: a scalar that requires grad, so that the node exists): outputs =
+    the heads' static outputs; the backward copies the incoming gradients into the static buffers, replays the backward
+    graphs last segment first and hands every segment's parameter gradients over as soon as its replay is issued."""
+
+    @staticmethod
+    def forward(ctx, plan, anchor):
+        ctx.plan = plan
+        outs = tuple(o.detach() for o in plan.heads)
+        ctx.mark_non_differentiable(*[o for o, g in zip(outs, plan.gout) if g is None])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        plan.backward([g for g, s in zip(grads, plan.gout) if s is not None])
+        return None, None

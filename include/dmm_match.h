@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DMM_ABI_VERSION 1
+#define DMM_ABI_VERSION 2
 
 typedef enum dmm_status {
     DMM_OK = 0,
@@ -626,6 +626,42 @@ DMM_API int dmm_im2col3x3_bf16(const void *x, int B, int H, int W, int C, int st
  * DMM_ERR_UNSUPPORTED when the library offers no kernel for the shape (callers fall back to torch.mm + (9)). */
 DMM_API int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias, const void *residual, int64_t rows, int cin,
                              int cout, int relu, void *y, void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (10) Training-mode BatchNorm (+ residual) (+ ReLU) of the encoder, channels-last bf16, fp32 statistics: two launches each
+ * way where the stock path issues five or six (three BatchNorm kernels + add + clamp).  Replaces, in the trainer's step
+ * (train.py:296-307), bn -> relu and bn -> (+ identity) -> relu of the torchvision blocks (dmm/modules/vision.py:6-38),
+ * the conv -> BN -> ReLU -> conv -> BN heads (base.py:43-54) and the skip projections' bn (model_encoder.py:137-140).
+ * x, residual, y, dy, dx, dres: [rows, C] bfloat16 (C % 8 == 0 and 256 % (C / 8) == 0, else DMM_ERR_UNSUPPORTED);
+ * everything else fp32.  Forward: dmm_bn_stats_bf16 accumulates sum(x), sum(x^2) per channel into stats [2, C] (the CALLER
+ * zeroes it beforehand; atomics, order free); dmm_bn_apply_bf16 turns them into mean / invstd (biased variance, eps inside
+ * the root), writes y = act(x * w * invstd + (b - mean * w * invstd) (+ residual)), saved [2, C] = (mean, invstd) and -- when
+ * running_mean / running_var are given -- running <- (1 - momentum) * running + momentum * batch with the UNBIASED variance
+ * (torch.nn.BatchNorm2d in training mode).  Backward: with g = dy * [y > 0] when relu, else dy: dmm_bn_bwd_reduce_bf16
+ * accumulates sum(g), sum(g * xhat) into sums [2, C] (caller-zeroed); dmm_bn_bwd_dx_bf16 writes
+ * dx = w * invstd * (g - mean(g) - xhat * mean(g * xhat)), dres = g (NULL: no residual branch), dweight = sum(g * xhat),
+ * dbias = sum(g).  y is only read when relu != 0.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stats, dmm_stream_t stream);
+DMM_API int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t rows, int C, const float *stats,
+                              const float *weight, const float *bias, float *running_mean, float *running_var,
+                              float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream);
+DMM_API int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                                   int relu, float *sums, dmm_stream_t stream);
+DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                               const float *weight, const float *sums, int relu, void *dx, void *dres, float *dweight,
+                               float *dbias, dmm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (11) HIP-graph hygiene for captured steps that contain other libraries' launches (MIOpen, hipBLASLt, torch): between the
+ * end of a stream capture and hipGraphInstantiate, replace every memset node (flags & 1; element size 1 / 2 / 4) and every
+ * 1-D device-to-device memcpy node (flags & 2) of `graph` (a hipGraph_t) by a kernel node with the same dependencies and
+ * dependents.  On the runtime of this image a replayed memset node is not reliably ordered before the kernel node behind it
+ * (profiles/r04_graph_memset_node.txt; round 6: MIOpen's bf16 weight-gradient solvers clear their split-K workspace that
+ * way).  n_memset / n_memcpy: nodes replaced; n_left: memset / memcpy nodes left as they were (other kinds, flags off).
+ * Nothing in the reference corresponds to it (train.py:296-307 launches eagerly); used by dmm_net_amd/train_encoder.py.
+ * ------------------------------------------------------------------------------------------- */
+DMM_API int dmm_graph_nodes_to_kernels(void *graph, int flags, int *n_memset, int *n_memcpy, int *n_left);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,8 @@ are data only -- no reference source text is stored.  Groups follow SURVEY.md se
      IoU > thresh suppresses as in nms.cu, stable order for ties): duplicates, exact-threshold pairs, score ties.
   G16 encoder heads first hand: the reference's FeatureExtractorBase (base.py:18-69, plain torch.nn behind the stubs)
      + the head calls of model_encoder.py:136-146 on seeded body features, train and eval mode, all parameters.
+  G22 the layer first hand at the product's plane sizes: 256 x 448 (the evaluator's default, 50 x 5, 40 x 5 iterations and
+     the trainer's 10 x 5 train mode) and 480 x 854 (DAVIS, 50 x 10)
   G21 the tail of compute_matching_loss first hand on tie-heavy inputs (empty masks, duplicate planes, one live target).
   G14 algo 'hun' through the imported MatchModel (hungarian_matching with its hard-coded .cuda() patched to a
      no-op on this CPU-only box): outputs + gradients of cost_loss (the only differentiable term under 'hun').
@@ -344,6 +346,30 @@ def g4():
                 o = run_layer(fr, 40, 5, 1, full=False)
                 d.update(flat(f"c{ci}/{kind}/eval40", o))
     save("g4_big", d)
+
+
+# ------------------------------------------------------------------------------------------ G22
+G22_CASES = (  # name, P, O, H, W, (max_iter, proj_iter, is_test) runs
+    ("eval_256x448", 50, 5, 256, 448, ((40, 5, 1), (10, 5, 0))),     # args.py:12-14 default evaluation height 256,
+    #   scripts/eval/eval_r50.sh:6-7 (40 x 5); HW = 114 688 is a multiple of every chunk size: no tail instantiation fires
+    ("davis_480x854", 50, 10, 480, 854, ((20, 5, 1),)),               # dmm/misc/config.py:41-42 (DAVIS 480p)
+)
+
+
+def g22():
+    """The product's plane sizes first hand (every bit-exact list topped out at 255 x 255 / 255 x 448): the
+    imported MatchModel on seeded structured / uniform frames at 256 x 448 (the evaluator's default height; 5 templates;
+    40 x 5 test mode and 10 x 5 train mode) and 480 x 854 (DAVIS): [M, N] tables, scores, iteration counts, samples and
+    sums of the big output."""
+    d = {}
+    for name, P, O, H, W, runs in G22_CASES:
+        for kind in ("structured", "uniform"):
+            fr = synth.make_frame(P, O, H, W, 512, seed=synth.BASE_SEED + 2200 + H, kind=kind)
+            d[f"{name}/{kind}/checksum"] = np.array(fr.checksum())
+            for (mi, pj, is_test) in runs:
+                o = run_layer(fr, mi, pj, is_test, full=False)
+                d.update(flat(f"{name}/{kind}/i{mi}_{pj}_t{is_test}", o))
+    save("g22_product_sizes", d)
 
 
 # ------------------------------------------------------------------------------------------ G5
@@ -1135,6 +1161,6 @@ def g21():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
-                             "g15", "g16", "g17", "g19", "g20", "g21"]   # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
+                             "g15", "g16", "g17", "g19", "g20", "g21", "g22"]   # g18 needs ATEN_CPU_CAPABILITY=default (see its docstring)
     for w in which:
         globals()[w]()

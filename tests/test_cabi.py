@@ -29,7 +29,7 @@ def test_load_and_status_strings():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     L = _lib.load()
-    assert L.dmm_abi_version() == 1
+    assert L.dmm_abi_version() == 2
     assert L.dmm_status_string(0) == b"ok"
     assert b"gfx950" in L.dmm_build_info()
     assert L.dmm_workspace_bytes(4, 50, 10, 512) > 4 * (50 + 10) * 512 * 4

@@ -277,7 +277,10 @@ def _mix_bwd_case(B, N, M, H, W, seed, dtype=torch.float32, density=0.3, ragged=
     (2, 50, 10, 48, 52, torch.float16, False),
     (2, 33, 7, 48, 52, torch.bfloat16, True),
     (2, 65, 4, 24, 24, torch.float32, False), (2, 20, 17, 24, 24, torch.float32, False),
-    (2, 120, 32, 24, 24, torch.float32, False), (1, 240, 16, 16, 16, torch.float32, False),    # the LDS gate's edge
+    (2, 120, 32, 24, 24, torch.float32, False), (1, 240, 16, 16, 16, torch.float32, False),    # just past the LDS gate: row kernel
+    (2, 112, 32, 24, 24, torch.float32, False), (1, 224, 16, 16, 16, torch.float32, False),    # ON the gate's edge --
+    #   56 KB of dense per-wave tables in the union kernel's dynamic block (pairs > 256 at this density) + 3.1 KB static
+    (2, 112, 32, 24, 24, torch.float16, True),
     (19, 50, 10, 40, 52, torch.float32, True)])        # two complete groups of 8 frames (XCD mapping) + 3, ragged
 def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
     """dmm_mask_mix_bwd (union kernel with the scalar-branch slot parking of round 5, and the row kernel it falls back to:

@@ -98,3 +98,30 @@ def test_bench_compacts_the_other_workloads_lines():
     c = bench.compact(train)
     assert c["roofline"] == {"bound": "hbm", "kernel": "k", "achieved": 6.4e3, "peak": 8e3, "unit": "GB/s", "frac": 0.8}
     assert c["by_batch"]["64"]["kernels"] == {"mask_mix_bwd": {"ms": 0.175, "frac": 0.686}, "relax_match_bwd": {"ms": 0.157}}
+
+
+def test_importing_the_matching_layer_leaves_the_environment_alone(tmp_path):
+    """The one-line swap imports ``dmm_net_amd.match_model`` only: that must neither touch ``os.environ`` (MIOpen's
+    MIOPEN_USER_DB_PATH is set when an ENCODER is constructed, not at import) nor write under the home directory."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import os, json, sys; sys.path.insert(0, %r); e0 = dict(os.environ); import dmm_net_amd.match_model; "
+            "import dmm_net_amd; e1 = dict(os.environ); h1 = sorted(os.listdir(os.environ['HOME'])); "
+            "from dmm_net_amd.encoder import FeatureEncoder; FeatureEncoder('resnet34'); e2 = dict(os.environ); "
+            "print(json.dumps({'same': e0 == e1, 'home_after_import': h1, 'home': sorted(os.listdir(os.environ['HOME'])), "
+            "'db_after_encoder': e2.get('MIOPEN_USER_DB_PATH')}))" % ROOT)
+    home = tmp_path / "home"
+    home.mkdir()
+    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_USER_DB_PATH"}
+    env["HOME"] = str(home)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["same"], "importing the package changed os.environ"
+    assert out["home_after_import"] == [], "importing the package wrote under the home directory"
+    # after the import nothing was written; the encoder's constructor is what seeds the find-db copy
+    assert out["db_after_encoder"] and out["db_after_encoder"].startswith(str(home))
+    assert out["home"] == [".cache"]
