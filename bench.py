@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
     ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
                                                               "fp16-state one BASELINE configs[4] names")
+    ap.add_argument("--bf16", action="store_true", help="config 4: the encoder as train_encoder.TrainEncoder -- bf16 channels-last, "
+                    "fp32 master weights, HIP-graph replays, own BatchNorm / weight-gradient kernels (the shipped bf16 training form)")
     ap.add_argument("--autocast", action="store_true", help="config 4: run the encoder under bf16 autocast (the reference "
                                                           "trains in fp32, which is the default here)")
     ap.add_argument("--repeats", type=int, default=3, help="config 4: timed repeats of K steps each; the line carries the "
@@ -712,6 +714,14 @@ def bench_config4(R):
     torch.manual_seed(rank)
     g = torch.Generator(device=dev).manual_seed(rank)
     enc = FeatureEncoder("resnet101").to(dev).train()
+    bf16 = bool(getattr(args, "bf16", False))
+    if bf16:
+        # same parameters (the optimiser and the bucketer below hold the fp32 masters); no gradient reaches the decoder's skip
+        # inputs in this step, like in the fp32 line (autograd skips them there)
+        from dmm_net_amd.train_encoder import TrainEncoder
+        run_enc = TrainEncoder(enc, skips_need_grad=False, miopen_find=True)
+    else:
+        run_enc = enc
     model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
                        "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
     params = list(enc.get_skip_params()) + list(enc.get_backbone_para())
@@ -742,11 +752,12 @@ def bench_config4(R):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if k is not None else None
         mark = (lambda i: e[i].record()) if e else (lambda i: None)
         mark(0)
-        if args.autocast:
+        if args.autocast and not bf16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 feats = enc(img)
         else:
-            feats = enc(img)                                      # fp32 like the reference's trainer (train.py: no autocast)
+            feats = run_enc(img)                                  # fp32 like the reference's trainer (train.py: no autocast),
+            #                                                       or the bf16 training form (--bf16)
         mark(1)
         tplt = model.fill_template_dict(None, tboxes, feats, None, valid)
         out, _, match_loss, _ = model(None, props, feats["backbone_feature"], mask_last, tplt, valid, targets)
@@ -805,10 +816,14 @@ def bench_config4(R):
                   "gradient mean over RCCL), YouTube-VOS-shaped synthetic clips (BASELINE configs[3])",
         "value": round(world * B / (step_ms * 1e-3), 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("bf16 autocast encoder" if args.autocast else "f32 encoder (as the reference trains)") +
+        "vs_baseline": None, "dtype": ("bf16 encoder (TrainEncoder: fp32 master weights, bf16 channels-last activations, "
+                                       "HIP-graph replays)" if bf16 else "bf16 autocast encoder" if args.autocast
+                                       else "f32 encoder (as the reference trains)") +
         ", f32 matching layer and optimiser", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3], per-GPU share: {B} frames of 255x448 (4 videos x clip 3), ResNet-101 "
-                               "+ heads (torch.nn on MIOpen, random init), 50 proposals, 5 template slots, DMM_Model "
+                               "+ heads (" + ("train_encoder.TrainEncoder: captured segments, dmm BatchNorm / weight-gradient "
+                               "kernels, hipBLASLt 1x1s, MIOpen 3x3 forward / data gradient" if bf16 else "torch.nn on MIOpen") +
+                               ", random init), 50 proposals, 5 template slots, DMM_Model "
                                "training forward (10x5 solver, dual IoU with the targets) + soft-IoU + matching loss, "
                                "backward, Adam; gradient mean = distributed.GradBucketer(overlap=True, 64 MB buckets)",
                    "frames_per_gpu_per_step": B, "sharding": f"clips x{world}, one RCCL all-reduce per bucket",
@@ -1240,7 +1255,8 @@ def main():
                                          "note": "the bit-exact fp32-state solver (--f32-solver) on the same planes"}
             return o
         for name, fn, kw in (("config5", config5_both, dict(steps=30, warmup=5, frames=0)),
-                             ("config4", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3)),
+                             ("config4", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3, bf16=False)),
+                             ("config4_bf16", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3, bf16=True)),
                              ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
                              ("frame_loop", bench_frame_loop, dict(frames=0)),
                              ("train", bench_train, dict(steps=40, warmup=6, frames=0)),

@@ -56,18 +56,20 @@ __device__ __forceinline__ void load8f(const float *p, float *f) {
 }
 
 // fold the 16 per-thread partials (two statistics x 8 channels) of the threads that share a channel group, then one
-// atomic per (channel, statistic) of the workgroup.  red: [256][16] floats.
-__device__ __forceinline__ void fold_and_add(const float *acc16, float *red, int c8, int C, float *__restrict__ out2C) {
+// atomic per (channel, statistic) of the workgroup.  red: [256][16] floats.  c8t = channel groups of this workgroup's tile
+// (threads per row), cg0 = first channel group of the tile.
+__device__ __forceinline__ void fold_and_add(const float *acc16, float *red, int c8t, int cg0, int C,
+                                             float *__restrict__ out2C) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 16; ++k) red[t * 16 + k] = acc16[k];
     __syncthreads();
-    const int rpp = 256 / c8;                            // threads (rows per pass) per channel group
-    for (int j = t; j < 16 * c8; j += 256) {             // j = cg * 16 + k
+    const int rpp = 256 / c8t;                           // threads (rows per pass) per channel group
+    for (int j = t; j < 16 * c8t; j += 256) {            // j = cg * 16 + k
         float s = 0.0f;
-        for (int r = 0; r < rpp; ++r) s += red[(r * c8) * 16 + j];
+        for (int r = 0; r < rpp; ++r) s += red[(r * c8t) * 16 + j];
         const int cg = j >> 4, k = j & 15;
-        unsafeAtomicAdd(&out2C[(k >> 3) * C + cg * 8 + (k & 7)], s);
+        unsafeAtomicAdd(&out2C[(k >> 3) * C + (cg0 + cg) * 8 + (k & 7)], s);
     }
 }
 
@@ -79,10 +81,14 @@ __device__ __forceinline__ void row_range(int64_t rows, int rpp, int64_t &r0, in
     r1 = r0 + per < rows ? r0 + per : rows;
 }
 
+// Statistics kernels: grid = (row groups, channel tiles of <= 256 channels).  Device-scope fp32 atomics run at ~50 G/s on
+// this part (a launch of 2048 workgroups x 2C atomics took 24 us where the data pass takes 5), so the ROW groups are few --
+// row groups x 2C <= 128 k atomics -- and wide layers get their parallelism from the channel tiles instead.
 __global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__restrict__ x, int64_t rows, int c8,
                                                             float *__restrict__ stats) {
     __shared__ float red[256 * 16];
-    const int cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    const int c8t = c8 < 32 ? c8 : 32, cg0 = blockIdx.y * c8t;
+    const int cg = cg0 + threadIdx.x % c8t, ro = threadIdx.x / c8t, rpp = 256 / c8t;
     int64_t r0, r1;
     row_range(rows, rpp, r0, r1);
     float acc[16];
@@ -90,12 +96,12 @@ __global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__re
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
     const u32x4t *xp = reinterpret_cast<const u32x4t *>(x);
     int64_t r = r0 + ro;
-    for (; r + 3 * rpp < r1; r += 4 * rpp) {             // four loads in flight
-        u32x4t v[4];
+    for (; r + 7 * rpp < r1; r += 8 * rpp) {             // eight loads in flight
+        u32x4t v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = xp[(r + u * rpp) * c8 + cg];
+        for (int u = 0; u < 8; ++u) v[u] = xp[(r + u * rpp) * c8 + cg];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             float f[8];
             unpack8(v[u], f);
 #pragma unroll
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__re
             acc[8 + k] = __builtin_fmaf(f[k], f[k], acc[8 + k]);
         }
     }
-    fold_and_add(acc, red, c8, c8 * 8, stats);
+    fold_and_add(acc, red, c8t, cg0, c8 * 8, stats);
 }
 
 template <bool RES, bool RELU>
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
                                                                  const uint16_t *__restrict__ y, int64_t rows, int c8,
                                                                  const float *__restrict__ saved, float *__restrict__ sums) {
     __shared__ float red[256 * 16];
-    const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    const int C = c8 * 8, c8t = c8 < 32 ? c8 : 32, cg0 = blockIdx.y * c8t;
+    const int cg = cg0 + threadIdx.x % c8t, ro = threadIdx.x / c8t, rpp = 256 / c8t;
     float mean[8], invstd[8];
     load8f(saved + cg * 8, mean);
     load8f(saved + C + cg * 8, invstd);
@@ -187,17 +194,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
                  *yp = reinterpret_cast<const u32x4t *>(y);
     int64_t r = r0 + ro;
-    for (; r + rpp < r1; r += 2 * rpp) {                 // two rows (4-6 loads) in flight
-        u32x4t vd[2], vx[2], vy[2];
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {             // four rows (8-12 loads) in flight
+        u32x4t vd[4], vx[4], vy[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int64_t i = (r + u * rpp) * c8 + cg;
             vd[u] = dp[i];
             vx[u] = xp[i];
             if (RELU) vy[u] = yp[i];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             float g[8], f[8], o[8];
             unpack8(vd[u], g);
             unpack8(vx[u], f);
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
             acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
         }
     }
-    fold_and_add(acc, red, c8, C, sums);
+    fold_and_add(acc, red, c8t, cg0, C, sums);
 }
 
 template <bool RELU, bool DRES>
@@ -280,7 +287,17 @@ static inline bool bn_shape_ok(int64_t rows, int C) {
     return c8 <= 256 && 256 % c8 == 0;
 }
 
-// workgroups: every thread gets >= `min_iters` rows where the tensor allows, at most `cap` workgroups
+// statistics kernels: (row groups, channel tiles); row groups x 2C atomics <= 128 k, >= 8 passes per workgroup
+static inline dim3 bn_stat_grid(int64_t rows, int c8) {
+    const int c8t = c8 < 32 ? c8 : 32, rpp = 256 / c8t;
+    int64_t g = (rows + (int64_t)rpp * 8 - 1) / ((int64_t)rpp * 8);
+    const int64_t cap = 65536 / (8 * c8) < 256 ? 65536 / (8 * c8) : 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g, (unsigned)(c8 / c8t));
+}
+
+// elementwise kernels: every thread gets >= `min_iters` rows where the tensor allows, at most `cap` workgroups
 static inline unsigned bn_grid(int64_t rows, int c8, int min_iters, int cap) {
     const int rpp = 256 / c8;
     int64_t g = (rows + (int64_t)rpp * min_iters - 1) / ((int64_t)rpp * min_iters);
@@ -297,7 +314,7 @@ extern "C" int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stat
     if (!x || !stats) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    hipLaunchKernelGGL(dmm::bn_stats_bf16_kernel, dim3(dmm::bn_grid(rows, c8, 16, 1024)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dmm::bn_stats_bf16_kernel, dmm::bn_stat_grid(rows, c8), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)x, rows, c8, stats);
     return dmm::check_launch();
 }
@@ -310,7 +327,7 @@ extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t ro
     if (!x || !stats || !weight || !bias || !y || !saved || (!running_mean) != (!running_var)) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid(dmm::bn_grid(rows, c8, 8, 2048));
+    const dim3 grid(dmm::bn_grid(rows, c8, 2, 4096));
 #define DMM_BNA(RES_, RELU_)                                                                                             \
     hipLaunchKernelGGL((dmm::bn_apply_bf16_kernel<RES_, RELU_>), grid, dim3(256), 0, (hipStream_t)stream,                \
                        (const uint16_t *)x, (const uint16_t *)residual, rows, c8, stats, weight, bias, running_mean,     \
@@ -328,7 +345,7 @@ extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void 
     if (!dy || !x || !saved || !sums || (relu && !y)) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid(dmm::bn_grid(rows, c8, 16, 1024));
+    const dim3 grid = dmm::bn_stat_grid(rows, c8);
     if (relu)
         hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, sums);
@@ -346,7 +363,7 @@ extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, 
     if (!dy || !x || !saved || !weight || !sums || !dx || !dweight || !dbias || (relu && !y)) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid(dmm::bn_grid(rows, c8, 8, 2048));
+    const dim3 grid(dmm::bn_grid(rows, c8, 2, 4096));
 #define DMM_BND(RELU_, DRES_)                                                                                            \
     hipLaunchKernelGGL((dmm::bn_bwd_dx_bf16_kernel<RELU_, DRES_>), grid, dim3(256), 0, (hipStream_t)stream,              \
                        (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, sums,    \

@@ -25,7 +25,9 @@ Gradient hand-over.  Parameter gradients are NOT returned through autograd (350 
 backward replay every parameter of the segment gets ``p.grad`` (the graph's static gradient buffer itself when ``p.grad is
 None``, else accumulated into the existing tensor) and its post-accumulate-grad hooks are called, exactly what autograd's
 AccumulateGrad does -- ``GradBucketer(overlap=True)`` and plain optimisers work unchanged.  As with DDP's bucket views, a
-gradient aliases a static buffer until the next backward: do not hold on to it across steps.
+gradient may alias a static buffer of the captured step: it is valid until the encoder's next forward (which moves a
+gradient that is still in place -- gradient accumulation -- into a tensor of its own first); do not hold on to the tensor
+object itself across steps.
 
 Not supported: double backward, ``retain_graph`` replays of the same forward, forward hooks on the wrapped modules.
 Off the GPU (or with ``graphs=False``) the same segment functions run eagerly under autograd -- that is what the CPU
@@ -45,6 +47,50 @@ from .graphs import SafeGraph
 _CL = torch.channels_last
 
 
+# ---- scratch for the BatchNorm statistics ------------------------------------------------------------------------------
+class _Arena:
+    """fp32 scratch the statistics kernels accumulate into (they need zeroed [2, C] blocks): inside a captured segment ONE
+    zeroing launch at the head of the graph clears the blocks of all its layers -- a ``torch.zeros`` per layer and direction
+    was 238 launches of ~4 us per ResNet-101 step (profiles/r06_cfg4_kernel_stats_train_first.csv).  A capture is traced
+    once, so handing out consecutive slices while it runs fixes every layer's block for all replays."""
+
+    def __init__(self, device, floats: int = 1 << 20):
+        self.buf = torch.zeros(int(floats), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, n: int) -> torch.Tensor:
+        n = (n + 63) & ~63
+        if self.off + n > self.buf.numel():
+            raise RuntimeError("TrainEncoder: statistics arena exhausted")
+        t = self.buf[self.off:self.off + n]
+        self.off += n
+        return t
+
+
+_ARENA: Optional[_Arena] = None          # set while a segment is being captured (captures never run side by side)
+
+
+def _zeroed(n: int, device) -> torch.Tensor:
+    if _ARENA is not None and _ARENA.buf.device == device:
+        return _ARENA.take(n)
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+class _arena_scope:
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _ARENA
+        _ARENA = self.arena
+        self.arena.buf.zero_()               # a fill KERNEL (captured: replayed at the head of the graph)
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = None
+
+
 # ---- BatchNorm (+ residual) (+ ReLU), training mode, bf16 NHWC: two launches each way -------------------------------
 class _BNActFn(torch.autograd.Function):
     """y = act(BN_train(x) (+ residual)) on a channels-last bf16 activation; statistics, scale and shift in fp32.
@@ -60,7 +106,7 @@ class _BNActFn(torch.autograd.Function):
         B, C, H, W = x.shape
         R = B * H * W
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        stats = _zeroed(2 * C, x.device)
         y = torch.empty_like(x, memory_format=_CL)
         saved = torch.empty((2, C), dtype=torch.float32, device=x.device)          # mean, invstd
         res = None
@@ -89,7 +135,7 @@ class _BNActFn(torch.autograd.Function):
         R = B * H * W
         dy = dy.contiguous(memory_format=_CL)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        sums = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        sums = _zeroed(2 * C, x.device)
         dx = torch.empty_like(x, memory_format=_CL)
         dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
         dw = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -104,13 +150,20 @@ class _BNActFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, dres
 
 
-def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True):
+def _bn_fusable(bn: nn.BatchNorm2d) -> bool:
+    c8 = bn.num_features // 8
+    return (bn.affine and bn.track_running_stats and bn.momentum is not None and bn.num_features % 8 == 0
+            and 0 < c8 <= 256 and 256 % c8 == 0)
+
+
+def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True, counted: bool = False):
     """BatchNorm2d module ``bn`` (its fp32 parameters and running statistics) on a bf16 channels-last activation,
-    followed by the optional residual add and ReLU.  ``fused`` and training and on the device: the two-launch HIP form."""
-    if (fused and bn.training and x.is_cuda and x.dtype == torch.bfloat16 and bn.affine and bn.track_running_stats
-            and x.shape[1] % 8 == 0 and bn.momentum is not None):
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+    followed by the optional residual add and ReLU.  ``fused`` and training and on the device: the two-launch HIP form
+    (``counted``: the caller has already advanced ``num_batches_tracked`` for its whole segment in one launch)."""
+    if fused and bn.training and x.is_cuda and x.dtype == torch.bfloat16 and _bn_fusable(bn):
+        if not counted:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
         return _BNActFn.apply(x.contiguous(memory_format=_CL), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                               bn.momentum, bn.eps, relu, residual)
     y = bn(x)
@@ -120,12 +173,109 @@ def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True
 
 
 # ---- convolutions ----------------------------------------------------------------------------------------------------
-def _conv(x, m: nn.Conv2d, dtype, linear_1x1: bool = True):
-    """Convolution ``m`` (fp32 master weight, cast here -- differentiably -- to the compute dtype) on a channels-last
-    activation.  A 1x1 convolution is the product of the activation matrix with W^T: ``F.linear`` on the NHWC view
-    (hipBLASLt forward, data gradient and weight gradient); stride 2 = a row subsample first."""
+def _wgrad_ok(m: nn.Conv2d) -> bool:
+    return (m.groups == 1 and m.dilation == (1, 1) and m.in_channels % 64 == 0 and m.out_channels % 64 == 0
+            and m.stride in ((1, 1), (2, 2)))
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 convolution of a channels-last bf16 activation with an fp32 MASTER weight: y = X W^T on the [B*H*W, Cin] activation
+    matrix (hipBLASLt); backward: dX = dY W (hipBLASLt) and dW = dY^T X straight into an fp32 gradient for the master
+    (``dmm_wgrad_bf16``: MFMA, split over the rows) -- no bf16 weight gradient, no cast launch.  stride 2 = a row subsample."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, shadow=None):
+        co, ci = weight.shape[0], weight.shape[1]
+        ctx.full = None
+        if stride != 1:
+            ctx.full = tuple(x.shape)
+            x = x[:, :, ::stride, ::stride].contiguous(memory_format=_CL)
+        B, _, H, W = x.shape
+        # shadow: the bf16 copy of the weight the caller refreshed for its whole segment in one multi-tensor launch
+        w = shadow if shadow is not None else weight.detach().view(co, ci).to(torch.bfloat16)
+        y = torch.mm(x.permute(0, 2, 3, 1).reshape(B * H * W, ci), w.t())
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y.view(B, H, W, co).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from . import _lib
+        x, w = ctx.saved_tensors
+        B, ci, H, W = x.shape
+        co = w.shape[0]
+        dy = dy.contiguous(memory_format=_CL)
+        dy_rows = dy.permute(0, 2, 3, 1).reshape(B * H * W, co)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy_rows, w).view(B, H, W, ci).permute(0, 3, 1, 2)
+            if ctx.full is not None:
+                full = torch.zeros(ctx.full, dtype=dx.dtype, device=dx.device).contiguous(memory_format=_CL)
+                full[:, :, ::ctx.stride, ::ctx.stride] = dx
+                dx = full
+        L = _lib.load()
+        dw = torch.empty((co, ci, 1, 1), dtype=torch.float32, device=x.device)
+        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * H * W, co, ci)), 16),), dtype=torch.uint8, device=x.device)
+        with _lib.device_guard(x.device):
+            _lib.check(L.dmm_wgrad_bf16(dy_rows.data_ptr(), x.data_ptr(), B * H * W, co, ci, co, ci, dw.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
+                       "dmm_wgrad_bf16")
+        return dx, dw, None, None
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """3x3 / padding 1 convolution (stride 1 or 2) of a channels-last bf16 activation with an fp32 MASTER weight: forward and
+    data gradient on MIOpen, the weight gradient by ``dmm_wgrad3x3_bf16`` (implicit patch matrix, MFMA, fp32 out) -- MIOpen's
+    bf16 weight-gradient solvers cost a zeroing and a cast launch each and clear their workspace with a memset node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        w = weight.detach().to(dtype=torch.bfloat16, memory_format=_CL)
+        b = None if bias is None else bias.detach().to(torch.bfloat16)
+        y = F.conv2d(x, w, b, stride, 1)
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from . import _lib
+        x, w = ctx.saved_tensors
+        B, ci, H, W = x.shape
+        co = w.shape[0]
+        dy = dy.contiguous(memory_format=_CL)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        L = _lib.load()
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)      # the master's own layout
+        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * Ho * Wo, co, 9 * ci)), 16),), dtype=torch.uint8,
+                         device=x.device)
+        with _lib.device_guard(x.device):
+            _lib.check(L.dmm_wgrad3x3_bf16(dy.data_ptr(), x.data_ptr(), B, H, W, ci, co, ctx.stride, dw.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
+                       "dmm_wgrad3x3_bf16")
+        db = dy.float().sum((0, 2, 3)) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+def _conv(x, m: nn.Conv2d, dtype, linear_1x1: bool = True, own_wgrad: bool = True, shadow=None):
+    """Convolution ``m`` (fp32 master weight) on a channels-last activation in the compute dtype.  On the device in bf16: a
+    1x1 convolution is the product of the activation matrix with W^T (hipBLASLt forward and data gradient), a 3x3 one runs on
+    MIOpen, and both take their weight gradient from ``dmm_wgrad*_bf16``; anything else (the 7x7 stem, widths that are not a
+    multiple of 64, fp32 mode, the CPU) goes through the stock ops with a differentiable cast of the weight."""
+    fast = own_wgrad and x.is_cuda and dtype == torch.bfloat16 and x.dtype == dtype and _wgrad_ok(m)
+    one = m.kernel_size == (1, 1) and m.padding == (0, 0)
+    if fast and linear_1x1 and one and m.bias is None:
+        return _Conv1x1Fn.apply(x.contiguous(memory_format=_CL), m.weight, m.stride[0], shadow)
+    if fast and m.kernel_size == (3, 3) and m.padding == (1, 1):
+        return _Conv3x3Fn.apply(x.contiguous(memory_format=_CL), m.weight, m.bias, m.stride[0])
     b = None if m.bias is None else m.bias.to(dtype)
-    if linear_1x1 and m.kernel_size == (1, 1) and m.groups == 1 and m.padding == (0, 0) and m.dilation == (1, 1):
+    if linear_1x1 and one and m.groups == 1 and m.dilation == (1, 1):
         if m.stride != (1, 1):
             x = x[:, :, ::m.stride[0], ::m.stride[1]].contiguous(memory_format=_CL)
         w = m.weight.view(m.out_channels, m.in_channels).to(dtype)
@@ -147,18 +297,58 @@ class TrainEncoder(nn.Module):
     SEGMENTS = ("front", "layer3", "layer4", "heads")
 
     def __init__(self, encoder: FeatureEncoder, dtype=torch.bfloat16, graphs: bool = True, linear_1x1: bool = True,
-                 fused_bn: bool = True, skips_need_grad: bool = True, miopen_find: bool = False, warmup: int = 2):
+                 fused_bn: bool = True, own_wgrad: bool = True, skips_need_grad: bool = True, miopen_find: bool = False,
+                 warmup: int = 2):
         super().__init__()
         if not isinstance(encoder.base, ResNetBody):
             raise NotImplementedError("TrainEncoder is the bf16 channels-last training form of the ResNet bodies")
         self.src = encoder
         self.dtype, self.graphs, self.linear_1x1, self.fused_bn = dtype, bool(graphs), bool(linear_1x1), bool(fused_bn)
+        self.own_wgrad = bool(own_wgrad)
         self.skips_need_grad, self.miopen_find, self.warmup = bool(skips_need_grad), bool(miopen_find), int(warmup)
         self.__dict__["_plans"] = {}             # (shape, device) -> _Plan; not module state
+        self.__dict__["_hubs"] = {}              # device index -> {segment: hub leaf}
+        self.__dict__["_pending"] = {}           # segment -> plans whose backward of it ran in the current backward pass
+        self.__dict__["_ticked"] = {}            # id(module) -> covered by the running segment's _tick (rebuilt per call)
+        self.__dict__["_shadows"] = {}           # id(1x1 conv) -> its persistent bf16 weight copy
 
     # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
     def _cbr(self, x, conv, bn, relu, residual=None):
-        return _bn_act(_conv(x, conv, self.dtype, self.linear_1x1), bn, relu, residual, self.fused_bn)
+        t = self.__dict__["_ticked"]
+        y = _conv(x, conv, self.dtype, self.linear_1x1, self.own_wgrad, t.get(id(conv)))
+        return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t)
+
+    def _tick(self, name: str, x: torch.Tensor):
+        """Per-segment housekeeping in ONE launch each instead of one per layer: ``num_batches_tracked += 1`` of every
+        BatchNorm that takes the fused kernels (116 launches per ResNet-101 step before), and the bf16 copies of the 1x1
+        weights (70).  ``_ticked`` tells ``_cbr`` which modules were covered."""
+        t = self.__dict__["_ticked"]
+        if not (x.is_cuda and self.dtype == torch.bfloat16 and self.training):
+            return
+        mods = [m for mod in self._seg_modules()[name] for m in mod.modules()]
+        if name == "heads" and not self.skips_need_grad:
+            pass                                           # (the skips run under no_grad but still in training mode: counted too)
+        if self.fused_bn:
+            bns = [m for m in mods if isinstance(m, nn.BatchNorm2d) and m.training and _bn_fusable(m)]
+            if bns:
+                with torch.no_grad():
+                    torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+                for m in bns:
+                    t[id(m)] = True
+        if self.own_wgrad and self.linear_1x1:
+            convs = [m for m in mods if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.padding == (0, 0)
+                     and m.bias is None and _wgrad_ok(m)]
+            if convs:
+                sh = self.__dict__["_shadows"]
+                dst = []
+                for m in convs:
+                    w = sh.get(id(m))
+                    if w is None or w.device != m.weight.device:
+                        w = sh[id(m)] = torch.empty((m.out_channels, m.in_channels), dtype=torch.bfloat16, device=m.weight.device)
+                    dst.append(w)
+                    t[id(m)] = w
+                with torch.no_grad():
+                    torch._foreach_copy_(dst, [m.weight.detach().view(m.out_channels, m.in_channels) for m in convs])
 
     def _block(self, x, blk):
         idt = x if blk.downsample is None else self._cbr(x, blk.downsample[0], blk.downsample[1], False)
@@ -176,6 +366,7 @@ class TrainEncoder(nn.Module):
 
     def _seg_front(self, img):
         body = self.src.base
+        self._tick("front", img)
         x = img.to(self.dtype).contiguous(memory_format=_CL)
         x = self._cbr(x, body.conv1, body.bn1, True)
         x = body.maxpool(x)
@@ -184,9 +375,11 @@ class TrainEncoder(nn.Module):
         return x2, x3
 
     def _seg_layer3(self, x3):
+        self._tick("layer3", x3)
         return (self._layer(x3, self.src.base.layer3),)
 
     def _seg_layer4(self, x4):
+        self._tick("layer4", x4)
         return (self._layer(x4, self.src.base.layer4),)
 
     def _head(self, x, head):
@@ -195,6 +388,7 @@ class TrainEncoder(nn.Module):
 
     def _seg_heads(self, x2, x3, x4, x5):
         s = self.src
+        self._tick("heads", x2)
         props = [self._head(x, getattr(s, f"prop{k}")) for k, x in ((2, x2), (3, x3), (4, x4), (5, x5))]
         with (torch.enable_grad() if self.skips_need_grad else torch.no_grad()):
             skips = [self._cbr(x, getattr(s, f"sk{k}"), getattr(s, f"bn{k}"), False)
@@ -202,14 +396,28 @@ class TrainEncoder(nn.Module):
         # the ROI feature kernel (forward and backward) works on fp32 NCHW levels
         return tuple(p.float().contiguous() for p in props) + tuple(skips)
 
-    def _seg_params(self) -> Dict[str, List[nn.Parameter]]:
+    def _seg_modules(self) -> Dict[str, List[nn.Module]]:
         s, body = self.src, self.src.base
-        P = lambda *mods: [p for m in mods for p in m.parameters() if p.requires_grad]
-        heads = P(s.prop2, s.prop3, s.prop4, s.prop5)
-        if self.skips_need_grad:
-            heads += P(s.sk2, s.sk3, s.sk4, s.sk5, s.bn2, s.bn3, s.bn4, s.bn5)
-        return {"front": P(body.conv1, body.bn1, body.layer1, body.layer2), "layer3": P(body.layer3),
-                "layer4": P(body.layer4), "heads": heads}
+        return {"front": [body.conv1, body.bn1, body.layer1, body.layer2], "layer3": [body.layer3], "layer4": [body.layer4],
+                "heads": [s.prop2, s.prop3, s.prop4, s.prop5, s.sk2, s.sk3, s.sk4, s.sk5, s.bn2, s.bn3, s.bn4, s.bn5]}
+
+    def _seg_params(self) -> Dict[str, List[nn.Parameter]]:
+        out = {}
+        for name, mods in self._seg_modules().items():
+            if name == "heads" and not self.skips_need_grad:
+                mods = mods[:4]
+            out[name] = [p for m in mods for p in m.parameters() if p.requires_grad]
+        return out
+
+    def _arena_floats(self, name: str, backward: bool) -> int:
+        """Upper bound of what a segment's graph takes from its arena: [2, C] per BatchNorm (+ 64 floats of rounding per
+        request), the same forward and backward (the weight-gradient kernels overwrite their outputs: nothing to zero)."""
+        n = 0
+        for mod in self._seg_modules()[name]:
+            for m in mod.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    n += 2 * m.num_features + 64
+        return n + 1024
 
     @staticmethod
     def _pack(outs_front, x4, x5, heads):
@@ -226,13 +434,44 @@ class TrainEncoder(nn.Module):
     # ---- entry ---------------------------------------------------------------------------------------------------------
     def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
         assert img.dim() == 4 and img.shape[1] == 3, img.shape           # model_encoder.py:91-92
+        self.__dict__["_ticked"].clear()
         if not (self.graphs and img.is_cuda and self.training and torch.is_grad_enabled()):
             return self._eager(img)
         key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad)
-        plan = self._plans.get(key)
+        plans = self._plans.setdefault(key, [])
+        # a plan's static buffers belong to ONE forward until its backward has run: a second forward of the same shape before
+        # that (the trainer's clip: one encoder call per frame, one backward; trainer.py:95-131) takes / captures another plan
+        plan = next((p for p in plans if not p.busy), None)
         if plan is None:
-            plan = self._plans[key] = _Plan(self, img)
+            plan = _Plan(self, img)
+            plans.append(plan)
         return plan.run(img)
+
+    def _hubs_for(self, device):
+        hubs = self._hubs.get(device.index)
+        if hubs is None:
+            hubs = self._hubs[device.index] = {}
+            for name in self.SEGMENTS:
+                h = hubs[name] = torch.zeros((), device=device, requires_grad=True)
+                h.register_post_accumulate_grad_hook(lambda t, name=name: self._flush(name, t))
+        return hubs
+
+    def _flush(self, name: str, hub: torch.Tensor):
+        """The hub leaf of ``name`` has received its gradient: every plan that took part in this backward pass has replayed the
+        segment's backward graph.  Their parameter gradients are summed (into the first plan's static buffers) and handed
+        over: ``p.grad`` set / accumulated, post-accumulate-grad hooks called -- once per parameter and backward pass, like
+        autograd's own AccumulateGrad."""
+        hub.grad = None
+        plans = self._pending.pop(name, [])
+        if not plans:
+            return
+        params, base = plans[0].params[name], plans[0].pgrads[name]
+        for other in plans[1:]:
+            pairs = [(b, g) for b, g in zip(base, other.pgrads[name]) if b is not None and g is not None]
+            if pairs:
+                torch._foreach_add_([b for b, _ in pairs], [g for _, g in pairs])
+        plans[0].aliased = True
+        _deliver(params, base)
 
 
 class _Plan:
@@ -270,14 +509,17 @@ class _Plan:
         # ---- forward captures, in replay order; a segment's inputs are DETACHED views of its predecessor's outputs that
         # require grad, so that every segment owns a separate autograd graph
         self.fwd, self.bwd, self.ins, self.outs = {}, {}, {}, {}
+        self.arenas = []                                  # statistics scratch of every captured graph (kept alive with it)
 
         def leaf(t):
             return t.detach().requires_grad_(True)
         def capture(name, *inputs):
             g = SafeGraph()
-            with g.capture(pool=pool):
+            arena = _Arena(dev, enc._arena_floats(name, False))
+            with g.capture(pool=pool), _arena_scope(arena):
                 outs = fns[name](*inputs)
             self.fwd[name], self.ins[name], self.outs[name] = g, inputs, outs
+            self.arenas.append(arena)
             return outs
         x2, x3 = capture("front", self.static_img)
         i3 = leaf(x3)
@@ -295,9 +537,11 @@ class _Plan:
             ps = self.params[name]
             wrt = [t for t in inputs if t.requires_grad] + ps
             g = SafeGraph()
-            with g.capture(pool=pool):
+            arena = _Arena(dev, enc._arena_floats(name, True))
+            with g.capture(pool=pool), _arena_scope(arena):
                 grads = torch.autograd.grad(outs, wrt, gouts, allow_unused=True)
             self.bwd[name] = g
+            self.arenas.append(arena)
             n_in = len(wrt) - len(ps)
             self.pgrads[name] = list(grads[n_in:])
             return grads[:n_in]
@@ -308,17 +552,24 @@ class _Plan:
         # backward); likewise x3 (layer3 + heads) and x2 (heads only) for the front segment
         wrt3 = [i3] + self.params["layer3"]
         gb = SafeGraph()
-        with gb.capture(pool=pool):
+        arena = _Arena(dev, enc._arena_floats("layer3", True))
+        self.arenas.append(arena)
+        with gb.capture(pool=pool), _arena_scope(arena):
             grads = torch.autograd.grad([x4], wrt3, [g4 + g4h], allow_unused=True)
         self.bwd["layer3"], self.pgrads["layer3"] = gb, list(grads[1:])
         g3 = grads[0]
         gf = SafeGraph()
-        with gf.capture(pool=pool):
+        arena = _Arena(dev, enc._arena_floats("front", True))
+        self.arenas.append(arena)
+        with gf.capture(pool=pool), _arena_scope(arena):
             grads = torch.autograd.grad([x2, x3], self.params["front"], [g2, g3 + g3h], allow_unused=True)
         self.bwd["front"], self.pgrads["front"] = gf, list(grads)
         self.result = TrainEncoder._pack((x2, x3), x4, x5, heads)
         self.heads = heads
-        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+        self.token = torch.zeros((), device=dev)           # what the segment nodes hand each other (autograd ordering only)
+        self.zero = torch.zeros((), device=dev)            # their gradient: the data moves in the static buffers
+        self.busy = False
+        self.aliased = False                               # some p.grad may still BE one of this plan's static buffers
         # what the rewrite found: {segment: (memset nodes, memcpy nodes) turned into kernel nodes} per direction
         self.rewritten = {"fwd": {k: g.rewritten for k, g in self.fwd.items()}, "bwd": {k: g.rewritten for k, g in self.bwd.items()}}
         for (rm, rv, nb), m in zip(keep, bns):
@@ -326,35 +577,50 @@ class _Plan:
                 m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
 
     def run(self, img):
+        enc = self.enc
+        if self.aliased:
+            # the last backward handed this plan's static gradient buffers out as ``p.grad``.  The pool reuses that memory for
+            # activations of the FORWARD graphs (a replayed step needs the two at different times), so a gradient that is still
+            # in place now -- gradient accumulation: no zero_grad / optimiser step in between -- moves into its own tensor first
+            for name in TrainEncoder.SEGMENTS:
+                for p, g in zip(self.params[name], self.pgrads[name]):
+                    if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                        p.grad = p.grad.clone()
+            self.aliased = False
         self.static_img.copy_(img)
         for name in TrainEncoder.SEGMENTS:
             self.fwd[name].replay()
-        outs = _PlanFn.apply(self, self.anchor)
+        self.busy = True
+        hubs = enc._hubs_for(img.device)
+        token = None
+        for name in TrainEncoder.SEGMENTS[:-1]:
+            token = _SegFn.apply(self, name, token, hubs[name])
+        outs = _SegFn.apply(self, "heads", token, hubs["heads"])
         # (the body's own levels are handed out detached: inside the graphs they are inputs of the heads, not autograd leaves
         # of the caller)
         return {"backbone_feature": tuple(outs[:4]), "refine_input_feat": tuple(outs[4:]),
                 "body_feature": tuple(t.detach() for t in self.result["body_feature"])}
 
-    def backward(self, grads: Sequence[Optional[torch.Tensor]]):
-        k = 0
-        for g, o in zip(self.gout, self.heads):
-            if g is None:
-                continue
-            gi = grads[k] if k < len(grads) else None
-            if gi is None:
-                g.zero_()
-            elif gi.data_ptr() != g.data_ptr():
-                g.copy_(gi)
-            k += 1
-        for name in reversed(TrainEncoder.SEGMENTS):
-            # gradient accumulation (a second backward before zero_grad): a gradient that still IS this graph's static
-            # buffer would be overwritten by the replay -- it moves into its own tensor first (the usual flow, gradients
-            # set to None or re-pointed at bucket views between steps, never takes this path)
-            for p, g in zip(self.params[name], self.pgrads[name]):
-                if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
-                    p.grad = p.grad.clone()
-            self.bwd[name].replay()
-            _deliver(self.params[name], self.pgrads[name])
+    def backward_segment(self, name: str, grads: Sequence[Optional[torch.Tensor]] = ()):
+        if name == "heads":
+            k = 0
+            for g in self.gout:
+                if g is None:
+                    continue
+                gi = grads[k] if k < len(grads) else None
+                if gi is None:
+                    g.zero_()
+                elif gi.data_ptr() != g.data_ptr():
+                    g.copy_(gi)
+                k += 1
+        # gradient accumulation (a second backward before zero_grad): a gradient that still IS this graph's static buffer
+        # would be overwritten by the replay -- it moves into its own tensor first (the usual flow, gradients set to None or
+        # re-pointed at bucket views between steps, never takes this path)
+        for p, g in zip(self.params[name], self.pgrads[name]):
+            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                p.grad = p.grad.clone()
+        self.bwd[name].replay()
+        self.enc.__dict__["_pending"].setdefault(name, []).append(self)
 
 
 def _deliver(params, grads):
@@ -376,22 +642,46 @@ def _deliver(params, grads):
                 h(p)
 
 
-class _PlanFn(torch.autograd.Function):
-    """The graphed encoder as one autograd node (``anchor``: a scalar that requires grad, so that the node exists): outputs =
-    the heads' static outputs; the backward copies the incoming gradients into the static buffers, replays the backward
-    graphs last segment first and hands every segment's parameter gradients over as soon as its replay is issued."""
+class _Lease:
+    """A plan is in flight from its forward until the backward of its first segment has run -- or until the autograd graph
+    that holds this object is freed without a backward."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.busy = False
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
+class _SegFn(torch.autograd.Function):
+    """One segment of a plan as an autograd node.  The nodes of a plan are chained by a token (front -> layer3 -> layer4 ->
+    heads; the heads' node returns the real outputs), so autograd runs their backwards last segment first; the data itself
+    moves between the captured graphs in their static buffers.  Every node also takes the encoder's HUB leaf of its segment:
+    autograd runs a leaf's AccumulateGrad once per backward pass, after the LAST node that uses it -- with several forwards
+    in flight (the trainer calls the encoder once per frame of a clip and backpropagates once, trainer.py:95-131) that is
+    the moment all of them have produced this segment's parameter gradients, and the hub's hook hands their sum over."""
 
     @staticmethod
-    def forward(ctx, plan, anchor):
-        ctx.plan = plan
+    def forward(ctx, plan, name, token, hub):
+        ctx.plan, ctx.name, ctx.has_token = plan, name, token is not None
+        ctx.lease = _Lease(plan) if name == TrainEncoder.SEGMENTS[0] else None
+        ctx.set_materialize_grads(False)
+        if name != "heads":
+            return plan.token.detach()
         outs = tuple(o.detach() for o in plan.heads)
         ctx.mark_non_differentiable(*[o for o, g in zip(outs, plan.gout) if g is None])
-        ctx.set_materialize_grads(False)
         return outs
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        plan = ctx.plan
-        plan.backward([g for g, s in zip(grads, plan.gout) if s is not None])
-        return None, None
+        plan, name = ctx.plan, ctx.name
+        plan.backward_segment(name, [g for g, s in zip(grads, plan.gout) if s is not None] if name == "heads" else ())
+        if ctx.lease is not None:
+            ctx.lease.release()
+        return None, None, (plan.zero if ctx.has_token else None), plan.zero

@@ -652,6 +652,23 @@ DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int
                                const float *weight, const float *sums, int relu, void *dx, void *dres, float *dweight,
                                float *dbias, dmm_stream_t stream);
 
+/* (10b) Weight gradient of the encoder's convolutions (channels-last bf16 activations, fp32 gradient), what autograd
+ * computes for conv1 / conv3 / downsample (1x1) and conv2 / the heads (3x3, padding 1) of dmm/modules/vision.py:6-38 and
+ * base.py:35-54 under the trainer's backward (train.py:296-307):
+ *   dmm_wgrad_bf16:     dw[co, ci]         = sum_r dy[r, co] * x[r, ci]            dy [rows, ldy], x [rows, ldx] (element strides)
+ *   dmm_wgrad3x3_bf16:  dw[co, ci, kh, kw] = sum_(b,ho,wo) dy[(b,ho,wo), co] * x[b, s*ho+kh-1, s*wo+kw-1, ci]   (zero outside)
+ *     dy [B*Ho*Wo, co], x [B, H, W, ci] dense, Ho = (H-1)/s + 1, s in {1, 2}; the patch matrix is never materialised; dw comes
+ *     out in the parameter's own [co, ci, 3, 3] contiguous layout.
+ * dw is fp32 and OVERWRITTEN (no zeroing, no atomics, deterministic: row slabs -> partial tables in the caller's workspace
+ * -> summed in slab order).  workspace: dmm_wgrad_workspace_bytes(rows, co, cv) bytes (cv = ci, or 9 * ci for the 3x3 form;
+ * 0 when the shape is not taken).  co % 64 == 0 and ci % 64 == 0 (every width of the ResNet bodies and 128-wide heads), else
+ * DMM_ERR_UNSUPPORTED (callers fall back to the library product).  MFMA 32x32x16 bf16, fp32 accumulation; memory bound. */
+DMM_API size_t dmm_wgrad_workspace_bytes(int64_t rows, int co, int cv);
+DMM_API int dmm_wgrad_bf16(const void *dy, const void *x, int64_t rows, int co, int ci, int64_t ldy, int64_t ldx, float *dw,
+                           void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+DMM_API int dmm_wgrad3x3_bf16(const void *dy, const void *x, int B, int H, int W, int ci, int co, int stride, float *dw,
+                              void *workspace, size_t workspace_bytes, dmm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (11) HIP-graph hygiene for captured steps that contain other libraries' launches (MIOpen, hipBLASLt, torch): between the
  * end of a stream capture and hipGraphInstantiate, replace every memset node (flags & 1; element size 1 / 2 / 4) and every

@@ -122,8 +122,11 @@ def _config4_inputs(B, F, P, H, W, g):
     return props, [SimpleBoxList(boxes(F), (W, H)) for _ in range(B)]
 
 
-def test_config4_per_gpu_share_trains_through_dmm_model(rccl_world1):
-    """BASELINE configs[3], the share of ONE GPU (scripts/train/train_101.sh:12-17: batch 4 videos, clip 3, 255x448,
+@pytest.mark.parametrize("form", ["fp32", "bf16"])
+def test_config4_per_gpu_share_trains_through_dmm_model(rccl_world1, form):
+    """(``form`` = "bf16": the same step with the encoder as ``train_encoder.TrainEncoder`` -- bf16 channels-last, HIP-graph
+    replays, three forwards in flight per backward, its gradient hand-over feeding the same bucketer.)
+    BASELINE configs[3], the share of ONE GPU (scripts/train/train_101.sh:12-17: batch 4 videos, clip 3, 255x448,
     ResNet-101): per frame encoder -> ROI features -> DMM_Model.forward (ragged batched HIP layer with targets) ->
     soft-IoU + match loss; backward through the HIP layer, the ROI scatter and MIOpen; bucketed RCCL gradient mean
     issued under backward; Adam.  The loss must go down on a fixed batch, and the ragged batched step must equal
@@ -135,6 +138,10 @@ def test_config4_per_gpu_share_trains_through_dmm_model(rccl_world1):
     torch.manual_seed(0)
     g = torch.Generator(device=DEV).manual_seed(4)
     enc = FeatureEncoder("resnet101").to(DEV).train()
+    run_enc = enc
+    if form == "bf16":
+        from dmm_net_amd.train_encoder import TrainEncoder
+        run_enc = TrainEncoder(enc, skips_need_grad=False)
     cfgs = {"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5, "relax_learning_rate": 0.1,
             "score_weight": 0.3}
     model = DMM_Model(cfgs, is_test=0, feature_extractor=FeatureExtractor())
@@ -154,7 +161,7 @@ def test_config4_per_gpu_share_trains_through_dmm_model(rccl_world1):
         mask_last = targets[:, 0]
         for t in range(T):
             props, tboxes = per_frame[t]
-            feats = enc(frames[:, t])
+            feats = run_enc(frames[:, t])
             if t == 0:
                 tplt = model.fill_template_dict(None, tboxes, feats, None, valid)        # trainer.py:308-327
             out, _, match_loss, last = model(None, props, feats["backbone_feature"], mask_last, tplt, valid,

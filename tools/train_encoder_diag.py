@@ -64,7 +64,7 @@ for model, shape in (("resnet50", (6, 3, 128, 224)),):
                               "eager_vs_fp32_body_err": round(rerr, 4), "eager_vs_eager_body_err": round(e2err, 4),
                               "eager_vs_eager": {k: round(rel(ge2, ge, k), 5) for k in ("prop", "base.layer4", "base.layer3", "base.layer2", "base.layer1", "base.conv1")},
                               "graph_vs_fp32": {k: round(rel(gg, g32, k), 5) for k in ("prop", "base.layer4", "base.layer3", "base.layer2", "base.layer1", "base.conv1")},
-                              "rewritten": next(iter(gr._plans.values())).rewritten if step == 0 else None,
+                              "rewritten": next(iter(gr._plans.values()))[0].rewritten if step == 0 else None,
                               "nonfinite_graph": nonfinite(gg)[:6], "nonfinite_eager": nonfinite(ge)[:6],
                               "graph_vs_eager": {k: round(rel(gg, ge, k), 5) for k in ks},
                               "eager_vs_fp32": {k: round(rel(ge, g32, k), 5) for k in ks}}), flush=True)
