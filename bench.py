@@ -67,8 +67,10 @@ def parse():
     ap.add_argument("--contiguous-planes", action="store_true", help="config 5: packed [B,K,H,W] planes (round 3's layout) "
                                                                      "instead of the 128-byte-aligned plane stride")
     ap.add_argument("--f32-out", action="store_true", help="config 5: write full_outmask in fp32 instead of fp16")
-    ap.add_argument("--f32-solver", action="store_true", help="config 5: the bit-exact fp32-state solver instead of the "
-                                                              "fp16-state one BASELINE configs[4] names")
+    ap.add_argument("--f16-solver", action="store_true", help="config 5: the fp16-state solver (tolerance mode: R within 1e-2, "
+                    "argmax identical where the fp32 top-2 gap exceeds 0.02) instead of the default bit-exact fp32-state one on the "
+                    "same fp16 planes; it buys ~1 % (round 5), so the bit-exact form is the default")
+    ap.add_argument("--f32-solver", action="store_true", help="(the default since round 6; accepted for old command lines)")
     ap.add_argument("--bf16", action="store_true", help="config 4: the encoder as train_encoder.TrainEncoder -- bf16 channels-last, "
                     "fp32 master weights, HIP-graph replays, own BatchNorm / weight-gradient kernels (the shipped bf16 training form)")
     ap.add_argument("--autocast", action="store_true", help="config 4: run the encoder under bf16 autocast (the reference "
@@ -394,8 +396,10 @@ def bench_layer(R, ci):
     inputs = make_inputs(B)
     # pre-allocated plan: nothing is allocated in the timed region.  pipeline = streaming lane (cost, mix) on the
     # current stream + latency lane (normalise, cosine, solver) on a side stream (ops.ForwardPlan)
-    # config 5 = "fp16 Sinkhorn with fp32 accumulate": the opt-in fp16-state solver (tolerance mode, include/dmm_match.h (3c))
-    sstate = "f16" if (ci == 5 and not getattr(args, "f32_solver", False)) else "f32"
+    # config 5 = "fp16 Sinkhorn with fp32 accumulate": fp16 planes, fp32 accumulation.  The solver keeps its state in fp32 -- bit
+    # exact against the reference like every other configuration -- unless --f16-solver asks for the fp16-state form (tolerance
+    # mode, include/dmm_match.h (3c)), which is ~1 % faster: VERDICT r5 item 7
+    sstate = "f16" if (ci == 5 and getattr(args, "f16_solver", False)) else "f32"
     plan = ops.ForwardPlan(B, N, M, H, W, D, dev, mask_dtype=mdt, pipeline=False if args.no_pipeline else (True if args.pipeline else None),
                            time_kernels=True, out_dtype=odt, parts=args.parts or 2, solver_state=sstate,
                            out_plane_align=128 if aligned else 0)
@@ -1167,7 +1171,7 @@ def compact(out):
     if "roofline_layer" in out:
         c["roofline_layer_b_cost_frac"] = out["roofline_layer"]["b_cost_basis"]["frac"]
     for k in ("stage_ms", "single_clip_ms_per_step", "boxlist_path_ms_per_step", "clip_of_36_frames_ms_per_step",
-              "mean_outer_iterations", "repeats", "solver_state", "f32_solver", "contiguous_planes"):
+              "mean_outer_iterations", "repeats", "solver_state", "f16_solver", "contiguous_planes"):
         if k in out["config"]:
             c[k] = out["config"][k]
     if "cases" in out["config"]:                                 # the drop-in: per-call wall / device / launches
@@ -1229,10 +1233,10 @@ def main():
         import copy
         others = {}
         def config5_both(r):
-            """BASELINE configs[4] names the fp16-state solver (tolerance mode); the bit-exact fp32-state figure beside it"""
+            """BASELINE configs[4] on fp16 planes: the bit-exact fp32-state solver (default), the fp16-state figure beside it"""
             o = bench_layer(r, 5)
             a3 = copy.copy(r.args)
-            a3.f32_solver = True
+            a3.f16_solver = True
             keep, r.args = r.args, a3
             try:
                 o32 = bench_layer(r, 5)
@@ -1249,15 +1253,18 @@ def main():
                                                 "roofline_frac": oc["roofline"]["frac"],
                                                 "note": "packed [B,K,255,255] fp16 planes (every other plane starts 2 bytes "
                                                         "off a dword) instead of the 128-byte-aligned plane stride"}
-            o["config"]["f32_solver"] = {"value": o32["value"], "unit": "frames/s", "ms_per_step": o32["ms_per_step"],
+            o["config"]["f16_solver"] = {"value": o32["value"], "unit": "frames/s", "ms_per_step": o32["ms_per_step"],
                                          "roofline_frac": o32["roofline"]["frac"],
                                          "roofline_layer_b_cost_frac": o32["roofline_layer"]["b_cost_basis"]["frac"],
-                                         "note": "the bit-exact fp32-state solver (--f32-solver) on the same planes"}
+                                         "note": "the fp16-state solver (--f16-solver; tolerance mode) on the same planes"}
             return o
         for name, fn, kw in (("config5", config5_both, dict(steps=30, warmup=5, frames=0)),
                              ("config4", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3, bf16=False)),
                              ("config4_bf16", bench_config4, dict(steps=4, warmup=1, frames=0, settle=5, repeats=3, bf16=True)),
                              ("config3", bench_config3, dict(steps=100, warmup=10, frames=0)),
+                             # the same encoder at a batch that fills the 256 CUs (is the 5 % of the MFMA peak
+                             # at 8 frames the batch or the path?)
+                             ("config3_64_frames", bench_config3, dict(steps=30, warmup=5, frames=64)),
                              ("frame_loop", bench_frame_loop, dict(frames=0)),
                              ("train", bench_train, dict(steps=40, warmup=6, frames=0)),
                              ("dropin", bench_dropin, dict(steps=100, warmup=0, frames=0))):

@@ -105,7 +105,11 @@ def cost_kernel(request):
 
 @pytest.mark.parametrize("N,M,H,W", [(8, 3, 64, 64), (50, 10, 255, 255), (1, 1, 1, 7), (5, 2, 1, 7), (3, 5, 17, 31),
                                      (64, 8, 33, 40), (65, 9, 40, 33), (130, 17, 50, 41), (200, 20, 255, 255),
-                                     (257, 33, 20, 23), (50, 10, 16, 16), (7, 4, 2, 2)])
+                                     (257, 33, 20, 23), (50, 10, 16, 16), (7, 4, 2, 2),
+                                     # the product's plane sizes: 256 x 448 = the evaluator's default height
+                                     # (args.py:12-14; HW a multiple of every chunk size: no tail instantiation fires),
+                                     # 480 x 854 = DAVIS (dmm/misc/config.py:41-42), and a 1080p frame
+                                     (50, 5, 256, 448), (50, 10, 480, 854), (20, 4, 1080, 1920)])
 def test_iou_counts_bit_exact(N, M, H, W, cost_kernel):
     fr = synth.make_frame(N, M, H, W, 8, seed=900 + N + M + H, kind="uniform")
     inter, ap, at = ops.iou_counts(dev(fr.proposed_mask)[None], dev(fr.mask_last_occurence)[None])
@@ -289,6 +293,21 @@ def test_g4_big(ci, kind, solver_kernel):
     if ci == 2:
         check_against_golden(run_frame(fr, 20, 5, 0), g.group(f"c{ci}/{kind}/t0"), 0, big=True)
         check_against_golden(run_frame(fr, 40, 5, 1), g.group(f"c{ci}/{kind}/eval40"), 1, big=True)
+
+
+@pytest.mark.parametrize("name,kind", [("eval_256x448", "structured"), ("eval_256x448", "uniform"),
+                                       ("davis_480x854", "structured"), ("davis_480x854", "uniform")])
+def test_g22_product_plane_sizes(name, kind):
+    """G22, first hand: the imported reference's MatchModel at the product's plane sizes -- 256 x 448 (the evaluator's
+    default: 50 x 5, 40 x 5 iterations in test mode and the trainer's 10 x 5 in train mode) and 480 x 854 (DAVIS, 50 x 10):
+    integer tables, cos / sim / R / Rb / scores / iteration counts bit exact, test-mode mask samples bit exact."""
+    g = golden("g22_product_sizes")
+    P, O, H, W, runs = {"eval_256x448": (50, 5, 256, 448, ((40, 5, 1), (10, 5, 0))),
+                        "davis_480x854": (50, 10, 480, 854, ((20, 5, 1),))}[name]
+    fr = synth.make_frame(P, O, H, W, 512, seed=synth.BASE_SEED + 2200 + H, kind=kind)
+    assert fr.checksum() == str(g[f"{name}/{kind}/checksum"])
+    for (mi, pj, is_test) in runs:
+        check_against_golden(run_frame(fr, mi, pj, is_test), g.group(f"{name}/{kind}/i{mi}_{pj}_t{is_test}"), is_test, big=True)
 
 
 def test_g5_edge_cases(solver_kernel):
@@ -1378,13 +1397,13 @@ def test_line_aligned_plane_stride_changes_no_result(dt):
 
 
 @pytest.mark.parametrize("N,M,H,W", [(50, 10, 255, 255), (7, 1, 9, 11), (64, 16, 33, 40), (200, 20, 31, 33), (256, 32, 20, 23),
-                                     (3, 5, 17, 31)])
+                                     (3, 5, 17, 31), (50, 5, 256, 448), (50, 10, 480, 854), (20, 4, 1080, 1920)])
 def test_shared_plane_mix_equals_the_row_kernel_bit_for_bit(N, M, H, W):
     """Train mode keeps every R > 0.01 (match_model.py:126-129): the rows share planes.  dmm_mask_mix_shared_to streams each
     plane of the union of the supports once; per row the accumulation is the row kernel's, so forward results are bit
     identical (option MIX_SHARED pins either kernel behind both entry points); the backward agrees with the row kernel
     and with torch within the fp32 accumulation-order bound.  Ragged batches, dead frames, 16-bit planes, empty rows."""
-    B = 5
+    B = 5 if H * W <= 70000 else 2                                       # (the product's plane sizes: two frames)
     g = torch.Generator(device=DEV).manual_seed(600 + N + M)
     Pp = max(N, M + 1)
     for dt in (torch.float32, torch.float16, torch.bfloat16):
@@ -1398,8 +1417,8 @@ def test_shared_plane_mix_equals_the_row_kernel_bit_for_bit(N, M, H, W):
         for ragged in (False, True):
             nv = mv = None
             if ragged:
-                nv = torch.tensor([N, max(1, N // 2), 0, N, 1], dtype=torch.int32, device=DEV)
-                mv = torch.tensor([M, M, M, max(1, M // 2), 0], dtype=torch.int32, device=DEV)
+                nv = torch.tensor([N, max(1, N // 2), 0, N, 1][:B], dtype=torch.int32, device=DEV)
+                mv = torch.tensor([M, M, M, max(1, M // 2), 0][:B], dtype=torch.int32, device=DEV)
             with _lib.options(MIX_SHARED=0):
                 rows = ops.mask_mix(Rb, pm, nv, mv, shared=True)
                 drows = ops.mask_mix_bwd(Rb, pm, dout, nv, mv)
@@ -1489,7 +1508,9 @@ def _forward_raw(L, bufs, B, N, M, H, W, D, ws, state=None, is_test=1, max_iter=
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,N,M,H,W,dt", [(1, 50, 10, 255, 255, torch.float32), (3, 50, 10, 64, 64, torch.float32),
                                           (4, 64, 16, 33, 41, torch.float16), (8, 25, 3, 17, 31, torch.bfloat16),
-                                          (2, 8, 3, 64, 64, torch.float32), (1, 2, 1, 9, 7, torch.float32)])
+                                          (2, 8, 3, 64, 64, torch.float32), (1, 2, 1, 9, 7, torch.float32),
+                                          (1, 50, 5, 256, 448, torch.float32), (2, 50, 10, 480, 854, torch.float32),
+                                          (1, 20, 4, 1080, 1920, torch.float32)])
 @pytest.mark.parametrize("is_test", [0, 1])
 def test_small_batch_front_kernel_changes_no_result(B, N, M, H, W, dt, is_test):
     """DMM_OPT_SMALL_FUSED: a handful of dense frames run the feature similarity INSIDE the count launch (similarity

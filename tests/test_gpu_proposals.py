@@ -25,6 +25,34 @@ def test_g9_paste_masks_matches_reference_steps():
         assert np.array_equal(got, om) and np.array_equal(nb.cpu().numpy(), ob)   # bit exact vs the oracle
 
 
+@pytest.mark.parametrize("H,W", [(256, 448), (480, 854), (1080, 1920)])
+def test_paste_boxes_and_label_merge_at_the_products_plane_sizes(H, W):
+    """Paste (28 x 28 -> frame), tight boxes, the 1-bit planes, the template boxes of ``ohw_mask2boxlist`` and the label merge
+    at the evaluator's default size, DAVIS 480p and a 1080p frame, bit exact against the oracle (every fixture and list
+    topped out at 255 x 448 before)."""
+    from dmm_net_amd import ops, video
+    rng = np.random.default_rng(H)
+    P, O = 30, 5
+    prob = rng.random((P, 28, 28), dtype=np.float32)
+    x1, y1 = rng.uniform(-4, W - 30, P), rng.uniform(-4, H - 30, P)
+    boxes = np.stack([x1, y1, np.minimum(x1 + rng.uniform(6, W * 0.6, P), W + 3), np.minimum(y1 + rng.uniform(6, H * 0.6, P), H + 3)],
+                     1).astype(np.float32)
+    planes, nb, packed = proposals.paste_masks(torch.from_numpy(prob).to(DEV), torch.from_numpy(boxes).to(DEV), H, W, 0.4, 1,
+                                               want_packed=True)
+    om, ob = oracle.paste_masks(prob, boxes, H, W, 0.4, 1)
+    assert np.array_equal(planes[:, 0].cpu().numpy(), om) and np.array_equal(nb.cpu().numpy(), ob)
+    assert torch.equal(packed, ops.pack_masks(planes.transpose(0, 1))[0])
+    keep = oracle.nms(ob, rng.random(P).astype(np.float32), 0.4, 50)
+    assert len(keep) >= 1
+    outs = planes[:O, 0] * torch.from_numpy(rng.random((O, 1, 1), dtype=np.float32)).to(DEV)
+    outs[1] = 0                                                        # an empty template plane: whole frame, invalid
+    gb, gv = video.mask_boxes(outs)
+    eb, ev = oracle.mask_boxes(outs.cpu().numpy())
+    assert np.array_equal(gb.cpu().numpy(), eb) and np.array_equal(gv.cpu().numpy(), ev)
+    lab = video.merge_labels(outs[None], torch.tensor([O], device=DEV))
+    assert np.array_equal(lab.cpu().numpy().reshape(1, -1), oracle.merge_labels(outs.cpu().numpy().reshape(1, O, -1), [O]))
+
+
 def test_nms_and_filter_results_match_oracle():
     rng = np.random.default_rng(4)
     lists, exp = [], []

@@ -281,6 +281,8 @@ def _mix_bwd_case(B, N, M, H, W, seed, dtype=torch.float32, density=0.3, ragged=
     (2, 112, 32, 24, 24, torch.float32, False), (1, 224, 16, 16, 16, torch.float32, False),    # ON the gate's edge --
     #   56 KB of dense per-wave tables in the union kernel's dynamic block (pairs > 256 at this density) + 3.1 KB static
     (2, 112, 32, 24, 24, torch.float16, True),
+    (1, 50, 5, 256, 448, torch.float32, False), (1, 50, 10, 480, 854, torch.float32, False),    # the product's plane sizes
+    (1, 20, 4, 1080, 1920, torch.float32, False),
     (19, 50, 10, 40, 52, torch.float32, True)])        # two complete groups of 8 frames (XCD mapping) + 3, ragged
 def test_mix_backward_against_the_float64_product(B, N, M, H, W, dtype, ragged):
     """dmm_mask_mix_bwd (union kernel with the scalar-branch slot parking of round 5, and the row kernel it falls back to:

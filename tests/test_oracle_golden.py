@@ -125,6 +125,21 @@ def test_g4_big(ci, kind):
         check_layer(fr, g.group(f"c{ci}/{kind}/eval40"), 40, 5, 1, big=True)
 
 
+# ------------------------------------------------------------------------------------------ G22
+@pytest.mark.parametrize("name,kind", [("eval_256x448", "structured"), ("eval_256x448", "uniform"),
+                                       ("davis_480x854", "structured"), ("davis_480x854", "uniform")])
+def test_g22_product_plane_sizes(name, kind):
+    """The oracle against the imported reference at the product's plane sizes (256 x 448: args.py:12-14 default evaluation
+    height, eval_r50.sh's 40 x 5 and the trainer's 10 x 5; 480 x 854: DAVIS)."""
+    g = golden("g22_product_sizes")
+    P, O, H, W, runs = {"eval_256x448": (50, 5, 256, 448, ((40, 5, 1), (10, 5, 0))),
+                        "davis_480x854": (50, 10, 480, 854, ((20, 5, 1),))}[name]
+    fr = synth.make_frame(P, O, H, W, 512, seed=synth.BASE_SEED + 2200 + H, kind=kind)
+    assert fr.checksum() == str(g[f"{name}/{kind}/checksum"])
+    for (mi, pj, is_test) in runs:
+        check_layer(fr, g.group(f"{name}/{kind}/i{mi}_{pj}_t{is_test}"), mi, pj, is_test, big=True)
+
+
 # ------------------------------------------------------------------------------------------ G5
 def test_g5_edge_cases():
     g = golden("g5_edge")
