@@ -57,6 +57,15 @@ _FUSED_TRAIN = True
 _EMPTY = torch.zeros(())
 
 
+def _no_grad_view(*tensors):
+    """Under ``torch.no_grad()`` a Function's ``ctx.needs_input_grad`` still says what the inputs' ``requires_grad`` says (it
+    ignores the grad mode): the layer would keep the solver's tape for a backward that cannot come.  Detached
+    views make the two agree."""
+    if torch.is_grad_enabled():
+        return tensors
+    return tuple(t.detach() if isinstance(t, torch.Tensor) else t for t in tensors)
+
+
 class _MatchLayerFn(torch.autograd.Function):
     """pf [B,P,D], tf [T,B,O,D] (T template-feature entries, DMM-Net uses T = 1), pm [B,P,H,W], tm [B,O,H,W],
     sc [B,P], targets [B,O,H,W] | None."""
@@ -227,6 +236,7 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
         tm = tm if tm.dtype == pm.dtype else tm.to(pm.dtype)
         if targets is not None and targets.dtype != pm.dtype:
             targets = targets.to(pm.dtype)
+        pf, tf = _no_grad_view(pf, tf)
         return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
                                    float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
     if isinstance(pm, (list, tuple)):
@@ -242,12 +252,14 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
                 tm = tm.to(pm.dtype)
             if targets is not None:
                 targets = targets.to(pm.dtype)
+            pf, tf = _no_grad_view(pf, tf)
             return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
                                        float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
     # 16-bit mask planes go to the kernels as they are (half the bytes of the cost pass; values are only thresholded and
     # scaled); anything else is matched in fp32 like the reference
     if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
         pm, tm = pm.float(), tm.float()
+    pf, tf = _no_grad_view(pf, tf)
     return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(),
                                None if targets is None else targets.float(), n_valid, m_valid, float(score_weight),
                                int(max_iter), int(proj_iter), float(lr), int(is_test), counts)
@@ -279,6 +291,7 @@ def match_layer_function(proposed_feature, proposed_mask, template_feature: List
         if not (pm.dtype == tm.dtype and pm.dtype in (torch.float16, torch.bfloat16)):
             pm, tm = pm.float(), tm.float()
         if frame_fused_ok(pm, tm):
+            proposed_feature, tf = _no_grad_view(proposed_feature, tf)
             out = _MatchFrameFn.apply(proposed_feature.float(), tf.float(), pm, tm, proposal_score.float(),
                                       None if tg is None else tg.to(pm.dtype), float(score_weight), int(max_iter),
                                       int(proj_iter), float(lr), int(is_test))

@@ -157,6 +157,8 @@ class DMM_Model(nn.Module):
         for b, f in enumerate(blocks):
             if f._base is not base or tuple(f.shape) != (P, D) or not f.is_contiguous() or f.data_ptr() != p0 + b * step:
                 return None
+            if f.requires_grad != base.requires_grad:              # views made under no_grad of a base that requires grad: the
+                return None                                        # gradient must not reach the base through this shortcut
         return base.view(B, P, D)
 
     def _match_single(self, prop_feat, prop_m, prop_score, tplt_feat, mask_last_occurence, O, targets):
@@ -178,16 +180,17 @@ class DMM_Model(nn.Module):
         """``_valid_layout`` once per CLIP: the reference builds ``tplt_valid_batch`` when a clip starts and hands the same
         tensor to every frame step (trainer.py:113-121, evaluator.py:114-126), so the answer for this very tensor object at
         this very version (no in-place write since) is kept -- a frame step after the first costs no host sync.  The tensor
-        is held weakly; a new tensor, or the same one after any in-place edit, is read again."""
+        is held weakly; a new tensor, or the same one after any in-place edit, is read again.  Contract: writes that do not
+        move ``_version`` (through ``.data``, ``set_``, a raw device copy) are not seen -- hand such a clip a new tensor."""
         c = _VALID_CACHE.get(self)                                 # (outside the module's __dict__: deepcopy / pickle safe)
         if c is not None and c[0]() is tplt_valid_batch and c[1] == tplt_valid_batch._version:
-            return c[2]
+            return list(c[2][0]), c[2][1]                          # (a copy of the list: a caller editing it must not edit the cache)
         got = self._valid_layout(tplt_valid_batch)
         try:
             _VALID_CACHE[self] = (weakref.ref(tplt_valid_batch), tplt_valid_batch._version, got)
         except TypeError:                                          # (an object that cannot be weakly referenced)
             _VALID_CACHE.pop(self, None)
-        return got
+        return list(got[0]), got[1]
 
     @staticmethod
     def _valid_layout(tplt_valid_batch, n_tplt_hint=None):

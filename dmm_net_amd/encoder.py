@@ -163,6 +163,14 @@ class VGG16(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
                 nn.init.constant_(m.bias, 0)
+        # the reference's VGG16 (vision.py:57-76) and torchvision state dicts carry classifier.{0,3,6}.* entries; DMM-Net never
+        # runs the classifier and it is not built here: the keys are dropped on load, so a strict load of such a dict works
+        self._register_load_state_dict_pre_hook(self._drop_classifier_keys)
+
+    @staticmethod
+    def _drop_classifier_keys(state_dict, prefix, *args):
+        for k in [k for k in state_dict if k.startswith(prefix + "classifier.")]:
+            del state_dict[k]
 
     def forward(self, x):
         outs = []

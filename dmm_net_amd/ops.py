@@ -731,7 +731,7 @@ def _train_tape_layout(L, B, N, M, max_iter, proj_iter):
     return got
 
 
-_TAPE_MAX_BYTES = 256 << 20
+_TAPE_MAX_BYTES = 32 << 20          # (held until the backward, per frame step alive in the autograd graph)
 
 
 def match_train_backward(masks_p, feat_p, feat_t, score_p, saved, has_loss, d_full, d_ms, d_ds, d_loss, n_valid, m_valid,

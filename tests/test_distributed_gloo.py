@@ -349,6 +349,45 @@ def test_gloo_world2_steady_mode_takes_the_host_read_off_the_step_and_heals():
     assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
 
 
+def _layout_worker(rank, world, port, q):
+    """A rank that builds its bucketer from a different parameter list (here: another bucket size on rank 1, then another
+    parameter order) must be caught at construction, on EVERY rank, by one all_gather -- not by a hang in the first
+    per-bucket collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    init_from_env("gloo")
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (1000,), (64, 64))]
+    ok = True
+    same = GradBucketer(params, bucket_mb=0.01)
+    ok &= same.layout_verified
+    for kw, plist in ((dict(bucket_mb=0.01 if rank == 0 else 0.02), params),
+                      (dict(bucket_mb=0.01), params if rank == 0 else params[::-1]),
+                      (dict(bucket_mb=0.01, overlap=(rank == 1)), params)):
+        try:
+            GradBucketer(plist, **kw)
+            ok = False
+        except RuntimeError as e:
+            ok &= "differs between ranks" in str(e) and "[1]" in str(e)
+    quiet = GradBucketer(params if rank == 0 else params[::-1], bucket_mb=0.01, verify_layout=False)   # opt-out: no collective
+    ok &= not quiet.layout_verified
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_gloo_world2_a_bucket_layout_mismatch_fails_loudly_on_every_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_host_thread_pinning_is_silent_without_a_gpu_topology():
     """``bind_host_threads_to_gpu``: no visible GPU / sysfs topology -> (None, no-op restore), masks untouched."""
     import os

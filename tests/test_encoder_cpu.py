@@ -128,3 +128,23 @@ def test_vgg16_backbone_option_cpu():
         FastEncoder(folded)
     with pytest.raises(Exception, match="not supported"):
         FeatureEncoder("alexnet")
+
+
+def test_vgg16_loads_a_state_dict_that_carries_classifier_keys():
+    """The reference's VGG16 / torchvision state dicts hold classifier.{0,3,6}.* (vision.py:57-76); the body here builds no
+    classifier and drops those keys on load: a STRICT load works, directly and as the encoder's ``base``."""
+    import torch
+    from dmm_net_amd.encoder import VGG16, FeatureEncoder
+    body = VGG16()
+    sd = {k: v.clone() for k, v in body.state_dict().items()}
+    sd["features.0.weight"] += 1.0
+    for i, shape in ((0, (8, 4)), (3, (8, 8)), (6, (10, 8))):
+        sd[f"classifier.{i}.weight"] = torch.zeros(shape)
+        sd[f"classifier.{i}.bias"] = torch.zeros(shape[0])
+    VGG16().load_state_dict(sd, strict=True)
+    enc = FeatureEncoder("vgg16", hidden_size=16)
+    full = {k: v.clone() for k, v in enc.state_dict().items()}
+    full.update({"base." + k: v for k, v in sd.items()})
+    enc.load_state_dict(full, strict=True)
+    assert torch.equal(enc.base.features[0].weight, sd["features.0.weight"])
+

@@ -62,14 +62,20 @@ def test_valid_layout_is_read_once_per_clip_tensor():
            "score_weight": 0.3}
     m = dmm_model.DMM_Model(cfg, 0)
     v = torch.tensor([[1., 1., 0.], [1., 0., 0.]])
+    reads = []
+    real = dmm_model.DMM_Model._valid_layout
+    m._valid_layout = lambda t, *a: (reads.append(1), real(t, *a))[1]
     a = m._valid_layout_of_clip(v)
-    assert a[0] == [2, 1] and a[1] is None and m._valid_layout_of_clip(v) is a
+    assert a[0] == [2, 1] and a[1] is None
+    a[0].append(99)                                # a caller editing its answer does not edit the cache
+    assert m._valid_layout_of_clip(v)[0] == [2, 1] and len(reads) == 1
     v[1, 1] = 1                                   # in-place edit: version moves, the flags are read again
     assert m._valid_layout_of_clip(v)[0] == [2, 2]
     w = torch.tensor([[1., 0., 1.], [0., 0., 0.]])  # another clip, templates not a prefix
     n_tplt, scale = m._valid_layout_of_clip(w)
     assert n_tplt == [2, 0] and scale.tolist() == [[1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
     assert m._valid_layout_of_clip(v)[0] == [2, 2]  # (one entry per model: v is read again, correctly)
+    del m._valid_layout                           # (the counting stand-in of this test is not part of the model)
     copy.deepcopy(m)
     pickle.dumps(m)
     assert not any(k.startswith("_valid") for k in m.__dict__)
