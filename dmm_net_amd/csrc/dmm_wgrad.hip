@@ -9,7 +9,7 @@
 //
 // Why not the libraries.  The product has a tiny output (<= 2048 x 1024) and a huge reduction (R = 1 344 .. 344 064): a
 // data-parallel GEMM gets a handful of tiles (hipBLASLt's pick for these shapes, MT64x64x256 without split-K: 66 us average,
-// 54 launches and 3.6 ms of a 24 ms ResNet-101 step; profiles/r06_cfg4_kernel_stats_train_first.csv), MIOpen's bf16
+// 54 launches and 3.6 ms of a 24 ms ResNet-101 step; profiles/r06_cfg4_train_encoder_steps.md), MIOpen's bf16
 // split-K solvers (18-60 us) come with a zeroing and a cast launch each and clear their workspace with a memset node
 // (dmm_graph.hip).  Memory bound by design: every dY / X element is read once per 64-wide tile of the other operand
 // (served by L2 for the neighbouring tiles), the matrix cores idle most of the time.
@@ -21,7 +21,7 @@
 // (channel 2i and channel 2i+1, each with the 8 rows as its k).  A and B use the same row-to-k assignment, so the sum over k
 // is the sum over the slab's rows whatever the hardware's k order is.  4 MFMAs per 16 rows and wave, accumulators
 // 4 x 16 fp32.  Epilogue WITHOUT atomics (device-scope fp32 atomics run at ~50 G/s on this part: the first form of this
-// kernel, slabs x Co x Ci atomic adds, took 70-97 us per launch -- profiles/r06_cfg4_kernel_stats_train_atomics.csv): the four
+// kernel, slabs x Co x Ci atomic adds, took 70-97 us per launch -- profiles/r06_cfg4_train_encoder_steps.md): the four
 // waves of a workgroup are folded through LDS in a fixed order, the workgroup stores its [64, 64] tile into the partial table
 // of its slab group, and a second launch sums the groups in order (and, for 3x3, writes the master's [co, ci, kh, kw]
 // layout).  Deterministic; dW is overwritten, never pre-zeroed.  Slabs: ~2048 waves per launch, partial tables <= 16 MB.

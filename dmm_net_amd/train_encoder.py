@@ -7,7 +7,7 @@ Counterpart of ``dmm/modules/model_encoder.py:86-162`` + ``base.py:18-69`` + ``v
 
 * **whole forward / backward as HIP-graph replays.**  At the trainer's batch (12 frames of 255 x 448) a ResNet-101 step is
   ~2 100 launches of 5-50 us kernels: the stock step is HOST bound (device kernel time 17.6 ms inside a 24.4 ms step under
-  bf16 autocast, ``profiles/r06_cfg4_*``).  The encoder is cut into a few SEGMENTS (stem + layer1 + layer2 | layer3 | layer4 |
+  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem + layer1 + layer2 | layer3 | layer4 |
   heads); each segment's forward and its backward (``torch.autograd.grad`` over the segment) are captured once per input
   shape and replayed.  Segment k+1 reads segment k's static output in place; backward replays run last segment first and
   after each one that segment's parameter gradients are handed over -- so a gradient all-reduce (``GradBucketer`` hooks)
@@ -51,7 +51,7 @@ _CL = torch.channels_last
 class _Arena:
     """fp32 scratch the statistics kernels accumulate into (they need zeroed [2, C] blocks): inside a captured segment ONE
     zeroing launch at the head of the graph clears the blocks of all its layers -- a ``torch.zeros`` per layer and direction
-    was 238 launches of ~4 us per ResNet-101 step (profiles/r06_cfg4_kernel_stats_train_first.csv).  A capture is traced
+    was 238 launches of ~4 us per ResNet-101 step (profiles/r06_cfg4_train_encoder_steps.md).  A capture is traced
     once, so handing out consecutive slices while it runs fixes every layer's block for all replays."""
 
     def __init__(self, device, floats: int = 1 << 20):

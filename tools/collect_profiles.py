@@ -6,7 +6,8 @@
   <tag>_bench.json                  python bench.py                      (all extras: cpu baseline, sweep, in-run traffic)
   <tag>_bench_single_stream.json    python bench.py --no-pipeline --no-extras
   <tag>_bench_config5.json / _config3.json     python bench.py --config 5 / 3
-  <tag>_bench_frame_loop.json / _bench_config4_1gpu(_autocast).json   python bench.py --config loop / --config 4 [--autocast]
+  <tag>_bench_frame_loop.json / _bench_config4_1gpu(_autocast|_bf16).json   python bench.py --config loop / --config 4 [--autocast|--bf16]
+  <tag>_kernel_stats_config4(_autocast|_bf16).csv   rocprofv3 --kernel-trace --stats of the same three settings of config 4
   <tag>_bench_dropin.json           python bench.py --config dropin --steps 200   (wall vs device per call of the drop-in)
   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats  -- python bench.py --no-extras
   <tag>_kernel_stats_single_stream.csv / _config5.csv / _config3.csv   same with --no-pipeline / --config 5 / --config 3
@@ -54,6 +55,8 @@ if not only_pmc and os.environ.get("ONLY_STATS") is None:
         last_json(run(bench + ["--config", "4", "--steps", "8", "--warmup", "2"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_config4_1gpu_autocast.json"), "w").write(
         last_json(run(bench + ["--config", "4", "--steps", "8", "--warmup", "2", "--autocast"]).stdout) + "\n")
+    open(os.path.join(out, f"{tag}_bench_config4_1gpu_bf16.json"), "w").write(
+        last_json(run(bench + ["--config", "4", "--steps", "8", "--warmup", "2", "--bf16"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_dropin.json"), "w").write(
         last_json(run(bench + ["--config", "dropin", "--steps", "200"]).stdout) + "\n")
     open(os.path.join(out, f"{tag}_bench_train.json"), "w").write(
@@ -63,7 +66,14 @@ only = os.environ.get("ONLY_STATS")                       # e.g. ONLY_STATS=_con
 for suffix, extra in (() if only_pmc else (("", []), ("_single_stream", ["--no-pipeline"]), ("_config5", ["--config", "5"]),
                                            ("_config3", ["--config", "3", "--steps", "50"]),
                                            ("_frame_loop", ["--config", "loop"]),
-                                           ("_train", ["--config", "train", "--frames", "512", "--steps", "16", "--warmup", "4"]))):
+                                           ("_train", ["--config", "train", "--frames", "512", "--steps", "16", "--warmup", "4"]),
+                                           # config 4's step, kernel by kernel: the reference's fp32 setting, stock bf16
+                                           # autocast, and the shipped bf16 training form
+                                           ("_config4", ["--config", "4", "--steps", "4", "--warmup", "1", "--repeats", "1", "--settle", "3"]),
+                                           ("_config4_autocast", ["--config", "4", "--steps", "4", "--warmup", "1", "--repeats", "1",
+                                                                  "--settle", "3", "--autocast"]),
+                                           ("_config4_bf16", ["--config", "4", "--steps", "4", "--warmup", "1", "--repeats", "1",
+                                                              "--settle", "3", "--bf16"]))):
     if only is not None and suffix != only:
         continue
     d = f"/tmp/prof_stats{suffix}"
