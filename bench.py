@@ -728,7 +728,10 @@ def bench_config4(R):
         run_enc = enc
     model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
                        "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
-    params = list(enc.get_skip_params()) + list(enc.get_backbone_para())
+    # forward order (body, then heads): the bucketer lays its buckets out in REVERSE parameter order = the order the backward
+    # produces gradients in (heads, layer4, layer3, ..., stem), so the last bucket to complete -- the only one whose all-reduce
+    # nothing hides -- is the small tail (layer1 / stem), not the heads that were ready first
+    params = list(enc.get_backbone_para()) + list(enc.get_skip_params())
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)          # one multi-tensor kernel (foreach form: 2.3 ms per step)
     # (steady mode is opt-in: every synthetic step uses the same parameters -- a fixed graph -- so the used-mask exchange
     # may run one step late; a trainer whose videos can be skipped keeps the default per-step exchange)

@@ -38,6 +38,7 @@ def CHECK4D(t):
     return t.shape
 
 
+_TABLE_MEMO = weakref.WeakKeyDictionary()           # DMM_Model instance -> memo of its last small-table upload (_lib.small_to_device_many)
 _VALID_CACHE = weakref.WeakKeyDictionary()          # DMM_Model instance -> (weakref of the clip's valid tensor, its version, layout)
 
 
@@ -92,20 +93,29 @@ class DMM_Model(nn.Module):
                 pf_blocks, pf_addr = ops.ragged_blocks([f.float() for f in prop_feat])
             else:
                 pf_addr = []
-            sc_blocks, sc_addr = ops.ragged_blocks([s_.detach().float().reshape(-1, 1) for s_ in prop_score])
+            dense_rows = all(int(p.shape[0]) == Pmax for p in prop_m)
+            if dense_rows:                            # every video has Pmax proposals: the score batch is a plain stack
+                sc_addr = []
+            else:
+                sc_blocks, sc_addr = ops.ragged_blocks([s_.detach().float().reshape(-1, 1) for s_ in prop_score])
             i32, i64 = torch.int32, torch.int64
             specs = [([int(p.shape[0]) for p in prop_m], i32), (m_counts, i32), (pf_addr, i64), (sc_addr, i64)]
             direct = not (any(t.requires_grad for t in pm) or len({t.dtype for t in pm}) > 1 or pm[0].dtype not in ops._DT)
             if direct:                                # (else match_layer_batched stacks a copy, autograd.py)
                 pm = ops.FramePlanes(pm, table=None)
                 specs.append((pm.addresses(), i64))
-            up = _lib.small_to_device_many(specs, dev)
+            # (the tables of a clip's frames repeat: same counts, and the allocator hands out the same addresses -- then the
+            # previous call's device tables are reused as they are)
+            up = _lib.small_to_device_many(specs, dev, memo=_TABLE_MEMO.setdefault(self, {}))
             n_valid, m_valid = up[0], up[1]
             if direct:
                 pm.table = up[4]
             if pf is None:
                 pf = ragged_pad(pf_blocks, Pmax, n_valid, up[2])
-            sc = ops.ragged_pad(sc_blocks, Pmax, n_valid, up[3]).view(B, Pmax)
+            if dense_rows:
+                sc = torch.stack([s_.detach().reshape(-1) for s_ in prop_score], 0).float()
+            else:
+                sc = ops.ragged_pad(sc_blocks, Pmax, n_valid, up[3]).view(B, Pmax)
         else:
             n_valid = torch.tensor([int(p.shape[0]) for p in prop_m], dtype=torch.int32, device=dev)
             m_valid = torch.tensor(m_counts, dtype=torch.int32, device=dev)
