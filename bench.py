@@ -723,7 +723,7 @@ def bench_config4(R):
         # same parameters (the optimiser and the bucketer below hold the fp32 masters); no gradient reaches the decoder's skip
         # inputs in this step, like in the fp32 line (autograd skips them there)
         from dmm_net_amd.train_encoder import TrainEncoder
-        run_enc = TrainEncoder(enc, skips_need_grad=False, miopen_find=True)
+        run_enc = TrainEncoder(enc, skips_need_grad=False)    # (its convolution shapes ship in dmm_net_amd/miopen_db: no search)
     else:
         run_enc = enc
     model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
