@@ -23,6 +23,7 @@ ap.add_argument("--pmc", action="store_true")
 ap.add_argument("--child", action="store_true")
 ap.add_argument("--steps", default="1", help="MIX_SHARED_STEPS values to try (the backward takes twice as many 4 KiB steps per workgroup)")
 ap.add_argument("--reps", type=int, default=8)
+ap.add_argument("--rows", type=int, default=10, help="templates per frame (10 = the training bench's shape, 5 = the product's)")
 ap.add_argument("--lockstep", type=int, default=-1, help="--pmc: pin MIX_SHARED_LOCKSTEP for the counter passes")
 ap.add_argument("--xcd", type=int, default=-1, help="pin MIX_XCD (1 = plain frame / step mapping of the union kernels, 3 = one "
                                                     "whole frame per XCD); default: both, one after the other")
@@ -43,7 +44,7 @@ def run():
     if args.xcd >= 0 and args.child:
         _lib.set_option("MIX_XCD", args.xcd)
     dev = torch.device("cuda", 0)
-    B, N, M, H, W = args.frames, 50, 10, 255, 255
+    B, N, M, H, W = args.frames, 50, args.rows, 255, 255
     g = torch.Generator(device=dev).manual_seed(7)
     pm = torch.rand((B, N, H, W), generator=g, device=dev)
     dout = torch.rand((B, M, H, W), generator=g, device=dev)
@@ -66,14 +67,15 @@ def run():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
     ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 10)                       # clocks up before the first figure
-    for steps in [int(v) for v in args.steps.split(",")]:
+    for visit in (16,):                                              # (32-byte visits: built, measured, removed -- r06_mix_bwd_visit32_nogo.md)
+      for steps in [int(v) for v in args.steps.split(",")]:
         for lock in ((args.lockstep,) if args.lockstep >= 0 else (0, 1)):
             for xcd in ((args.xcd,) if args.xcd >= 0 else (1, 3, 1, 3)):
                 with _lib.options(MIX_SHARED_STEPS=steps, MIX_SHARED_LOCKSTEP=lock, MIX_XCD=xcd):
                     t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), args.reps)
                     tf = ms(lambda: ops.mask_mix(Rb, pm, shared=True), args.reps)
                 for name, tt in (("bwd_union", t), ("fwd_union", tf)):
-                    out["runs"].setdefault(f"{name}_steps{steps}_lockstep{lock}_xcd{xcd}", []).append(
+                    out["runs"].setdefault(f"{name}_visit{visit}_steps{steps}_lockstep{lock}_xcd{xcd}", []).append(
                         {"ms": round(tt, 4), "frac_of_8TBps": round(alg / tt / 1e6 / 8000, 4)})
     with _lib.options(MIX_SHARED=0):
         t = ms(lambda: ops.mask_mix_bwd(Rb, pm, dout), 3)
