@@ -219,13 +219,16 @@ def test_bench_multi_rank_control_flow_is_launched_like_the_driver():
     assert 0 < out["roofline"]["frac"] < 1.0
 
 
-def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean():
-    """``bench.py --config 4 --gpus 2`` launched like the driver would for the 8-GPU line (BASELINE configs[3]): every
+@pytest.mark.parametrize("form", [[], ["--bf16"]])
+def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean(form):
+    """(``--bf16``: the same rehearsal with ``TrainEncoder`` handing its gradients to the bucketer on both ranks: the layout
+    check at construction, the hub-driven hand-over and the overlapped collectives with a real peer.)
+    ``bench.py --config 4 --gpus 2`` launched like the driver would for the 8-GPU line (BASELINE configs[3]): every
     rank trains its own frames through DMM_Model, gradients are averaged by the overlapped bucketer, rank 0 prints one
     JSON line with the all-reduce accounting.  gloo, because two RCCL ranks cannot share this box's one GPU."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", "2",
-           "--steps", "2", "--warmup", "1", "--frames", "2", "--backend", "gloo", "--settle", "3"]
+           "--steps", "2", "--warmup", "1", "--frames", "2", "--backend", "gloo", "--settle", "3"] + form
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -238,7 +241,7 @@ def test_bench_config4_two_ranks_train_with_the_bucketed_gradient_mean():
     assert gm["used_mask_mode"] == "steady" and gm["host_reads_in_timed_steps"] == 0 and gm["gradients_are_bucket_views"]
     assert out["per_rank"]["backend"] == "gloo" and out["rccl_ranks"] == 0
     assert abs(gm["busbw_GBps"] - gm["algbw_GBps"]) <= 0.06 * gm["algbw_GBps"] + 0.1        # 2 (N-1) / N = 1 at N = 2
-    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"]
+    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"] + 0.06   # (value has one decimal)
 
 
 def test_bench_plain_invocation_with_gpus_2_launches_two_ranks_itself():
