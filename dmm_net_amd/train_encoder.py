@@ -29,7 +29,10 @@ gradient may alias a static buffer of the captured step: it is valid until the e
 gradient that is still in place -- gradient accumulation -- into a tensor of its own first); do not hold on to the tensor
 object itself across steps.
 
-Not supported: double backward, ``retain_graph`` replays of the same forward, forward hooks on the wrapped modules.
+Not supported: double backward, ``retain_graph`` replays of the same forward, forward hooks on the wrapped modules, changing
+``requires_grad`` of a parameter after the first forward of a shape (the captured backward computes the gradients of the
+parameters that required one at capture time).  In-place parameter updates (optimiser steps, ``load_state_dict``) are seen
+by the replays; ``.to()`` / ``.cuda()`` drop the captured plans.
 Off the GPU (or with ``graphs=False``) the same segment functions run eagerly under autograd -- that is what the CPU
 tests compare with the fp32 ``FeatureEncoder``.
 """
@@ -311,6 +314,12 @@ class TrainEncoder(nn.Module):
         self.__dict__["_pending"] = {}           # segment -> plans whose backward of it ran in the current backward pass
         self.__dict__["_ticked"] = {}            # id(module) -> covered by the running segment's _tick (rebuilt per call)
         self.__dict__["_shadows"] = {}           # id(1x1 conv) -> its persistent bf16 weight copy
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() re-create the parameters' storage: the captured graphs (which hold the old addresses), the
+        # bf16 weight copies and the hub leaves go; the next forward captures again
+        self._plans.clear(), self._shadows.clear(), self._hubs.clear(), self._pending.clear()
+        return super()._apply(fn, *args, **kwargs)
 
     # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
     def _cbr(self, x, conv, bn, relu, residual=None):

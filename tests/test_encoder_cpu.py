@@ -148,3 +148,45 @@ def test_vgg16_loads_a_state_dict_that_carries_classifier_keys():
     enc.load_state_dict(full, strict=True)
     assert torch.equal(enc.base.features[0].weight, sd["features.0.weight"])
 
+
+
+def test_train_encoder_segments_compute_the_encoder_on_the_cpu():
+    """``train_encoder.TrainEncoder`` off the GPU runs its segment functions eagerly under autograd: in fp32 mode they ARE the
+    encoder (same outputs, gradients and BatchNorm buffers as ``FeatureEncoder``; the 1x1 convolutions as products of the
+    activation matrix), in bf16 mode they give finite gradients for the same set of parameters; with ``skips_need_grad=False``
+    the decoder's skip projections get none, like under autograd when nothing consumes them."""
+    import copy
+    import math
+    import torch
+    from dmm_net_amd.encoder import FeatureEncoder
+    from dmm_net_amd.train_encoder import TrainEncoder
+    torch.manual_seed(0)
+    ref = FeatureEncoder("resnet50", hidden_size=32).train()
+    enc = copy.deepcopy(ref)
+    te = TrainEncoder(enc, dtype=torch.float32)
+    img = torch.randn(2, 3, 64, 96)
+    o, r = te(img), ref(img)
+    outs = lambda f: f["backbone_feature"] + f["refine_input_feat"]
+    for a, b in zip(outs(o), outs(r)):
+        assert a.shape == b.shape and float((a.float() - b).abs().max()) <= 2e-3 * float(b.abs().max())
+    w = [torch.sin(torch.arange(t.numel(), dtype=torch.float32).view(t.shape) * 0.37 + k) for k, t in enumerate(outs(r))]
+    sum((a.float() * t).mean() for a, t in zip(outs(o), w)).backward()
+    sum((a * t).mean() for a, t in zip(outs(r), w)).backward()
+    num = den = 0.0
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if q.grad is not None:
+            num += float((p.grad - q.grad).square().sum())
+            den += float(q.grad.square().sum())
+    assert math.sqrt(num / den) <= 2e-2                 # (a random-init ResNet-50 amplifies fp32 summation-order noise)
+    for (n, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-3 * (float(b.float().abs().max()) + 1.0), n
+    half = TrainEncoder(copy.deepcopy(ref), skips_need_grad=False)
+    f = half(img)
+    assert f["backbone_feature"][0].dtype == torch.float32 and not f["refine_input_feat"][0].requires_grad
+    sum(p.float().mean() for p in f["backbone_feature"]).backward()
+    for n, p in half.src.named_parameters():
+        if n.startswith(("sk", "bn")) or n.startswith("base.fc"):
+            assert p.grad is None, n
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
