@@ -175,6 +175,39 @@ def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True
     return F.relu(y) if relu else y
 
 
+# ---- weight gradients: launched where the backward reaches them, or collected for a graph of their own -------------------
+_DEFER: Optional[list] = None            # set while a segment's backward is captured with ``overlap_wgrad``: the launches are
+#                                          recorded (operands kept alive) and captured afterwards into a SECOND graph that replays
+#                                          on a side stream beside the next segment's backward chain
+
+
+def _wgrad_launch(rec):
+    from . import _lib
+    L = _lib.load()
+    kind, dy, x, dims, dw = rec
+    dev = x.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if kind == "1x1":
+        rows, co, ci = dims
+        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(rows, co, ci)), 16),), dtype=torch.uint8, device=dev)
+        with _lib.device_guard(dev):
+            _lib.check(L.dmm_wgrad_bf16(dy.data_ptr(), x.data_ptr(), rows, co, ci, co, ci, dw.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), stream), "dmm_wgrad_bf16")
+    else:
+        B, H, W, ci, co, stride, Ho, Wo = dims
+        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * Ho * Wo, co, 9 * ci)), 16),), dtype=torch.uint8, device=dev)
+        with _lib.device_guard(dev):
+            _lib.check(L.dmm_wgrad3x3_bf16(dy.data_ptr(), x.data_ptr(), B, H, W, ci, co, stride, dw.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), stream), "dmm_wgrad3x3_bf16")
+
+
+def _wgrad(rec):
+    if _DEFER is not None:
+        _DEFER.append(rec)
+    else:
+        _wgrad_launch(rec)
+
+
 # ---- convolutions ----------------------------------------------------------------------------------------------------
 def _wgrad_ok(m: nn.Conv2d) -> bool:
     return (m.groups == 1 and m.dilation == (1, 1) and m.in_channels % 64 == 0 and m.out_channels % 64 == 0
@@ -217,13 +250,8 @@ class _Conv1x1Fn(torch.autograd.Function):
                 full = torch.zeros(ctx.full, dtype=dx.dtype, device=dx.device).contiguous(memory_format=_CL)
                 full[:, :, ::ctx.stride, ::ctx.stride] = dx
                 dx = full
-        L = _lib.load()
         dw = torch.empty((co, ci, 1, 1), dtype=torch.float32, device=x.device)
-        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * H * W, co, ci)), 16),), dtype=torch.uint8, device=x.device)
-        with _lib.device_guard(x.device):
-            _lib.check(L.dmm_wgrad_bf16(dy_rows.data_ptr(), x.data_ptr(), B * H * W, co, ci, co, ci, dw.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
-                       "dmm_wgrad_bf16")
+        _wgrad(("1x1", dy_rows, x, (B * H * W, co, ci), dw))
         return dx, dw, None, None
 
 
@@ -253,15 +281,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
-        L = _lib.load()
         Ho, Wo = dy.shape[2], dy.shape[3]
         dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)      # the master's own layout
-        ws = torch.empty((max(int(L.dmm_wgrad_workspace_bytes(B * Ho * Wo, co, 9 * ci)), 16),), dtype=torch.uint8,
-                         device=x.device)
-        with _lib.device_guard(x.device):
-            _lib.check(L.dmm_wgrad3x3_bf16(dy.data_ptr(), x.data_ptr(), B, H, W, ci, co, ctx.stride, dw.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
-                       "dmm_wgrad3x3_bf16")
+        _wgrad(("3x3", dy, x, (B, H, W, ci, co, ctx.stride, Ho, Wo), dw))
         db = dy.float().sum((0, 2, 3)) if ctx.has_bias else None
         return dx, dw, db, None
 
@@ -300,14 +322,15 @@ class TrainEncoder(nn.Module):
     SEGMENTS = ("front", "layer3", "layer4", "heads")
 
     def __init__(self, encoder: FeatureEncoder, dtype=torch.bfloat16, graphs: bool = True, linear_1x1: bool = True,
-                 fused_bn: bool = True, own_wgrad: bool = True, skips_need_grad: bool = True, miopen_find: bool = False,
-                 warmup: int = 2):
+                 fused_bn: bool = True, own_wgrad: bool = True, overlap_wgrad: bool = True, skips_need_grad: bool = True,
+                 miopen_find: bool = False, warmup: int = 2):
         super().__init__()
         if not isinstance(encoder.base, ResNetBody):
             raise NotImplementedError("TrainEncoder is the bf16 channels-last training form of the ResNet bodies")
         self.src = encoder
         self.dtype, self.graphs, self.linear_1x1, self.fused_bn = dtype, bool(graphs), bool(linear_1x1), bool(fused_bn)
         self.own_wgrad = bool(own_wgrad)
+        self.overlap_wgrad = bool(overlap_wgrad) and self.own_wgrad
         self.skips_need_grad, self.miopen_find, self.warmup = bool(skips_need_grad), bool(miopen_find), int(warmup)
         self.__dict__["_plans"] = {}             # (shape, device) -> _Plan; not module state
         self.__dict__["_hubs"] = {}              # device index -> {segment: hub leaf}
@@ -444,6 +467,7 @@ class TrainEncoder(nn.Module):
     def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
         assert img.dim() == 4 and img.shape[1] == 3, img.shape           # model_encoder.py:91-92
         self.__dict__["_ticked"].clear()
+        self.__dict__.pop("_late", None)         # (a hand-over left behind by a backward pass that raised)
         if not (self.graphs and img.is_cuda and self.training and torch.is_grad_enabled()):
             return self._eager(img)
         key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad)
@@ -467,13 +491,27 @@ class TrainEncoder(nn.Module):
 
     def _flush(self, name: str, hub: torch.Tensor):
         """The hub leaf of ``name`` has received its gradient: every plan that took part in this backward pass has replayed the
-        segment's backward graph.  Their parameter gradients are summed (into the first plan's static buffers) and handed
+        segment's backward graph(s).  Their parameter gradients are summed (into the first plan's static buffers) and handed
         over: ``p.grad`` set / accumulated, post-accumulate-grad hooks called -- once per parameter and backward pass, like
-        autograd's own AccumulateGrad."""
+        autograd's own AccumulateGrad.  With the weight gradients on a side stream the hand-over of a segment happens ONE
+        SEGMENT LATE (the current stream has to wait for that segment's side-stream graph, and must not do so before the next
+        segment's chain -- which the side stream runs beside -- has been enqueued); the first segment of the network, whose
+        backward runs last, is handed over together with its predecessor."""
         hub.grad = None
         plans = self._pending.pop(name, [])
+        late = self.__dict__.pop("_late", None)
+        if late is not None:
+            self._hand_over(*late)
         if not plans:
             return
+        if any(name in p.wgrad for p in plans) and name != self.SEGMENTS[0]:
+            self.__dict__["_late"] = (name, plans)
+        else:
+            self._hand_over(name, plans)
+
+    def _hand_over(self, name: str, plans):
+        for p in plans:
+            p.wait_wgrad(name)
         params, base = plans[0].params[name], plans[0].pgrads[name]
         for other in plans[1:]:
             pairs = [(b, g) for b, g in zip(base, other.pgrads[name]) if b is not None and g is not None]
@@ -542,37 +580,51 @@ class _Plan:
         self.gout = [torch.zeros_like(o) if o.requires_grad else None for o in heads]
         self.pgrads = {}
 
-        def capture_bwd(name, outs, gouts, inputs):
+        # weight gradients on a side stream (``overlap_wgrad``): a segment's backward is captured as TWO graphs -- the chain
+        # (BatchNorm backward, data gradients, everything the next layer down waits for) and, from the launches recorded while
+        # that capture ran, the weight gradients.  On replay the second graph runs on a side stream beside the NEXT segment's
+        # chain (two graphs on two streams do run side by side on this runtime; forked branches inside one graph do not:
+        # tools/graph_branch_probe.py).  The recorded operands (dY, X) are kept alive for the plan's lifetime -- the chain of
+        # the next segment must not reuse their memory while the side stream reads it -- and the second graphs allocate from a
+        # pool of their own.
+        self.wgrad, self.keep = {}, {}
+        pool_w = torch.cuda.graph_pool_handle() if enc.overlap_wgrad else None
+        self.side = torch.cuda.Stream(device=dev) if enc.overlap_wgrad else None
+        self.ev_chain = {n: torch.cuda.Event() for n in TrainEncoder.SEGMENTS}
+        self.ev_wgrad = {n: torch.cuda.Event() for n in TrainEncoder.SEGMENTS}
+
+        def capture_bwd(name, outs, make_gouts, inputs):
+            """``make_gouts``: called INSIDE the capture (sums of gradient buffers of two consumers are part of the graph)."""
+            global _DEFER
             ps = self.params[name]
             wrt = [t for t in inputs if t.requires_grad] + ps
             g = SafeGraph()
             arena = _Arena(dev, enc._arena_floats(name, True))
-            with g.capture(pool=pool), _arena_scope(arena):
-                grads = torch.autograd.grad(outs, wrt, gouts, allow_unused=True)
+            _DEFER = [] if enc.overlap_wgrad else None
+            try:
+                with g.capture(pool=pool), _arena_scope(arena):
+                    grads = torch.autograd.grad(outs, wrt, make_gouts(), allow_unused=True)
+                records = _DEFER
+            finally:
+                _DEFER = None
             self.bwd[name] = g
             self.arenas.append(arena)
+            if records:
+                gw = SafeGraph()
+                with gw.capture(pool=pool_w):
+                    for rec in records:
+                        _wgrad_launch(rec)
+                self.wgrad[name], self.keep[name] = gw, records
             n_in = len(wrt) - len(ps)
             self.pgrads[name] = list(grads[n_in:])
             return grads[:n_in]
         ho = [o for o in heads if o.requires_grad]
-        g2, g3h, g4h, g5h = capture_bwd("heads", ho, [g for g in self.gout if g is not None], (h2, h3, h4, h5))
-        (g4,) = capture_bwd("layer4", [x5], [g5h], (i4,))
+        g2, g3h, g4h, g5h = capture_bwd("heads", ho, lambda: [g for g in self.gout if g is not None], (h2, h3, h4, h5))
+        (g4,) = capture_bwd("layer4", [x5], lambda: [g5h], (i4,))
         # x4 feeds layer4 AND the heads: its gradient is the sum of the two static buffers (one add, captured with layer3's
         # backward); likewise x3 (layer3 + heads) and x2 (heads only) for the front segment
-        wrt3 = [i3] + self.params["layer3"]
-        gb = SafeGraph()
-        arena = _Arena(dev, enc._arena_floats("layer3", True))
-        self.arenas.append(arena)
-        with gb.capture(pool=pool), _arena_scope(arena):
-            grads = torch.autograd.grad([x4], wrt3, [g4 + g4h], allow_unused=True)
-        self.bwd["layer3"], self.pgrads["layer3"] = gb, list(grads[1:])
-        g3 = grads[0]
-        gf = SafeGraph()
-        arena = _Arena(dev, enc._arena_floats("front", True))
-        self.arenas.append(arena)
-        with gf.capture(pool=pool), _arena_scope(arena):
-            grads = torch.autograd.grad([x2, x3], self.params["front"], [g2, g3 + g3h], allow_unused=True)
-        self.bwd["front"], self.pgrads["front"] = gf, list(grads)
+        (g3,) = capture_bwd("layer3", [x4], lambda: [g4 + g4h], (i3,))
+        capture_bwd("front", [x2, x3], lambda: [g2, g3 + g3h], ())
         self.result = TrainEncoder._pack((x2, x3), x4, x5, heads)
         self.heads = heads
         self.token = torch.zeros((), device=dev)           # what the segment nodes hand each other (autograd ordering only)
@@ -580,7 +632,8 @@ class _Plan:
         self.busy = False
         self.aliased = False                               # some p.grad may still BE one of this plan's static buffers
         # what the rewrite found: {segment: (memset nodes, memcpy nodes) turned into kernel nodes} per direction
-        self.rewritten = {"fwd": {k: g.rewritten for k, g in self.fwd.items()}, "bwd": {k: g.rewritten for k, g in self.bwd.items()}}
+        self.rewritten = {"fwd": {k: g.rewritten for k, g in self.fwd.items()}, "bwd": {k: g.rewritten for k, g in self.bwd.items()},
+                          "wgrad": {k: g.rewritten for k, g in self.wgrad.items()}}
         for (rm, rv, nb), m in zip(keep, bns):
             with torch.no_grad():
                 m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
@@ -629,7 +682,20 @@ class _Plan:
             if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
                 p.grad = p.grad.clone()
         self.bwd[name].replay()
+        gw = self.wgrad.get(name)
+        if gw is not None:
+            main = torch.cuda.current_stream(self.static_img.device)
+            self.ev_chain[name].record(main)
+            self.side.wait_event(self.ev_chain[name])
+            with torch.cuda.stream(self.side):
+                gw.replay()
+                self.ev_wgrad[name].record(self.side)
         self.enc.__dict__["_pending"].setdefault(name, []).append(self)
+
+    def wait_wgrad(self, name: str):
+        """The current stream waits for this plan's weight-gradient graph of ``name`` (a no-op without one)."""
+        if name in self.wgrad:
+            torch.cuda.current_stream(self.static_img.device).wait_event(self.ev_wgrad[name])
 
 
 def _deliver(params, grads):

@@ -176,7 +176,7 @@ def test_graphed_fp32_mode_equals_the_plain_encoder_on_replays(model):
         _loss(ft).backward()
         gr, gt = _grads(ref), _grads(enc)
         assert all((gr[k] is None) == (gt[k] is None) for k in gr), step
-        assert _rel(gt, gr) <= 5e-3, (step, _rel(gt, gr))
+        assert _rel(gt, gr) <= 1e-2, (step, _rel(gt, gr))     # (fp32 summation-order noise of MIOpen's atomics through 34-50 layers: 1e-3 .. 6e-3)
         for (n, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
             assert float((a.float() - b.float()).abs().max()) <= 1e-3 * (float(b.float().abs().max()) + 1.0), (step, n)
 
@@ -239,6 +239,38 @@ def test_graphed_bf16_step_is_as_close_to_fp32_as_the_eager_bf16_step():
             record_achieved(f"train_encoder/step{step}/{tag}", v)
     plan = next(iter(graph._plans.values()))[0]
     record_achieved("train_encoder/memset_nodes_rewritten", sum(v[0] for d in plan.rewritten.values() for v in d.values()))
+
+
+def test_weight_gradients_on_the_side_stream_change_no_gradient():
+    """``overlap_wgrad``: a segment's weight gradients are captured into a second graph that replays on a side stream beside
+    the next segment's backward chain, and the segment is handed over one segment late.  Against the same plan with the
+    launches inline: the heads' weight gradients and all gradients together are no further apart than two runs of the inline
+    form are from each other (the body's bf16 features are not reproducible run to run, see ``_tame``), no gradient is missing
+    or non-finite -- over replays, and with three forwards in flight.  (The kernels themselves are pinned bit-reproducibly in
+    ``test_wgrad_*``; what this test adds is that the deferred launches read the right, still-live operands.)"""
+    torch.manual_seed(21)
+    ref = _tame(FeatureEncoder("resnet50").to(DEV).train())
+    a, b = copy.deepcopy(ref), copy.deepcopy(ref)
+    side, inline = TrainEncoder(a, skips_need_grad=False), TrainEncoder(b, overlap_wgrad=False, skips_need_grad=False)
+    assert side.overlap_wgrad and not inline.overlap_wgrad
+    loss = lambda f: _loss(f, skips=False)
+    heads_w = lambda g: {k: v for k, v in g.items() if k.startswith("prop") and v is not None and v.dim() == 4}
+    for step in range(3):
+        frames = [torch.randn(4, 3, 128, 224, device=DEV) for _ in range(3 if step == 2 else 1)]
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+        sum(loss(side(f)) for f in frames).backward()
+        sum(loss(inline(f)) for f in frames).backward()
+        gs, gi = _grads(a), _grads(b)
+        b.zero_grad(set_to_none=True)
+        sum(loss(inline(f)) for f in frames).backward()
+        gi2 = _grads(b)
+        assert all((gs[k] is None) == (gi[k] is None) for k in gi)
+        assert not [k for k, v in gs.items() if v is not None and not bool(torch.isfinite(v).all())]
+        assert _rel(heads_w(gs), heads_w(gi)) <= 1.5 * _rel(heads_w(gi2), heads_w(gi)) + 0.02
+        assert _rel(gs, gi) <= 1.5 * _rel(gi2, gi) + 0.02, (step, _rel(gs, gi), _rel(gi2, gi))
+    plan = next(iter(side._plans.values()))[0]
+    assert set(plan.wgrad) == {"front", "layer3", "layer4", "heads"} and not plan.busy
 
 
 def test_gradient_hand_over_feeds_the_bucketer_and_accumulates():

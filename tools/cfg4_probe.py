@@ -31,7 +31,7 @@ def one(variant, find, steps, frames):
     if variant.startswith("train"):
         from dmm_net_amd.train_encoder import TrainEncoder
         enc = TrainEncoder(enc, graphs="nograph" not in variant, linear_1x1="nolin" not in variant,
-                           fused_bn="nofuse" not in variant, own_wgrad="nowgrad" not in variant, skips_need_grad=False,
+                           fused_bn="nofuse" not in variant, own_wgrad="nowgrad" not in variant, overlap_wgrad="inline" not in variant, skips_need_grad=False,
                            miopen_find=find)
         torch.backends.cudnn.benchmark = False
     elif nhwc:
