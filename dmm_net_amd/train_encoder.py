@@ -7,7 +7,7 @@ Counterpart of ``dmm/modules/model_encoder.py:86-162`` + ``base.py:18-69`` + ``v
 
 * **whole forward / backward as HIP-graph replays.**  At the trainer's batch (12 frames of 255 x 448) a ResNet-101 step is
   ~2 100 launches of 5-50 us kernels: the stock step is HOST bound (device kernel time 17.6 ms inside a 24.4 ms step under
-  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem + layer1 + layer2 | layer3 | layer4 |
+  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem + layer1 | layer2 | layer3 in parts | layer4 |
   heads); each segment's forward and its backward (``torch.autograd.grad`` over the segment) are captured once per input
   shape and replayed.  Segment k+1 reads segment k's static output in place; backward replays run last segment first and
   after each one that segment's parameter gradients are handed over -- so a gradient all-reduce (``GradBucketer`` hooks)
@@ -319,11 +319,9 @@ class TrainEncoder(nn.Module):
     trainer with the refine decoder leaves it on; a step that never sends a gradient there (bench.py's config 4: no decoder)
     switches it off so that the backward graph does not run those four convolutions on zeros."""
 
-    SEGMENTS = ("front", "layer3", "layer4", "heads")
-
     def __init__(self, encoder: FeatureEncoder, dtype=torch.bfloat16, graphs: bool = True, linear_1x1: bool = True,
                  fused_bn: bool = True, own_wgrad: bool = True, overlap_wgrad: bool = True, skips_need_grad: bool = True,
-                 miopen_find: bool = False, warmup: int = 2):
+                 miopen_find: bool = False, warmup: int = 2, layer3_parts: int = 3):
         super().__init__()
         if not isinstance(encoder.base, ResNetBody):
             raise NotImplementedError("TrainEncoder is the bf16 channels-last training form of the ResNet bodies")
@@ -332,6 +330,20 @@ class TrainEncoder(nn.Module):
         self.own_wgrad = bool(own_wgrad)
         self.overlap_wgrad = bool(overlap_wgrad) and self.own_wgrad
         self.skips_need_grad, self.miopen_find, self.warmup = bool(skips_need_grad), bool(miopen_find), int(warmup)
+        # the body as a CHAIN of segments: stem + layer1 | layer2 | layer3 in ``layer3_parts`` runs of blocks | layer4, then the
+        # heads.  (name, the blocks it runs, which of the four taps x2..x5 its output is, or None.)  Finer segments = a finer
+        # pipeline between the backward chain and the weight-gradient graphs on the side stream: the exposed tail is the FIRST
+        # segment's weight gradients, and a segment's weight gradients should not outlast the next segment's chain (layer3 is
+        # half of a ResNet-101: as ONE segment its 2.5 ms of weight gradients ran beside 1.7 ms of chain).
+        body = encoder.base
+        l3 = list(body.layer3)
+        n3 = max(1, min(int(layer3_parts), len(l3)))
+        cuts = [round(i * len(l3) / n3) for i in range(n3 + 1)]
+        chain = [("stem1", ["stem"] + list(body.layer1), 0), ("layer2", list(body.layer2), 1)]
+        chain += [(f"layer3_{i}" if n3 > 1 else "layer3", l3[cuts[i]:cuts[i + 1]], 2 if i == n3 - 1 else None) for i in range(n3)]
+        chain.append(("layer4", list(body.layer4), 3))
+        self.__dict__["_chain"] = chain
+        self.segments = tuple(c[0] for c in chain) + ("heads",)
         self.__dict__["_plans"] = {}             # (shape, device) -> _Plan; not module state
         self.__dict__["_hubs"] = {}              # device index -> {segment: hub leaf}
         self.__dict__["_pending"] = {}           # segment -> plans whose backward of it ran in the current backward pass
@@ -396,23 +408,17 @@ class TrainEncoder(nn.Module):
             x = self._block(x, blk)
         return x
 
-    def _seg_front(self, img):
+    def _seg_body(self, name: str, x):
+        """One body segment of the chain: (the stem when it is the first,) its blocks in order.  -> (output,)"""
         body = self.src.base
-        self._tick("front", img)
-        x = img.to(self.dtype).contiguous(memory_format=_CL)
-        x = self._cbr(x, body.conv1, body.bn1, True)
-        x = body.maxpool(x)
-        x2 = self._layer(x, body.layer1)
-        x3 = self._layer(x2, body.layer2)
-        return x2, x3
-
-    def _seg_layer3(self, x3):
-        self._tick("layer3", x3)
-        return (self._layer(x3, self.src.base.layer3),)
-
-    def _seg_layer4(self, x4):
-        self._tick("layer4", x4)
-        return (self._layer(x4, self.src.base.layer4),)
+        self._tick(name, x)
+        for op in next(c[1] for c in self._chain if c[0] == name):
+            if isinstance(op, str):                                      # "stem": conv1 -> bn1 -> relu -> maxpool
+                x = x.to(self.dtype).contiguous(memory_format=_CL)
+                x = body.maxpool(self._cbr(x, body.conv1, body.bn1, True))
+            else:
+                x = self._block(x, op)
+        return (x,)
 
     def _head(self, x, head):
         out = self._cbr(x, head[0], head[1], True)                       # base.py:43-54: conv -> BN -> ReLU -> conv -> BN
@@ -430,8 +436,14 @@ class TrainEncoder(nn.Module):
 
     def _seg_modules(self) -> Dict[str, List[nn.Module]]:
         s, body = self.src, self.src.base
-        return {"front": [body.conv1, body.bn1, body.layer1, body.layer2], "layer3": [body.layer3], "layer4": [body.layer4],
-                "heads": [s.prop2, s.prop3, s.prop4, s.prop5, s.sk2, s.sk3, s.sk4, s.sk5, s.bn2, s.bn3, s.bn4, s.bn5]}
+        out = {}
+        for name, ops, _ in self._chain:
+            mods = []
+            for op in ops:
+                mods += [body.conv1, body.bn1] if isinstance(op, str) else [op]
+            out[name] = mods
+        out["heads"] = [s.prop2, s.prop3, s.prop4, s.prop5, s.sk2, s.sk3, s.sk4, s.sk5, s.bn2, s.bn3, s.bn4, s.bn5]
+        return out
 
     def _seg_params(self) -> Dict[str, List[nn.Parameter]]:
         out = {}
@@ -452,16 +464,16 @@ class TrainEncoder(nn.Module):
         return n + 1024
 
     @staticmethod
-    def _pack(outs_front, x4, x5, heads):
-        x2, x3 = outs_front
-        return {"backbone_feature": tuple(heads[:4]), "refine_input_feat": tuple(heads[4:]),
-                "body_feature": (x2, x3, x4, x5)}
+    def _pack(taps, heads):
+        return {"backbone_feature": tuple(heads[:4]), "refine_input_feat": tuple(heads[4:]), "body_feature": tuple(taps)}
 
     def _eager(self, img):
-        front = self._seg_front(img)
-        (x4,) = self._seg_layer3(front[1])
-        (x5,) = self._seg_layer4(x4)
-        return self._pack(front, x4, x5, self._seg_heads(front[0], front[1], x4, x5))
+        x, taps = img, [None] * 4
+        for name, _, tap in self._chain:
+            (x,) = self._seg_body(name, x)
+            if tap is not None:
+                taps[tap] = x
+        return self._pack(taps, self._seg_heads(*taps))
 
     # ---- entry ---------------------------------------------------------------------------------------------------------
     def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
@@ -484,7 +496,7 @@ class TrainEncoder(nn.Module):
         hubs = self._hubs.get(device.index)
         if hubs is None:
             hubs = self._hubs[device.index] = {}
-            for name in self.SEGMENTS:
+            for name in self.segments:
                 h = hubs[name] = torch.zeros((), device=device, requires_grad=True)
                 h.register_post_accumulate_grad_hook(lambda t, name=name: self._flush(name, t))
         return hubs
@@ -504,7 +516,7 @@ class TrainEncoder(nn.Module):
             self._hand_over(*late)
         if not plans:
             return
-        if any(name in p.wgrad for p in plans) and name != self.SEGMENTS[0]:
+        if any(name in p.wgrad for p in plans) and name != self.segments[0]:
             self.__dict__["_late"] = (name, plans)
         else:
             self._hand_over(name, plans)
@@ -522,14 +534,14 @@ class TrainEncoder(nn.Module):
 
 
 class _Plan:
-    """The captured graphs of one input shape: forward graphs front -> layer3 -> layer4 -> heads (each reads its
-    predecessor's static outputs in place), backward graphs in the reverse order (each reads its successors' static input
+    """The captured graphs of one input shape: forward graphs along ``enc.segments`` (stem + layer1 -> layer2 -> layer3 in parts
+    -> layer4 -> heads; each reads its predecessor's static outputs in place), backward graphs in the reverse order (each reads its successors' static input
     gradients in place), all in one memory pool and captured in the order they replay."""
 
     def __init__(self, enc: TrainEncoder, img: torch.Tensor):
         self.enc = enc
         dev = img.device
-        fns = {"front": enc._seg_front, "layer3": enc._seg_layer3, "layer4": enc._seg_layer4, "heads": enc._seg_heads}
+        chain = enc._chain
         self.params = enc._seg_params()
         self.static_img = img.detach().clone()
         pool = torch.cuda.graph_pool_handle()
@@ -553,28 +565,29 @@ class _Plan:
             torch.backends.cudnn.benchmark = old
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        # ---- forward captures, in replay order; a segment's inputs are DETACHED views of its predecessor's outputs that
-        # require grad, so that every segment owns a separate autograd graph
+        # ---- forward captures, in replay order; a segment's input is a DETACHED view of its predecessor's output that
+        # requires grad, so that every segment owns a separate autograd graph
         self.fwd, self.bwd, self.ins, self.outs = {}, {}, {}, {}
         self.arenas = []                                  # statistics scratch of every captured graph (kept alive with it)
 
         def leaf(t):
             return t.detach().requires_grad_(True)
-        def capture(name, *inputs):
+        def capture(name, fn, *inputs):
             g = SafeGraph()
             arena = _Arena(dev, enc._arena_floats(name, False))
             with g.capture(pool=pool), _arena_scope(arena):
-                outs = fns[name](*inputs)
+                outs = fn(*inputs)
             self.fwd[name], self.ins[name], self.outs[name] = g, inputs, outs
             self.arenas.append(arena)
             return outs
-        x2, x3 = capture("front", self.static_img)
-        i3 = leaf(x3)
-        (x4,) = capture("layer3", i3)
-        i4 = leaf(x4)
-        (x5,) = capture("layer4", i4)
-        h2, h3, h4, h5 = leaf(x2), leaf(x3), leaf(x4), leaf(x5)
-        heads = capture("heads", h2, h3, h4, h5)
+        taps, x = [None] * 4, self.static_img
+        for k_, (name, _, tap) in enumerate(chain):
+            inp = x if k_ == 0 else leaf(x)
+            (x,) = capture(name, lambda t, name=name: enc._seg_body(name, t), inp)
+            if tap is not None:
+                taps[tap] = x
+        hin = [leaf(t) for t in taps]
+        heads = capture("heads", enc._seg_heads, *hin)
         # ---- backward captures, reverse order.  Gradients that arrive from outside: one static buffer per head output that
         # requires grad.  Gradients between segments: the tensors autograd.grad returned in the successor's capture.
         self.gout = [torch.zeros_like(o) if o.requires_grad else None for o in heads]
@@ -590,8 +603,8 @@ class _Plan:
         self.wgrad, self.keep = {}, {}
         pool_w = torch.cuda.graph_pool_handle() if enc.overlap_wgrad else None
         self.side = torch.cuda.Stream(device=dev) if enc.overlap_wgrad else None
-        self.ev_chain = {n: torch.cuda.Event() for n in TrainEncoder.SEGMENTS}
-        self.ev_wgrad = {n: torch.cuda.Event() for n in TrainEncoder.SEGMENTS}
+        self.ev_chain = {n: torch.cuda.Event() for n in enc.segments}
+        self.ev_wgrad = {n: torch.cuda.Event() for n in enc.segments}
 
         def capture_bwd(name, outs, make_gouts, inputs):
             """``make_gouts``: called INSIDE the capture (sums of gradient buffers of two consumers are part of the graph)."""
@@ -603,7 +616,13 @@ class _Plan:
             _DEFER = [] if enc.overlap_wgrad else None
             try:
                 with g.capture(pool=pool), _arena_scope(arena):
-                    grads = torch.autograd.grad(outs, wrt, make_gouts(), allow_unused=True)
+                    grads = list(torch.autograd.grad(outs, wrt, make_gouts(), allow_unused=True))
+                    # a gradient is handed over in its PARAMETER's layout (the multi-tensor optimisers refuse anything else:
+                    # "params, grads ... must have same dtype, device, and layout"): the stock convolutions' weight gradients
+                    # come back channels-last strided (the 7x7 stem, widths the library's kernels do not take)
+                    for k_, (t, g_) in enumerate(zip(wrt, grads)):
+                        if g_ is not None and isinstance(t, nn.Parameter) and (g_.stride() != t.stride() or g_.dtype != t.dtype):
+                            grads[k_] = torch.empty_like(t).copy_(g_)
                 records = _DEFER
             finally:
                 _DEFER = None
@@ -619,13 +638,17 @@ class _Plan:
             self.pgrads[name] = list(grads[n_in:])
             return grads[:n_in]
         ho = [o for o in heads if o.requires_grad]
-        g2, g3h, g4h, g5h = capture_bwd("heads", ho, lambda: [g for g in self.gout if g is not None], (h2, h3, h4, h5))
-        (g4,) = capture_bwd("layer4", [x5], lambda: [g5h], (i4,))
-        # x4 feeds layer4 AND the heads: its gradient is the sum of the two static buffers (one add, captured with layer3's
-        # backward); likewise x3 (layer3 + heads) and x2 (heads only) for the front segment
-        (g3,) = capture_bwd("layer3", [x4], lambda: [g4 + g4h], (i3,))
-        capture_bwd("front", [x2, x3], lambda: [g2, g3 + g3h], ())
-        self.result = TrainEncoder._pack((x2, x3), x4, x5, heads)
+        gh = capture_bwd("heads", ho, lambda: [g for g in self.gout if g is not None], tuple(hin))
+        # a tap feeds the next body segment AND the heads: its gradient is the sum of the two static buffers (one add, captured
+        # at the head of the segment's backward)
+        g_next = None
+        for k_ in range(len(chain) - 1, -1, -1):
+            name, _, tap = chain[k_]
+            terms = [t for t in (g_next, gh[tap] if tap is not None else None) if t is not None]
+            make = (lambda terms=terms: [terms[0] + terms[1]]) if len(terms) == 2 else (lambda terms=terms: [terms[0]])
+            got = capture_bwd(name, list(self.outs[name]), make, self.ins[name] if k_ > 0 else ())
+            g_next = got[0] if k_ > 0 else None
+        self.result = TrainEncoder._pack(taps, heads)
         self.heads = heads
         self.token = torch.zeros((), device=dev)           # what the segment nodes hand each other (autograd ordering only)
         self.zero = torch.zeros((), device=dev)            # their gradient: the data moves in the static buffers
@@ -644,18 +667,18 @@ class _Plan:
             # the last backward handed this plan's static gradient buffers out as ``p.grad``.  The pool reuses that memory for
             # activations of the FORWARD graphs (a replayed step needs the two at different times), so a gradient that is still
             # in place now -- gradient accumulation: no zero_grad / optimiser step in between -- moves into its own tensor first
-            for name in TrainEncoder.SEGMENTS:
+            for name in enc.segments:
                 for p, g in zip(self.params[name], self.pgrads[name]):
                     if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
                         p.grad = p.grad.clone()
             self.aliased = False
         self.static_img.copy_(img)
-        for name in TrainEncoder.SEGMENTS:
+        for name in enc.segments:
             self.fwd[name].replay()
         self.busy = True
         hubs = enc._hubs_for(img.device)
         token = None
-        for name in TrainEncoder.SEGMENTS[:-1]:
+        for name in enc.segments[:-1]:
             token = _SegFn.apply(self, name, token, hubs[name])
         outs = _SegFn.apply(self, "heads", token, hubs["heads"])
         # (the body's own levels are handed out detached: inside the graphs they are inputs of the heads, not autograd leaves
@@ -734,7 +757,7 @@ class _Lease:
 
 
 class _SegFn(torch.autograd.Function):
-    """One segment of a plan as an autograd node.  The nodes of a plan are chained by a token (front -> layer3 -> layer4 ->
+    """One segment of a plan as an autograd node.  The nodes of a plan are chained by a token (stem1 -> layer2 -> layer3_* -> layer4 ->
     heads; the heads' node returns the real outputs), so autograd runs their backwards last segment first; the data itself
     moves between the captured graphs in their static buffers.  Every node also takes the encoder's HUB leaf of its segment:
     autograd runs a leaf's AccumulateGrad once per backward pass, after the LAST node that uses it -- with several forwards
@@ -744,7 +767,7 @@ class _SegFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, name, token, hub):
         ctx.plan, ctx.name, ctx.has_token = plan, name, token is not None
-        ctx.lease = _Lease(plan) if name == TrainEncoder.SEGMENTS[0] else None
+        ctx.lease = _Lease(plan) if name == plan.enc.segments[0] else None
         ctx.set_materialize_grads(False)
         if name != "heads":
             return plan.token.detach()

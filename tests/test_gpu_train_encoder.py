@@ -270,7 +270,30 @@ def test_weight_gradients_on_the_side_stream_change_no_gradient():
         assert _rel(heads_w(gs), heads_w(gi)) <= 1.5 * _rel(heads_w(gi2), heads_w(gi)) + 0.02
         assert _rel(gs, gi) <= 1.5 * _rel(gi2, gi) + 0.02, (step, _rel(gs, gi), _rel(gi2, gi))
     plan = next(iter(side._plans.values()))[0]
-    assert set(plan.wgrad) == {"front", "layer3", "layer4", "heads"} and not plan.busy
+    assert set(plan.wgrad) == set(side.segments) and side.segments[0] == "stem1" and side.segments[-1] == "heads"
+    assert not plan.busy
+
+
+def test_a_plain_fused_optimiser_steps_on_the_handed_over_gradients():
+    """Without a bucketer the optimiser reads the handed-over gradients as they are: every gradient must have its
+    parameter's dtype and layout (torch's multi-tensor Adam refuses anything else) -- also for the convolutions that stay on
+    the stock path (the 7x7 stem, the 32-wide head), whose weight gradients autograd returns channels-last strided."""
+    torch.manual_seed(4)
+    enc = _tame(FeatureEncoder("resnet50").to(DEV).train())
+    te = TrainEncoder(enc, skips_need_grad=False)
+    opt = torch.optim.Adam([p for p in enc.parameters()], lr=1e-4, fused=True)
+    before = enc.base.conv1.weight.detach().clone()
+    losses = []
+    img = torch.randn(4, 3, 128, 224, device=DEV)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        l = _loss(te(img), skips=False)
+        l.backward()
+        for n, p in enc.named_parameters():
+            assert p.grad is None or (p.grad.stride() == p.stride() and p.grad.dtype == p.dtype), n
+        opt.step()
+        losses.append(float(l))
+    assert not torch.equal(before, enc.base.conv1.weight) and losses[-1] < losses[0], losses
 
 
 def test_gradient_hand_over_feeds_the_bucketer_and_accumulates():

@@ -32,6 +32,7 @@ def one(variant, find, steps, frames):
         from dmm_net_amd.train_encoder import TrainEncoder
         enc = TrainEncoder(enc, graphs="nograph" not in variant, linear_1x1="nolin" not in variant,
                            fused_bn="nofuse" not in variant, own_wgrad="nowgrad" not in variant, overlap_wgrad="inline" not in variant, skips_need_grad=False,
+                           layer3_parts=int(sys.argv[sys.argv.index("--l3") + 1]) if "--l3" in sys.argv else 3,
                            miopen_find=find)
         torch.backends.cudnn.benchmark = False
     elif nhwc:
@@ -63,6 +64,8 @@ def one(variant, find, steps, frames):
     # (a fixed pseudo-random direction per head output: sum(p^2) behind a BatchNorm has a zero gradient)
     tgt = [torch.randn(frames, 128, -(-255 // s), -(-448 // s), device=dev) for s in (4, 8, 16, 32)]
 
+    adam = torch.optim.Adam(params, lr=1e-6, fused=True) if "--adam" in sys.argv else None
+
     def step(ev=None):
         if ev:
             ev[0].record()
@@ -76,6 +79,8 @@ def one(variant, find, steps, frames):
         loss.backward()
         if ev:
             ev[2].record()
+        if adam is not None:                                 # (something between two steps, like a trainer has)
+            adam.step()
         return loss
 
     t0 = time.perf_counter()
@@ -92,6 +97,22 @@ def one(variant, find, steps, frames):
     wall = (time.perf_counter() - t0) / steps * 1e3
     fwd = sorted(e[0].elapsed_time(e[1]) for e in evs)[steps // 2]
     bwd = sorted(e[1].elapsed_time(e[2]) for e in evs)[steps // 2]
+    if variant.startswith("train") and "nograph" not in variant and "--segments" in sys.argv:
+        # replay time of every captured graph alone (no overlap): where the step's time sits, segment by segment
+        plan = next(iter(enc._plans.values()))[0]
+        def rep(g, n=20):
+            for _ in range(3):
+                g.replay()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            return round(a.elapsed_time(b) / n, 3)
+        seg = {"fwd": {k: rep(g) for k, g in plan.fwd.items()}, "bwd_chain": {k: rep(g) for k, g in plan.bwd.items()},
+               "bwd_wgrad": {k: rep(g) for k, g in plan.wgrad.items()}}
+        print(json.dumps({"segments_ms": seg}), flush=True)
     print(json.dumps({"variant": variant, "find": bool(find), "frames": frames,
                       "suggest_nhwc": os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC"),
                       "suggest_nhwc_bn": os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"),
