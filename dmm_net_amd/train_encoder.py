@@ -7,7 +7,7 @@ Counterpart of ``dmm/modules/model_encoder.py:86-162`` + ``base.py:18-69`` + ``v
 
 * **whole forward / backward as HIP-graph replays.**  At the trainer's batch (12 frames of 255 x 448) a ResNet-101 step is
   ~2 100 launches of 5-50 us kernels: the stock step is HOST bound (device kernel time 17.6 ms inside a 24.4 ms step under
-  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem + layer1 | layer2 | layer3 in parts | layer4 |
+  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem | layer1 | layer2 | layer3 in parts | layer4 |
   heads); each segment's forward and its backward (``torch.autograd.grad`` over the segment) are captured once per input
   shape and replayed.  Segment k+1 reads segment k's static output in place; backward replays run last segment first and
   after each one that segment's parameter gradients are handed over -- so a gradient all-reduce (``GradBucketer`` hooks)
@@ -330,7 +330,7 @@ class TrainEncoder(nn.Module):
         self.own_wgrad = bool(own_wgrad)
         self.overlap_wgrad = bool(overlap_wgrad) and self.own_wgrad
         self.skips_need_grad, self.miopen_find, self.warmup = bool(skips_need_grad), bool(miopen_find), int(warmup)
-        # the body as a CHAIN of segments: stem + layer1 | layer2 | layer3 in ``layer3_parts`` runs of blocks | layer4, then the
+        # the body as a CHAIN of segments: stem | layer1 | layer2 | layer3 in ``layer3_parts`` runs of blocks | layer4, then the
         # heads.  (name, the blocks it runs, which of the four taps x2..x5 its output is, or None.)  Finer segments = a finer
         # pipeline between the backward chain and the weight-gradient graphs on the side stream: the exposed tail is the FIRST
         # segment's weight gradients, and a segment's weight gradients should not outlast the next segment's chain (layer3 is
@@ -339,7 +339,7 @@ class TrainEncoder(nn.Module):
         l3 = list(body.layer3)
         n3 = max(1, min(int(layer3_parts), len(l3)))
         cuts = [round(i * len(l3) / n3) for i in range(n3 + 1)]
-        chain = [("stem1", ["stem"] + list(body.layer1), 0), ("layer2", list(body.layer2), 1)]
+        chain = [("stem", ["stem"], None), ("layer1", list(body.layer1), 0), ("layer2", list(body.layer2), 1)]
         chain += [(f"layer3_{i}" if n3 > 1 else "layer3", l3[cuts[i]:cuts[i + 1]], 2 if i == n3 - 1 else None) for i in range(n3)]
         chain.append(("layer4", list(body.layer4), 3))
         self.__dict__["_chain"] = chain
@@ -534,7 +534,7 @@ class TrainEncoder(nn.Module):
 
 
 class _Plan:
-    """The captured graphs of one input shape: forward graphs along ``enc.segments`` (stem + layer1 -> layer2 -> layer3 in parts
+    """The captured graphs of one input shape: forward graphs along ``enc.segments`` (stem -> layer1 -> layer2 -> layer3 in parts
     -> layer4 -> heads; each reads its predecessor's static outputs in place), backward graphs in the reverse order (each reads its successors' static input
     gradients in place), all in one memory pool and captured in the order they replay."""
 
@@ -572,22 +572,23 @@ class _Plan:
 
         def leaf(t):
             return t.detach().requires_grad_(True)
-        def capture(name, fn, *inputs):
-            g = SafeGraph()
-            arena = _Arena(dev, enc._arena_floats(name, False))
-            with g.capture(pool=pool), _arena_scope(arena):
-                outs = fn(*inputs)
-            self.fwd[name], self.ins[name], self.outs[name] = g, inputs, outs
-            self.arenas.append(arena)
-            return outs
-        taps, x = [None] * 4, self.static_img
-        for k_, (name, _, tap) in enumerate(chain):
-            inp = x if k_ == 0 else leaf(x)
-            (x,) = capture(name, lambda t, name=name: enc._seg_body(name, t), inp)
-            if tap is not None:
-                taps[tap] = x
-        hin = [leaf(t) for t in taps]
-        heads = capture("heads", enc._seg_heads, *hin)
+        # ONE graph for the whole forward (the segments only matter to the backward: each still gets an autograd graph of its
+        # own, because its input is a detached leaf) -- seven replays with their launch gaps were ~0.5 ms of a 5 ms forward
+        gfw = SafeGraph()
+        arena = _Arena(dev, sum(enc._arena_floats(n, False) for n in enc.segments))
+        self.arenas.append(arena)
+        with gfw.capture(pool=pool), _arena_scope(arena):
+            taps, x = [None] * 4, self.static_img
+            for k_, (name, _, tap) in enumerate(chain):
+                inp = x if k_ == 0 else leaf(x)
+                (x,) = enc._seg_body(name, inp)
+                self.ins[name], self.outs[name] = (inp,), (x,)
+                if tap is not None:
+                    taps[tap] = x
+            hin = [leaf(t) for t in taps]
+            heads = enc._seg_heads(*hin)
+            self.ins["heads"], self.outs["heads"] = tuple(hin), heads
+        self.fwd = {"all": gfw}
         # ---- backward captures, reverse order.  Gradients that arrive from outside: one static buffer per head output that
         # requires grad.  Gradients between segments: the tensors autograd.grad returned in the successor's capture.
         self.gout = [torch.zeros_like(o) if o.requires_grad else None for o in heads]
@@ -673,8 +674,7 @@ class _Plan:
                         p.grad = p.grad.clone()
             self.aliased = False
         self.static_img.copy_(img)
-        for name in enc.segments:
-            self.fwd[name].replay()
+        self.fwd["all"].replay()
         self.busy = True
         hubs = enc._hubs_for(img.device)
         token = None
@@ -757,7 +757,7 @@ class _Lease:
 
 
 class _SegFn(torch.autograd.Function):
-    """One segment of a plan as an autograd node.  The nodes of a plan are chained by a token (stem1 -> layer2 -> layer3_* -> layer4 ->
+    """One segment of a plan as an autograd node.  The nodes of a plan are chained by a token (stem -> layer1 -> layer2 -> layer3_* -> layer4 ->
     heads; the heads' node returns the real outputs), so autograd runs their backwards last segment first; the data itself
     moves between the captured graphs in their static buffers.  Every node also takes the encoder's HUB leaf of its segment:
     autograd runs a leaf's AccumulateGrad once per backward pass, after the LAST node that uses it -- with several forwards
