@@ -44,7 +44,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .encoder import Bottleneck, FeatureEncoder, ResNetBody
+from .encoder import _NO_CTX, Bottleneck, FeatureEncoder, ResNetBody
 from .graphs import SafeGraph
 
 _CL = torch.channels_last
@@ -362,16 +362,14 @@ class TrainEncoder(nn.Module):
         y = _conv(x, conv, self.dtype, self.linear_1x1, self.own_wgrad, t.get(id(conv)))
         return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t)
 
-    def _tick(self, name: str, x: torch.Tensor):
+    def _tick(self, name: str, x: torch.Tensor, mods=None):
         """Per-segment housekeeping in ONE launch each instead of one per layer: ``num_batches_tracked += 1`` of every
         BatchNorm that takes the fused kernels (116 launches per ResNet-101 step before), and the bf16 copies of the 1x1
         weights (70).  ``_ticked`` tells ``_cbr`` which modules were covered."""
         t = self.__dict__["_ticked"]
         if not (x.is_cuda and self.dtype == torch.bfloat16 and self.training):
             return
-        mods = [m for mod in self._seg_modules()[name] for m in mod.modules()]
-        if name == "heads" and not self.skips_need_grad:
-            pass                                           # (the skips run under no_grad but still in training mode: counted too)
+        mods = [m for mod in (self._seg_modules()[name] if mods is None else mods) for m in mod.modules()]
         if self.fused_bn:
             bns = [m for m in mods if isinstance(m, nn.BatchNorm2d) and m.training and _bn_fusable(m)]
             if bns:
@@ -424,15 +422,31 @@ class TrainEncoder(nn.Module):
         out = self._cbr(x, head[0], head[1], True)                       # base.py:43-54: conv -> BN -> ReLU -> conv -> BN
         return self._cbr(out, head[3], head[4], False)
 
-    def _seg_heads(self, x2, x3, x4, x5):
+    def _head_level(self, k: int, x, tick: bool = True):
+        """The heads of ONE pyramid level (k = 2..5) on that level's tap: ``prop_k`` (-> fp32 NCHW: what the ROI feature kernel,
+        forward and backward, works on) and the decoder's skip projection ``bn_k(sk_k(x))``.  -> (prop, skip)"""
         s = self.src
-        self._tick("heads", x2)
-        props = [self._head(x, getattr(s, f"prop{k}")) for k, x in ((2, x2), (3, x3), (4, x4), (5, x5))]
+        if tick:
+            self._tick("heads", x, mods=self._head_modules(k))
+        prop = self._head(x, getattr(s, f"prop{k}"))
         with (torch.enable_grad() if self.skips_need_grad else torch.no_grad()):
-            skips = [self._cbr(x, getattr(s, f"sk{k}"), getattr(s, f"bn{k}"), False)
-                     for k, x in ((5, x5), (4, x4), (3, x3), (2, x2))]
-        # the ROI feature kernel (forward and backward) works on fp32 NCHW levels
-        return tuple(p.float().contiguous() for p in props) + tuple(skips)
+            skip = self._cbr(x, getattr(s, f"sk{k}"), getattr(s, f"bn{k}"), False)
+        return prop.float().contiguous(), skip
+
+    def _head_modules(self, k: int):
+        s = self.src
+        return [getattr(s, f"prop{k}"), getattr(s, f"sk{k}"), getattr(s, f"bn{k}")]
+
+    def _head_params(self, k: int) -> List[nn.Parameter]:
+        mods = self._head_modules(k)
+        if not self.skips_need_grad:
+            mods = mods[:1]
+        return [p for m in mods for p in m.parameters() if p.requires_grad]
+
+    def _seg_heads(self, x2, x3, x4, x5):
+        self._tick("heads", x2)
+        lv = [self._head_level(k, x, tick=False) for k, x in ((2, x2), (3, x3), (4, x4), (5, x5))]
+        return tuple(p for p, _ in lv) + tuple(sk for _, sk in reversed(lv))       # props 2..5, skips 5..2
 
     def _seg_modules(self) -> Dict[str, List[nn.Module]]:
         s, body = self.src, self.src.base
@@ -448,9 +462,10 @@ class TrainEncoder(nn.Module):
     def _seg_params(self) -> Dict[str, List[nn.Parameter]]:
         out = {}
         for name, mods in self._seg_modules().items():
-            if name == "heads" and not self.skips_need_grad:
-                mods = mods[:4]
-            out[name] = [p for m in mods for p in m.parameters() if p.requires_grad]
+            if name == "heads":
+                out[name] = [p for k in (2, 3, 4, 5) for p in self._head_params(k)]
+            else:
+                out[name] = [p for m in mods for p in m.parameters() if p.requires_grad]
         return out
 
     def _arena_floats(self, name: str, backward: bool) -> int:
@@ -516,7 +531,7 @@ class TrainEncoder(nn.Module):
             self._hand_over(*late)
         if not plans:
             return
-        if any(name in p.wgrad for p in plans) and name != self.segments[0]:
+        if any(p.side is not None and (name in p.wgrad or name == "heads") for p in plans) and name != self.segments[0]:
             self.__dict__["_late"] = (name, plans)
         else:
             self._hand_over(name, plans)
@@ -566,29 +581,53 @@ class _Plan:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # ---- forward captures, in replay order; a segment's input is a DETACHED view of its predecessor's output that
-        # requires grad, so that every segment owns a separate autograd graph
-        self.fwd, self.bwd, self.ins, self.outs = {}, {}, {}, {}
+        # requires grad, so that every segment owns a separate autograd graph.  The BODY is captured as one graph per tap
+        # interval (stem + layer1 | layer2 | layer3 | layer4: what the forward needs between two taps; the finer segments only
+        # matter to the backward), the heads as one graph per pyramid level: a level's heads only need that level's tap, so
+        # their graph replays on the SIDE stream beside the deeper body graphs (two graphs on two streams overlap on this
+        # runtime, tools/graph_branch_probe.py); likewise their backward runs beside the body's backward chain.  Everything
+        # that replays on the side stream allocates from a pool of its own.
+        self.bwd, self.ins, self.outs = {}, {}, {}
         self.arenas = []                                  # statistics scratch of every captured graph (kept alive with it)
+        overlap = enc.overlap_wgrad
+        self.side = torch.cuda.Stream(device=dev) if overlap else None
+        pool_s = torch.cuda.graph_pool_handle()           # the side stream's graphs (head levels, weight gradients)
 
         def leaf(t):
             return t.detach().requires_grad_(True)
-        # ONE graph for the whole forward (the segments only matter to the backward: each still gets an autograd graph of its
-        # own, because its input is a detached leaf) -- seven replays with their launch gaps were ~0.5 ms of a 5 ms forward
-        gfw = SafeGraph()
-        arena = _Arena(dev, sum(enc._arena_floats(n, False) for n in enc.segments))
-        self.arenas.append(arena)
-        with gfw.capture(pool=pool), _arena_scope(arena):
-            taps, x = [None] * 4, self.static_img
-            for k_, (name, _, tap) in enumerate(chain):
-                inp = x if k_ == 0 else leaf(x)
-                (x,) = enc._seg_body(name, inp)
-                self.ins[name], self.outs[name] = (inp,), (x,)
-                if tap is not None:
-                    taps[tap] = x
-            hin = [leaf(t) for t in taps]
-            heads = enc._seg_heads(*hin)
-            self.ins["heads"], self.outs["heads"] = tuple(hin), heads
-        self.fwd = {"all": gfw}
+
+        def new_arena(floats):
+            a = _Arena(dev, floats)
+            self.arenas.append(a)
+            return a
+        head_floats = enc._arena_floats("heads", False)
+        self.fwd_body, self.fwd_head = [], []             # per tap interval: the body graph, the level's heads graph
+        taps, hin, lv, x, k_ = [None] * 4, [None] * 4, [None] * 4, self.static_img, 0
+        while k_ < len(chain):
+            g = SafeGraph()
+            todo = []
+            for q in range(k_, len(chain)):
+                todo.append(chain[q])
+                if chain[q][2] is not None:
+                    break
+            with g.capture(pool=pool), _arena_scope(new_arena(sum(enc._arena_floats(n, False) for n, _, _ in todo))):
+                for (name, _, tap) in todo:
+                    inp = x if name == chain[0][0] else leaf(x)
+                    (x,) = enc._seg_body(name, inp)
+                    self.ins[name], self.outs[name] = (inp,), (x,)
+            tap = todo[-1][2]
+            taps[tap] = x
+            k_ += len(todo)
+            self.fwd_body.append(g)
+            gh_ = SafeGraph()
+            hin[tap] = leaf(x)
+            with gh_.capture(pool=pool_s), _arena_scope(new_arena(head_floats)):
+                lv[tap] = enc._head_level(tap + 2, hin[tap])
+            self.fwd_head.append(gh_)
+        heads = tuple(p_ for p_, _ in lv) + tuple(sk for _, sk in reversed(lv))     # props 2..5, skips 5..2 (as _seg_heads)
+        self.ins["heads"], self.outs["heads"] = tuple(hin), heads
+        self.ev_tap = [torch.cuda.Event() for _ in range(4)]
+        self.ev_heads_fwd = torch.cuda.Event()
         # ---- backward captures, reverse order.  Gradients that arrive from outside: one static buffer per head output that
         # requires grad.  Gradients between segments: the tensors autograd.grad returned in the successor's capture.
         self.gout = [torch.zeros_like(o) if o.requires_grad else None for o in heads]
@@ -597,49 +636,62 @@ class _Plan:
         # weight gradients on a side stream (``overlap_wgrad``): a segment's backward is captured as TWO graphs -- the chain
         # (BatchNorm backward, data gradients, everything the next layer down waits for) and, from the launches recorded while
         # that capture ran, the weight gradients.  On replay the second graph runs on a side stream beside the NEXT segment's
-        # chain (two graphs on two streams do run side by side on this runtime; forked branches inside one graph do not:
-        # tools/graph_branch_probe.py).  The recorded operands (dY, X) are kept alive for the plan's lifetime -- the chain of
-        # the next segment must not reuse their memory while the side stream reads it -- and the second graphs allocate from a
-        # pool of their own.
+        # chain.  The recorded operands (dY, X) are kept alive for the plan's lifetime -- the chain of the next segment must
+        # not reuse their memory while the side stream reads it.
         self.wgrad, self.keep = {}, {}
-        pool_w = torch.cuda.graph_pool_handle() if enc.overlap_wgrad else None
-        self.side = torch.cuda.Stream(device=dev) if enc.overlap_wgrad else None
         self.ev_chain = {n: torch.cuda.Event() for n in enc.segments}
         self.ev_wgrad = {n: torch.cuda.Event() for n in enc.segments}
 
-        def capture_bwd(name, outs, make_gouts, inputs):
-            """``make_gouts``: called INSIDE the capture (sums of gradient buffers of two consumers are part of the graph)."""
+        def capture_bwd(name, outs, make_gouts, inputs, ps, chain_pool):
+            """-> (gradients of ``inputs``, gradients of ``ps``, chain graph, recorded weight-gradient launches or None).
+            ``make_gouts``: called INSIDE the capture (sums of gradient buffers of two consumers are part of the graph)."""
             global _DEFER
-            ps = self.params[name]
             wrt = [t for t in inputs if t.requires_grad] + ps
             g = SafeGraph()
-            arena = _Arena(dev, enc._arena_floats(name, True))
-            _DEFER = [] if enc.overlap_wgrad else None
+            _DEFER = [] if overlap else None
             try:
-                with g.capture(pool=pool), _arena_scope(arena):
+                with g.capture(pool=chain_pool), _arena_scope(new_arena(enc._arena_floats(name, True))):
                     grads = list(torch.autograd.grad(outs, wrt, make_gouts(), allow_unused=True))
                     # a gradient is handed over in its PARAMETER's layout (the multi-tensor optimisers refuse anything else:
                     # "params, grads ... must have same dtype, device, and layout"): the stock convolutions' weight gradients
                     # come back channels-last strided (the 7x7 stem, widths the library's kernels do not take)
-                    for k_, (t, g_) in enumerate(zip(wrt, grads)):
+                    for q, (t, g_) in enumerate(zip(wrt, grads)):
                         if g_ is not None and isinstance(t, nn.Parameter) and (g_.stride() != t.stride() or g_.dtype != t.dtype):
-                            grads[k_] = torch.empty_like(t).copy_(g_)
+                            grads[q] = torch.empty_like(t).copy_(g_)
                 records = _DEFER
             finally:
                 _DEFER = None
-            self.bwd[name] = g
-            self.arenas.append(arena)
-            if records:
-                gw = SafeGraph()
-                with gw.capture(pool=pool_w):
-                    for rec in records:
-                        _wgrad_launch(rec)
-                self.wgrad[name], self.keep[name] = gw, records
             n_in = len(wrt) - len(ps)
-            self.pgrads[name] = list(grads[n_in:])
-            return grads[:n_in]
-        ho = [o for o in heads if o.requires_grad]
-        gh = capture_bwd("heads", ho, lambda: [g for g in self.gout if g is not None], tuple(hin))
+            return grads[:n_in], list(grads[n_in:]), g, records
+
+        def capture_wgrad(name, records):
+            if not records:
+                return None
+            gw = SafeGraph()
+            with gw.capture(pool=pool_s):
+                for rec in records:
+                    _wgrad_launch(rec)
+            self.keep.setdefault(name, []).extend(records)
+            return gw
+        # the heads, level by level, deepest first (the order the body's backward needs their tap gradients in)
+        self.bwd_head, self.ev_bh = [None] * 4, [torch.cuda.Event() for _ in range(4)]
+        gh, hgrads, hrec = [None] * 4, {}, []
+        where = {id(o): n for n, o in enumerate(heads)}
+        for tap in (3, 2, 1, 0):
+            prop, skip = lv[tap]
+            outs_ = [o for o in (prop, skip) if o.requires_grad]
+            gbuf = [self.gout[where[id(o)]] for o in outs_]
+            ps = enc._head_params(tap + 2)
+            (gin,), pg, g, records = capture_bwd("heads", outs_, lambda gbuf=gbuf: list(gbuf), (hin[tap],), ps, pool_s)
+            gh[tap], self.bwd_head[tap] = gin, g
+            hgrads.update({id(p_): g_ for p_, g_ in zip(ps, pg)})
+            hrec.append(records)
+        self.pgrads["heads"] = [hgrads.get(id(p_)) for p_ in self.params["heads"]]
+        # (captured in the order they replay on the side stream -- the four chains, then the four weight-gradient graphs: graphs
+        # that share a pool replay in their capture order)
+        hw = [g for g in (capture_wgrad("heads", r) for r in hrec) if g is not None]
+        if hw:
+            self.wgrad["heads"] = hw
         # a tap feeds the next body segment AND the heads: its gradient is the sum of the two static buffers (one add, captured
         # at the head of the segment's backward)
         g_next = None
@@ -647,8 +699,14 @@ class _Plan:
             name, _, tap = chain[k_]
             terms = [t for t in (g_next, gh[tap] if tap is not None else None) if t is not None]
             make = (lambda terms=terms: [terms[0] + terms[1]]) if len(terms) == 2 else (lambda terms=terms: [terms[0]])
-            got = capture_bwd(name, list(self.outs[name]), make, self.ins[name] if k_ > 0 else ())
-            g_next = got[0] if k_ > 0 else None
+            gin, pg, g, records = capture_bwd(name, list(self.outs[name]), make, self.ins[name] if k_ > 0 else (),
+                                              self.params[name], pool)
+            self.bwd[name], self.pgrads[name] = g, pg
+            gw = capture_wgrad(name, records)
+            if gw is not None:
+                self.wgrad[name] = [gw]
+            g_next = gin[0] if k_ > 0 else None
+        self.tap_of = {name: tap for name, _, tap in chain}
         self.result = TrainEncoder._pack(taps, heads)
         self.heads = heads
         self.token = torch.zeros((), device=dev)           # what the segment nodes hand each other (autograd ordering only)
@@ -656,8 +714,10 @@ class _Plan:
         self.busy = False
         self.aliased = False                               # some p.grad may still BE one of this plan's static buffers
         # what the rewrite found: {segment: (memset nodes, memcpy nodes) turned into kernel nodes} per direction
-        self.rewritten = {"fwd": {k: g.rewritten for k, g in self.fwd.items()}, "bwd": {k: g.rewritten for k, g in self.bwd.items()},
-                          "wgrad": {k: g.rewritten for k, g in self.wgrad.items()}}
+        tot = lambda gs: tuple(sum(g.rewritten[q] for g in gs) for q in (0, 1))
+        self.rewritten = {"fwd": {"body": tot(self.fwd_body), "heads": tot(self.fwd_head)},
+                          "bwd": dict({k: g.rewritten for k, g in self.bwd.items()}, heads=tot(self.bwd_head)),
+                          "wgrad": {k: tot(gs) for k, gs in self.wgrad.items()}}
         for (rm, rv, nb), m in zip(keep, bns):
             with torch.no_grad():
                 m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
@@ -674,7 +734,19 @@ class _Plan:
                         p.grad = p.grad.clone()
             self.aliased = False
         self.static_img.copy_(img)
-        self.fwd["all"].replay()
+        main = torch.cuda.current_stream(img.device)
+        for t in range(4):
+            self.fwd_body[t].replay()
+            if self.side is None:
+                self.fwd_head[t].replay()
+            else:                                          # this level's heads beside the deeper body graphs
+                self.ev_tap[t].record(main)
+                self.side.wait_event(self.ev_tap[t])
+                with torch.cuda.stream(self.side):
+                    self.fwd_head[t].replay()
+        if self.side is not None:
+            self.ev_heads_fwd.record(self.side)
+            main.wait_event(self.ev_heads_fwd)
         self.busy = True
         hubs = enc._hubs_for(img.device)
         token = None
@@ -704,20 +776,44 @@ class _Plan:
         for p, g in zip(self.params[name], self.pgrads[name]):
             if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
                 p.grad = p.grad.clone()
-        self.bwd[name].replay()
-        gw = self.wgrad.get(name)
-        if gw is not None:
-            main = torch.cuda.current_stream(self.static_img.device)
-            self.ev_chain[name].record(main)
-            self.side.wait_event(self.ev_chain[name])
-            with torch.cuda.stream(self.side):
-                gw.replay()
-                self.ev_wgrad[name].record(self.side)
+        main = torch.cuda.current_stream(self.static_img.device)
+        side = self.side
+        if name == "heads":
+            # the heads' backward, deepest level first, on the side stream: the body's chain only waits for the level whose tap
+            # gradient it needs next
+            if side is not None:
+                self.ev_chain[name].record(main)           # (the incoming gradients are in their static buffers)
+                side.wait_event(self.ev_chain[name])
+            with (torch.cuda.stream(side) if side is not None else _NO_CTX):
+                for tap in (3, 2, 1, 0):
+                    self.bwd_head[tap].replay()
+                    if side is not None:
+                        self.ev_bh[tap].record(side)
+                for gw in self.wgrad.get(name, ()):
+                    gw.replay()
+                if side is not None:
+                    self.ev_wgrad[name].record(side)
+        else:
+            tap = self.tap_of[name]
+            if side is not None and tap is not None:
+                main.wait_event(self.ev_bh[tap])
+            self.bwd[name].replay()
+            if name in self.wgrad:
+                if side is None:
+                    for gw in self.wgrad[name]:
+                        gw.replay()
+                else:
+                    self.ev_chain[name].record(main)
+                    side.wait_event(self.ev_chain[name])
+                    with torch.cuda.stream(side):
+                        for gw in self.wgrad[name]:
+                            gw.replay()
+                        self.ev_wgrad[name].record(side)
         self.enc.__dict__["_pending"].setdefault(name, []).append(self)
 
     def wait_wgrad(self, name: str):
         """The current stream waits for this plan's weight-gradient graph of ``name`` (a no-op without one)."""
-        if name in self.wgrad:
+        if self.side is not None and (name in self.wgrad or name == "heads"):
             torch.cuda.current_stream(self.static_img.device).wait_event(self.ev_wgrad[name])
 
 

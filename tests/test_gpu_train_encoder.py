@@ -272,6 +272,7 @@ def test_weight_gradients_on_the_side_stream_change_no_gradient():
     plan = next(iter(side._plans.values()))[0]
     # (the stem's 7x7 convolution stays on the stock path: its segment has no weight-gradient graph of its own)
     assert set(plan.wgrad) == set(side.segments) - {"stem"} and side.segments[0] == "stem" and side.segments[-1] == "heads"
+    assert len(plan.fwd_body) == 4 and len(plan.fwd_head) == 4 and plan.side is not None
     assert not plan.busy
 
 

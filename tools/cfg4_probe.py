@@ -110,8 +110,13 @@ def one(variant, find, steps, frames):
             b.record()
             torch.cuda.synchronize()
             return round(a.elapsed_time(b) / n, 3)
-        seg = {"fwd": {k: rep(g) for k, g in plan.fwd.items()}, "bwd_chain": {k: rep(g) for k, g in plan.bwd.items()},
-               "bwd_wgrad": {k: rep(g) for k, g in plan.wgrad.items()}}
+        class _Seq:
+            def __init__(self, gs): self.gs = gs
+            def replay(self):
+                for g_ in self.gs: g_.replay()
+        seg = {"fwd_body": [rep(g) for g in plan.fwd_body], "fwd_heads": [rep(g) for g in plan.fwd_head],
+               "bwd_heads": [rep(g) for g in plan.bwd_head], "bwd_chain": {k: rep(g) for k, g in plan.bwd.items()},
+               "bwd_wgrad": {k: rep(_Seq(gs)) for k, gs in plan.wgrad.items()}}
         print(json.dumps({"segments_ms": seg}), flush=True)
     print(json.dumps({"variant": variant, "find": bool(find), "frames": frames,
                       "suggest_nhwc": os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC"),
