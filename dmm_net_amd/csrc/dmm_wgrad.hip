@@ -140,6 +140,114 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t *__restr
             *reinterpret_cast<const float4 *>(&tile_s[row * 64 + c4 + 4 * k]);
 }
 
+// The same product for shapes whose widths are multiples of 128 (everything from layer2 on): one workgroup = a 128 (co) x 128 (cv)
+// tile over ONE slab of rows, its four waves the 2 x 2 sub-tiles of 64 x 64 -- all on the same rows.  The rows of both
+// operands go through LDS: 32 rows x 128 channels of dY and of X per stage, fetched with 16-byte lane loads (two per operand
+// and thread) while the previous stage is being multiplied (two LDS buffers, one barrier per stage); a wave then reads its
+// fragments' dwords from LDS exactly as the 64-wide kernel reads them from memory.  Every operand element now leaves L2 once
+// per 128-wide tile of the other operand and in 16-byte pieces: 0.5 KB of operand per MFMA instead of 1 KB in 4-byte pieces.
+// No fold: each wave stores its own sub-tile (float2 per lane: 256 contiguous bytes per 32 lanes).
+template <bool PATCH>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                        int64_t R, int Co, int Cv, int64_t ldy, int64_t ldx,
+                                                        float *__restrict__ out, int64_t group_stride, int64_t rows_per_group,
+                                                        int cv_tiles, PatchGeom pg) {
+    __shared__ __attribute__((aligned(16))) uint16_t sA[2][32][128];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[2][32][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int tile = blockIdx.x;
+    const int co0 = (tile / cv_tiles) * 128, cv0 = (tile % cv_tiles) * 128;
+    const int co_w = (wave >> 1) * 64, cv_w = (wave & 1) * 64;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_group;
+    int64_t r1 = r0 + rows_per_group;
+    if (r1 > R) r1 = R;
+    int tap_dh = 0, tap_dw = 0, cin0 = cv0;
+    if (PATCH) {
+        const int tap = cv0 / pg.Ci;
+        cin0 = cv0 - tap * pg.Ci;
+        tap_dh = tap / 3 - 1;
+        tap_dw = tap % 3 - 1;
+    }
+    // this thread's two 16-byte pieces of a stage: rows lr and lr + 16, channels 8 * lc .. 8 * lc + 7
+    const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
+    u32x4w ra[2], rb[2];
+    auto fetch = [&](int64_t r) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = r + lr + 16 * q;
+            const bool ok = row < r1;
+            const u32x4w z = {0u, 0u, 0u, 0u};
+            ra[q] = ok ? *reinterpret_cast<const u32x4w *>(dy + row * ldy + co0 + 8 * lc) : z;
+            if (!PATCH) {
+                rb[q] = ok ? *reinterpret_cast<const u32x4w *>(x + row * ldx + cin0 + 8 * lc) : z;
+            } else {
+                const int64_t qd = row / pg.Wo;
+                const int pw = (int)(row - qd * pg.Wo);
+                const int pb = (int)(qd / pg.Ho);
+                const int ph = (int)(qd - (int64_t)pb * pg.Ho);
+                const int hi = ph * pg.stride + tap_dh, wi = pw * pg.stride + tap_dw;
+                const bool in = ok && hi >= 0 && hi < pg.H && wi >= 0 && wi < pg.W;
+                rb[q] = in ? *reinterpret_cast<const u32x4w *>(x + (((int64_t)pb * pg.H + hi) * pg.W + wi) * ldx + cin0 + 8 * lc)
+                           : z;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<u32x4w *>(&sA[buf][lr + 16 * q][8 * lc]) = ra[q];
+            *reinterpret_cast<u32x4w *>(&sB[buf][lr + 16 * q][8 * lc]) = rb[q];
+        }
+    };
+    f32x16w acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc00[k] = acc01[k] = acc10[k] = acc11[k] = 0.0f;
+    if (r0 < r1) {
+        fetch(r0);
+        stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t r = r0; r < r1; r += 32, buf ^= 1) {
+        const bool more = r + 32 < r1;
+        if (more) fetch(r + 32);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                      // two 16-row MFMA steps per stage
+            uint32_t wa[8], wb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wa[j] = *reinterpret_cast<const uint32_t *>(&sA[buf][16 * h + 8 * g + j][co_w + 2 * i]);
+                wb[j] = *reinterpret_cast<const uint32_t *>(&sB[buf][16 * h + 8 * g + j][cv_w + 2 * i]);
+            }
+            u32x4w a0, a1, b0, b1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                a0[p] = pair_lo(wa[2 * p], wa[2 * p + 1]);
+                a1[p] = pair_hi(wa[2 * p], wa[2 * p + 1]);
+                b0[p] = pair_lo(wb[2 * p], wb[2 * p + 1]);
+                b1[p] = pair_hi(wb[2 * p], wb[2 * p + 1]);
+            }
+            const bf16x8w fa0 = __builtin_bit_cast(bf16x8w, a0), fa1 = __builtin_bit_cast(bf16x8w, a1);
+            const bf16x8w fb0 = __builtin_bit_cast(bf16x8w, b0), fb1 = __builtin_bit_cast(bf16x8w, b1);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    float *o = out + (int64_t)blockIdx.y * group_stride;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * g;
+        float *p0 = o + (int64_t)(co0 + co_w + 2 * m) * Cv + cv0 + cv_w + 2 * i;
+        *reinterpret_cast<float2 *>(p0) = make_float2(acc00[reg], acc01[reg]);
+        *reinterpret_cast<float2 *>(p0 + Cv) = make_float2(acc10[reg], acc11[reg]);
+    }
+}
+
 // dw[...] = sum over the groups' partial tables, in group order (deterministic).  taps = 1: dw is [Co, Cv] like the partials;
 // taps = 9: partial column v = tap * Ci + cin goes to the master's layout dw[co, cin, tap] ([Co, Ci, 3, 3] contiguous).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int groups, int64_t n, int Cv,
@@ -162,13 +270,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 struct WgradPlan {
-    int64_t rows_per_wave, groups;
+    int64_t rows_per_wave, groups;       // (wide: rows per GROUP -- one workgroup takes one slab)
     int cv_tiles;
     int64_t tiles;
+    bool wide;                           // the 128 x 128 LDS-staged kernel
 };
 
-static WgradPlan wgrad_plan(int64_t R, int Co, int Cv) {
+static WgradPlan wgrad_plan(int64_t R, int Co, int Cv, int Ci_patch) {
     WgradPlan p;
+    p.wide = !(Co & 127) && !(Cv & 127) && (Ci_patch == 0 || !(Ci_patch & 127));
+    if (p.wide) {
+        p.cv_tiles = Cv / 128;
+        p.tiles = (int64_t)(Co / 128) * p.cv_tiles;
+        // ~768 workgroups per launch, >= 2 stages of 32 rows each, partial tables of <= ~32 MB in all
+        int64_t groups = (768 + p.tiles - 1) / p.tiles;
+        const int64_t by_rows = (R + 63) / 64, by_bytes = (8LL << 20) / ((int64_t)Co * Cv);
+        if (groups > by_rows) groups = by_rows;
+        if (groups > by_bytes) groups = by_bytes;
+        if (groups < 1) groups = 1;
+        int64_t rpg = (R + groups - 1) / groups;
+        p.rows_per_wave = (rpg + 31) / 32 * 32;
+        p.groups = (R + p.rows_per_wave - 1) / p.rows_per_wave;
+        return p;
+    }
     p.cv_tiles = Cv / 64;
     p.tiles = (int64_t)(Co / 64) * p.cv_tiles;
     // slabs: ~2048 waves per launch, >= 8 steps of 16 rows per wave, partial tables of <= ~16 MB in all; 4 slabs = 1 group
@@ -187,14 +311,23 @@ static WgradPlan wgrad_plan(int64_t R, int Co, int Cv) {
 
 static int wgrad_launch(const void *dy, const void *x, int64_t R, int Co, int Cv, int64_t ldy, int64_t ldx, float *dw,
                         void *workspace, size_t workspace_bytes, bool patch, PatchGeom pg, hipStream_t stream) {
-    const WgradPlan p = wgrad_plan(R, Co, Cv);
+    const WgradPlan p = wgrad_plan(R, Co, Cv, patch ? pg.Ci : 0);
     if (p.tiles > 0x7fffffffLL || p.groups > 65535) return DMM_ERR_UNSUPPORTED;
     const int64_t n = (int64_t)Co * Cv;
     const bool direct = p.groups == 1 && !patch;          // one group and nothing to transpose: straight into dw
     if (!direct && (!workspace || workspace_bytes < sizeof(float) * (size_t)(p.groups * n))) return DMM_ERR_WORKSPACE;
     float *out = direct ? dw : (float *)workspace;
     const dim3 grid((unsigned)p.tiles, (unsigned)p.groups);
-    if (patch)
+    if (p.wide && (ldy & 7) == 0 && (ldx & 7) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0) {
+        if (patch)
+            hipLaunchKernelGGL((wgrad_lds_kernel<true>), grid, dim3(256), 0, stream, (const uint16_t *)dy, (const uint16_t *)x,
+                               R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+        else
+            hipLaunchKernelGGL((wgrad_lds_kernel<false>), grid, dim3(256), 0, stream, (const uint16_t *)dy,
+                               (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+    } else if (p.wide) {
+        return DMM_ERR_UNSUPPORTED;                        // (16-byte pieces need 16-byte aligned rows)
+    } else if (patch)
         hipLaunchKernelGGL((wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, (const uint16_t *)dy, (const uint16_t *)x, R,
                            Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
     else
@@ -211,7 +344,8 @@ static int wgrad_launch(const void *dy, const void *x, int64_t R, int Co, int Cv
 
 extern "C" size_t dmm_wgrad_workspace_bytes(int64_t rows, int co, int cv) {
     if (rows <= 0 || co <= 0 || cv <= 0 || (co & 63) || (cv & 63)) return 0;
-    const dmm::WgradPlan p = dmm::wgrad_plan(rows, co, cv);
+    // (the 3x3 form asks with cv = 9 * ci: 128 divides 9 * ci exactly when it divides ci, so the plan is the launcher's)
+    const dmm::WgradPlan p = dmm::wgrad_plan(rows, co, cv, 0);
     return sizeof(float) * (size_t)(p.groups * (int64_t)co * cv);
 }
 
