@@ -48,6 +48,8 @@ from .encoder import _NO_CTX, Bottleneck, FeatureEncoder, ResNetBody
 from .graphs import SafeGraph
 
 _CL = torch.channels_last
+_CAPTURE_LOCK = __import__("threading").Lock()     # plan captures set module-level scratch (_ARENA, _DEFER) and put the process
+#                                                    into HIP's global capture mode: one at a time (nn.DataParallel threads)
 
 
 # ---- scratch for the BatchNorm statistics ------------------------------------------------------------------------------
@@ -503,7 +505,8 @@ class TrainEncoder(nn.Module):
         # that (the trainer's clip: one encoder call per frame, one backward; trainer.py:95-131) takes / captures another plan
         plan = next((p for p in plans if not p.busy), None)
         if plan is None:
-            plan = _Plan(self, img)
+            with _CAPTURE_LOCK:
+                plan = _Plan(self, img)
             plans.append(plan)
         return plan.run(img)
 
