@@ -3,38 +3,44 @@
 Counterpart of ``dmm/modules/model_encoder.py:86-162`` + ``base.py:18-69`` + ``vision.py:6-38`` under
 ``train.py:296-307`` (forward, ``loss.backward()``, optimiser step).  Same parameters as ``FeatureEncoder`` -- the fp32
 ``nn.Parameter`` objects of the wrapped encoder stay the masters the optimiser, the checkpoints and
-``distributed.GradBucketer`` see -- evaluated the way that is fast on MI355X:
+``distributed.GradBucketer`` see -- evaluated the way that is fast on MI355X (12 frames of 255 x 448, ResNet-101: 31.25 ms
+per training step with the stock fp32 modules, 15.4 ms here; ``profiles/r06_cfg4_train_encoder_steps.md`` has every step in
+between):
 
-* **whole forward / backward as HIP-graph replays.**  At the trainer's batch (12 frames of 255 x 448) a ResNet-101 step is
-  ~2 100 launches of 5-50 us kernels: the stock step is HOST bound (device kernel time 17.6 ms inside a 24.4 ms step under
-  bf16 autocast, ``profiles/r06_cfg4_train_encoder_steps.md``).  The encoder is cut into a few SEGMENTS (stem | layer1 | layer2 | layer3 in parts | layer4 |
-  heads); each segment's forward and its backward (``torch.autograd.grad`` over the segment) are captured once per input
-  shape and replayed.  Segment k+1 reads segment k's static output in place; backward replays run last segment first and
-  after each one that segment's parameter gradients are handed over -- so a gradient all-reduce (``GradBucketer`` hooks)
-  starts under the backward of the segments still to run.
-* **bf16 activations, channels-last, end to end; fp32 master weights.**  Weights are cast inside the graphs (differentiable
-  cast: the backward graph ends in fp32 gradients for the masters); BatchNorm runs on bf16 activations with fp32 parameters
-  and statistics.  No autocast (its per-call weight casts and cache are what ``make_graphed_callables`` has to switch off).
-* **1x1 convolutions are matrix products** of the [B*H*W, Cin] activation matrix (2/3 of a bottleneck): forward, data
-  gradient and weight gradient go to hipBLASLt as plain GEMMs instead of MIOpen's implicit-GEMM kernels and their
-  zero / cast helper launches.
+* **forward and backward as HIP-graph replays.**  The stock step is ~2 100 launches of 5-50 us kernels and HOST bound (17.6 ms
+  of kernels inside a 24.4 ms step under bf16 autocast).  The body is cut into a CHAIN of segments (stem | layer1 | layer2 |
+  layer3 in parts | layer4) plus the heads; the forward between two taps and every segment's backward
+  (``torch.autograd.grad`` over the segment) are captured once per input shape and replayed; segments hand activations and
+  gradients to each other in static buffers.  Memset nodes of a capture are rewritten into kernel nodes (``graphs.SafeGraph``).
+* **two streams.**  In the backward only the data gradients are on the critical chain.  A segment's weight gradients are
+  recorded while its chain is captured and captured afterwards into a graph of their own that replays on a SIDE stream beside
+  the next segment's chain; the heads of a pyramid level (forward and backward) are side-stream graphs too.  (Two graphs on
+  two streams overlap on this runtime; forked branches inside one graph do not: ``tools/graph_branch_probe.py``.)
+* **bf16 activations, channels-last, end to end; fp32 master weights.**  BatchNorm runs on bf16 activations with fp32
+  parameters and statistics.  No autocast.
+* **1x1 convolutions are matrix products** of the [B*H*W, Cin] activation matrix (2/3 of a bottleneck): forward and data
+  gradient on hipBLASLt; 3x3 forward / data gradient on MIOpen; EVERY weight gradient from ``dmm_wgrad*_bf16``
+  (``csrc/dmm_wgrad.hip``: MFMA, split over the rows, fp32 straight into the master's gradient, no atomics) -- hipBLASLt's pick
+  for these products has no split-K (66 us each), MIOpen's bf16 solvers bring a zeroing and a cast launch each.
 * **BatchNorm (+ residual) (+ ReLU) as two launches each way** (``dmm_bn_*`` in ``csrc/dmm_encoder_train.hip``) where the
   stock path issues 5-6 (three MIOpen BatchNorm kernels + add + clamp; backward likewise).
 
-Gradient hand-over.  Parameter gradients are NOT returned through autograd (350 inputs to one Function): after a segment's
-backward replay every parameter of the segment gets ``p.grad`` (the graph's static gradient buffer itself when ``p.grad is
-None``, else accumulated into the existing tensor) and its post-accumulate-grad hooks are called, exactly what autograd's
-AccumulateGrad does -- ``GradBucketer(overlap=True)`` and plain optimisers work unchanged.  As with DDP's bucket views, a
-gradient may alias a static buffer of the captured step: it is valid until the encoder's next forward (which moves a
-gradient that is still in place -- gradient accumulation -- into a tensor of its own first); do not hold on to the tensor
-object itself across steps.
+Gradient hand-over.  Parameter gradients are NOT returned through autograd (350 inputs to one node).  Each segment is an
+autograd node chained to its neighbours by a token, and also takes the segment's HUB leaf: a leaf's AccumulateGrad runs once
+per backward pass after its last user -- the moment every forward in flight (the reference's trainer calls the encoder once
+per frame of a clip and backpropagates once, ``trainer.py:95-131``; each such forward owns a plan) has produced the segment's
+gradients.  The hub's hook sums them, sets / accumulates ``p.grad`` and calls the parameters' post-accumulate-grad hooks, like
+AccumulateGrad does -- ``GradBucketer(overlap=True)`` and plain optimisers work unchanged.  A segment is handed over one
+segment late (the hand-over waits for its side-stream graph).  As with DDP's bucket views, a gradient may alias a static
+buffer of the captured step: it is valid until the encoder's next forward (which moves a gradient that is still in place --
+gradient accumulation -- into a tensor of its own first); do not hold on to the tensor object itself across steps.
 
 Not supported: double backward, ``retain_graph`` replays of the same forward, forward hooks on the wrapped modules, changing
 ``requires_grad`` of a parameter after the first forward of a shape (the captured backward computes the gradients of the
 parameters that required one at capture time).  In-place parameter updates (optimiser steps, ``load_state_dict``) are seen
-by the replays; ``.to()`` / ``.cuda()`` drop the captured plans.
-Off the GPU (or with ``graphs=False``) the same segment functions run eagerly under autograd -- that is what the CPU
-tests compare with the fp32 ``FeatureEncoder``.
+by the replays; ``.to()`` / ``.cuda()`` drop the captured plans.  Fallbacks inside the same segments: the 7x7 stem and widths
+that are not multiples of 64 take the stock convolution ops, ``dtype=float32`` the stock BatchNorm as well (the mode the tests
+pin the plumbing with).  Off the GPU (or with ``graphs=False``) the same segment functions run eagerly under autograd.
 """
 from __future__ import annotations
 
@@ -319,7 +325,14 @@ class TrainEncoder(nn.Module):
 
     ``skips_need_grad``: the decoder's inputs (``refine_input_feat``: ``sk_k`` + ``bn_k``) take part in the backward.  A
     trainer with the refine decoder leaves it on; a step that never sends a gradient there (bench.py's config 4: no decoder)
-    switches it off so that the backward graph does not run those four convolutions on zeros."""
+    switches it off so that the backward graph does not run those four convolutions on zeros.
+
+    A/B switches (each measured in ``profiles/r06_cfg4_train_encoder_steps.md``; the defaults are the fast settings):
+    ``graphs`` (False: the same segment functions eagerly), ``linear_1x1`` (False: 1x1 convolutions on MIOpen too),
+    ``fused_bn`` (False: ``torch.nn.BatchNorm2d`` + add + relu), ``own_wgrad`` (False: the libraries' weight gradients),
+    ``overlap_wgrad`` (False: one stream -- weight gradients inline in the chain, heads on the main stream), ``layer3_parts``
+    (segments layer3 is cut into), ``miopen_find`` (let MIOpen search its solvers during the warm-up of a new shape; the
+    shapes of BASELINE configs[3] ship in ``dmm_net_amd/miopen_db``)."""
 
     def __init__(self, encoder: FeatureEncoder, dtype=torch.bfloat16, graphs: bool = True, linear_1x1: bool = True,
                  fused_bn: bool = True, own_wgrad: bool = True, overlap_wgrad: bool = True, skips_need_grad: bool = True,
