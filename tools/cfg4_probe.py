@@ -66,12 +66,17 @@ def one(variant, find, steps, frames):
 
     adam = torch.optim.Adam(params, lr=1e-6, fused=True) if "--adam" in sys.argv else None
 
+    clip = int(sys.argv[sys.argv.index("--clip") + 1]) if "--clip" in sys.argv else 1
+    imgs = [img] + [torch.randn_like(img) for _ in range(clip - 1)]
+
     def step(ev=None):
         if ev:
             ev[0].record()
-        with ctx():
-            feats = enc(img)
-        loss = sum((p.float() * tgt[k]).mean() for k, p in enumerate(feats["backbone_feature"]))
+        loss = 0.0
+        for im in imgs:                                       # --clip T: T encoder calls, ONE backward (trainer.py:95-131)
+            with ctx():
+                feats = enc(im)
+            loss = loss + sum((p.float() * tgt[k]).mean() for k, p in enumerate(feats["backbone_feature"]))
         if ev:
             ev[1].record()
         for p in params:
