@@ -236,6 +236,15 @@ def match_layer_batched(pf, pm, tf, tm, sc, targets=None, n_valid=None, m_valid=
         tm = tm if tm.dtype == pm.dtype else tm.to(pm.dtype)
         if targets is not None and targets.dtype != pm.dtype:
             targets = targets.to(pm.dtype)
+        if not torch.is_grad_enabled() and counts is None and tf.shape[0] == 1 and _FUSED_TRAIN:
+            # no gradient can be asked for (the evaluator's call): the library call itself, without an autograd node around it
+            # (Function.apply costs ~10-15 us of host time per call, and the zero loss tensor of the no-targets case a launch)
+            got = ops.match_train_forward(pm, tm, targets, pf.detach().float().contiguous(), tf[0].detach().float().contiguous(),
+                                          sc.detach().float().contiguous(), n_valid, m_valid, score_weight=float(score_weight),
+                                          max_iter=int(max_iter), proj_iter=int(proj_iter), lr=float(lr), is_test=int(is_test),
+                                          want_tape=False)
+            if got is not None:
+                return got[0], got[1], got[2], got[3], got[4]
         pf, tf = _no_grad_view(pf, tf)
         return _MatchLayerFn.apply(pf.float(), tf.float(), pm, tm, sc.float(), targets, n_valid, m_valid,
                                    float(score_weight), int(max_iter), int(proj_iter), float(lr), int(is_test), counts)

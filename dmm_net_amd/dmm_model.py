@@ -38,6 +38,7 @@ def CHECK4D(t):
     return t.shape
 
 
+_TF_MEMO = weakref.WeakKeyDictionary()              # DMM_Model instance -> (key, weak refs, stacked template features of the clip)
 _TABLE_MEMO = weakref.WeakKeyDictionary()           # DMM_Model instance -> memo of its last small-table upload (_lib.small_to_device_many)
 _VALID_CACHE = weakref.WeakKeyDictionary()          # DMM_Model instance -> (weakref of the clip's valid tensor, its version, layout)
 
@@ -127,7 +128,21 @@ class DMM_Model(nn.Module):
                 sc[b, :P] = prop_score[b]
         # the mask planes stay where they are: one tensor per video, handed to the kernels as a pointer table (the
         # round-1 driver copied them into a [B, Pmax, H, W] batch: 2 x 13 MB per video in front of a 15.6 MB cost pass)
-        tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
+        # the templates of a clip are fixed from frame 0 (dmm_model.py:44): when they carry no gradient, their stacked batch is
+        # kept for as long as the same tensors (same objects, same versions) come back -- one launch less per frame step
+        if any(t.requires_grad for t in tplt_feat):
+            tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
+        else:
+            key = tuple((id(t), t._version, t.data_ptr()) for t in tplt_feat)
+            memo = _TF_MEMO.get(self)
+            if memo is not None and memo[0] == key and all(r() is t for r, t in zip(memo[1], tplt_feat)):
+                tf = memo[2]
+            else:
+                tf = torch.stack([t.view(F, -1) for t in tplt_feat], 0)
+                try:
+                    _TF_MEMO[self] = (key, [weakref.ref(t) for t in tplt_feat], tf)
+                except TypeError:
+                    _TF_MEMO.pop(self, None)
         if row_scale is not None:
             # valid templates that are NOT a prefix: the reference's OF_matrix = diag(valid)[:O] (dmm_model.py:151-156)
             # zeroes the feature rows -- and, transposed, the scattered output rows (:78-80) -- of slots i < O with
