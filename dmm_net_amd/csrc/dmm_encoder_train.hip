@@ -176,16 +176,28 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__re
     }
 }
 
-template <bool RELU>
+// RELU: 0 = none, 1 = the mask from the rounded output y, 2 = the mask recomputed from x (no residual in front of the ReLU:
+// y > 0 exactly when x * scale + shift > 0, the forward's own fma with the forward's own scale / shift -- one plane less to read)
+template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                                  const uint16_t *__restrict__ y, int64_t rows, int c8,
-                                                                 const float *__restrict__ saved, float *__restrict__ sums) {
+                                                                 const float *__restrict__ saved, const float *__restrict__ weight,
+                                                                 const float *__restrict__ bias, float *__restrict__ sums) {
     __shared__ float red[256 * 16];
     const int C = c8 * 8, c8t = c8 < 32 ? c8 : 32, cg0 = blockIdx.y * c8t;
     const int cg = cg0 + threadIdx.x % c8t, ro = threadIdx.x / c8t, rpp = 256 / c8t;
-    float mean[8], invstd[8];
+    float mean[8], invstd[8], scale[8], shift[8];
     load8f(saved + cg * 8, mean);
     load8f(saved + C + cg * 8, invstd);
+    if (RELU == 2) {
+        load8f(weight + cg * 8, scale);
+        load8f(bias + cg * 8, shift);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            scale[k] = scale[k] * invstd[k];
+            shift[k] = __builtin_fmaf(-mean[k], scale[k], shift[k]);
+        }
+    }
     int64_t r0, r1;
     row_range(rows, rpp, r0, r1);
     float acc[16];
@@ -201,17 +213,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
             const int64_t i = (r + u * rpp) * c8 + cg;
             vd[u] = dp[i];
             vx[u] = xp[i];
-            if (RELU) vy[u] = yp[i];
+            if (RELU == 1) vy[u] = yp[i];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float g[8], f[8], o[8];
             unpack8(vd[u], g);
             unpack8(vx[u], f);
-            if (RELU) unpack8(vy[u], o);
+            if (RELU == 1) unpack8(vy[u], o);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+                const float gk = (RELU == 0 || (RELU == 1 ? o[k] > 0.0f : __builtin_fmaf(f[k], scale[k], shift[k]) > 0.0f)) ? g[k] : 0.0f;
                 acc[k] += gk;
                 acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
             }
@@ -222,10 +234,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
         float g[8], f[8], o[8];
         unpack8(dp[i], g);
         unpack8(xp[i], f);
-        if (RELU) unpack8(yp[i], o);
+        if (RELU == 1) unpack8(yp[i], o);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+            const float gk = (RELU == 0 || (RELU == 1 ? o[k] > 0.0f : __builtin_fmaf(f[k], scale[k], shift[k]) > 0.0f)) ? g[k] : 0.0f;
             acc[k] += gk;
             acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
         }
@@ -233,24 +245,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     fold_and_add(acc, red, c8t, cg0, C, sums);
 }
 
-template <bool RELU, bool DRES>
+template <int RELU, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                              const uint16_t *__restrict__ y, int64_t rows, int c8,
                                                              const float *__restrict__ saved, const float *__restrict__ weight,
+                                                             const float *__restrict__ bias,
                                                              const float *__restrict__ sums, uint16_t *__restrict__ dx,
                                                              uint16_t *__restrict__ dres, float *__restrict__ dweight,
                                                              float *__restrict__ dbias) {
     const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
-    float mean[8], invstd[8], w[8], sg[8], sgx[8], a[8], mg[8], mgx[8];
+    float mean[8], invstd[8], w[8], sg[8], sgx[8], a[8], mg[8], mgx[8], shift[8];
     load8f(saved + cg * 8, mean);
     load8f(saved + C + cg * 8, invstd);
     load8f(weight + cg * 8, w);
     load8f(sums + cg * 8, sg);
     load8f(sums + C + cg * 8, sgx);
+    if (RELU == 2) load8f(bias + cg * 8, shift);
     const float inv_n = 1.0f / (float)rows;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         a[k] = w[k] * invstd[k];
+        if (RELU == 2) shift[k] = __builtin_fmaf(-mean[k], a[k], shift[k]);     // (a = the forward's scale)
         mg[k] = sg[k] * inv_n;
         mgx[k] = sgx[k] * inv_n;
         if (blockIdx.x == 0 && ro == 0) {
@@ -268,10 +283,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
         float g[8], f[8], o[8];
         unpack8(dp[i], g);
         unpack8(xp[i], f);
-        if (RELU) unpack8(yp[i], o);
+        if (RELU == 1) unpack8(yp[i], o);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gk = (!RELU || o[k] > 0.0f) ? g[k] : 0.0f;
+            const float gk = (RELU == 0 || (RELU == 1 ? o[k] > 0.0f : __builtin_fmaf(f[k], a[k], shift[k]) > 0.0f)) ? g[k] : 0.0f;
             g[k] = gk;
             const float xhat = (f[k] - mean[k]) * invstd[k];
             f[k] = a[k] * ((gk - mg[k]) - xhat * mgx[k]);
@@ -339,37 +354,39 @@ extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t ro
 }
 
 extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                                      int relu, float *sums, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+                                      const float *weight, const float *bias, int relu, float *sums, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || relu < 0 || relu > 2) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
-    if (!dy || !x || !saved || !sums || (relu && !y)) return DMM_ERR_BAD_ARG;
+    if (!dy || !x || !saved || !sums || (relu == 1 && !y) || (relu == 2 && (!weight || !bias))) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
     const dim3 grid = dmm::bn_stat_grid(rows, c8);
-    if (relu)
-        hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, sums);
-    else
-        hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, sums);
+#define DMM_BNR(R_)                                                                                                    \
+    hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<R_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy, \
+                       (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, bias, sums)
+    if (relu == 2) DMM_BNR(2); else if (relu == 1) DMM_BNR(1); else DMM_BNR(0);
+#undef DMM_BNR
     return dmm::check_launch();
 }
 
 extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                                  const float *weight, const float *sums, int relu, void *dx, void *dres, float *dweight,
-                                  float *dbias, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+                                  const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
+                                  float *dweight, float *dbias, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || relu < 0 || relu > 2) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
-    if (!dy || !x || !saved || !weight || !sums || !dx || !dweight || !dbias || (relu && !y)) return DMM_ERR_BAD_ARG;
+    if (!dy || !x || !saved || !weight || !sums || !dx || !dweight || !dbias || (relu == 1 && !y) || (relu == 2 && !bias))
+        return DMM_ERR_BAD_ARG;
+    if (relu == 2 && dres) return DMM_ERR_BAD_ARG;        // (a residual in front of the ReLU: the mask needs the output)
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
     const dim3 grid(dmm::bn_grid(rows, c8, 2, 4096));
 #define DMM_BND(RELU_, DRES_)                                                                                            \
     hipLaunchKernelGGL((dmm::bn_bwd_dx_bf16_kernel<RELU_, DRES_>), grid, dim3(256), 0, (hipStream_t)stream,              \
-                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, sums,    \
+                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, bias, sums, \
                        (uint16_t *)dx, (uint16_t *)dres, dweight, dbias)
-    if (relu) { if (dres) DMM_BND(true, true); else DMM_BND(true, false); }
-    else { if (dres) DMM_BND(false, true); else DMM_BND(false, false); }
+    if (relu == 2) DMM_BND(2, false);
+    else if (relu == 1) { if (dres) DMM_BND(1, true); else DMM_BND(1, false); }
+    else { if (dres) DMM_BND(0, true); else DMM_BND(0, false); }
 #undef DMM_BND
     return dmm::check_launch();
 }

@@ -132,7 +132,7 @@ class _BNActFn(torch.autograd.Function):
                                            None if running_var is None else running_var.data_ptr(), float(momentum),
                                            float(eps), int(relu), y.data_ptr(), saved.data_ptr(), stream),
                        "dmm_bn_apply_bf16")
-        ctx.save_for_backward(x, y, weight, saved)
+        ctx.save_for_backward(x, y, weight, bias, saved)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
         return y
 
@@ -141,7 +141,9 @@ class _BNActFn(torch.autograd.Function):
     def backward(ctx, dy):
         from . import _lib
         L = _lib.load()
-        x, y, weight, saved = ctx.saved_tensors
+        x, y, weight, bias, saved = ctx.saved_tensors
+        # no residual in front of the ReLU: the mask is recomputed from x (the forward's own fma), y is not read
+        mode = 0 if not ctx.relu else (1 if ctx.has_res else 2)
         B, C, H, W = x.shape
         R = B * H * W
         dy = dy.contiguous(memory_format=_CL)
@@ -153,9 +155,10 @@ class _BNActFn(torch.autograd.Function):
         db = torch.empty((C,), dtype=torch.float32, device=x.device)
         with _lib.device_guard(x.device):
             _lib.check(L.dmm_bn_bwd_reduce_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
-                                                int(ctx.relu), sums.data_ptr(), stream), "dmm_bn_bwd_reduce_bf16")
+                                                weight.data_ptr(), bias.data_ptr(), mode, sums.data_ptr(), stream),
+                       "dmm_bn_bwd_reduce_bf16")
             _lib.check(L.dmm_bn_bwd_dx_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
-                                            weight.data_ptr(), sums.data_ptr(), int(ctx.relu), dx.data_ptr(),
+                                            weight.data_ptr(), bias.data_ptr(), sums.data_ptr(), mode, dx.data_ptr(),
                                             None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                             stream), "dmm_bn_bwd_dx_bf16")
         return dx, dw, db, None, None, None, None, None, dres

@@ -640,17 +640,18 @@ DMM_API int dmm_conv1x1_bf16(const void *x, const void *w, const float *bias, co
  * (torch.nn.BatchNorm2d in training mode).  Backward: with g = dy * [y > 0] when relu, else dy: dmm_bn_bwd_reduce_bf16
  * accumulates sum(g), sum(g * xhat) into sums [2, C] (caller-zeroed); dmm_bn_bwd_dx_bf16 writes
  * dx = w * invstd * (g - mean(g) - xhat * mean(g * xhat)), dres = g (NULL: no residual branch), dweight = sum(g * xhat),
- * dbias = sum(g).  y is only read when relu != 0.
+ * dbias = sum(g).  relu: 0 none; 1 the mask from the output y; 2 (no residual: dres NULL) the mask recomputed from x with the forward's
+ * own fma, x * (w * invstd) + (b - mean * w * invstd) > 0 -- weight / bias as the forward saw them; y is then not read at all.
  * ------------------------------------------------------------------------------------------- */
 DMM_API int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stats, dmm_stream_t stream);
 DMM_API int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t rows, int C, const float *stats,
                               const float *weight, const float *bias, float *running_mean, float *running_var,
                               float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream);
 DMM_API int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                                   int relu, float *sums, dmm_stream_t stream);
+                                   const float *weight, const float *bias, int relu, float *sums, dmm_stream_t stream);
 DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                               const float *weight, const float *sums, int relu, void *dx, void *dres, float *dweight,
-                               float *dbias, dmm_stream_t stream);
+                               const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
+                               float *dweight, float *dbias, dmm_stream_t stream);
 
 /* (10b) Weight gradient of the encoder's convolutions (channels-last bf16 activations, fp32 gradient), what autograd
  * computes for conv1 / conv3 / downsample (1x1) and conv2 / the heads (3x3, padding 1) of dmm/modules/vision.py:6-38 and
