@@ -296,6 +296,18 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
     }
 }
 
+// wt[ci][2 - kh][2 - kw][co] = w[co][kh][kw][ci]: the weight of the convolution that computes the DATA gradient of a 3x3 /
+// stride 1 / padding 1 convolution (both in channels-last storage).  One thread per element; the tensors are small (<= 4.7 MB).
+__global__ __launch_bounds__(256) void wflip3x3_bf16_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ wt, int co,
+                                                            int ci, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;            // over wt: ((c * 9 + t) * co + o)
+    if (e >= n) return;
+    const int o = (int)(e % co);
+    const int64_t q = e / co;
+    const int t = (int)(q % 9), c = (int)(q / 9);
+    wt[e] = w[((int64_t)o * 9 + (8 - t)) * ci + c];
+}
+
 static inline bool bn_shape_ok(int64_t rows, int C) {
     if (rows <= 0 || C <= 0 || (C & 7)) return false;
     const int c8 = C / 8;
@@ -388,5 +400,14 @@ extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, 
     else if (relu == 1) { if (dres) DMM_BND(1, true); else DMM_BND(1, false); }
     else { if (dres) DMM_BND(0, true); else DMM_BND(0, false); }
 #undef DMM_BND
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_wflip3x3_bf16(const void *w, int co, int ci, void *wt, dmm_stream_t stream) {
+    if (co <= 0 || ci <= 0) return DMM_ERR_BAD_ARG;
+    if (!w || !wt) return DMM_ERR_BAD_ARG;
+    const int64_t n = (int64_t)co * ci * 9;
+    hipLaunchKernelGGL(dmm::wflip3x3_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)w, (uint16_t *)wt, co, ci, n);
     return dmm::check_launch();
 }

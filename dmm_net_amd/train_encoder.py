@@ -187,6 +187,7 @@ def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True
 
 
 # ---- weight gradients: launched where the backward reaches them, or collected for a graph of their own -------------------
+_DGRAD_AS_FORWARD = True                 # (module switch for the A/B in tools/cfg4_probe.py)
 _DEFER: Optional[list] = None            # set while a segment's backward is captured with ``overlap_wgrad``: the launches are
 #                                          recorded (operands kept alive) and captured afterwards into a SECOND graph that replays
 #                                          on a side stream beside the next segment's backward chain
@@ -276,22 +277,36 @@ class _Conv3x3Fn(torch.autograd.Function):
         w = weight.detach().to(dtype=torch.bfloat16, memory_format=_CL)
         b = None if bias is None else bias.detach().to(torch.bfloat16)
         y = F.conv2d(x, w, b, stride, 1)
-        ctx.save_for_backward(x, w)
-        ctx.stride, ctx.has_bias = stride, bias is not None
+        # stride 1 and as many channels in as out (conv2 of a bottleneck): the data gradient is the SAME convolution problem with
+        # the weight flipped and transposed, dX = conv(dY, W'[ci, co, kh, kw] = W[co, ci, 2 - kh, 2 - kw]) -- MIOpen's forward
+        # kernel for it takes 28 us where its backward-data kernel takes 50 (profiles/r06_kernel_stats_config4_bf16.csv), on
+        # the backward's critical chain; the flipped copy is made here, off that chain
+        wt = None
+        if _DGRAD_AS_FORWARD and stride == 1 and w.shape[0] == w.shape[1] and x.requires_grad:
+            from . import _lib
+            wt = torch.empty((w.shape[1], w.shape[0], 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=_CL)
+            with _lib.device_guard(w.device):
+                _lib.check(_lib.load().dmm_wflip3x3_bf16(w.data_ptr(), w.shape[0], w.shape[1], wt.data_ptr(),
+                                                         torch.cuda.current_stream(w.device).cuda_stream), "dmm_wflip3x3_bf16")
+        ctx.save_for_backward(x, w, wt if wt is not None else w)
+        ctx.stride, ctx.has_bias, ctx.flipped = stride, bias is not None, wt is not None
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         from . import _lib
-        x, w = ctx.saved_tensors
+        x, w, wt = ctx.saved_tensors
         B, ci, H, W = x.shape
         co = w.shape[0]
         dy = dy.contiguous(memory_format=_CL)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            if ctx.flipped:
+                dx = F.conv2d(dy, wt, None, 1, 1)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [ctx.stride] * 2, [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         Ho, Wo = dy.shape[2], dy.shape[3]
         dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)      # the master's own layout
         _wgrad(("3x3", dy, x, (B, H, W, ci, co, ctx.stride, Ho, Wo), dw))

@@ -664,6 +664,11 @@ DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int
  * -> summed in slab order).  workspace: dmm_wgrad_workspace_bytes(rows, co, cv) bytes (cv = ci, or 9 * ci for the 3x3 form;
  * 0 when the shape is not taken).  co % 64 == 0 and ci % 64 == 0 (every width of the ResNet bodies and 128-wide heads), else
  * DMM_ERR_UNSUPPORTED (callers fall back to the library product).  MFMA 32x32x16 bf16, fp32 accumulation; memory bound. */
+/* (10c) wt[ci, 2-kh, 2-kw, co] = w[co, kh, kw, ci] (bf16, both channels-last [out, kh, kw, in]): the weight with which the DATA gradient
+ * of a 3x3 / stride 1 / padding 1 convolution is itself a forward convolution, dX = conv(dY, wt) -- what autograd computes for conv2
+ * of the torchvision bottlenecks (dmm/modules/vision.py:6-38) under train.py:296-307; MIOpen's forward kernel for that problem is
+ * ~1.8x faster than its backward-data kernel on gfx950. */
+DMM_API int dmm_wflip3x3_bf16(const void *w, int co, int ci, void *wt, dmm_stream_t stream);
 DMM_API size_t dmm_wgrad_workspace_bytes(int64_t rows, int co, int cv);
 DMM_API int dmm_wgrad_bf16(const void *dy, const void *x, int64_t rows, int co, int ci, int64_t ldy, int64_t ldx, float *dw,
                            void *workspace, size_t workspace_bytes, dmm_stream_t stream);

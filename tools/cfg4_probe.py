@@ -29,6 +29,8 @@ def one(variant, find, steps, frames):
     nhwc = variant.endswith("nhwc")
     ctx = lambda: torch.autocast("cuda", dtype=torch.bfloat16, enabled=variant.startswith("ac_"))
     if variant.startswith("train"):
+        from dmm_net_amd import train_encoder
+        train_encoder._DGRAD_AS_FORWARD = "bwddata" not in variant
         from dmm_net_amd.train_encoder import TrainEncoder
         enc = TrainEncoder(enc, graphs="nograph" not in variant, linear_1x1="nolin" not in variant,
                            fused_bn="nofuse" not in variant, own_wgrad="nowgrad" not in variant, overlap_wgrad="inline" not in variant, skips_need_grad=False,
