@@ -296,16 +296,69 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
     }
 }
 
-// wt[ci][2 - kh][2 - kw][co] = w[co][kh][kw][ci]: the weight of the convolution that computes the DATA gradient of a 3x3 /
-// stride 1 / padding 1 convolution (both in channels-last storage).  One thread per element; the tensors are small (<= 4.7 MB).
-__global__ __launch_bounds__(256) void wflip3x3_bf16_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ wt, int co,
-                                                            int ci, int64_t n) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;            // over wt: ((c * 9 + t) * co + o)
+// 3x3 weights of a whole segment in ONE launch: for every entry of a device table, the fp32 master [co, ci, 3, 3] becomes the bf16
+// channels-last weight dst[co][kh][kw][ci] and (dstT != null) the weight of the convolution that computes the DATA gradient of a
+// stride 1 / padding 1 convolution, dstT[ci][2 - kh][2 - kw][co].  One workgroup per 32 x 32 (co, ci) tile: the 288 floats of a
+// (co, 32 ci) run are contiguous in the master, the 32-channel runs of both outputs are 64-byte segments.
+struct WPrep {
+    const float *src;
+    uint16_t *dst, *dstT;
+    int co, ci;
+    int64_t tile0;                        // first workgroup of this entry
+};
+
+__global__ __launch_bounds__(256) void wprep3x3_bf16_kernel(const WPrep *__restrict__ tab, int n) {
+    constexpr int SO = 290;               // LDS row of one co: 288 values + 2 (odd dword stride: the transposed read is conflict free)
+    __shared__ uint16_t s[32 * SO];
+    const int64_t b = blockIdx.x;
+    int k = 0;
+    for (int i = 1; i < n; ++i) k = tab[i].tile0 <= b ? i : k;
+    const WPrep e = tab[k];
+    const int t = (int)(b - e.tile0), ct = e.ci / 32, o0 = (t / ct) * 32, c0 = (t % ct) * 32;
+    for (int j = threadIdx.x; j < 32 * 288; j += 256) {
+        const int o = j / 288, r = j - o * 288;
+        s[o * SO + r] = (uint16_t)bf16_round(e.src[((int64_t)(o0 + o) * e.ci + c0) * 9 + r]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 32 * 288; j += 256) {
+        const int c = j & 31, tt = (j >> 5) % 9, o = j / 288;
+        e.dst[((int64_t)(o0 + o) * 9 + tt) * e.ci + c0 + c] = s[o * SO + c * 9 + tt];
+    }
+    if (!e.dstT) return;
+    for (int j = threadIdx.x; j < 32 * 288; j += 256) {
+        const int o = j & 31, tt = (j >> 5) % 9, c = j / 288;
+        e.dstT[((int64_t)(c0 + c) * 9 + (8 - tt)) * e.co + o0 + o] = s[o * SO + c * 9 + tt];
+    }
+}
+
+// y[b, ho, wo, :] = x[b, 2 ho, 2 wo, :] (the row subsample in front of a stride-2 1x1 convolution), 16 bytes per thread
+__global__ __launch_bounds__(256) void subsample2_bf16_kernel(const u32x4t *__restrict__ x, int H, int W, int c8, int Ho, int Wo,
+                                                              int64_t n, u32x4t *__restrict__ y) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    const int o = (int)(e % co);
-    const int64_t q = e / co;
-    const int t = (int)(q % 9), c = (int)(q / 9);
-    wt[e] = w[((int64_t)o * 9 + (8 - t)) * ci + c];
+    const int cg = (int)(e % c8);
+    int64_t q = e / c8;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int64_t b = q / Ho;
+    y[e] = x[((b * H + 2 * ho) * W + 2 * wo) * c8 + cg];
+}
+
+// its gradient: dx[b, h, w, :] = dy[b, h / 2, w / 2, :] at even (h, w), zero elsewhere -- the whole tensor written once
+__global__ __launch_bounds__(256) void upsample2_zero_bf16_kernel(const u32x4t *__restrict__ dy, int H, int W, int c8, int Ho, int Wo,
+                                                                  int64_t n, u32x4t *__restrict__ dx) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int cg = (int)(e % c8);
+    int64_t q = e / c8;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H);
+    const int64_t b = q / H;
+    u32x4t v = {0u, 0u, 0u, 0u};
+    if (!((h | w) & 1)) v = dy[((b * Ho + (h >> 1)) * Wo + (w >> 1)) * c8 + cg];
+    dx[e] = v;
 }
 
 static inline bool bn_shape_ok(int64_t rows, int C) {
@@ -403,11 +456,35 @@ extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, 
     return dmm::check_launch();
 }
 
-extern "C" int dmm_wflip3x3_bf16(const void *w, int co, int ci, void *wt, dmm_stream_t stream) {
-    if (co <= 0 || ci <= 0) return DMM_ERR_BAD_ARG;
-    if (!w || !wt) return DMM_ERR_BAD_ARG;
-    const int64_t n = (int64_t)co * ci * 9;
-    hipLaunchKernelGGL(dmm::wflip3x3_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)w, (uint16_t *)wt, co, ci, n);
+extern "C" int dmm_wprep3x3_bf16(const void *table, int n, int64_t tiles, dmm_stream_t stream) {
+    if (n < 0 || tiles < 0 || tiles > 0x7fffffffLL) return DMM_ERR_BAD_ARG;
+    if (n == 0 || tiles == 0) return DMM_OK;
+    if (!table) return DMM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dmm::wprep3x3_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const dmm::WPrep *)table, n);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_subsample2_bf16(const void *x, int B, int H, int W, int C, void *y, dmm_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (C & 7) return DMM_ERR_UNSUPPORTED;
+    if (B == 0) return DMM_OK;
+    if (!x || !y) return DMM_ERR_BAD_ARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c8 = C / 8;
+    const int64_t n = (int64_t)B * Ho * Wo * c8;
+    hipLaunchKernelGGL(dmm::subsample2_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const dmm::u32x4t *)x, H, W, c8, Ho, Wo, n, (dmm::u32x4t *)y);
+    return dmm::check_launch();
+}
+
+extern "C" int dmm_upsample2_zero_bf16(const void *dy, int B, int H, int W, int C, void *dx, dmm_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0) return DMM_ERR_BAD_ARG;
+    if (C & 7) return DMM_ERR_UNSUPPORTED;
+    if (B == 0) return DMM_OK;
+    if (!dy || !dx) return DMM_ERR_BAD_ARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c8 = C / 8;
+    const int64_t n = (int64_t)B * H * W * c8;
+    hipLaunchKernelGGL(dmm::upsample2_zero_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const dmm::u32x4t *)dy, H, W, c8, Ho, Wo, n, (dmm::u32x4t *)dx);
     return dmm::check_launch();
 }

@@ -226,6 +226,37 @@ def _wgrad_ok(m: nn.Conv2d) -> bool:
             and m.stride in ((1, 1), (2, 2)))
 
 
+def _subsample(x, stride: int):
+    """x[:, :, ::stride, ::stride] of a channels-last activation as a tensor of its own: one 16-byte-per-thread launch for stride 2
+    in bf16 (the stock strided copy moves 2 bytes per thread: 52 us for layer2's downsample input at config 4, 5 with this)."""
+    B, C, H, W = x.shape
+    if stride == 2 and x.is_cuda and x.dtype == torch.bfloat16 and C % 8 == 0 and x.is_contiguous(memory_format=_CL):
+        from . import _lib
+        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device).contiguous(memory_format=_CL)
+        with _lib.device_guard(x.device):
+            _lib.check(_lib.load().dmm_subsample2_bf16(x.data_ptr(), B, H, W, C, y.data_ptr(),
+                                                       torch.cuda.current_stream(x.device).cuda_stream), "dmm_subsample2_bf16")
+        return y
+    return x[:, :, ::stride, ::stride].contiguous(memory_format=_CL)
+
+
+def _upsample_zero(dy, full, stride: int):
+    """The gradient of ``_subsample``: a ``full``-shaped tensor with dy at the sampled positions and zero elsewhere, written once."""
+    B, C, H, W = full
+    if stride == 2 and dy.is_cuda and dy.dtype == torch.bfloat16 and C % 8 == 0:
+        from . import _lib
+        dy = dy.contiguous(memory_format=_CL)
+        dx = torch.empty(full, dtype=dy.dtype, device=dy.device).contiguous(memory_format=_CL)
+        with _lib.device_guard(dy.device):
+            _lib.check(_lib.load().dmm_upsample2_zero_bf16(dy.data_ptr(), B, H, W, C, dx.data_ptr(),
+                                                           torch.cuda.current_stream(dy.device).cuda_stream),
+                       "dmm_upsample2_zero_bf16")
+        return dx
+    dx = torch.zeros(full, dtype=dy.dtype, device=dy.device).contiguous(memory_format=_CL)
+    dx[:, :, ::stride, ::stride] = dy
+    return dx
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     """1x1 convolution of a channels-last bf16 activation with an fp32 MASTER weight: y = X W^T on the [B*H*W, Cin] activation
     matrix (hipBLASLt); backward: dX = dY W (hipBLASLt) and dW = dY^T X straight into an fp32 gradient for the master
@@ -237,7 +268,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         ctx.full = None
         if stride != 1:
             ctx.full = tuple(x.shape)
-            x = x[:, :, ::stride, ::stride].contiguous(memory_format=_CL)
+            x = _subsample(x, stride)
         B, _, H, W = x.shape
         # shadow: the bf16 copy of the weight the caller refreshed for its whole segment in one multi-tensor launch
         w = shadow if shadow is not None else weight.detach().view(co, ci).to(torch.bfloat16)
@@ -259,9 +290,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy_rows, w).view(B, H, W, ci).permute(0, 3, 1, 2)
             if ctx.full is not None:
-                full = torch.zeros(ctx.full, dtype=dx.dtype, device=dx.device).contiguous(memory_format=_CL)
-                full[:, :, ::ctx.stride, ::ctx.stride] = dx
-                dx = full
+                dx = _upsample_zero(dx, ctx.full, ctx.stride)
         dw = torch.empty((co, ci, 1, 1), dtype=torch.float32, device=x.device)
         _wgrad(("1x1", dy_rows, x, (B * H * W, co, ci), dw))
         return dx, dw, None, None
@@ -273,21 +302,23 @@ class _Conv3x3Fn(torch.autograd.Function):
     bf16 weight-gradient solvers cost a zeroing and a cast launch each and clear their workspace with a memset node."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride):
-        w = weight.detach().to(dtype=torch.bfloat16, memory_format=_CL)
-        b = None if bias is None else bias.detach().to(torch.bfloat16)
-        y = F.conv2d(x, w, b, stride, 1)
+    def forward(ctx, x, weight, bias, stride, shadow=None):
         # stride 1 and as many channels in as out (conv2 of a bottleneck): the data gradient is the SAME convolution problem with
         # the weight flipped and transposed, dX = conv(dY, W'[ci, co, kh, kw] = W[co, ci, 2 - kh, 2 - kw]) -- MIOpen's forward
         # kernel for it takes 28 us where its backward-data kernel takes 50 (profiles/r06_kernel_stats_config4_bf16.csv), on
-        # the backward's critical chain; the flipped copy is made here, off that chain
-        wt = None
-        if _DGRAD_AS_FORWARD and stride == 1 and w.shape[0] == w.shape[1] and x.requires_grad:
-            from . import _lib
-            wt = torch.empty((w.shape[1], w.shape[0], 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=_CL)
-            with _lib.device_guard(w.device):
-                _lib.check(_lib.load().dmm_wflip3x3_bf16(w.data_ptr(), w.shape[0], w.shape[1], wt.data_ptr(),
-                                                         torch.cuda.current_stream(w.device).cuda_stream), "dmm_wflip3x3_bf16")
+        # the backward's critical chain; the flipped copy is made in the forward, off that chain.
+        # shadow = (w, wt): both made for the caller's whole segment in one launch (``TrainEncoder._tick``)
+        if shadow is not None:
+            w, wt = shadow
+        else:
+            w = weight.detach().to(dtype=torch.bfloat16, memory_format=_CL)
+            wt = None
+            if _DGRAD_AS_FORWARD and stride == 1 and w.shape[0] == w.shape[1] and x.requires_grad:
+                wt = torch.flip(w, (2, 3)).transpose(0, 1).contiguous(memory_format=_CL)
+        if not (_DGRAD_AS_FORWARD and stride == 1 and w.shape[0] == w.shape[1]):
+            wt = None
+        b = None if bias is None else bias.detach().to(torch.bfloat16)
+        y = F.conv2d(x, w, b, stride, 1)
         ctx.save_for_backward(x, w, wt if wt is not None else w)
         ctx.stride, ctx.has_bias, ctx.flipped = stride, bias is not None, wt is not None
         return y
@@ -295,7 +326,6 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        from . import _lib
         x, w, wt = ctx.saved_tensors
         B, ci, H, W = x.shape
         co = w.shape[0]
@@ -310,8 +340,23 @@ class _Conv3x3Fn(torch.autograd.Function):
         Ho, Wo = dy.shape[2], dy.shape[3]
         dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)      # the master's own layout
         _wgrad(("3x3", dy, x, (B, H, W, ci, co, ctx.stride, Ho, Wo), dw))
-        db = dy.float().sum((0, 2, 3)) if ctx.has_bias else None
-        return dx, dw, db, None
+        db = _channel_sums(dy) if ctx.has_bias else None
+        return dx, dw, db, None, None
+
+
+def _channel_sums(dy):
+    """sum over (batch, rows, columns) of a channels-last bf16 gradient in fp32 (a bias gradient): the statistics kernel's first
+    row -- one launch where ``dy.float().sum((0, 2, 3))`` is a cast of the whole tensor and a reduction."""
+    B, C, H, W = dy.shape
+    c8 = C // 8
+    if dy.is_cuda and dy.dtype == torch.bfloat16 and C % 8 == 0 and c8 <= 256 and 256 % c8 == 0:
+        from . import _lib
+        stats = _zeroed(2 * C, dy.device)
+        with _lib.device_guard(dy.device):
+            _lib.check(_lib.load().dmm_bn_stats_bf16(dy.data_ptr(), B * H * W, C, stats.data_ptr(),
+                                                     torch.cuda.current_stream(dy.device).cuda_stream), "dmm_bn_stats_bf16")
+        return stats[:C]
+    return dy.float().sum((0, 2, 3))
 
 
 def _conv(x, m: nn.Conv2d, dtype, linear_1x1: bool = True, own_wgrad: bool = True, shadow=None):
@@ -324,7 +369,7 @@ def _conv(x, m: nn.Conv2d, dtype, linear_1x1: bool = True, own_wgrad: bool = Tru
     if fast and linear_1x1 and one and m.bias is None:
         return _Conv1x1Fn.apply(x.contiguous(memory_format=_CL), m.weight, m.stride[0], shadow)
     if fast and m.kernel_size == (3, 3) and m.padding == (1, 1):
-        return _Conv3x3Fn.apply(x.contiguous(memory_format=_CL), m.weight, m.bias, m.stride[0])
+        return _Conv3x3Fn.apply(x.contiguous(memory_format=_CL), m.weight, m.bias, m.stride[0], shadow)
     b = None if m.bias is None else m.bias.to(dtype)
     if linear_1x1 and one and m.groups == 1 and m.dilation == (1, 1):
         if m.stride != (1, 1):
@@ -387,6 +432,7 @@ class TrainEncoder(nn.Module):
         # .to() / .cuda() / .float() re-create the parameters' storage: the captured graphs (which hold the old addresses), the
         # bf16 weight copies and the hub leaves go; the next forward captures again
         self._plans.clear(), self._shadows.clear(), self._hubs.clear(), self._pending.clear()
+        self.__dict__.get("_wprep", {}).clear()
         return super()._apply(fn, *args, **kwargs)
 
     # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
@@ -424,6 +470,44 @@ class TrainEncoder(nn.Module):
                     t[id(m)] = w
                 with torch.no_grad():
                     torch._foreach_copy_(dst, [m.weight.detach().view(m.out_channels, m.in_channels) for m in convs])
+        if self.own_wgrad:
+            convs = [m for m in mods if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1)
+                     and _wgrad_ok(m)]
+            if convs:
+                self._prep_3x3(convs, t)
+
+    def _prep_3x3(self, convs, t):
+        """bf16 channels-last copies of the 3x3 weights of one segment (and the flipped + transposed ones their data gradients
+        run on as forward convolutions) by ONE launch over a device table -- a cast, a layout copy and a flip launch per
+        convolution before: 99 launches of ~5.5 us in a ResNet-101 forward."""
+        from . import _lib
+        memo = self.__dict__.setdefault("_wprep", {})
+        key = tuple(id(m) for m in convs)
+        ptrs = tuple(m.weight.data_ptr() for m in convs)
+        got = memo.get(key)
+        if got is None or got[0] != ptrs:
+            if torch.cuda.is_current_stream_capturing():
+                return                                   # (no table yet and no upload inside a capture: per-convolution copies)
+            dev = convs[0].weight.device
+            rec, pairs, tile = [], [], 0
+            for m in convs:
+                co, ci = m.out_channels, m.in_channels
+                w = torch.empty((co, ci, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=_CL)
+                wt = None
+                if _DGRAD_AS_FORWARD and m.stride == (1, 1) and co == ci:
+                    wt = torch.empty((ci, co, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=_CL)
+                rec += [m.weight.data_ptr(), w.data_ptr(), 0 if wt is None else wt.data_ptr(), co | (ci << 32), tile]
+                tile += (co // 32) * (ci // 32)
+                pairs.append((w, wt))
+            table = _lib.small_to_device(rec, torch.int64, dev)
+            got = memo[key] = (ptrs, table, pairs, tile)
+        _, table, pairs, tiles = got
+        dev = convs[0].weight.device
+        with _lib.device_guard(dev):
+            _lib.check(_lib.load().dmm_wprep3x3_bf16(table.data_ptr(), len(convs), tiles,
+                                                     torch.cuda.current_stream(dev).cuda_stream), "dmm_wprep3x3_bf16")
+        for m, pr in zip(convs, pairs):
+            t[id(m)] = pr
 
     def _block(self, x, blk):
         idt = x if blk.downsample is None else self._cbr(x, blk.downsample[0], blk.downsample[1], False)
@@ -502,13 +586,16 @@ class TrainEncoder(nn.Module):
         return out
 
     def _arena_floats(self, name: str, backward: bool) -> int:
-        """Upper bound of what a segment's graph takes from its arena: [2, C] per BatchNorm (+ 64 floats of rounding per
-        request), the same forward and backward (the weight-gradient kernels overwrite their outputs: nothing to zero)."""
+        """Upper bound of what a segment's graph takes from its arena: [2, C] per BatchNorm and per convolution bias (+ 64
+        floats of rounding per request), the same forward and backward (the weight-gradient kernels overwrite their
+        outputs: nothing to zero)."""
         n = 0
         for mod in self._seg_modules()[name]:
             for m in mod.modules():
                 if isinstance(m, nn.BatchNorm2d):
                     n += 2 * m.num_features + 64
+                elif isinstance(m, nn.Conv2d) and m.bias is not None:
+                    n += 2 * m.out_channels + 64            # (its bias gradient: the statistics kernel's sums)
         return n + 1024
 
     @staticmethod

@@ -664,11 +664,18 @@ DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int
  * -> summed in slab order).  workspace: dmm_wgrad_workspace_bytes(rows, co, cv) bytes (cv = ci, or 9 * ci for the 3x3 form;
  * 0 when the shape is not taken).  co % 64 == 0 and ci % 64 == 0 (every width of the ResNet bodies and 128-wide heads), else
  * DMM_ERR_UNSUPPORTED (callers fall back to the library product).  MFMA 32x32x16 bf16, fp32 accumulation; memory bound. */
-/* (10c) wt[ci, 2-kh, 2-kw, co] = w[co, kh, kw, ci] (bf16, both channels-last [out, kh, kw, in]): the weight with which the DATA gradient
- * of a 3x3 / stride 1 / padding 1 convolution is itself a forward convolution, dX = conv(dY, wt) -- what autograd computes for conv2
- * of the torchvision bottlenecks (dmm/modules/vision.py:6-38) under train.py:296-307; MIOpen's forward kernel for that problem is
- * ~1.8x faster than its backward-data kernel on gfx950. */
-DMM_API int dmm_wflip3x3_bf16(const void *w, int co, int ci, void *wt, dmm_stream_t stream);
+/* (10c) Weight and layout helpers of the training encoder (dmm/modules/vision.py:6-38 under train.py:296-307).
+ * dmm_wprep3x3_bf16: every 3x3 weight of a segment in one launch.  `table` = n device records of 40 bytes
+ * {const float *src; uint16 *dst; uint16 *dstT; int32 co; int32 ci; int64 tile0}: src the fp32 master [co, ci, 3, 3], dst the bf16
+ * channels-last weight [co, kh, kw, ci], dstT (may be null) [ci, 2-kh, 2-kw, co] -- the weight with which the DATA gradient of a
+ * stride 1 / padding 1 convolution is itself a forward convolution, dX = conv(dY, dstT) (MIOpen's forward kernel for that problem
+ * is ~1.8x faster than its backward-data kernel on gfx950).  co, ci multiples of 32; tile0 = sum of (co/32)*(ci/32) of the records
+ * before; tiles = that sum over all records.
+ * dmm_subsample2_bf16: y[b, ho, wo, :] = x[b, 2ho, 2wo, :] on channels-last bf16 (the stride of a 1x1 downsample convolution);
+ * dmm_upsample2_zero_bf16: its gradient, dx [B, H, W, C] written once (dy at even positions, zero elsewhere).  C % 8 == 0. */
+DMM_API int dmm_wprep3x3_bf16(const void *table, int n, int64_t tiles, dmm_stream_t stream);
+DMM_API int dmm_subsample2_bf16(const void *x, int B, int H, int W, int C, void *y, dmm_stream_t stream);
+DMM_API int dmm_upsample2_zero_bf16(const void *dy, int B, int H, int W, int C, void *dx, dmm_stream_t stream);
 DMM_API size_t dmm_wgrad_workspace_bytes(int64_t rows, int co, int cv);
 DMM_API int dmm_wgrad_bf16(const void *dy, const void *x, int64_t rows, int co, int ci, int64_t ldy, int64_t ldx, float *dw,
                            void *workspace, size_t workspace_bytes, dmm_stream_t stream);

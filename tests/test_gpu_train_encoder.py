@@ -156,6 +156,66 @@ def _loss(f, skips=True):
     return sum((p.float() * _target(p, k)).mean() for k, p in enumerate(outs))
 
 
+def test_weight_preparation_of_a_segment_in_one_launch_is_the_cast_layout_and_flip():
+    """dmm_wprep3x3_bf16 over a table of several convolutions == per convolution: the bf16 channels-last cast of the master and
+    (square, stride 1) the flipped + transposed weight its data gradient runs on as a forward convolution -- bit for bit;
+    and the data gradient computed that way equals autograd's."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(64, 64, True), (128, 64, False), (256, 256, True), (64, 192, False), (512, 512, True)]
+    ws = [torch.randn((co, ci, 3, 3), generator=g, device=DEV) for co, ci, _ in shapes]
+    rec, outs, tile = [], [], 0
+    for w, (co, ci, sq) in zip(ws, shapes):
+        d = torch.empty((co, ci, 3, 3), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+        dt = torch.empty((ci, co, 3, 3), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last) if sq else None
+        rec += [w.data_ptr(), d.data_ptr(), 0 if dt is None else dt.data_ptr(), co | (ci << 32), tile]
+        tile += (co // 32) * (ci // 32)
+        outs.append((d, dt))
+    table = torch.tensor(rec, dtype=torch.int64, device=DEV)
+    L = _lib.load()
+    _lib.check(L.dmm_wprep3x3_bf16(table.data_ptr(), len(ws), tile, torch.cuda.current_stream().cuda_stream), "wprep")
+    torch.cuda.synchronize()
+    for w, (d, dt) in zip(ws, outs):
+        ref = w.to(torch.bfloat16)
+        assert torch.equal(d, ref) and d.is_contiguous(memory_format=torch.channels_last)
+        if dt is not None:
+            assert torch.equal(dt, torch.flip(ref, (2, 3)).transpose(0, 1))
+    # the flipped weight computes the data gradient
+    w, (d, dt) = ws[2], outs[2]
+    x = torch.randn((2, 256, 9, 11), generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    dy = torch.randn((2, 256, 9, 11), generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    F.conv2d(x, d, None, 1, 1).backward(dy)
+    got = F.conv2d(dy, dt, None, 1, 1)
+    assert (got.float() - x.grad.float()).abs().max().item() <= 2e-2 * x.grad.float().abs().max().item()
+    assert L.dmm_wprep3x3_bf16(None, 0, 0, None) == 0 and L.dmm_wprep3x3_bf16(None, 2, 5, None) != 0
+
+
+@pytest.mark.parametrize("B,C,H,W", [(12, 256, 64, 112), (2, 512, 33, 57), (3, 64, 7, 9), (1, 8, 1, 1)])
+def test_stride_2_subsample_and_its_gradient_are_the_strided_copies(B, C, H, W):
+    from dmm_net_amd.train_encoder import _subsample, _upsample_zero
+    g = torch.Generator(device=DEV).manual_seed(B + C)
+    x = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = _subsample(x, 2)
+    assert torch.equal(y, x[:, :, ::2, ::2]) and y.is_contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(y.shape, generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dx = _upsample_zero(dy, tuple(x.shape), 2)
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = dy
+    assert torch.equal(dx, ref) and dx.is_contiguous(memory_format=torch.channels_last)
+    L = _lib.load()
+    assert L.dmm_subsample2_bf16(x.data_ptr(), 1, 4, 4, 12, y.data_ptr(), None) != 0       # C % 8
+    assert L.dmm_upsample2_zero_bf16(None, 1, 4, 4, 8, None, None) != 0
+
+
+def test_bias_gradient_through_the_statistics_kernel():
+    from dmm_net_amd.train_encoder import _channel_sums
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for shape in ((12, 256, 16, 28), (2, 64, 5, 7), (3, 24, 4, 4)):          # (24 channels: the fallback)
+        dy = torch.randn(shape, generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+        ref = dy.double().sum((0, 2, 3))
+        got = _channel_sums(dy).double()
+        assert (got - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item()) * math.sqrt(dy.numel() / shape[1])
+
+
 @pytest.mark.parametrize("model", ["resnet34", "resnet50"])
 def test_graphed_fp32_mode_equals_the_plain_encoder_on_replays(model):
     """``TrainEncoder(dtype=float32)`` computes what ``FeatureEncoder`` computes (stock BatchNorm, fp32 GEMMs): outputs,
