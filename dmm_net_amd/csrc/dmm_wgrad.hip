@@ -29,6 +29,12 @@
 
 namespace dmm {
 
+#ifndef WGRAD_DEPTH
+#define WGRAD_DEPTH 2
+#endif
+#ifndef WGRAD_KS
+#define WGRAD_KS 2
+#endif
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef float f32x16w __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
@@ -141,20 +147,31 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t *__restr
 }
 
 // The same product for shapes whose widths are multiples of 128 (everything from layer2 on): one workgroup = a 128 (co) x 128 (cv)
-// tile over ONE slab of rows, its four waves the 2 x 2 sub-tiles of 64 x 64 -- all on the same rows.  The rows of both
-// operands go through LDS: 32 rows x 128 channels of dY and of X per stage, fetched with 16-byte lane loads (two per operand
-// and thread) while the previous stage is being multiplied (two LDS buffers, one barrier per stage); a wave then reads its
-// fragments' dwords from LDS exactly as the 64-wide kernel reads them from memory.  Every operand element now leaves L2 once
-// per 128-wide tile of the other operand and in 16-byte pieces: 0.5 KB of operand per MFMA instead of 1 KB in 4-byte pieces.
-// No fold: each wave stores its own sub-tile (float2 per lane: 256 contiguous bytes per 32 lanes).
-template <bool PATCH>
-__global__ __launch_bounds__(256) void wgrad_lds_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
-                                                        int64_t R, int Co, int Cv, int64_t ldy, int64_t ldx,
-                                                        float *__restrict__ out, int64_t group_stride, int64_t rows_per_group,
-                                                        int cv_tiles, PatchGeom pg) {
-    __shared__ __attribute__((aligned(16))) uint16_t sA[2][32][128];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[2][32][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// tile over ONE slab of rows.  The rows of both operands go through LDS in stages of 32 rows x 128 channels of dY and of X,
+// fetched with 16-byte lane loads; a wave reads its fragments' dwords from LDS exactly as the 64-wide kernel reads them from
+// memory.  Every operand element leaves L2 once per 128-wide tile of the other operand and in 16-byte pieces: 0.5 KB of operand
+// per MFMA instead of 1 KB in 4-byte pieces.
+//
+// KS k-slices.  A stage is a dependent chain (LDS store -> barrier -> LDS reads -> v_perm -> MFMA): measured 0.68 us per stage
+// and workgroup whether one or two workgroups share a compute unit -- latency, not throughput (time = 2.5 + 0.68 * stages +
+// 0.24 * MB of partial table, tools/wgrad_probe.py).  So a workgroup is KS x 4 waves: slice s multiplies stages s, s + KS, ...
+// of the slab into its own accumulators (own LDS buffers, the 2 x 2 sub-tiles of 64 x 64 over its four waves), the slices
+// are folded through LDS in a fixed order at the end.  KS x the waves per compute unit for the same bytes of partial table --
+// which is what more slabs would cost.  D register sets keep D stages in flight between memory and LDS.
+//
+// Branch-free inner loop: a piece outside the slab / the image is loaded from a valid address and zeroed when it moves to LDS
+// (loads under a branch make the compiler wait for ALL outstanding loads before every LDS store), and stages are fetched in
+// order, so row offsets and the (image, row, column) of a piece's output pixel advance by additions and two carries (the four
+// 64-bit divisions per stage of the first form were most of its ~700 instructions: the 3x3 form was VALU bound).
+template <bool PATCH, int KS>
+__global__ __launch_bounds__(256 * KS) void wgrad_lds_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                             int64_t R, int Co, int Cv, int64_t ldy, int64_t ldx,
+                                                             float *__restrict__ out, int64_t group_stride,
+                                                             int64_t rows_per_group, int cv_tiles, PatchGeom pg) {
+    constexpr int D = WGRAD_DEPTH;
+    __shared__ __attribute__((aligned(16))) uint16_t lds_[KS * 2 * 2 * 32 * 128];        // [slice][buffer][A | B][32][128]
+    const int slice = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int lane = t & 63, wave = t >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int tile = blockIdx.x;
     const int co0 = (tile / cv_tiles) * 128, cv0 = (tile % cv_tiles) * 128;
@@ -169,74 +186,143 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const uint16_t *__restri
         tap_dh = tap / 3 - 1;
         tap_dw = tap % 3 - 1;
     }
+    uint16_t *sA0 = lds_ + slice * (2 * 2 * 32 * 128), *sB0 = sA0 + 32 * 128;             // buffer b: + b * 2 * 32 * 128
     // this thread's two 16-byte pieces of a stage: rows lr and lr + 16, channels 8 * lc .. 8 * lc + 7
-    const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
-    u32x4w ra[2], rb[2];
-    auto fetch = [&](int64_t r) {
+    const int lr = t >> 4, lc = t & 15;
+    u32x4w ra[D][2], rb[D][2];
+    uint32_t okm[D];                                      // bit q: row of piece q inside the slab; bit 2 + q: its X pixel inside the image
+    int64_t a_off[2], b_off[2], row_n[2];
+    int pb_[2] = {0, 0}, ph_[2] = {0, 0}, pw_[2] = {0, 0};
+    int adv_w = 0, adv_h = 0, adv_b = 0;
+    const int64_t a_first = r0 * ldy + co0 + 8 * lc, b_first = PATCH ? 0 : r0 * ldx + cin0 + 8 * lc;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        row_n[q] = r0 + 32 * slice + lr + 16 * q;
+        a_off[q] = row_n[q] * ldy + co0 + 8 * lc;
+        b_off[q] = row_n[q] * ldx + cin0 + 8 * lc;
+        if (PATCH) {
+            const int64_t qd = row_n[q] / pg.Wo;
+            pw_[q] = (int)(row_n[q] - qd * pg.Wo);
+            pb_[q] = (int)(qd / pg.Ho);
+            ph_[q] = (int)(qd - (int64_t)pb_[q] * pg.Ho);
+        }
+    }
+    if (PATCH) {                                          // 32 * KS output pixels further = adv_b images + adv_h rows + adv_w columns
+        adv_w = (32 * KS) % pg.Wo;
+        const int q_ = (32 * KS) / pg.Wo;
+        adv_h = q_ % pg.Ho;
+        adv_b = q_ / pg.Ho;
+    }
+    auto fetch = [&](u32x4w (&fa)[2], u32x4w (&fb)[2], uint32_t &ok_bits) {
+        ok_bits = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int64_t row = r + lr + 16 * q;
-            const bool ok = row < r1;
-            const u32x4w z = {0u, 0u, 0u, 0u};
-            ra[q] = ok ? *reinterpret_cast<const u32x4w *>(dy + row * ldy + co0 + 8 * lc) : z;
+            const bool ok = row_n[q] < r1;
+            fa[q] = *reinterpret_cast<const u32x4w *>(dy + (ok ? a_off[q] : a_first));
             if (!PATCH) {
-                rb[q] = ok ? *reinterpret_cast<const u32x4w *>(x + row * ldx + cin0 + 8 * lc) : z;
+                fb[q] = *reinterpret_cast<const u32x4w *>(x + (ok ? b_off[q] : b_first));
+                ok_bits |= ok ? (5u << q) : 0u;
+                b_off[q] += 32 * KS * ldx;
             } else {
-                const int64_t qd = row / pg.Wo;
-                const int pw = (int)(row - qd * pg.Wo);
-                const int pb = (int)(qd / pg.Ho);
-                const int ph = (int)(qd - (int64_t)pb * pg.Ho);
-                const int hi = ph * pg.stride + tap_dh, wi = pw * pg.stride + tap_dw;
+                const int hi = ph_[q] * pg.stride + tap_dh, wi = pw_[q] * pg.stride + tap_dw;
                 const bool in = ok && hi >= 0 && hi < pg.H && wi >= 0 && wi < pg.W;
-                rb[q] = in ? *reinterpret_cast<const u32x4w *>(x + (((int64_t)pb * pg.H + hi) * pg.W + wi) * ldx + cin0 + 8 * lc)
-                           : z;
+                const int64_t off = in ? (((int64_t)pb_[q] * pg.H + hi) * pg.W + wi) * ldx : 0;
+                fb[q] = *reinterpret_cast<const u32x4w *>(x + off + cin0 + 8 * lc);
+                ok_bits |= (ok ? (1u << q) : 0u) | (in ? (4u << q) : 0u);
+                pw_[q] += adv_w;
+                const int cw = pw_[q] >= pg.Wo;
+                pw_[q] -= cw ? pg.Wo : 0;
+                ph_[q] += adv_h + cw;
+                const int ch = ph_[q] >= pg.Ho;
+                ph_[q] -= ch ? pg.Ho : 0;
+                pb_[q] += adv_b + ch;
             }
+            a_off[q] += 32 * KS * ldy;
+            row_n[q] += 32 * KS;
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const u32x4w (&fa)[2], const u32x4w (&fb)[2], uint32_t ok_bits) {
+        const u32x4w z = {0u, 0u, 0u, 0u};
+        uint16_t *sa = sA0 + buf * (2 * 32 * 128), *sb = sB0 + buf * (2 * 32 * 128);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<u32x4w *>(&sA[buf][lr + 16 * q][8 * lc]) = ra[q];
-            *reinterpret_cast<u32x4w *>(&sB[buf][lr + 16 * q][8 * lc]) = rb[q];
+            *reinterpret_cast<u32x4w *>(sa + (lr + 16 * q) * 128 + 8 * lc) = (ok_bits >> q) & 1u ? fa[q] : z;
+            *reinterpret_cast<u32x4w *>(sb + (lr + 16 * q) * 128 + 8 * lc) = (ok_bits >> (2 + q)) & 1u ? fb[q] : z;
         }
     };
     f32x16w acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc00[k] = acc01[k] = acc10[k] = acc11[k] = 0.0f;
-    if (r0 < r1) {
-        fetch(r0);
-        stash(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int64_t r = r0; r < r1; r += 32, buf ^= 1) {
-        const bool more = r + 32 < r1;
-        if (more) fetch(r + 32);
+    // stage: registers -> LDS buffer, the registers refilled D stages ahead, ONE barrier, multiply.  (The buffer the next stage
+    // overwrites was read by the stage before this one; this stage's barrier lies between.)  The stage count is padded to a
+    // multiple of D -- the launcher makes slabs of 32 * KS * D rows, so only the last slab multiplies a few stages of zeros --:
+    // the loop body is ONE straight-line block and the compiler counts the outstanding loads exactly.
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                      // two 16-row MFMA steps per stage
-            uint32_t wa[8], wb[8];
+    for (int d = 0; d < D; ++d) fetch(ra[d], rb[d], okm[d]);
+    const int64_t rounds = (r1 - r0 + 32 * KS * D - 1) / (32 * KS * D);
+    for (int64_t it = 0; it < rounds; ++it) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                wa[j] = *reinterpret_cast<const uint32_t *>(&sA[buf][16 * h + 8 * g + j][co_w + 2 * i]);
-                wb[j] = *reinterpret_cast<const uint32_t *>(&sB[buf][16 * h + 8 * g + j][cv_w + 2 * i]);
+        for (int d = 0; d < D; ++d) {
+            const int buf = (d & 1) ^ ((D & 1) ? (int)(it & 1) : 0);
+            stash(buf, ra[d], rb[d], okm[d]);
+            fetch(ra[d], rb[d], okm[d]);
+            __syncthreads();
+            const uint16_t *sa = sA0 + buf * (2 * 32 * 128), *sb = sB0 + buf * (2 * 32 * 128);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                  // two 16-row MFMA steps per stage
+                uint32_t wa[8], wb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    wa[j] = *reinterpret_cast<const uint32_t *>(sa + (16 * h + 8 * g + j) * 128 + co_w + 2 * i);
+                    wb[j] = *reinterpret_cast<const uint32_t *>(sb + (16 * h + 8 * g + j) * 128 + cv_w + 2 * i);
+                }
+                u32x4w a0, a1, b0, b1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    a0[p] = pair_lo(wa[2 * p], wa[2 * p + 1]);
+                    a1[p] = pair_hi(wa[2 * p], wa[2 * p + 1]);
+                    b0[p] = pair_lo(wb[2 * p], wb[2 * p + 1]);
+                    b1[p] = pair_hi(wb[2 * p], wb[2 * p + 1]);
+                }
+                const bf16x8w fa0 = __builtin_bit_cast(bf16x8w, a0), fa1 = __builtin_bit_cast(bf16x8w, a1);
+                const bf16x8w fb0 = __builtin_bit_cast(bf16x8w, b0), fb1 = __builtin_bit_cast(bf16x8w, b1);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
             }
-            u32x4w a0, a1, b0, b1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                a0[p] = pair_lo(wa[2 * p], wa[2 * p + 1]);
-                a1[p] = pair_hi(wa[2 * p], wa[2 * p + 1]);
-                b0[p] = pair_lo(wb[2 * p], wb[2 * p + 1]);
-                b1[p] = pair_hi(wb[2 * p], wb[2 * p + 1]);
-            }
-            const bf16x8w fa0 = __builtin_bit_cast(bf16x8w, a0), fa1 = __builtin_bit_cast(bf16x8w, a1);
-            const bf16x8w fb0 = __builtin_bit_cast(bf16x8w, b0), fb1 = __builtin_bit_cast(bf16x8w, b1);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
         }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
+    }
+    // fold the slices, a fixed tree: slices [h, 2h) hand their 64 accumulators per thread to slices [0, h) through LDS
+    // (region per pair: [64][256] floats = the operand buffers of two slices)
+    if (KS > 1) {
+        float *ex = reinterpret_cast<float *>(lds_);
+#pragma unroll
+        for (int h = KS / 2; h >= 1; h /= 2) {
+            __syncthreads();                               // (the last stage's LDS reads / the previous round's are done)
+            if (slice >= h && slice < 2 * h) {
+                float *e = ex + (slice - h) * (64 * 256) + t;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    e[(k) * 256] = acc00[k];
+                    e[(16 + k) * 256] = acc01[k];
+                    e[(32 + k) * 256] = acc10[k];
+                    e[(48 + k) * 256] = acc11[k];
+                }
+            }
+            __syncthreads();
+            if (slice < h) {
+                const float *e = ex + slice * (64 * 256) + t;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    acc00[k] += e[(k) * 256];
+                    acc01[k] += e[(16 + k) * 256];
+                    acc10[k] += e[(32 + k) * 256];
+                    acc11[k] += e[(48 + k) * 256];
+                }
+            }
+        }
+        if (slice != 0) return;
     }
     float *o = out + (int64_t)blockIdx.y * group_stride;
 #pragma unroll
@@ -248,25 +334,53 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const uint16_t *__restri
     }
 }
 
-// dw[...] = sum over the groups' partial tables, in group order (deterministic).  taps = 1: dw is [Co, Cv] like the partials;
-// taps = 9: partial column v = tap * Ci + cin goes to the master's layout dw[co, cin, tap] ([Co, Ci, 3, 3] contiguous).
+// dw[...] = sum over the groups' partial tables (a fixed order: deterministic).  T9 = false: dw is [Co, Cv] like the partials, a
+// thread owns 4 consecutive outputs.  T9 = true: partial column v = tap * Ci + cin goes to the master's layout dw[co, cin, tap]
+// ([Co, Ci, 3, 3] contiguous); a thread owns the 9 taps of one (co, cin), the workgroup writes its 256 / S x 9 contiguous outputs
+// through LDS.  S = threads per output: the groups are dealt round robin to S slices which are folded through LDS -- with one
+// thread per output a [64, 256] gradient summed over 123 groups was 16 workgroups of 123 dependent loads: 30 us.
+template <int S, bool T9>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int groups, int64_t n, int Cv,
-                                                           int Ci, int taps, float *__restrict__ dw) {
-    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= n) return;
-    float4 s = *reinterpret_cast<const float4 *>(part + e);
-    for (int gph = 1; gph < groups; ++gph) {
-        const float4 v = *reinterpret_cast<const float4 *>(part + (int64_t)gph * n + e);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                                                           int Ci, float *__restrict__ dw) {
+    constexpr int OUT = 256 / S, W = T9 ? 9 : 4;
+    __shared__ float fold[S][OUT * W + 1];
+    const int o = threadIdx.x % OUT, sl = threadIdx.x / OUT;
+    const int64_t idx = (int64_t)blockIdx.x * OUT + o;                      // float4 index / (co, cin) index
+    const int64_t total = T9 ? n / 9 : n / 4;
+    float acc[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = 0.0f;
+    if (idx < total) {
+        if (!T9) {
+            for (int gph = sl; gph < groups; gph += S) {
+                const float4 v = *reinterpret_cast<const float4 *>(part + (int64_t)gph * n + idx * 4);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            }
+        } else {
+            const int64_t co = idx / Ci;
+            const int cin = (int)(idx - co * Ci);
+            const float *p = part + co * Cv + cin;
+            for (int gph = sl; gph < groups; gph += S) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) acc[tp] += p[(int64_t)gph * n + (int64_t)tp * Ci];
+            }
+        }
     }
-    if (taps == 1) {
-        *reinterpret_cast<float4 *>(dw + e) = s;
+    if (S == 1 && !T9) {
+        if (idx < total) *reinterpret_cast<float4 *>(dw + idx * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         return;
     }
-    const int64_t co = e / Cv;
-    const int v = (int)(e - co * Cv), tap = v / Ci, cin = v - tap * Ci;       // (4 consecutive v share co and tap: Ci % 64 == 0)
-    float *o = dw + (co * Ci + cin) * taps + tap;
-    o[0] = s.x; o[taps] = s.y; o[2 * taps] = s.z; o[3 * taps] = s.w;
+#pragma unroll
+    for (int k = 0; k < W; ++k) fold[sl][o * W + k] = acc[k];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * OUT * W;                     // the workgroup's outputs are contiguous in dw
+    for (int j = threadIdx.x; j < OUT * W; j += 256) {
+        if (base + j >= n) break;
+        float v = fold[0][j];
+#pragma unroll
+        for (int q = 1; q < S; ++q) v += fold[q][j];
+        dw[base + j] = v;
+    }
 }
 
 struct WgradPlan {
@@ -282,14 +396,17 @@ static WgradPlan wgrad_plan(int64_t R, int Co, int Cv, int Ci_patch) {
     if (p.wide) {
         p.cv_tiles = Cv / 128;
         p.tiles = (int64_t)(Co / 128) * p.cv_tiles;
-        // ~768 workgroups per launch, >= 2 stages of 32 rows each, partial tables of <= ~32 MB in all
-        int64_t groups = (768 + p.tiles - 1) / p.tiles;
-        const int64_t by_rows = (R + 63) / 64, by_bytes = (8LL << 20) / ((int64_t)Co * Cv);
+        // ~512 workgroups per launch, partial tables of <= ~16 MB in all, slabs of whole rounds (32 rows x slices x depth):
+        // the best of a sweep over {256, 512, 768} x {8, 16, 32} MB x KS {1, 2, 4} x D {1, 2, 3} on ResNet-101's shapes at
+        // 12 x 255 x 448 (tools/wgrad_probe.py: 1.84 ms for a step's 109 gradients; 2.76 with 768 / 32 MB / KS 1 / D 1)
+        constexpr int64_t RND = 32 * WGRAD_KS * WGRAD_DEPTH;
+        int64_t groups = (512 + p.tiles - 1) / p.tiles;
+        const int64_t by_rows = (R + RND - 1) / RND, by_bytes = (4LL << 20) / ((int64_t)Co * Cv);
         if (groups > by_rows) groups = by_rows;
         if (groups > by_bytes) groups = by_bytes;
         if (groups < 1) groups = 1;
         int64_t rpg = (R + groups - 1) / groups;
-        p.rows_per_wave = (rpg + 31) / 32 * 32;
+        p.rows_per_wave = (rpg + RND - 1) / RND * RND;
         p.groups = (R + p.rows_per_wave - 1) / p.rows_per_wave;
         return p;
     }
@@ -320,10 +437,10 @@ static int wgrad_launch(const void *dy, const void *x, int64_t R, int Co, int Cv
     const dim3 grid((unsigned)p.tiles, (unsigned)p.groups);
     if (p.wide && (ldy & 7) == 0 && (ldx & 7) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0) {
         if (patch)
-            hipLaunchKernelGGL((wgrad_lds_kernel<true>), grid, dim3(256), 0, stream, (const uint16_t *)dy, (const uint16_t *)x,
-                               R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+            hipLaunchKernelGGL((wgrad_lds_kernel<true, WGRAD_KS>), grid, dim3(256 * WGRAD_KS), 0, stream, (const uint16_t *)dy,
+                               (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
         else
-            hipLaunchKernelGGL((wgrad_lds_kernel<false>), grid, dim3(256), 0, stream, (const uint16_t *)dy,
+            hipLaunchKernelGGL((wgrad_lds_kernel<false, WGRAD_KS>), grid, dim3(256 * WGRAD_KS), 0, stream, (const uint16_t *)dy,
                                (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
     } else if (p.wide) {
         return DMM_ERR_UNSUPPORTED;                        // (16-byte pieces need 16-byte aligned rows)
@@ -335,8 +452,29 @@ static int wgrad_launch(const void *dy, const void *x, int64_t R, int Co, int Cv
                            R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
     int rc = check_launch();
     if (rc != DMM_OK || direct) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (const float *)out,
-                       (int)p.groups, n, Cv, patch ? pg.Ci : Cv, patch ? 9 : 1, dw);
+    // threads per output: enough workgroups to fill the chip (>= ~1024 where the table allows), never more slices than groups
+    const int64_t outs = patch ? n / 9 : n / 4;
+    int S = 1;
+    while (S < 16 && 2 * S <= p.groups && outs * S < 256 * 1024) S *= 2;
+    const int ci_ = patch ? pg.Ci : Cv;
+#define DMM_WRED(S_)                                                                                                          \
+    do {                                                                                                                      \
+        const dim3 rg((unsigned)((outs + 256 / S_ - 1) / (256 / S_)));                                                        \
+        if (patch)                                                                                                            \
+            hipLaunchKernelGGL((wgrad_reduce_kernel<S_, true>), rg, dim3(256), 0, stream, (const float *)out, (int)p.groups,  \
+                               n, Cv, ci_, dw);                                                                               \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((wgrad_reduce_kernel<S_, false>), rg, dim3(256), 0, stream, (const float *)out, (int)p.groups, \
+                               n, Cv, ci_, dw);                                                                               \
+    } while (0)
+    switch (S) {
+        case 1: DMM_WRED(1); break;
+        case 2: DMM_WRED(2); break;
+        case 4: DMM_WRED(4); break;
+        case 8: DMM_WRED(8); break;
+        default: DMM_WRED(16); break;
+    }
+#undef DMM_WRED
     return check_launch();
 }
 
