@@ -35,7 +35,7 @@ SYMBOLS = (
     "dmm_matching_loss_f32", "dmm_match_train_tape_bytes", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
     "dmm_match_train_backward_workspace_bytes", "dmm_match_train_backward",
     "dmm_bn_stats_bf16", "dmm_bn_apply_bf16", "dmm_bn_bwd_reduce_bf16", "dmm_bn_bwd_dx_bf16",
-    "dmm_graph_nodes_to_kernels", "dmm_wprep3x3_bf16", "dmm_subsample2_bf16", "dmm_upsample2_zero_bf16", "dmm_wgrad_workspace_bytes", "dmm_wgrad_bf16", "dmm_wgrad3x3_bf16",
+    "dmm_graph_nodes_to_kernels", "dmm_wprep3x3_bf16", "dmm_cast_many_bf16", "dmm_subsample2_bf16", "dmm_upsample2_zero_bf16", "dmm_wgrad_workspace_bytes", "dmm_wgrad_bf16", "dmm_wgrad3x3_bf16",
 )
 
 _lib = None
@@ -152,6 +152,8 @@ def load():
     L.dmm_wgrad3x3_bf16.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, sz, vp]
     L.dmm_wprep3x3_bf16.argtypes = [vp, c_int, c_i64, vp]
     L.dmm_wprep3x3_bf16.restype = c_int
+    L.dmm_cast_many_bf16.argtypes = [vp, c_int, c_i64, vp]
+    L.dmm_cast_many_bf16.restype = c_int
     L.dmm_subsample2_bf16.argtypes = [vp, c_int, c_int, c_int, c_int, vp, vp]
     L.dmm_subsample2_bf16.restype = c_int
     L.dmm_upsample2_zero_bf16.argtypes = [vp, c_int, c_int, c_int, c_int, vp, vp]

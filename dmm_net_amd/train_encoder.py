@@ -232,7 +232,7 @@ def _subsample(x, stride: int):
     B, C, H, W = x.shape
     if stride == 2 and x.is_cuda and x.dtype == torch.bfloat16 and C % 8 == 0 and x.is_contiguous(memory_format=_CL):
         from . import _lib
-        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device).contiguous(memory_format=_CL)
+        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device, memory_format=_CL)
         with _lib.device_guard(x.device):
             _lib.check(_lib.load().dmm_subsample2_bf16(x.data_ptr(), B, H, W, C, y.data_ptr(),
                                                        torch.cuda.current_stream(x.device).cuda_stream), "dmm_subsample2_bf16")
@@ -246,13 +246,13 @@ def _upsample_zero(dy, full, stride: int):
     if stride == 2 and dy.is_cuda and dy.dtype == torch.bfloat16 and C % 8 == 0:
         from . import _lib
         dy = dy.contiguous(memory_format=_CL)
-        dx = torch.empty(full, dtype=dy.dtype, device=dy.device).contiguous(memory_format=_CL)
+        dx = torch.empty(full, dtype=dy.dtype, device=dy.device, memory_format=_CL)
         with _lib.device_guard(dy.device):
             _lib.check(_lib.load().dmm_upsample2_zero_bf16(dy.data_ptr(), B, H, W, C, dx.data_ptr(),
                                                            torch.cuda.current_stream(dy.device).cuda_stream),
                        "dmm_upsample2_zero_bf16")
         return dx
-    dx = torch.zeros(full, dtype=dy.dtype, device=dy.device).contiguous(memory_format=_CL)
+    dx = torch.zeros(full, dtype=dy.dtype, device=dy.device).to(memory_format=_CL)
     dx[:, :, ::stride, ::stride] = dy
     return dx
 
@@ -433,6 +433,7 @@ class TrainEncoder(nn.Module):
         # bf16 weight copies and the hub leaves go; the next forward captures again
         self._plans.clear(), self._shadows.clear(), self._hubs.clear(), self._pending.clear()
         self.__dict__.get("_wprep", {}).clear()
+        self.__dict__.get("_wcast", {}).clear()
         return super()._apply(fn, *args, **kwargs)
 
     # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
@@ -468,13 +469,37 @@ class TrainEncoder(nn.Module):
                         w = sh[id(m)] = torch.empty((m.out_channels, m.in_channels), dtype=torch.bfloat16, device=m.weight.device)
                     dst.append(w)
                     t[id(m)] = w
-                with torch.no_grad():
-                    torch._foreach_copy_(dst, [m.weight.detach().view(m.out_channels, m.in_channels) for m in convs])
+                self._cast_1x1(convs, dst)
         if self.own_wgrad:
             convs = [m for m in mods if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1)
                      and _wgrad_ok(m)]
             if convs:
                 self._prep_3x3(convs, t)
+
+    def _cast_1x1(self, convs, dst):
+        """The bf16 copies of a segment's 1x1 weights by ONE launch over a device table (``torch._foreach_copy_`` with a dtype
+        change: 20-38 us per segment); inside a capture without a table yet, the multi-tensor copy."""
+        from . import _lib
+        memo = self.__dict__.setdefault("_wcast", {})
+        key = tuple(id(m) for m in convs)
+        ptrs = tuple(m.weight.data_ptr() for m in convs) + tuple(d.data_ptr() for d in dst)
+        got = memo.get(key)
+        ok = all(m.weight.is_contiguous() and m.weight.numel() % 8 == 0 for m in convs)
+        if not ok or ((got is None or got[0] != ptrs) and torch.cuda.is_current_stream_capturing()):
+            with torch.no_grad():
+                torch._foreach_copy_(dst, [m.weight.detach().view(m.out_channels, m.in_channels) for m in convs])
+            return
+        dev = convs[0].weight.device
+        if got is None or got[0] != ptrs:
+            rec, blk = [], 0
+            for m, d in zip(convs, dst):
+                n = m.weight.numel()
+                rec += [m.weight.data_ptr(), d.data_ptr(), n, blk]
+                blk += (n + 8191) // 8192
+            got = memo[key] = (ptrs, _lib.small_to_device(rec, torch.int64, dev), blk)
+        with _lib.device_guard(dev):
+            _lib.check(_lib.load().dmm_cast_many_bf16(got[1].data_ptr(), len(convs), got[2],
+                                                      torch.cuda.current_stream(dev).cuda_stream), "dmm_cast_many_bf16")
 
     def _prep_3x3(self, convs, t):
         """bf16 channels-last copies of the 3x3 weights of one segment (and the flipped + transposed ones their data gradients
@@ -492,10 +517,10 @@ class TrainEncoder(nn.Module):
             rec, pairs, tile = [], [], 0
             for m in convs:
                 co, ci = m.out_channels, m.in_channels
-                w = torch.empty((co, ci, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=_CL)
+                w = torch.empty((co, ci, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=_CL)
                 wt = None
                 if _DGRAD_AS_FORWARD and m.stride == (1, 1) and co == ci:
-                    wt = torch.empty((ci, co, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(memory_format=_CL)
+                    wt = torch.empty((ci, co, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=_CL)
                 rec += [m.weight.data_ptr(), w.data_ptr(), 0 if wt is None else wt.data_ptr(), co | (ci << 32), tile]
                 tile += (co // 32) * (ci // 32)
                 pairs.append((w, wt))

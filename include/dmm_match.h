@@ -674,6 +674,10 @@ DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int
  * dmm_subsample2_bf16: y[b, ho, wo, :] = x[b, 2ho, 2wo, :] on channels-last bf16 (the stride of a 1x1 downsample convolution);
  * dmm_upsample2_zero_bf16: its gradient, dx [B, H, W, C] written once (dy at even positions, zero elsewhere).  C % 8 == 0. */
 DMM_API int dmm_wprep3x3_bf16(const void *table, int n, int64_t tiles, dmm_stream_t stream);
+/* fp32 -> bf16 copies of n tensors in one launch (the 1x1 weights of a segment): device records of 32 bytes
+ * {const float *src; uint16 *dst; int64 n; int64 block0}, n a multiple of 8, both 16-byte aligned; a workgroup converts 8192
+ * elements: block0 = sum of ceil(n / 8192) of the records before, blocks = that sum over all records. */
+DMM_API int dmm_cast_many_bf16(const void *table, int n, int64_t blocks, dmm_stream_t stream);
 DMM_API int dmm_subsample2_bf16(const void *x, int B, int H, int W, int C, void *y, dmm_stream_t stream);
 DMM_API int dmm_upsample2_zero_bf16(const void *dy, int B, int H, int W, int C, void *dx, dmm_stream_t stream);
 DMM_API size_t dmm_wgrad_workspace_bytes(int64_t rows, int co, int cv);

@@ -189,6 +189,23 @@ def test_weight_preparation_of_a_segment_in_one_launch_is_the_cast_layout_and_fl
     assert L.dmm_wprep3x3_bf16(None, 0, 0, None) == 0 and L.dmm_wprep3x3_bf16(None, 2, 5, None) != 0
 
 
+def test_casting_many_weights_in_one_launch_is_the_bf16_cast():
+    g = torch.Generator(device=DEV).manual_seed(11)
+    srcs = [torch.randn(n, generator=g, device=DEV) for n in (64 * 64, 8192, 8200, 2048 * 512, 8, 1024 * 256 + 8)]
+    dsts = [torch.zeros(s_.numel() + 8, dtype=torch.bfloat16, device=DEV) for s_ in srcs]          # (+ 8: nothing behind n is touched)
+    rec, blk = [], 0
+    for s_, d in zip(srcs, dsts):
+        rec += [s_.data_ptr(), d.data_ptr(), s_.numel(), blk]
+        blk += (s_.numel() + 8191) // 8192
+    table = torch.tensor(rec, dtype=torch.int64, device=DEV)
+    L = _lib.load()
+    _lib.check(L.dmm_cast_many_bf16(table.data_ptr(), len(srcs), blk, torch.cuda.current_stream().cuda_stream), "cast_many")
+    torch.cuda.synchronize()
+    for s_, d in zip(srcs, dsts):
+        assert torch.equal(d[:-8], s_.to(torch.bfloat16)) and not d[-8:].any()
+    assert L.dmm_cast_many_bf16(None, 0, 0, None) == 0 and L.dmm_cast_many_bf16(None, 1, 1, None) != 0
+
+
 @pytest.mark.parametrize("B,C,H,W", [(12, 256, 64, 112), (2, 512, 33, 57), (3, 64, 7, 9), (1, 8, 1, 1)])
 def test_stride_2_subsample_and_its_gradient_are_the_strided_copies(B, C, H, W):
     from dmm_net_amd.train_encoder import _subsample, _upsample_zero
