@@ -95,29 +95,25 @@ __global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__re
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
     const u32x4t *xp = reinterpret_cast<const u32x4t *>(x);
-    int64_t r = r0 + ro;
-    for (; r + 7 * rpp < r1; r += 8 * rpp) {             // eight loads in flight
+    // eight loads in flight, the tail included: a pass beyond the range reads the thread's first row again and counts as zeros
+    // (a serial tail of up to seven dependent loads was half the kernel's time on the short tensors of layer3 / layer4)
+    const u32x4t z = {0u, 0u, 0u, 0u};
+    for (int64_t r = r0 + ro; r < r1; r += 8 * rpp) {
         u32x4t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = xp[(r + u * rpp) * c8 + cg];
+        for (int u = 0; u < 8; ++u) {
+            const int64_t rr = r + u * rpp;
+            v[u] = xp[(rr < r1 ? rr : r) * c8 + cg];
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float f[8];
-            unpack8(v[u], f);
+            unpack8(r + u * rpp < r1 ? v[u] : z, f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 acc[k] += f[k];
                 acc[8 + k] = __builtin_fmaf(f[k], f[k], acc[8 + k]);
             }
-        }
-    }
-    for (; r < r1; r += rpp) {
-        float f[8];
-        unpack8(xp[r * c8 + cg], f);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            acc[k] += f[k];
-            acc[8 + k] = __builtin_fmaf(f[k], f[k], acc[8 + k]);
         }
     }
     fold_and_add(acc, red, c8t, cg0, c8 * 8, stats);
@@ -205,20 +201,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
     const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
                  *yp = reinterpret_cast<const u32x4t *>(y);
-    int64_t r = r0 + ro;
-    for (; r + 3 * rpp < r1; r += 4 * rpp) {             // four rows (8-12 loads) in flight
-        u32x4t vd[4], vx[4], vy[4];
+    // U rows (12-16 loads) in flight, the tail included: a pass beyond the range reads the thread's first row again with a zero
+    // gradient (contributes nothing to either sum)
+    constexpr int U = RELU == 1 ? 4 : 8;
+    const u32x4t z = {0u, 0u, 0u, 0u};
+    for (int64_t r = r0 + ro; r < r1; r += U * rpp) {
+        u32x4t vd[U], vx[U], vy[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = (r + u * rpp) * c8 + cg;
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r + u * rpp;
+            const int64_t i = (rr < r1 ? rr : r) * c8 + cg;
             vd[u] = dp[i];
             vx[u] = xp[i];
             if (RELU == 1) vy[u] = yp[i];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             float g[8], f[8], o[8];
-            unpack8(vd[u], g);
+            unpack8(r + u * rpp < r1 ? vd[u] : z, g);
             unpack8(vx[u], f);
             if (RELU == 1) unpack8(vy[u], o);
 #pragma unroll
@@ -227,19 +227,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
                 acc[k] += gk;
                 acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
             }
-        }
-    }
-    for (; r < r1; r += rpp) {
-        const int64_t i = r * c8 + cg;
-        float g[8], f[8], o[8];
-        unpack8(dp[i], g);
-        unpack8(xp[i], f);
-        if (RELU == 1) unpack8(yp[i], o);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float gk = (RELU == 0 || (RELU == 1 ? o[k] > 0.0f : __builtin_fmaf(f[k], scale[k], shift[k]) > 0.0f)) ? g[k] : 0.0f;
-            acc[k] += gk;
-            acc[8 + k] = __builtin_fmaf(gk, (f[k] - mean[k]) * invstd[k], acc[8 + k]);
         }
     }
     fold_and_add(acc, red, c8t, cg0, C, sums);
