@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--f32-solver", action="store_true", help="(the default since round 6; accepted for old command lines)")
     ap.add_argument("--bf16", action="store_true", help="config 4: the encoder as train_encoder.TrainEncoder -- bf16 channels-last, "
                     "fp32 master weights, HIP-graph replays, own BatchNorm / weight-gradient kernels (the shipped bf16 training form)")
+    ap.add_argument("--bn-groups", type=int, default=0, help="config 4 --bf16: BatchNorm statistics groups of the encoder call "
+                    "(0 = the clip length 3 when it divides the frames: statistics per frame step, as the reference's per-frame "
+                    "encoder calls compute them; 1 = over all frames of the call)")
     ap.add_argument("--autocast", action="store_true", help="config 4: run the encoder under bf16 autocast (the reference "
                                                           "trains in fp32, which is the default here)")
     ap.add_argument("--repeats", type=int, default=3, help="config 4: timed repeats of K steps each; the line carries the "
@@ -726,6 +729,11 @@ def bench_config4(R):
         run_enc = TrainEncoder(enc, skips_need_grad=False)    # (its convolution shapes ship in dmm_net_amd/miopen_db: no search)
     else:
         run_enc = enc
+    # BatchNorm statistics per FRAME STEP (the 4 videos of one frame), as trainer.py:95-131's one-encoder-call-per-frame loop
+    # computes them: the clip's frames are one batch for the convolutions and 3 statistics groups for BatchNorm
+    bn_groups = int(getattr(args, "bn_groups", 0) or 0) or (3 if bf16 and B % 3 == 0 else 1)
+    if not bf16:
+        bn_groups = 1                                          # (the stock modules: one call = one statistics group)
     model = DMM_Model({"matching": {"algo": "relax"}, "relax_max_iter": 10, "relax_proj_iter": 5,
                        "relax_learning_rate": 0.1, "score_weight": 0.3}, is_test=0, feature_extractor=FeatureExtractor())
     # forward order (body, then heads): the bucketer lays its buckets out in REVERSE parameter order = the order the backward
@@ -763,7 +771,7 @@ def bench_config4(R):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 feats = enc(img)
         else:
-            feats = run_enc(img)                                  # fp32 like the reference's trainer (train.py: no autocast),
+            feats = run_enc(img, bn_groups=bn_groups) if bf16 else run_enc(img)   # fp32 like the reference's trainer (train.py: no autocast),
             #                                                       or the bf16 training form (--bf16)
         mark(1)
         tplt = model.fill_template_dict(None, tboxes, feats, None, valid)
@@ -834,6 +842,9 @@ def bench_config4(R):
                                "training forward (10x5 solver, dual IoU with the targets) + soft-IoU + matching loss, "
                                "backward, Adam; gradient mean = distributed.GradBucketer(overlap=True, 64 MB buckets)",
                    "frames_per_gpu_per_step": B, "sharding": f"clips x{world}, one RCCL all-reduce per bucket",
+                   "batchnorm_statistics": (f"{bn_groups} groups of {B // bn_groups} images = per frame step, what the reference's "
+                                            "one-encoder-call-per-frame loop computes (trainer.py:95-131)" if bn_groups > 1 else
+                                            f"one group: all {B} images of the call"),
                    "stage_ms": {"encoder_fwd": round(avg(0, 1), 3), "roi_layer_loss_fwd": round(avg(1, 2), 3),
                                 "backward_incl_overlapped_allreduce": round(avg(2, 3), 3),
                                 "allreduce_exposed_after_backward": round(avg(3, 4), 3), "adam": round(avg(4, 5), 3)},

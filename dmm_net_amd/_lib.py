@@ -35,6 +35,7 @@ SYMBOLS = (
     "dmm_matching_loss_f32", "dmm_match_train_tape_bytes", "dmm_match_train_forward_workspace_bytes", "dmm_match_train_forward",
     "dmm_match_train_backward_workspace_bytes", "dmm_match_train_backward",
     "dmm_bn_stats_bf16", "dmm_bn_apply_bf16", "dmm_bn_bwd_reduce_bf16", "dmm_bn_bwd_dx_bf16",
+    "dmm_bn_stats_grouped_bf16", "dmm_bn_apply_grouped_bf16", "dmm_bn_bwd_reduce_grouped_bf16", "dmm_bn_bwd_dx_grouped_bf16",
     "dmm_graph_nodes_to_kernels", "dmm_wprep3x3_bf16", "dmm_cast_many_bf16", "dmm_subsample2_bf16", "dmm_upsample2_zero_bf16", "dmm_wgrad_workspace_bytes", "dmm_wgrad_bf16", "dmm_wgrad3x3_bf16",
 )
 
@@ -147,6 +148,10 @@ def load():
     L.dmm_bn_apply_bf16.argtypes = [vp, vp, c_i64, c_int, vp, vp, vp, vp, vp, c_float, c_float, c_int, vp, vp, vp]
     L.dmm_bn_bwd_reduce_bf16.argtypes = [vp, vp, vp, c_i64, c_int, vp, vp, vp, c_int, vp, vp]
     L.dmm_bn_bwd_dx_bf16.argtypes = [vp, vp, vp, c_i64, c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
+    L.dmm_bn_stats_grouped_bf16.argtypes = [vp, c_i64, c_int, c_int, vp, vp]
+    L.dmm_bn_apply_grouped_bf16.argtypes = [vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, vp, c_float, c_float, c_int, vp, vp, vp]
+    L.dmm_bn_bwd_reduce_grouped_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, c_int, vp, vp]
+    L.dmm_bn_bwd_dx_grouped_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
     L.dmm_graph_nodes_to_kernels.argtypes = [vp, c_int, vp, vp, vp]
     L.dmm_wgrad_bf16.argtypes = [vp, vp, c_i64, c_int, c_int, c_i64, c_i64, vp, vp, sz, vp]
     L.dmm_wgrad3x3_bf16.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, sz, vp]
@@ -162,7 +167,8 @@ def load():
     L.dmm_wgrad_workspace_bytes.restype = sz
     L.dmm_wgrad_bf16.restype = L.dmm_wgrad3x3_bf16.restype = c_int
     for f in ("dmm_bn_stats_bf16", "dmm_bn_apply_bf16", "dmm_bn_bwd_reduce_bf16", "dmm_bn_bwd_dx_bf16",
-              "dmm_graph_nodes_to_kernels"):
+              "dmm_bn_stats_grouped_bf16", "dmm_bn_apply_grouped_bf16", "dmm_bn_bwd_reduce_grouped_bf16",
+              "dmm_bn_bwd_dx_grouped_bf16", "dmm_graph_nodes_to_kernels"):
         getattr(L, f).restype = c_int
     L.dmm_mask_mix_to.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, c_int, c_i64,
                                   c_i64, vp]

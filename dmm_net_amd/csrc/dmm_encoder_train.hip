@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void bn_stats_bf16_kernel(const uint16_t *__re
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
-    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x);
+    // (blockIdx.z = the statistics group: `rows` consecutive rows with their own [2, C] block)
+    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x) + (int64_t)blockIdx.z * rows * c8;
+    stats += (int64_t)blockIdx.z * 2 * c8 * 8;
     // eight loads in flight, the tail included: a pass beyond the range reads the thread's first row again and counts as zeros
     // (a serial tail of up to seven dependent loads was half the kernel's time on the short tensors of layer3 / layer4)
     const u32x4t z = {0u, 0u, 0u, 0u};
@@ -127,9 +129,10 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__re
                                                             float momentum, float eps, uint16_t *__restrict__ y,
                                                             float *__restrict__ saved) {
     const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    const int grp = blockIdx.z, groups = gridDim.z;       // statistics groups: `rows` consecutive rows each
     float s[8], q[8], w[8], b[8], scale[8], shift[8];
-    load8f(stats + cg * 8, s);
-    load8f(stats + C + cg * 8, q);
+    load8f(stats + (int64_t)grp * 2 * C + cg * 8, s);
+    load8f(stats + (int64_t)grp * 2 * C + C + cg * 8, q);
     load8f(weight + cg * 8, w);
     load8f(bias + cg * 8, b);
     const float inv_n = 1.0f / (float)rows;
@@ -143,9 +146,22 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__re
         shift[k] = __builtin_fmaf(-mean, scale[k], b[k]);
         if (blockIdx.x == 0 && ro == 0) {
             const int c = cg * 8 + k;
-            saved[c] = mean;
-            saved[C + c] = invstd;
-            if (running_mean) {                           // torch: running = (1 - m) * running + m * batch, unbiased variance
+            saved[(int64_t)grp * 2 * C + c] = mean;
+            saved[(int64_t)grp * 2 * C + C + c] = invstd;
+        }
+    }
+    if (running_mean && blockIdx.x == 0 && grp == 0 && ro == 0) {
+        // torch: running = (1 - m) * running + m * batch with the unbiased variance -- once per group, in group order (what
+        // `groups` calls of the module, one per group, leave behind)
+        for (int gq = 0; gq < groups; ++gq) {
+            load8f(stats + (int64_t)gq * 2 * C + cg * 8, s);
+            load8f(stats + (int64_t)gq * 2 * C + C + cg * 8, q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = cg * 8 + k;
+                const float mean = s[k] * inv_n;
+                float var = __builtin_fmaf(-mean, mean, q[k] * inv_n);
+                var = var > 0.0f ? var : 0.0f;
                 const float unb = rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
                 running_mean[c] = __builtin_fmaf(momentum, mean - running_mean[c], running_mean[c]);
                 running_var[c] = __builtin_fmaf(momentum, unb - running_var[c], running_var[c]);
@@ -154,8 +170,9 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__re
     }
     int64_t r0, r1;
     row_range(rows, rpp, r0, r1);
-    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x), *rp = reinterpret_cast<const u32x4t *>(res);
-    u32x4t *yp = reinterpret_cast<u32x4t *>(y);
+    const int64_t gofs = (int64_t)grp * rows * c8;
+    const u32x4t *xp = reinterpret_cast<const u32x4t *>(x) + gofs, *rp = reinterpret_cast<const u32x4t *>(res) + gofs;
+    u32x4t *yp = reinterpret_cast<u32x4t *>(y) + gofs;
     for (int64_t r = r0 + ro; r < r1; r += rpp) {
         const int64_t i = r * c8 + cg;
         float f[8], g[8];
@@ -182,6 +199,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     __shared__ float red[256 * 16];
     const int C = c8 * 8, c8t = c8 < 32 ? c8 : 32, cg0 = blockIdx.y * c8t;
     const int cg = cg0 + threadIdx.x % c8t, ro = threadIdx.x / c8t, rpp = 256 / c8t;
+    saved += (int64_t)blockIdx.z * 2 * C;                 // (blockIdx.z = the statistics group)
+    sums += (int64_t)blockIdx.z * 2 * C;
     float mean[8], invstd[8], scale[8], shift[8];
     load8f(saved + cg * 8, mean);
     load8f(saved + C + cg * 8, invstd);
@@ -199,8 +218,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
-    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
-                 *yp = reinterpret_cast<const u32x4t *>(y);
+    const int64_t gofs = (int64_t)blockIdx.z * rows * c8;
+    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy) + gofs, *xp = reinterpret_cast<const u32x4t *>(x) + gofs,
+                 *yp = reinterpret_cast<const u32x4t *>(y) + gofs;
     // U rows (12-16 loads) in flight, the tail included: a pass beyond the range reads the thread's first row again with a zero
     // gradient (contributes nothing to either sum)
     constexpr int U = RELU == 1 ? 4 : 8;
@@ -241,12 +261,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
                                                              uint16_t *__restrict__ dres, float *__restrict__ dweight,
                                                              float *__restrict__ dbias) {
     const int C = c8 * 8, cg = threadIdx.x % c8, ro = threadIdx.x / c8, rpp = 256 / c8;
+    const int grp = blockIdx.z, groups = gridDim.z;       // statistics groups: `rows` consecutive rows each
     float mean[8], invstd[8], w[8], sg[8], sgx[8], a[8], mg[8], mgx[8], shift[8];
-    load8f(saved + cg * 8, mean);
-    load8f(saved + C + cg * 8, invstd);
+    load8f(saved + (int64_t)grp * 2 * C + cg * 8, mean);
+    load8f(saved + (int64_t)grp * 2 * C + C + cg * 8, invstd);
     load8f(weight + cg * 8, w);
-    load8f(sums + cg * 8, sg);
-    load8f(sums + C + cg * 8, sgx);
+    load8f(sums + (int64_t)grp * 2 * C + cg * 8, sg);
+    load8f(sums + (int64_t)grp * 2 * C + C + cg * 8, sgx);
     if (RELU == 2) load8f(bias + cg * 8, shift);
     const float inv_n = 1.0f / (float)rows;
 #pragma unroll
@@ -255,16 +276,33 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
         if (RELU == 2) shift[k] = __builtin_fmaf(-mean[k], a[k], shift[k]);     // (a = the forward's scale)
         mg[k] = sg[k] * inv_n;
         mgx[k] = sgx[k] * inv_n;
-        if (blockIdx.x == 0 && ro == 0) {
-            dweight[cg * 8 + k] = sgx[k];
-            dbias[cg * 8 + k] = sg[k];
+    }
+    if (blockIdx.x == 0 && grp == 0 && ro == 0) {         // the parameters' gradients: the groups' sums added in group order
+        float tg[8], tgx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tg[k] = tgx[k] = 0.0f;
+        for (int gq = 0; gq < groups; ++gq) {
+            float u[8], v[8];
+            load8f(sums + (int64_t)gq * 2 * C + cg * 8, u);
+            load8f(sums + (int64_t)gq * 2 * C + C + cg * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                tg[k] += u[k];
+                tgx[k] += v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            dweight[cg * 8 + k] = tgx[k];
+            dbias[cg * 8 + k] = tg[k];
         }
     }
     int64_t r0, r1;
     row_range(rows, rpp, r0, r1);
-    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy), *xp = reinterpret_cast<const u32x4t *>(x),
-                 *yp = reinterpret_cast<const u32x4t *>(y);
-    u32x4t *op = reinterpret_cast<u32x4t *>(dx), *rp = reinterpret_cast<u32x4t *>(dres);
+    const int64_t gofs = (int64_t)grp * rows * c8;
+    const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy) + gofs, *xp = reinterpret_cast<const u32x4t *>(x) + gofs,
+                 *yp = reinterpret_cast<const u32x4t *>(y) + gofs;
+    u32x4t *op = reinterpret_cast<u32x4t *>(dx) + gofs, *rp = reinterpret_cast<u32x4t *>(dres) + gofs;
     for (int64_t r = r0 + ro; r < r1; r += rpp) {
         const int64_t i = r * c8 + cg;
         float g[8], f[8], o[8];
@@ -381,13 +419,14 @@ static inline bool bn_shape_ok(int64_t rows, int C) {
 }
 
 // statistics kernels: (row groups, channel tiles); row groups x 2C atomics <= 128 k, >= 8 passes per workgroup
-static inline dim3 bn_stat_grid(int64_t rows, int c8) {
+static inline dim3 bn_stat_grid(int64_t rows, int c8, int groups) {      // rows: of ONE statistics group
     const int c8t = c8 < 32 ? c8 : 32, rpp = 256 / c8t;
     int64_t g = (rows + (int64_t)rpp * 8 - 1) / ((int64_t)rpp * 8);
-    const int64_t cap = 65536 / (8 * c8) < 256 ? 65536 / (8 * c8) : 256;
+    int64_t cap = 65536 / (8 * c8) < 256 ? 65536 / (8 * c8) : 256;
+    cap = cap / groups > 0 ? cap / groups : 1;                             // (the atomics of all groups count)
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    return dim3((unsigned)g, (unsigned)(c8 / c8t));
+    return dim3((unsigned)g, (unsigned)(c8 / c8t), (unsigned)groups);
 }
 
 // elementwise kernels: every thread gets >= `min_iters` rows where the tensor allows, at most `cap` workgroups
@@ -401,29 +440,39 @@ static inline unsigned bn_grid(int64_t rows, int c8, int min_iters, int cap) {
 
 }  // namespace dmm
 
-extern "C" int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stats, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+// rows = ALL rows; `groups` statistics groups of rows / groups consecutive rows each (groups calls of the layer on the groups'
+// row ranges, in order, in one launch).  stats / saved / sums: [groups][2][C].
+static inline bool bn_groups_ok(int64_t rows, int groups) { return groups >= 1 && groups <= 64 && rows % groups == 0; }
+
+extern "C" int dmm_bn_stats_grouped_bf16(const void *x, int64_t rows, int C, int groups, float *stats, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!x || !stats) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    hipLaunchKernelGGL(dmm::bn_stats_bf16_kernel, dmm::bn_stat_grid(rows, c8), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)x, rows, c8, stats);
+    hipLaunchKernelGGL(dmm::bn_stats_bf16_kernel, dmm::bn_stat_grid(rows / groups, c8, groups), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t *)x, rows / groups, c8, stats);
     return dmm::check_launch();
 }
 
-extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t rows, int C, const float *stats,
-                                 const float *weight, const float *bias, float *running_mean, float *running_var,
-                                 float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0) return DMM_ERR_BAD_ARG;
+extern "C" int dmm_bn_stats_bf16(const void *x, int64_t rows, int C, float *stats, dmm_stream_t stream) {
+    return dmm_bn_stats_grouped_bf16(x, rows, C, 1, stats, stream);
+}
+
+extern "C" int dmm_bn_apply_grouped_bf16(const void *x, const void *residual, int64_t rows, int C, int groups,
+                                         const float *stats, const float *weight, const float *bias, float *running_mean,
+                                         float *running_var, float momentum, float eps, int relu, void *y, float *saved,
+                                         dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!x || !stats || !weight || !bias || !y || !saved || (!running_mean) != (!running_var)) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid(dmm::bn_grid(rows, c8, 2, 4096));
+    const int64_t grows = rows / groups;
+    const dim3 grid(dmm::bn_grid(grows, c8, 2, 4096 / groups), 1, (unsigned)groups);
 #define DMM_BNA(RES_, RELU_)                                                                                             \
     hipLaunchKernelGGL((dmm::bn_apply_bf16_kernel<RES_, RELU_>), grid, dim3(256), 0, (hipStream_t)stream,                \
-                       (const uint16_t *)x, (const uint16_t *)residual, rows, c8, stats, weight, bias, running_mean,     \
+                       (const uint16_t *)x, (const uint16_t *)residual, grows, c8, stats, weight, bias, running_mean,    \
                        running_var, momentum, eps, (uint16_t *)y, saved)
     if (residual) { if (relu) DMM_BNA(true, true); else DMM_BNA(true, false); }
     else { if (relu) DMM_BNA(false, true); else DMM_BNA(false, false); }
@@ -431,42 +480,63 @@ extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t ro
     return dmm::check_launch();
 }
 
-extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                                      const float *weight, const float *bias, int relu, float *sums, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0 || relu < 0 || relu > 2) return DMM_ERR_BAD_ARG;
+extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t rows, int C, const float *stats,
+                                 const float *weight, const float *bias, float *running_mean, float *running_var,
+                                 float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream) {
+    return dmm_bn_apply_grouped_bf16(x, residual, rows, C, 1, stats, weight, bias, running_mean, running_var, momentum, eps,
+                                     relu, y, saved, stream);
+}
+
+extern "C" int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+                                              const float *saved, const float *weight, const float *bias, int relu,
+                                              float *sums, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || relu < 0 || relu > 2 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!dy || !x || !saved || !sums || (relu == 1 && !y) || (relu == 2 && (!weight || !bias))) return DMM_ERR_BAD_ARG;
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid = dmm::bn_stat_grid(rows, c8);
+    const int64_t grows = rows / groups;
+    const dim3 grid = dmm::bn_stat_grid(grows, c8, groups);
 #define DMM_BNR(R_)                                                                                                    \
     hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<R_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy, \
-                       (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, bias, sums)
+                       (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved, weight, bias, sums)
     if (relu == 2) DMM_BNR(2); else if (relu == 1) DMM_BNR(1); else DMM_BNR(0);
 #undef DMM_BNR
     return dmm::check_launch();
 }
 
-extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
-                                  const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
-                                  float *dweight, float *dbias, dmm_stream_t stream) {
-    if (rows < 0 || C <= 0 || relu < 0 || relu > 2) return DMM_ERR_BAD_ARG;
+extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                                      const float *weight, const float *bias, int relu, float *sums, dmm_stream_t stream) {
+    return dmm_bn_bwd_reduce_grouped_bf16(dy, x, y, rows, C, 1, saved, weight, bias, relu, sums, stream);
+}
+
+extern "C" int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+                                          const float *saved, const float *weight, const float *bias, const float *sums,
+                                          int relu, void *dx, void *dres, float *dweight, float *dbias, dmm_stream_t stream) {
+    if (rows < 0 || C <= 0 || relu < 0 || relu > 2 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
     if (rows == 0) return DMM_OK;
     if (!dy || !x || !saved || !weight || !sums || !dx || !dweight || !dbias || (relu == 1 && !y) || (relu == 2 && !bias))
         return DMM_ERR_BAD_ARG;
     if (relu == 2 && dres) return DMM_ERR_BAD_ARG;        // (a residual in front of the ReLU: the mask needs the output)
     if (!dmm::bn_shape_ok(rows, C)) return DMM_ERR_UNSUPPORTED;
     const int c8 = C / 8;
-    const dim3 grid(dmm::bn_grid(rows, c8, 2, 4096));
+    const int64_t grows = rows / groups;
+    const dim3 grid(dmm::bn_grid(grows, c8, 2, 4096 / groups), 1, (unsigned)groups);
 #define DMM_BND(RELU_, DRES_)                                                                                            \
     hipLaunchKernelGGL((dmm::bn_bwd_dx_bf16_kernel<RELU_, DRES_>), grid, dim3(256), 0, (hipStream_t)stream,              \
-                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, rows, c8, saved, weight, bias, sums, \
+                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved, weight, bias, sums, \
                        (uint16_t *)dx, (uint16_t *)dres, dweight, dbias)
     if (relu == 2) DMM_BND(2, false);
     else if (relu == 1) { if (dres) DMM_BND(1, true); else DMM_BND(1, false); }
     else { if (dres) DMM_BND(0, true); else DMM_BND(0, false); }
 #undef DMM_BND
     return dmm::check_launch();
+}
+
+extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
+                                  const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
+                                  float *dweight, float *dbias, dmm_stream_t stream) {
+    return dmm_bn_bwd_dx_grouped_bf16(dy, x, y, rows, C, 1, saved, weight, bias, sums, relu, dx, dres, dweight, dbias, stream);
 }
 
 extern "C" int dmm_wprep3x3_bf16(const void *table, int n, int64_t tiles, dmm_stream_t stream) {

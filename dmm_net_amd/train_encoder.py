@@ -110,30 +110,32 @@ class _BNActFn(torch.autograd.Function):
     ``dmm_bn_bwd_dx_bf16`` (dx, and g as the residual branch's gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual, groups=1):
         from . import _lib
         L = _lib.load()
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
         B, C, H, W = x.shape
+        assert B % groups == 0, (B, groups)
         R = B * H * W
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        stats = _zeroed(2 * C, x.device)
+        stats = _zeroed(groups * 2 * C, x.device)
         y = torch.empty_like(x, memory_format=_CL)
-        saved = torch.empty((2, C), dtype=torch.float32, device=x.device)          # mean, invstd
+        saved = torch.empty((groups, 2, C), dtype=torch.float32, device=x.device)  # mean, invstd of every statistics group
         res = None
         if residual is not None:
             assert residual.shape == x.shape and residual.dtype == x.dtype
             res = residual.contiguous(memory_format=_CL)
         with _lib.device_guard(x.device):
-            _lib.check(L.dmm_bn_stats_bf16(x.data_ptr(), R, C, stats.data_ptr(), stream), "dmm_bn_stats_bf16")
-            _lib.check(L.dmm_bn_apply_bf16(x.data_ptr(), None if res is None else res.data_ptr(), R, C, stats.data_ptr(),
-                                           weight.data_ptr(), bias.data_ptr(),
-                                           None if running_mean is None else running_mean.data_ptr(),
-                                           None if running_var is None else running_var.data_ptr(), float(momentum),
-                                           float(eps), int(relu), y.data_ptr(), saved.data_ptr(), stream),
-                       "dmm_bn_apply_bf16")
+            _lib.check(L.dmm_bn_stats_grouped_bf16(x.data_ptr(), R, C, groups, stats.data_ptr(), stream),
+                       "dmm_bn_stats_grouped_bf16")
+            _lib.check(L.dmm_bn_apply_grouped_bf16(x.data_ptr(), None if res is None else res.data_ptr(), R, C, groups,
+                                                   stats.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                   None if running_mean is None else running_mean.data_ptr(),
+                                                   None if running_var is None else running_var.data_ptr(), float(momentum),
+                                                   float(eps), int(relu), y.data_ptr(), saved.data_ptr(), stream),
+                       "dmm_bn_apply_grouped_bf16")
         ctx.save_for_backward(x, y, weight, bias, saved)
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.relu, ctx.has_res, ctx.groups = bool(relu), residual is not None, groups
         return y
 
     @staticmethod
@@ -148,20 +150,21 @@ class _BNActFn(torch.autograd.Function):
         R = B * H * W
         dy = dy.contiguous(memory_format=_CL)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        sums = _zeroed(2 * C, x.device)
+        groups = ctx.groups
+        sums = _zeroed(groups * 2 * C, x.device)
         dx = torch.empty_like(x, memory_format=_CL)
         dres = torch.empty_like(x, memory_format=_CL) if ctx.has_res else None
         dw = torch.empty((C,), dtype=torch.float32, device=x.device)
         db = torch.empty((C,), dtype=torch.float32, device=x.device)
         with _lib.device_guard(x.device):
-            _lib.check(L.dmm_bn_bwd_reduce_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
-                                                weight.data_ptr(), bias.data_ptr(), mode, sums.data_ptr(), stream),
-                       "dmm_bn_bwd_reduce_bf16")
-            _lib.check(L.dmm_bn_bwd_dx_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, saved.data_ptr(),
-                                            weight.data_ptr(), bias.data_ptr(), sums.data_ptr(), mode, dx.data_ptr(),
-                                            None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
-                                            stream), "dmm_bn_bwd_dx_bf16")
-        return dx, dw, db, None, None, None, None, None, dres
+            _lib.check(L.dmm_bn_bwd_reduce_grouped_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, groups,
+                                                        saved.data_ptr(), weight.data_ptr(), bias.data_ptr(), mode,
+                                                        sums.data_ptr(), stream), "dmm_bn_bwd_reduce_grouped_bf16")
+            _lib.check(L.dmm_bn_bwd_dx_grouped_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, groups, saved.data_ptr(),
+                                                    weight.data_ptr(), bias.data_ptr(), sums.data_ptr(), mode, dx.data_ptr(),
+                                                    None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                    stream), "dmm_bn_bwd_dx_grouped_bf16")
+        return dx, dw, db, None, None, None, None, None, dres, None
 
 
 def _bn_fusable(bn: nn.BatchNorm2d) -> bool:
@@ -170,17 +173,22 @@ def _bn_fusable(bn: nn.BatchNorm2d) -> bool:
             and 0 < c8 <= 256 and 256 % c8 == 0)
 
 
-def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True, counted: bool = False):
+def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True, counted: bool = False, groups: int = 1):
     """BatchNorm2d module ``bn`` (its fp32 parameters and running statistics) on a bf16 channels-last activation,
     followed by the optional residual add and ReLU.  ``fused`` and training and on the device: the two-launch HIP form
-    (``counted``: the caller has already advanced ``num_batches_tracked`` for its whole segment in one launch)."""
+    (``counted``: the caller has already advanced ``num_batches_tracked`` for its whole segment in one launch).
+    ``groups`` > 1 (training): the batch is ``groups`` consecutive sub-batches, each normalised with its OWN statistics and
+    counted as a call of its own by the running statistics -- what ``groups`` calls of the module on the sub-batches do."""
     if fused and bn.training and x.is_cuda and x.dtype == torch.bfloat16 and _bn_fusable(bn):
         if not counted:
             with torch.no_grad():
-                bn.num_batches_tracked.add_(1)
+                bn.num_batches_tracked.add_(groups)
         return _BNActFn.apply(x.contiguous(memory_format=_CL), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                              bn.momentum, bn.eps, relu, residual)
-    y = bn(x)
+                              bn.momentum, bn.eps, relu, residual, groups)
+    if groups > 1 and bn.training:
+        y = torch.cat([bn(c) for c in x.chunk(groups, 0)], 0)
+    else:
+        y = bn(x)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
@@ -440,7 +448,7 @@ class TrainEncoder(nn.Module):
     def _cbr(self, x, conv, bn, relu, residual=None):
         t = self.__dict__["_ticked"]
         y = _conv(x, conv, self.dtype, self.linear_1x1, self.own_wgrad, t.get(id(conv)))
-        return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t)
+        return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t, groups=self.__dict__.get("_bn_groups", 1))
 
     def _tick(self, name: str, x: torch.Tensor, mods=None):
         """Per-segment housekeeping in ONE launch each instead of one per layer: ``num_batches_tracked += 1`` of every
@@ -454,7 +462,7 @@ class TrainEncoder(nn.Module):
             bns = [m for m in mods if isinstance(m, nn.BatchNorm2d) and m.training and _bn_fusable(m)]
             if bns:
                 with torch.no_grad():
-                    torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+                    torch._foreach_add_([m.num_batches_tracked for m in bns], self.__dict__.get("_bn_groups", 1))
                 for m in bns:
                     t[id(m)] = True
         if self.own_wgrad and self.linear_1x1:
@@ -618,7 +626,7 @@ class TrainEncoder(nn.Module):
         for mod in self._seg_modules()[name]:
             for m in mod.modules():
                 if isinstance(m, nn.BatchNorm2d):
-                    n += 2 * m.num_features + 64
+                    n += self.__dict__.get("_bn_groups", 1) * 2 * m.num_features + 64
                 elif isinstance(m, nn.Conv2d) and m.bias is not None:
                     n += 2 * m.out_channels + 64            # (its bias gradient: the statistics kernel's sums)
         return n + 1024
@@ -636,13 +644,20 @@ class TrainEncoder(nn.Module):
         return self._pack(taps, self._seg_heads(*taps))
 
     # ---- entry ---------------------------------------------------------------------------------------------------------
-    def forward(self, img: torch.Tensor) -> Dict[str, Tuple[torch.Tensor, ...]]:
+    def forward(self, img: torch.Tensor, bn_groups: int = 1) -> Dict[str, Tuple[torch.Tensor, ...]]:
+        """``bn_groups`` = G > 1 (training): ``img`` is G consecutive sub-batches and every BatchNorm takes its batch statistics
+        per sub-batch -- the features, gradients and running statistics of G calls on the sub-batches in order (the reference's
+        trainer calls the encoder once per frame step of a clip, trainer.py:95-131; a clip's frames stacked along the batch
+        with G = frames is the same computation in one pass: convolutions never mix images)."""
         assert img.dim() == 4 and img.shape[1] == 3, img.shape           # model_encoder.py:91-92
+        bn_groups = int(bn_groups) if self.training else 1
+        assert bn_groups >= 1 and img.shape[0] % bn_groups == 0, (img.shape[0], bn_groups)
+        self.__dict__["_bn_groups"] = bn_groups
         self.__dict__["_ticked"].clear()
         self.__dict__.pop("_late", None)         # (a hand-over left behind by a backward pass that raised)
         if not (self.graphs and img.is_cuda and self.training and torch.is_grad_enabled()):
             return self._eager(img)
-        key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad)
+        key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad, bn_groups)
         plans = self._plans.setdefault(key, [])
         # a plan's static buffers belong to ONE forward until its backward has run: a second forward of the same shape before
         # that (the trainer's clip: one encoder call per frame, one backward; trainer.py:95-131) takes / captures another plan

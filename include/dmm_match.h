@@ -652,6 +652,22 @@ DMM_API int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y,
 DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
                                const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
                                float *dweight, float *dbias, dmm_stream_t stream);
+/* The same four with `groups` STATISTICS GROUPS: the rows are `groups` consecutive ranges of rows / groups rows, each normalised
+ * with its own batch statistics -- one launch computes what `groups` calls of the layer on the ranges, in order, compute: the
+ * reference's trainer calls the encoder once per frame of a clip (trainer.py:95-131: BatchNorm statistics over the videos of ONE
+ * frame step), and a clip batched into one encoder call keeps exactly those statistics with groups = frames.  stats / saved / sums
+ * are [groups][2][C]; the running statistics take `groups` momentum updates in group order; dweight / dbias are the sums over the
+ * groups.  rows % groups == 0, 1 <= groups <= 64.  (The plain entries are groups = 1.) */
+DMM_API int dmm_bn_stats_grouped_bf16(const void *x, int64_t rows, int C, int groups, float *stats, dmm_stream_t stream);
+DMM_API int dmm_bn_apply_grouped_bf16(const void *x, const void *residual, int64_t rows, int C, int groups, const float *stats,
+                                      const float *weight, const float *bias, float *running_mean, float *running_var,
+                                      float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream);
+DMM_API int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+                                           const float *saved, const float *weight, const float *bias, int relu, float *sums,
+                                           dmm_stream_t stream);
+DMM_API int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+                                       const float *saved, const float *weight, const float *bias, const float *sums, int relu,
+                                       void *dx, void *dres, float *dweight, float *dbias, dmm_stream_t stream);
 
 /* (10b) Weight gradient of the encoder's convolutions (channels-last bf16 activations, fp32 gradient), what autograd
  * computes for conv1 / conv3 / downsample (1x1) and conv2 / the heads (3x3, padding 1) of dmm/modules/vision.py:6-38 and

@@ -258,6 +258,95 @@ def test_graphed_fp32_mode_equals_the_plain_encoder_on_replays(model):
             assert float((a.float() - b.float()).abs().max()) <= 1e-3 * (float(b.float().abs().max()) + 1.0), (step, n)
 
 
+@pytest.mark.parametrize("B,C,H,W,G", [(12, 256, 16, 28, 3), (6, 1024, 8, 14, 2), (8, 64, 9, 11, 4), (3, 512, 4, 5, 3)])
+@pytest.mark.parametrize("relu,has_res", [(True, False), (True, True), (False, False)])
+def test_grouped_bn_kernels_are_the_plain_kernels_called_once_per_group(B, C, H, W, G, relu, has_res):
+    """``groups`` statistics groups in one launch == the layer called on the G sub-batches in order: outputs, saved statistics,
+    the running statistics after G momentum updates, dx / dres per group, dweight / dbias as the sums over the groups."""
+    g = torch.Generator(device=DEV).manual_seed(C + G)
+    cl = torch.channels_last
+    x = (torch.randn((B, C, H, W), generator=g, device=DEV) * 1.5 + 0.3).bfloat16().contiguous(memory_format=cl)
+    res = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=cl) if has_res else None
+    dy = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=cl)
+    w = torch.rand(C, generator=g, device=DEV) + 0.5
+    b = torch.randn(C, generator=g, device=DEV) * 0.1
+
+    def run(groups):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        outs = []
+        if groups == G:
+            xs, rs, ds = [x], [res], [dy]
+        else:
+            xs, ds = list(x.chunk(G, 0)), list(dy.chunk(G, 0))
+            rs = list(res.chunk(G, 0)) if has_res else [None] * G
+        dws, dbs = 0, 0
+        for xi, ri, di in zip(xs, rs, ds):
+            xi = xi.contiguous(memory_format=cl).detach().requires_grad_(True)
+            ri = None if ri is None else ri.contiguous(memory_format=cl).detach().requires_grad_(True)
+            wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = _BNActFn.apply(xi, wi, bi, rm, rv, 0.1, 1e-5, relu, ri, groups if groups == G else 1)
+            y.backward(di.contiguous(memory_format=cl))
+            outs.append((y.detach(), xi.grad, None if ri is None else ri.grad))
+            dws, dbs = dws + wi.grad, dbs + bi.grad
+        cat = lambda k: None if outs[0][k] is None else torch.cat([o[k] for o in outs], 0)
+        return cat(0), cat(1), cat(2), dws, dbs, rm, rv
+    got, want = run(G), run(1)
+    for k, (a, c) in enumerate(zip(got, want)):
+        if a is None:
+            assert c is None
+            continue
+        a, c = a.float(), c.float()
+        tol = 2e-2 if k < 3 else 2e-3                                        # (bf16 planes: an ulp where the sums' order differs)
+        assert float((a - c).abs().max()) <= tol * (float(c.abs().max()) + 1e-3), (k, float((a - c).abs().max()))
+    L = _lib.load()
+    assert L.dmm_bn_stats_grouped_bf16(x.data_ptr(), 10, 64, 3, x.data_ptr(), None) == 1      # rows % groups
+
+
+def test_a_clip_in_one_call_with_per_frame_statistics_is_the_trainers_loop_of_calls():
+    """``TrainEncoder.forward(cat(frames), bn_groups=T)`` against the reference's loop (one encoder call per frame step, one
+    backward; trainer.py:95-131) on the plain ``FeatureEncoder``: features per frame, the gradients of the summed loss, the
+    running statistics after T updates and ``num_batches_tracked``.  fp32 mode (same arithmetic as the plain encoder), graph
+    replays included; then the bf16 form: first-layer statistics and the count."""
+    torch.manual_seed(7)
+    ref = _tame(FeatureEncoder("resnet50", hidden_size=32).to(DEV).train())
+    enc = copy.deepcopy(ref)
+    te = TrainEncoder(enc, dtype=torch.float32)
+    T = 3
+    for step in range(3):
+        frames = [torch.randn(2, 3, 96, 128, device=DEV) for _ in range(T)]
+        for m in (ref, enc):
+            m.zero_grad(set_to_none=True)
+        fr = [ref(f) for f in frames]
+        ft = te(torch.cat(frames, 0), bn_groups=T)
+        for t_ in range(T):
+            for a, b in zip(ft["backbone_feature"] + ft["refine_input_feat"],
+                            fr[t_]["backbone_feature"] + fr[t_]["refine_input_feat"]):
+                a = a[2 * t_:2 * t_ + 2]
+                assert float((a.float() - b).abs().max()) <= 2e-3 * float(b.abs().max()), (step, t_)
+        sum(_loss(f) for f in fr).backward()
+        # the same loss on the stacked features, frame by frame (_loss: fixed directions per output element)
+        sum(_loss({k: tuple(v[2 * t_:2 * t_ + 2] for v in ft[k]) for k in ft}) for t_ in range(T)).backward()
+        gr, gt = _grads(ref), _grads(enc)
+        assert all((gr[k] is None) == (gt[k] is None) for k in gr), step
+        assert _rel(gt, gr) <= 1e-2, (step, _rel(gt, gr))
+        for (n, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
+            assert float((a.float() - b.float()).abs().max()) <= 1e-3 * (float(b.float().abs().max()) + 1.0), (step, n)
+    # the bf16 form: the stem's BatchNorm sees the same bf16 convolution outputs either way
+    ref2 = _tame(FeatureEncoder("resnet50", hidden_size=32).to(DEV).train())
+    enc2 = copy.deepcopy(ref2)
+    loop = TrainEncoder(ref2, graphs=False)
+    clip = TrainEncoder(enc2)
+    frames = [torch.randn(2, 3, 96, 128, device=DEV) for _ in range(T)]
+    for f in frames:
+        loop(f)
+    clip(torch.cat(frames, 0), bn_groups=T)
+    n0 = int(ref2.base.bn1.num_batches_tracked)
+    # (the capturing call runs its warm-up passes too: the counts differ by a multiple of T, the statistics converge to the same)
+    assert (int(enc2.base.bn1.num_batches_tracked) - n0) % T == 0
+    out = clip(torch.cat(frames, 0), bn_groups=T)
+    assert all(torch.isfinite(o.float()).all() for o in out["backbone_feature"])
+
+
 def _tame(enc, gamma=0.2):
     """Residual branches start small (torchvision's ``zero_init_residual`` idea).  A random-init ResNet with unit gammas doubles
     a perturbation every few blocks: ANY two bf16 evaluations of it -- two eager runs of the same code: MIOpen's split-K
