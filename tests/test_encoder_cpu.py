@@ -190,3 +190,30 @@ def test_train_encoder_segments_compute_the_encoder_on_the_cpu():
             assert p.grad is None, n
         else:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_train_encoder_clip_call_keeps_the_per_frame_batchnorm_statistics_on_the_cpu():
+    """``TrainEncoder.forward(cat(frames), bn_groups=T)`` == T calls of the encoder, one per frame step (the reference's
+    trainer loop, trainer.py:95-131): features per frame, running statistics after T updates, ``num_batches_tracked``."""
+    import copy
+    import torch
+    from dmm_net_amd.encoder import FeatureEncoder
+    from dmm_net_amd.train_encoder import TrainEncoder
+    torch.manual_seed(1)
+    ref = FeatureEncoder("resnet34", hidden_size=16).train()
+    enc = copy.deepcopy(ref)
+    te = TrainEncoder(enc, dtype=torch.float32)
+    frames = [torch.randn(2, 3, 48, 64) for _ in range(3)]
+    per_frame = [ref(f) for f in frames]
+    clip = te(torch.cat(frames, 0), bn_groups=3)
+    for t, fr in enumerate(per_frame):
+        for a, b in zip(clip["backbone_feature"] + clip["refine_input_feat"], fr["backbone_feature"] + fr["refine_input_feat"]):
+            assert float((a[2 * t:2 * t + 2].float() - b).abs().max()) <= 2e-3 * float(b.abs().max()), t
+    for (n, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-4 * (float(b.float().abs().max()) + 1.0), n
+    assert int(enc.base.bn1.num_batches_tracked) == 3
+    one = te(torch.cat(frames, 0))                               # (one statistics group: a different normalisation)
+    assert float((one["backbone_feature"][0] - clip["backbone_feature"][0]).abs().max()) > 1e-3
+    import pytest
+    with pytest.raises(AssertionError):
+        te(torch.cat(frames, 0), bn_groups=4)                    # 6 images do not split into 4 groups

@@ -69,6 +69,9 @@ def one(variant, find, steps, frames):
     adam = torch.optim.Adam(params, lr=1e-6, fused=True) if "--adam" in sys.argv else None
 
     clip = int(sys.argv[sys.argv.index("--clip") + 1]) if "--clip" in sys.argv else 1
+    # --bn-groups G (train variants): the call's images as G BatchNorm statistics groups -- a clip's frames in ONE call with the
+    # per-frame statistics of --clip's loop of calls
+    bn_groups = int(sys.argv[sys.argv.index("--bn-groups") + 1]) if "--bn-groups" in sys.argv else 1
     imgs = [img] + [torch.randn_like(img) for _ in range(clip - 1)]
 
     def step(ev=None):
@@ -77,7 +80,7 @@ def one(variant, find, steps, frames):
         loss = 0.0
         for im in imgs:                                       # --clip T: T encoder calls, ONE backward (trainer.py:95-131)
             with ctx():
-                feats = enc(im)
+                feats = enc(im, bn_groups=bn_groups) if bn_groups > 1 else enc(im)
             loss = loss + sum((p.float() * tgt[k]).mean() for k, p in enumerate(feats["backbone_feature"]))
         if ev:
             ev[1].record()
@@ -125,7 +128,7 @@ def one(variant, find, steps, frames):
                "bwd_heads": [rep(g) for g in plan.bwd_head], "bwd_chain": {k: rep(g) for k, g in plan.bwd.items()},
                "bwd_wgrad": {k: rep(_Seq(gs)) for k, gs in plan.wgrad.items()}}
         print(json.dumps({"segments_ms": seg}), flush=True)
-    print(json.dumps({"variant": variant, "find": bool(find), "frames": frames,
+    print(json.dumps({"variant": variant, "find": bool(find), "frames": frames, "clip_calls": clip, "bn_groups": bn_groups,
                       "suggest_nhwc": os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC"),
                       "suggest_nhwc_bn": os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"),
                       "ms_per_step_wall": round(wall, 3), "fwd_ms": round(fwd, 3), "bwd_ms": round(bwd, 3),
