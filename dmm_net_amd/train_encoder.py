@@ -657,6 +657,15 @@ class TrainEncoder(nn.Module):
         self.__dict__.pop("_late", None)         # (a hand-over left behind by a backward pass that raised)
         if not (self.graphs and img.is_cuda and self.training and torch.is_grad_enabled()):
             return self._eager(img)
+        # the captured graphs hold the ADDRESSES of parameters and buffers: storage that was swapped since (``p.data = ...``,
+        # ``load_state_dict(assign=True)``; ``.to()`` goes through ``_apply``) makes every plan stale -- captured again
+        fp = tuple(t.data_ptr() for t in self.src.parameters()) + tuple(t.data_ptr() for t in self.src.buffers())
+        if fp != self.__dict__.get("_storage"):
+            if self.__dict__.get("_storage") is not None:
+                self._plans.clear(), self._shadows.clear(), self._pending.clear()
+                self.__dict__.get("_wprep", {}).clear()
+                self.__dict__.get("_wcast", {}).clear()
+            self.__dict__["_storage"] = fp
         key = (tuple(img.shape), img.dtype, img.device.index, self.skips_need_grad, bn_groups)
         plans = self._plans.setdefault(key, [])
         # a plan's static buffers belong to ONE forward until its backward has run: a second forward of the same shape before

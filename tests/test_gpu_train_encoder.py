@@ -546,6 +546,26 @@ def test_several_forwards_in_flight_like_the_trainers_clip():
         assert len(plans) == 3 and not any(p.busy for p in plans)
 
 
+def test_swapped_parameter_storage_is_seen_by_the_next_call():
+    """The graphs hold parameter ADDRESSES: after ``p.data = other_tensor`` (what ``load_state_dict(assign=True)`` does) the
+    next forward must compute with the new storage -- the plans are captured again -- not replay on the old one."""
+    torch.manual_seed(2)
+    enc = _tame(FeatureEncoder("resnet34", hidden_size=32).to(DEV).train())
+    te = TrainEncoder(enc, dtype=torch.float32)
+    img = torch.randn(2, 3, 96, 128, device=DEV)
+    a = te(img)["backbone_feature"][0].detach().clone()
+    b = te(img)["backbone_feature"][0].detach().clone()                       # (a replay: the same up to the running statistics)
+    assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    with torch.no_grad():
+        enc.base.layer1[0].conv1.weight.data = torch.zeros_like(enc.base.layer1[0].conv1.weight)
+    c = te(img)["backbone_feature"][0].detach().clone()
+    ref = TrainEncoder(enc, dtype=torch.float32, graphs=False)(img)["backbone_feature"][0].detach()
+    assert float((c - a).abs().max()) > 1e-3 * float(a.abs().max())          # the zeroed weight is in effect
+    assert float((c - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    sum(p.float().mean() for p in te(img)["backbone_feature"]).backward()     # and a backward through the new plans runs
+    assert enc.base.layer1[0].conv1.weight.grad is not None
+
+
 def test_safe_graph_turns_memset_and_memcpy_nodes_into_kernel_nodes():
     """``graphs.SafeGraph``: a capture that contains hipMemsetAsync calls and a device-to-device hipMemcpyAsync (what MIOpen /
     torch issue inside a captured step) is rewritten before it is instantiated -- the memset nodes become kernel nodes -- and
