@@ -346,7 +346,7 @@ class GraphedEncoder:
                 entry = self._graphs[key] = self._capture_levels(static_in)
             else:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static_out = self._forward(static_in)
                 entry = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = entry
@@ -378,17 +378,17 @@ class GraphedEncoder:
         x = static_in
         for i, k in enumerate(fast.LEVELS):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pools[0]), torch.no_grad():
+            with torch.cuda.graph(g, pool=pools[0], capture_error_mode="thread_local"), torch.no_grad():
                 x = fast._level(i, fast._stem(static_in) if i == 0 else x)
             h = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(h, pool=pools[1]), torch.no_grad():
+            with torch.cuda.graph(h, pool=pools[1], capture_error_mode="thread_local"), torch.no_grad():
                 p = fast._prop(k, x, on_side=True)
                 if k != fast.LEVELS[-1]:
                     sk = fast._skip(k, x, on_side=True)
             body.append(g), heads.append(h), feats.append(x), props.append(p)
             if k == fast.LEVELS[-1]:                     # nothing left to hide under: the last pair is split over both
                 g = torch.cuda.CUDAGraph()               # streams (this graph follows the fork on the caller's stream)
-                with torch.cuda.graph(g, pool=pools[0]), torch.no_grad():
+                with torch.cuda.graph(g, pool=pools[0], capture_error_mode="thread_local"), torch.no_grad():
                     sk = fast._skip(k, x)
                 body.append(g)
             skips.append(sk)

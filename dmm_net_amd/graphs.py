@@ -29,7 +29,10 @@ class SafeGraph:
     @contextlib.contextmanager
     def capture(self, pool=None, stream=None):
         kw = {} if stream is None else {"stream": stream}
-        with torch.cuda.graph(self.graph, pool=pool, **kw):
+        # thread_local: other threads of the process (a DataLoader's pin-memory thread, a second nn.DataParallel replica) may
+        # allocate / record events while this thread captures; the work of THIS capture is issued by this thread and by autograd's
+        # device thread onto the capturing stream
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local", **kw):
             yield self
         n_set, n_cpy, left = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         raw = self.graph.raw_cuda_graph()

@@ -546,6 +546,45 @@ def test_several_forwards_in_flight_like_the_trainers_clip():
         assert len(plans) == 3 and not any(p.busy for p in plans)
 
 
+def test_capture_survives_another_thread_allocating_pinned_and_device_memory():
+    """A trainer's DataLoader pins batches on a thread of its own and copies them up while the main thread runs the step: the
+    captures (first call of a shape) must not be invalidated by that thread's hipHostMalloc / hipMalloc / event calls
+    (``capture_error_mode="thread_local"``; the default, global, mode fails the capture)."""
+    import threading
+    stop, err = threading.Event(), []
+
+    def loader():
+        try:
+            s_ = torch.cuda.Stream()
+            k = 0
+            while not stop.is_set():
+                k += 1
+                h = torch.empty((1 << 18) + k * 4096).pin_memory()             # (new sizes: the caching allocators must allocate)
+                with torch.cuda.stream(s_):
+                    d = h.to(DEV, non_blocking=True)
+                    d.add_(1.0)
+                s_.synchronize()
+        except Exception as e:                                                  # pragma: no cover
+            err.append(e)
+    th = threading.Thread(target=loader, daemon=True)
+    th.start()
+    try:
+        torch.manual_seed(4)
+        enc = _tame(FeatureEncoder("resnet34", hidden_size=32).to(DEV).train())
+        te = TrainEncoder(enc)
+        for shape in ((2, 3, 96, 128), (2, 3, 64, 96)):                         # two shapes: two rounds of captures
+            img = torch.randn(*shape, device=DEV)
+            for _ in range(2):
+                enc.zero_grad(set_to_none=True)
+                f = te(img)
+                _loss(f).backward()
+                assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in enc.parameters())
+    finally:
+        stop.set()
+        th.join(timeout=30)
+    assert not err, err
+
+
 def test_swapped_parameter_storage_is_seen_by_the_next_call():
     """The graphs hold parameter ADDRESSES: after ``p.data = other_tensor`` (what ``load_state_dict(assign=True)`` does) the
     next forward must compute with the new storage -- the plans are captured again -- not replay on the old one."""
