@@ -66,7 +66,7 @@ class _Arena:
     once, so handing out consecutive slices while it runs fixes every layer's block for all replays."""
 
     def __init__(self, device, floats: int = 1 << 20):
-        self.buf = torch.zeros(int(floats), dtype=torch.float32, device=device)
+        self.buf = torch.empty(int(floats), dtype=torch.float32, device=device)     # (zeroed by the scope, once per replay)
         self.off = 0
 
     def take(self, n: int) -> torch.Tensor:
