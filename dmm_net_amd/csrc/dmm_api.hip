@@ -131,7 +131,9 @@ extern "C" int dmm_last_hip_error(void) { return dmm::g_last_hip_error; }
 
 extern "C" long long dmm_launch_count(void) { return dmm::g_launches.load(std::memory_order_relaxed); }
 
-extern "C" const char *dmm_build_info(void) { return "libdmm_match gfx950 (CDNA4, wave64) abi " "1"; }
+#define DMM_STR_(x) #x
+#define DMM_STR(x) DMM_STR_(x)
+extern "C" const char *dmm_build_info(void) { return "libdmm_match gfx950 (CDNA4, wave64) abi " DMM_STR(DMM_ABI_VERSION); }
 
 extern "C" size_t dmm_workspace_bytes(int B, int N, int M, int D) {
     if (B <= 0 || N <= 0 || M <= 0 || D < 0) return 0;

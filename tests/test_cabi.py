@@ -31,7 +31,7 @@ def test_load_and_status_strings():
     L = _lib.load()
     assert L.dmm_abi_version() == 2
     assert L.dmm_status_string(0) == b"ok"
-    assert b"gfx950" in L.dmm_build_info()
+    assert b"gfx950" in L.dmm_build_info() and L.dmm_build_info().endswith(b"abi %d" % L.dmm_abi_version())
     assert L.dmm_workspace_bytes(4, 50, 10, 512) > 4 * (50 + 10) * 512 * 4
     assert L.dmm_workspace_bytes(0, 50, 10, 512) == 0
 
