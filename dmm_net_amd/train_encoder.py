@@ -492,7 +492,8 @@ class TrainEncoder(nn.Module):
         key = tuple(id(m) for m in convs)
         ptrs = tuple(m.weight.data_ptr() for m in convs) + tuple(d.data_ptr() for d in dst)
         got = memo.get(key)
-        ok = all(m.weight.is_contiguous() and m.weight.numel() % 8 == 0 for m in convs)
+        ok = all(m.weight.is_contiguous() and m.weight.numel() % 8 == 0 and m.weight.data_ptr() % 16 == 0 for m in convs) \
+            and all(d.data_ptr() % 16 == 0 for d in dst)        # (16-byte pieces; e.g. parameters that are views of a flat buffer)
         if not ok or ((got is None or got[0] != ptrs) and torch.cuda.is_current_stream_capturing()):
             with torch.no_grad():
                 torch._foreach_copy_(dst, [m.weight.detach().view(m.out_channels, m.in_channels) for m in convs])
