@@ -551,7 +551,10 @@ class FastEncoder(nn.Module):
         epilogue (``dmm_conv1x1_bf16``: hipBLASLt, residual as the C operand).  stride 2 = a row subsample first."""
         from . import _lib
         wt, b32, bl = self._p[id(conv)]
-        if conv.stride != (1, 1):
+        if conv.stride == (2, 2) and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+            from .train_encoder import _subsample                       # 16 bytes per thread (the strided copy below: 2)
+            x = _subsample(x, 2)
+        elif conv.stride != (1, 1):
             x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
         x = x.contiguous(memory_format=torch.channels_last)
         B, _, H, W = x.shape
