@@ -150,8 +150,8 @@ def load():
     L.dmm_bn_bwd_dx_bf16.argtypes = [vp, vp, vp, c_i64, c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
     L.dmm_bn_stats_grouped_bf16.argtypes = [vp, c_i64, c_int, c_int, vp, vp]
     L.dmm_bn_apply_grouped_bf16.argtypes = [vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, vp, c_float, c_float, c_int, vp, vp, vp]
-    L.dmm_bn_bwd_reduce_grouped_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, c_int, vp, vp]
-    L.dmm_bn_bwd_dx_grouped_bf16.argtypes = [vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
+    L.dmm_bn_bwd_reduce_grouped_bf16.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, c_int, vp, vp]
+    L.dmm_bn_bwd_dx_grouped_bf16.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp]
     L.dmm_graph_nodes_to_kernels.argtypes = [vp, c_int, vp, vp, vp]
     L.dmm_wgrad_bf16.argtypes = [vp, vp, c_i64, c_int, c_int, c_i64, c_i64, vp, vp, sz, vp]
     L.dmm_wgrad3x3_bf16.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, sz, vp]

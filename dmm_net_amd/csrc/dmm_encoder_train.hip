@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const uint16_t *__re
 // RELU: 0 = none, 1 = the mask from the rounded output y, 2 = the mask recomputed from x (no residual in front of the ReLU:
 // y > 0 exactly when x * scale + shift > 0, the forward's own fma with the forward's own scale / shift -- one plane less to read)
 template <int RELU>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy2,
+                                                                 const uint16_t *__restrict__ x,
                                                                  const uint16_t *__restrict__ y, int64_t rows, int c8,
                                                                  const float *__restrict__ saved, const float *__restrict__ weight,
                                                                  const float *__restrict__ bias, float *__restrict__ sums) {
@@ -221,24 +222,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
     const int64_t gofs = (int64_t)blockIdx.z * rows * c8;
     const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy) + gofs, *xp = reinterpret_cast<const u32x4t *>(x) + gofs,
                  *yp = reinterpret_cast<const u32x4t *>(y) + gofs;
+    // dy2 (may be null): the gradient is dy + dy2 -- the layer's output went to two consumers (the next block's first
+    // convolution and its identity branch) and their gradients are added HERE, in fp32, instead of by a launch of their own
+    const u32x4t *dp2 = dy2 ? reinterpret_cast<const u32x4t *>(dy2) + gofs : nullptr;
     // U rows (12-16 loads) in flight, the tail included: a pass beyond the range reads the thread's first row again with a zero
     // gradient (contributes nothing to either sum)
     constexpr int U = RELU == 1 ? 4 : 8;
     const u32x4t z = {0u, 0u, 0u, 0u};
     for (int64_t r = r0 + ro; r < r1; r += U * rpp) {
-        u32x4t vd[U], vx[U], vy[U];
+        u32x4t vd[U], vx[U], vy[U], ve[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t rr = r + u * rpp;
             const int64_t i = (rr < r1 ? rr : r) * c8 + cg;
             vd[u] = dp[i];
+            ve[u] = dp2 ? dp2[i] : z;
             vx[u] = xp[i];
             if (RELU == 1) vy[u] = yp[i];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float g[8], f[8], o[8];
+            float g[8], f[8], o[8], g2[8];
             unpack8(r + u * rpp < r1 ? vd[u] : z, g);
+            unpack8(r + u * rpp < r1 ? ve[u] : z, g2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] += g2[k];
             unpack8(vx[u], f);
             if (RELU == 1) unpack8(vy[u], o);
 #pragma unroll
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const uint16_t 
 }
 
 template <int RELU, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ dy2,
+                                                             const uint16_t *__restrict__ x,
                                                              const uint16_t *__restrict__ y, int64_t rows, int c8,
                                                              const float *__restrict__ saved, const float *__restrict__ weight,
                                                              const float *__restrict__ bias,
@@ -303,10 +312,17 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_bf16_kernel(const uint16_t *__r
     const u32x4t *dp = reinterpret_cast<const u32x4t *>(dy) + gofs, *xp = reinterpret_cast<const u32x4t *>(x) + gofs,
                  *yp = reinterpret_cast<const u32x4t *>(y) + gofs;
     u32x4t *op = reinterpret_cast<u32x4t *>(dx) + gofs, *rp = reinterpret_cast<u32x4t *>(dres) + gofs;
+    const u32x4t *dp2 = dy2 ? reinterpret_cast<const u32x4t *>(dy2) + gofs : nullptr;
     for (int64_t r = r0 + ro; r < r1; r += rpp) {
         const int64_t i = r * c8 + cg;
         float g[8], f[8], o[8];
         unpack8(dp[i], g);
+        if (dp2) {
+            float g2[8];
+            unpack8(dp2[i], g2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] += g2[k];
+        }
         unpack8(xp[i], f);
         if (RELU == 1) unpack8(yp[i], o);
 #pragma unroll
@@ -487,7 +503,7 @@ extern "C" int dmm_bn_apply_bf16(const void *x, const void *residual, int64_t ro
                                      relu, y, saved, stream);
 }
 
-extern "C" int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+extern "C" int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *dy2, const void *x, const void *y, int64_t rows, int C, int groups,
                                               const float *saved, const float *weight, const float *bias, int relu,
                                               float *sums, dmm_stream_t stream) {
     if (rows < 0 || C <= 0 || relu < 0 || relu > 2 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
@@ -499,7 +515,7 @@ extern "C" int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, con
     const dim3 grid = dmm::bn_stat_grid(grows, c8, groups);
 #define DMM_BNR(R_)                                                                                                    \
     hipLaunchKernelGGL((dmm::bn_bwd_reduce_bf16_kernel<R_>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy, \
-                       (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved, weight, bias, sums)
+                       (const uint16_t *)dy2, (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved, weight, bias, sums)
     if (relu == 2) DMM_BNR(2); else if (relu == 1) DMM_BNR(1); else DMM_BNR(0);
 #undef DMM_BNR
     return dmm::check_launch();
@@ -507,10 +523,10 @@ extern "C" int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, con
 
 extern "C" int dmm_bn_bwd_reduce_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
                                       const float *weight, const float *bias, int relu, float *sums, dmm_stream_t stream) {
-    return dmm_bn_bwd_reduce_grouped_bf16(dy, x, y, rows, C, 1, saved, weight, bias, relu, sums, stream);
+    return dmm_bn_bwd_reduce_grouped_bf16(dy, nullptr, x, y, rows, C, 1, saved, weight, bias, relu, sums, stream);
 }
 
-extern "C" int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+extern "C" int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *dy2, const void *x, const void *y, int64_t rows, int C, int groups,
                                           const float *saved, const float *weight, const float *bias, const float *sums,
                                           int relu, void *dx, void *dres, float *dweight, float *dbias, dmm_stream_t stream) {
     if (rows < 0 || C <= 0 || relu < 0 || relu > 2 || !bn_groups_ok(rows, groups)) return DMM_ERR_BAD_ARG;
@@ -524,8 +540,8 @@ extern "C" int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const v
     const dim3 grid(dmm::bn_grid(grows, c8, 2, 4096 / groups), 1, (unsigned)groups);
 #define DMM_BND(RELU_, DRES_)                                                                                            \
     hipLaunchKernelGGL((dmm::bn_bwd_dx_bf16_kernel<RELU_, DRES_>), grid, dim3(256), 0, (hipStream_t)stream,              \
-                       (const uint16_t *)dy, (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved, weight, bias, sums, \
-                       (uint16_t *)dx, (uint16_t *)dres, dweight, dbias)
+                       (const uint16_t *)dy, (const uint16_t *)dy2, (const uint16_t *)x, (const uint16_t *)y, grows, c8, saved,  \
+                       weight, bias, sums, (uint16_t *)dx, (uint16_t *)dres, dweight, dbias)
     if (relu == 2) DMM_BND(2, false);
     else if (relu == 1) { if (dres) DMM_BND(1, true); else DMM_BND(1, false); }
     else { if (dres) DMM_BND(0, true); else DMM_BND(0, false); }
@@ -536,7 +552,7 @@ extern "C" int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const v
 extern "C" int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, const float *saved,
                                   const float *weight, const float *bias, const float *sums, int relu, void *dx, void *dres,
                                   float *dweight, float *dbias, dmm_stream_t stream) {
-    return dmm_bn_bwd_dx_grouped_bf16(dy, x, y, rows, C, 1, saved, weight, bias, sums, relu, dx, dres, dweight, dbias, stream);
+    return dmm_bn_bwd_dx_grouped_bf16(dy, nullptr, x, y, rows, C, 1, saved, weight, bias, sums, relu, dx, dres, dweight, dbias, stream);
 }
 
 extern "C" int dmm_wprep3x3_bf16(const void *table, int n, int64_t tiles, dmm_stream_t stream) {

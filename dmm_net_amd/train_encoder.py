@@ -110,7 +110,7 @@ class _BNActFn(torch.autograd.Function):
     ``dmm_bn_bwd_dx_bf16`` (dx, and g as the residual branch's gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual, groups=1):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual, groups=1, fork=False):
         from . import _lib
         L = _lib.load()
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=_CL)
@@ -136,11 +136,13 @@ class _BNActFn(torch.autograd.Function):
                        "dmm_bn_apply_grouped_bf16")
         ctx.save_for_backward(x, y, weight, bias, saved)
         ctx.relu, ctx.has_res, ctx.groups = bool(relu), residual is not None, groups
-        return y
+        # fork: the output as TWO tensors (the second an alias) for its two consumers -- a residual block's first convolution and
+        # its identity branch --, so that their gradients arrive separately and are added inside the backward kernels
+        return (y, y.view_as(y)) if fork else y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         from . import _lib
         L = _lib.load()
         x, y, weight, bias, saved = ctx.saved_tensors
@@ -148,7 +150,11 @@ class _BNActFn(torch.autograd.Function):
         mode = 0 if not ctx.relu else (1 if ctx.has_res else 2)
         B, C, H, W = x.shape
         R = B * H * W
+        if dy is None:                                    # (only the alias was used)
+            dy, dy2 = dy2, None
         dy = dy.contiguous(memory_format=_CL)
+        if dy2 is not None:
+            dy2 = dy2.to(dy.dtype).contiguous(memory_format=_CL)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         groups = ctx.groups
         sums = _zeroed(groups * 2 * C, x.device)
@@ -157,14 +163,15 @@ class _BNActFn(torch.autograd.Function):
         dw = torch.empty((C,), dtype=torch.float32, device=x.device)
         db = torch.empty((C,), dtype=torch.float32, device=x.device)
         with _lib.device_guard(x.device):
-            _lib.check(L.dmm_bn_bwd_reduce_grouped_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, groups,
+            p2 = None if dy2 is None else dy2.data_ptr()
+            _lib.check(L.dmm_bn_bwd_reduce_grouped_bf16(dy.data_ptr(), p2, x.data_ptr(), y.data_ptr(), R, C, groups,
                                                         saved.data_ptr(), weight.data_ptr(), bias.data_ptr(), mode,
                                                         sums.data_ptr(), stream), "dmm_bn_bwd_reduce_grouped_bf16")
-            _lib.check(L.dmm_bn_bwd_dx_grouped_bf16(dy.data_ptr(), x.data_ptr(), y.data_ptr(), R, C, groups, saved.data_ptr(),
+            _lib.check(L.dmm_bn_bwd_dx_grouped_bf16(dy.data_ptr(), p2, x.data_ptr(), y.data_ptr(), R, C, groups, saved.data_ptr(),
                                                     weight.data_ptr(), bias.data_ptr(), sums.data_ptr(), mode, dx.data_ptr(),
                                                     None if dres is None else dres.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                                     stream), "dmm_bn_bwd_dx_grouped_bf16")
-        return dx, dw, db, None, None, None, None, None, dres, None
+        return dx, dw, db, None, None, None, None, None, dres, None, None
 
 
 def _bn_fusable(bn: nn.BatchNorm2d) -> bool:
@@ -173,7 +180,8 @@ def _bn_fusable(bn: nn.BatchNorm2d) -> bool:
             and 0 < c8 <= 256 and 256 % c8 == 0)
 
 
-def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True, counted: bool = False, groups: int = 1):
+def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True, counted: bool = False, groups: int = 1,
+            fork: bool = False):
     """BatchNorm2d module ``bn`` (its fp32 parameters and running statistics) on a bf16 channels-last activation,
     followed by the optional residual add and ReLU.  ``fused`` and training and on the device: the two-launch HIP form
     (``counted``: the caller has already advanced ``num_batches_tracked`` for its whole segment in one launch).
@@ -184,14 +192,15 @@ def _bn_act(x, bn: nn.BatchNorm2d, relu: bool, residual=None, fused: bool = True
             with torch.no_grad():
                 bn.num_batches_tracked.add_(groups)
         return _BNActFn.apply(x.contiguous(memory_format=_CL), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                              bn.momentum, bn.eps, relu, residual, groups)
+                              bn.momentum, bn.eps, relu, residual, groups, fork)
     if groups > 1 and bn.training:
         y = torch.cat([bn(c) for c in x.chunk(groups, 0)], 0)
     else:
         y = bn(x)
     if residual is not None:
         y = y + residual
-    return F.relu(y) if relu else y
+    y = F.relu(y) if relu else y
+    return (y, y) if fork else y                          # (``fork``: the output for two consumers; only the fused form makes it two tensors)
 
 
 # ---- weight gradients: launched where the backward reaches them, or collected for a graph of their own -------------------
@@ -445,10 +454,11 @@ class TrainEncoder(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     # ---- the encoder in segments (plain functions of tensors; parameters come from self.src) ------------------------
-    def _cbr(self, x, conv, bn, relu, residual=None):
+    def _cbr(self, x, conv, bn, relu, residual=None, fork=False):
         t = self.__dict__["_ticked"]
         y = _conv(x, conv, self.dtype, self.linear_1x1, self.own_wgrad, t.get(id(conv)))
-        return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t, groups=self.__dict__.get("_bn_groups", 1))
+        return _bn_act(y, bn, relu, residual, self.fused_bn, counted=id(bn) in t, groups=self.__dict__.get("_bn_groups", 1),
+                       fork=fork)
 
     def _tick(self, name: str, x: torch.Tensor, mods=None):
         """Per-segment housekeeping in ONE launch each instead of one per layer: ``num_batches_tracked += 1`` of every
@@ -543,30 +553,37 @@ class TrainEncoder(nn.Module):
         for m, pr in zip(convs, pairs):
             t[id(m)] = pr
 
-    def _block(self, x, blk):
-        idt = x if blk.downsample is None else self._cbr(x, blk.downsample[0], blk.downsample[1], False)
+    def _block(self, x, blk, fork=False):
+        """One residual block.  ``x``: a tensor, or the PAIR (x, alias) a predecessor made with ``fork`` -- the first convolution
+        takes one, the identity branch (or the downsample convolution) the other, so that the two gradients reach the
+        predecessor's BatchNorm separately and are added inside its backward kernels (autograd's own add of them: one launch
+        over the whole tensor per block).  ``fork``: return such a pair for the next block."""
+        xa, xb = x if isinstance(x, tuple) else (x, x)
+        idt = xb if blk.downsample is None else self._cbr(xb, blk.downsample[0], blk.downsample[1], False)
         if isinstance(blk, Bottleneck):
-            out = self._cbr(x, blk.conv1, blk.bn1, True)
+            out = self._cbr(xa, blk.conv1, blk.bn1, True)
             out = self._cbr(out, blk.conv2, blk.bn2, True)
-            return self._cbr(out, blk.conv3, blk.bn3, True, idt)
-        out = self._cbr(x, blk.conv1, blk.bn1, True)
-        return self._cbr(out, blk.conv2, blk.bn2, True, idt)
+            return self._cbr(out, blk.conv3, blk.bn3, True, idt, fork=fork)
+        out = self._cbr(xa, blk.conv1, blk.bn1, True)
+        return self._cbr(out, blk.conv2, blk.bn2, True, idt, fork=fork)
 
     def _layer(self, x, layer):
-        for blk in layer:
-            x = self._block(x, blk)
+        for q, blk in enumerate(layer):
+            x = self._block(x, blk, fork=q + 1 < len(layer))
         return x
 
     def _seg_body(self, name: str, x):
         """One body segment of the chain: (the stem when it is the first,) its blocks in order.  -> (output,)"""
         body = self.src.base
         self._tick(name, x)
-        for op in next(c[1] for c in self._chain if c[0] == name):
+        ops_ = next(c[1] for c in self._chain if c[0] == name)
+        for q, op in enumerate(ops_):
             if isinstance(op, str):                                      # "stem": conv1 -> bn1 -> relu -> maxpool
                 x = x.to(self.dtype).contiguous(memory_format=_CL)
                 x = body.maxpool(self._cbr(x, body.conv1, body.bn1, True))
             else:
-                x = self._block(x, op)
+                # (the segment's last block hands ONE tensor on: its consumers are other graphs)
+                x = self._block(x, op, fork=q + 1 < len(ops_) and not isinstance(ops_[q + 1], str))
         return (x,)
 
     def _head(self, x, head):

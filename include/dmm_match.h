@@ -657,15 +657,17 @@ DMM_API int dmm_bn_bwd_dx_bf16(const void *dy, const void *x, const void *y, int
  * reference's trainer calls the encoder once per frame of a clip (trainer.py:95-131: BatchNorm statistics over the videos of ONE
  * frame step), and a clip batched into one encoder call keeps exactly those statistics with groups = frames.  stats / saved / sums
  * are [groups][2][C]; the running statistics take `groups` momentum updates in group order; dweight / dbias are the sums over the
- * groups.  rows % groups == 0, 1 <= groups <= 64.  (The plain entries are groups = 1.) */
+ * groups.  rows % groups == 0, 1 <= groups <= 64.  (The plain entries are groups = 1.)  The two backward entries take a SECOND
+ * gradient plane dy2 (may be NULL): the layer's output went to two consumers (a residual block's first convolution and its identity
+ * branch, dmm/modules/vision.py:26-38) and the gradient is dy + dy2, added in fp32 inside the kernels instead of by a launch. */
 DMM_API int dmm_bn_stats_grouped_bf16(const void *x, int64_t rows, int C, int groups, float *stats, dmm_stream_t stream);
 DMM_API int dmm_bn_apply_grouped_bf16(const void *x, const void *residual, int64_t rows, int C, int groups, const float *stats,
                                       const float *weight, const float *bias, float *running_mean, float *running_var,
                                       float momentum, float eps, int relu, void *y, float *saved, dmm_stream_t stream);
-DMM_API int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+DMM_API int dmm_bn_bwd_reduce_grouped_bf16(const void *dy, const void *dy2, const void *x, const void *y, int64_t rows, int C, int groups,
                                            const float *saved, const float *weight, const float *bias, int relu, float *sums,
                                            dmm_stream_t stream);
-DMM_API int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *x, const void *y, int64_t rows, int C, int groups,
+DMM_API int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *dy2, const void *x, const void *y, int64_t rows, int C, int groups,
                                        const float *saved, const float *weight, const float *bias, const float *sums, int relu,
                                        void *dx, void *dres, float *dweight, float *dbias, dmm_stream_t stream);
 

@@ -302,6 +302,48 @@ def test_grouped_bn_kernels_are_the_plain_kernels_called_once_per_group(B, C, H,
     assert L.dmm_bn_stats_grouped_bf16(x.data_ptr(), 10, 64, 3, x.data_ptr(), None) == 1      # rows % groups
 
 
+@pytest.mark.parametrize("relu,has_res,G", [(True, True, 1), (True, False, 1), (False, False, 3), (True, True, 3)])
+def test_forked_output_adds_its_two_gradients_inside_the_backward_kernels(relu, has_res, G):
+    """``fork=True``: the layer's output as two tensors for two consumers; the gradients that arrive for them are added inside
+    the backward kernels (fp32) -- the same dx / dres / dweight / dbias as one output with the summed gradient."""
+    g = torch.Generator(device=DEV).manual_seed(17 + G)
+    cl = torch.channels_last
+    B, C, H, W = 6, 256, 9, 13
+    x = (torch.randn((B, C, H, W), generator=g, device=DEV) * 1.3).bfloat16().contiguous(memory_format=cl)
+    res = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=cl) if has_res else None
+    da = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=cl)
+    db_ = torch.randn((B, C, H, W), generator=g, device=DEV).bfloat16().contiguous(memory_format=cl)
+    w = torch.rand(C, generator=g, device=DEV) + 0.5
+    b = torch.randn(C, generator=g, device=DEV) * 0.1
+
+    def run(fork):
+        xi = x.detach().clone().requires_grad_(True)
+        ri = None if res is None else res.detach().clone().requires_grad_(True)
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        out = _BNActFn.apply(xi, wi, bi, rm, rv, 0.1, 1e-5, relu, ri, G, fork)
+        if fork:
+            assert torch.equal(out[0], out[1])
+            torch.autograd.backward(list(out), [da, db_])
+        else:
+            out.backward((da.float() + db_.float()).to(torch.bfloat16))
+        return xi.grad, None if ri is None else ri.grad, wi.grad, bi.grad
+    got, want = run(True), run(False)
+    for k, (a, c) in enumerate(zip(got, want)):
+        if a is None:
+            assert c is None
+            continue
+        a, c = a.float(), c.float()
+        tol = 3e-2 if k < 2 else 1e-2                   # (the reference rounds the summed gradient to bf16 first)
+        assert float((a - c).abs().max()) <= tol * (float(c.abs().max()) + 1e-3), (k, float((a - c).abs().max()))
+    # only one of the two outputs used
+    xi = x.detach().clone().requires_grad_(True)
+    y1, y2 = _BNActFn.apply(xi, w.clone().requires_grad_(True), b.clone().requires_grad_(True), None, None, 0.1, 1e-5, relu,
+                            None, G, True)
+    y2.backward(da)
+    assert xi.grad is not None and bool(torch.isfinite(xi.grad.float()).all())
+
+
 def test_a_clip_in_one_call_with_per_frame_statistics_is_the_trainers_loop_of_calls():
     """``TrainEncoder.forward(cat(frames), bn_groups=T)`` against the reference's loop (one encoder call per frame step, one
     backward; trainer.py:95-131) on the plain ``FeatureEncoder``: features per frame, the gradients of the summed loss, the
