@@ -18,9 +18,22 @@ import torch
 from . import _lib
 
 
+class CaptureFailed(RuntimeError):
+    """A stream capture was invalidated (by an API call elsewhere in the process, or by a launch the runtime refuses under
+    capture): nothing was instantiated, the calling thread's current stream is what it was before."""
+
+
 class SafeGraph:
     """``with g.capture(pool=...): ...`` then ``g.replay()``.  ``g.rewritten`` = (memset nodes, memcpy nodes) replaced by
-    kernel nodes, ``g.left`` = memset / memcpy nodes that stayed (2-D / 3-D copies, host copies)."""
+    kernel nodes, ``g.left`` = memset / memcpy nodes that stayed (2-D / 3-D copies, host copies).
+
+    The capture is driven by ``capture_begin`` / ``capture_end`` directly, inside a ``torch.cuda.stream`` scope:
+    ``torch.cuda.graph.__exit__`` leaves the CAPTURE stream current when ``capture_end`` raises (every later launch of the
+    process then fails with "operation not permitted when stream is capturing"), here the previous stream always comes back
+    and a failed capture surfaces as ``CaptureFailed``.  Thread-local capture mode: other threads of the process (a DataLoader's
+    pin-memory thread, a second ``nn.DataParallel`` replica) may allocate / record events while this one captures."""
+
+    _streams = {}                                         # device index -> the capture stream (captures never run side by side)
 
     def __init__(self):
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
@@ -28,12 +41,32 @@ class SafeGraph:
 
     @contextlib.contextmanager
     def capture(self, pool=None, stream=None):
-        kw = {} if stream is None else {"stream": stream}
-        # thread_local: other threads of the process (a DataLoader's pin-memory thread, a second nn.DataParallel replica) may
-        # allocate / record events while this thread captures; the work of THIS capture is issued by this thread and by autograd's
-        # device thread onto the capturing stream
-        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local", **kw):
-            yield self
+        dev = torch.cuda.current_device()
+        if stream is None:
+            stream = SafeGraph._streams.get(dev)
+            if stream is None:
+                stream = SafeGraph._streams[dev] = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        failed = None
+        with torch.cuda.stream(stream):
+            try:
+                self.graph.capture_begin(pool=pool, capture_error_mode="thread_local")
+            except Exception as e:                        # (e.g. the stream is still in a capture that was invalidated)
+                raise CaptureFailed(f"capture_begin: {e}") from e
+            try:
+                yield self
+            except BaseException as e:
+                failed = e
+            try:
+                self.graph.capture_end()
+            except Exception as e:
+                failed = failed or e
+        if failed is not None:
+            SafeGraph._streams.pop(dev, None)             # (a stream whose capture was invalidated is not reused)
+            if isinstance(failed, Exception) and not isinstance(failed, CaptureFailed):
+                raise CaptureFailed(f"{type(failed).__name__}: {failed}") from failed
+            raise failed
+        torch.cuda.current_stream().wait_stream(stream)
         n_set, n_cpy, left = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         raw = self.graph.raw_cuda_graph()
         rc = _lib.load().dmm_graph_nodes_to_kernels(ctypes.c_void_p(int(raw)), 3, ctypes.byref(n_set), ctypes.byref(n_cpy),

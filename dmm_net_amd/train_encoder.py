@@ -51,7 +51,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .encoder import _NO_CTX, Bottleneck, FeatureEncoder, ResNetBody
-from .graphs import SafeGraph
+from .graphs import CaptureFailed, SafeGraph
 
 _CL = torch.channels_last
 _CAPTURE_LOCK = __import__("threading").Lock()     # plan captures set module-level scratch (_ARENA, _DEFER) and put the process
@@ -690,8 +690,18 @@ class TrainEncoder(nn.Module):
         # that (the trainer's clip: one encoder call per frame, one backward; trainer.py:95-131) takes / captures another plan
         plan = next((p for p in plans if not p.busy), None)
         if plan is None:
-            with _CAPTURE_LOCK:
-                plan = _Plan(self, img)
+            try:
+                with _CAPTURE_LOCK:
+                    plan = _Plan(self, img)
+            except CaptureFailed as e:
+                # a capture was invalidated (an API call of another thread of the process the runtime does not tolerate beside a
+                # capture, even in thread-local mode): this call runs the same functions eagerly, the next call of the shape
+                # captures again.  The calling thread's stream is intact (graphs.SafeGraph).
+                import warnings
+                warnings.warn(f"TrainEncoder: graph capture failed ({str(e)[:200]}); this call runs eagerly", RuntimeWarning)
+                torch.cuda.synchronize(img.device)
+                self.__dict__["_ticked"].clear()
+                return self._eager(img)
             plans.append(plan)
         return plan.run(img)
 
@@ -752,6 +762,14 @@ class _Plan:
         # BatchNorm's running statistics are put back afterwards (the warm-up and the captures are not training steps)
         bns = [m for m in enc.src.modules() if isinstance(m, nn.BatchNorm2d)]
         keep = [(m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for m in bns]
+        try:
+            self._build(enc, img, dev, chain, pool)
+        finally:                                          # (also when a capture failed: the caller falls back to the eager step)
+            for (rm, rv, nb), m in zip(keep, bns):
+                with torch.no_grad():
+                    m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
+
+    def _build(self, enc, img, dev, chain, pool):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         old = torch.backends.cudnn.benchmark
@@ -906,9 +924,6 @@ class _Plan:
         self.rewritten = {"fwd": {"body": tot(self.fwd_body), "heads": tot(self.fwd_head)},
                           "bwd": dict({k: g.rewritten for k, g in self.bwd.items()}, heads=tot(self.bwd_head)),
                           "wgrad": {k: tot(gs) for k, gs in self.wgrad.items()}}
-        for (rm, rv, nb), m in zip(keep, bns):
-            with torch.no_grad():
-                m.running_mean.copy_(rm), m.running_var.copy_(rv), m.num_batches_tracked.copy_(nb)
 
     def run(self, img):
         enc = self.enc
