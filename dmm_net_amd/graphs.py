@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import gc
 
 import torch
 
@@ -33,19 +34,23 @@ class SafeGraph:
     and a failed capture surfaces as ``CaptureFailed``.  Thread-local capture mode: other threads of the process (a DataLoader's
     pin-memory thread, a second ``nn.DataParallel`` replica) may allocate / record events while this one captures."""
 
-    _streams = {}                                         # device index -> the capture stream (captures never run side by side)
-
     def __init__(self):
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         self.rewritten, self.left = (0, 0), 0
 
     @contextlib.contextmanager
     def capture(self, pool=None, stream=None):
-        dev = torch.cuda.current_device()
         if stream is None:
-            stream = SafeGraph._streams.get(dev)
-            if stream is None:
-                stream = SafeGraph._streams[dev] = torch.cuda.Stream()
+            # torch's own capture stream (what ``torch.cuda.graph`` uses by default): ONE capture stream per process.  With a
+            # stream of its own here, a step captured after other captures of the process (bench.py's default line) replayed
+            # 15 % slower -- 15.1 against 13.3 ms (A / B in one process; the standalone step was unaffected)
+            if torch.cuda.graph.default_capture_stream is None:
+                torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+            stream = torch.cuda.graph.default_capture_stream
+        # what torch.cuda.graph does on entry: cached blocks go back, so that the graph's private pool gets fresh segments
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
         stream.wait_stream(torch.cuda.current_stream())
         failed = None
         with torch.cuda.stream(stream):
@@ -62,11 +67,15 @@ class SafeGraph:
             except Exception as e:
                 failed = failed or e
         if failed is not None:
-            SafeGraph._streams.pop(dev, None)             # (a stream whose capture was invalidated is not reused)
+            if stream is torch.cuda.graph.default_capture_stream:
+                torch.cuda.graph.default_capture_stream = None      # (a stream whose capture was invalidated is not reused)
             if isinstance(failed, Exception) and not isinstance(failed, CaptureFailed):
                 raise CaptureFailed(f"{type(failed).__name__}: {failed}") from failed
             raise failed
         torch.cuda.current_stream().wait_stream(stream)
+        self._finish()
+
+    def _finish(self):
         n_set, n_cpy, left = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         raw = self.graph.raw_cuda_graph()
         rc = _lib.load().dmm_graph_nodes_to_kernels(ctypes.c_void_p(int(raw)), 3, ctypes.byref(n_set), ctypes.byref(n_cpy),
