@@ -361,14 +361,23 @@ __global__ __launch_bounds__(256) void wprep3x3_bf16_kernel(const WPrep *__restr
         s[o * SO + r] = (uint16_t)bf16_round(e.src[((int64_t)(o0 + o) * e.ci + c0) * 9 + r]);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < 32 * 288; j += 256) {
-        const int c = j & 31, tt = (j >> 5) % 9, o = j / 288;
-        e.dst[((int64_t)(o0 + o) * 9 + tt) * e.ci + c0 + c] = s[o * SO + c * 9 + tt];
+    // 16-byte stores: 8 consecutive channels per thread (2-byte stores made this kernel 25 us per segment of a ResNet-101)
+    for (int v = threadIdx.x; v < 32 * 36; v += 256) {
+        const int c8 = (v & 3) * 8, tt = (v >> 2) % 9, o = v / 36;
+        u32x4t w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            w[k] = (uint32_t)s[o * SO + (c8 + 2 * k) * 9 + tt] | ((uint32_t)s[o * SO + (c8 + 2 * k + 1) * 9 + tt] << 16);
+        *reinterpret_cast<u32x4t *>(e.dst + ((int64_t)(o0 + o) * 9 + tt) * e.ci + c0 + c8) = w;
     }
     if (!e.dstT) return;
-    for (int j = threadIdx.x; j < 32 * 288; j += 256) {
-        const int o = j & 31, tt = (j >> 5) % 9, c = j / 288;
-        e.dstT[((int64_t)(c0 + c) * 9 + (8 - tt)) * e.co + o0 + o] = s[o * SO + c * 9 + tt];
+    for (int v = threadIdx.x; v < 32 * 36; v += 256) {
+        const int o8 = (v & 3) * 8, tt = (v >> 2) % 9, c = v / 36;
+        u32x4t w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            w[k] = (uint32_t)s[(o8 + 2 * k) * SO + c * 9 + tt] | ((uint32_t)s[(o8 + 2 * k + 1) * SO + c * 9 + tt] << 16);
+        *reinterpret_cast<u32x4t *>(e.dstT + ((int64_t)(c0 + c) * 9 + (8 - tt)) * e.co + o0 + o8) = w;
     }
 }
 

@@ -687,7 +687,7 @@ DMM_API int dmm_bn_bwd_dx_grouped_bf16(const void *dy, const void *dy2, const vo
  * {const float *src; uint16 *dst; uint16 *dstT; int32 co; int32 ci; int64 tile0}: src the fp32 master [co, ci, 3, 3], dst the bf16
  * channels-last weight [co, kh, kw, ci], dstT (may be null) [ci, 2-kh, 2-kw, co] -- the weight with which the DATA gradient of a
  * stride 1 / padding 1 convolution is itself a forward convolution, dX = conv(dY, dstT) (MIOpen's forward kernel for that problem
- * is ~1.8x faster than its backward-data kernel on gfx950).  co, ci multiples of 32; tile0 = sum of (co/32)*(ci/32) of the records
+ * is ~1.8x faster than its backward-data kernel on gfx950).  co, ci multiples of 32, dst / dstT 16-byte aligned; tile0 = sum of (co/32)*(ci/32) of the records
  * before; tiles = that sum over all records.
  * dmm_subsample2_bf16: y[b, ho, wo, :] = x[b, 2ho, 2wo, :] on channels-last bf16 (the stride of a 1x1 downsample convolution);
  * dmm_upsample2_zero_bf16: its gradient, dx [B, H, W, C] written once (dy at even positions, zero elsewhere).  C % 8 == 0. */
