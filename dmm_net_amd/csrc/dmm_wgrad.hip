@@ -334,6 +334,200 @@ __global__ __launch_bounds__(256 * KS) void wgrad_lds_kernel(const uint16_t *__r
     }
 }
 
+// The LDS form for the NARROW layers (layer1 of a ResNet: 64 output or 64 input channels), tile TCO x TCV in {64 x 128, 128 x 64}:
+// the 64-wide kernel above feeds its MFMAs with 4-byte lane loads (16 load instructions per 4 MFMAs: 22 / 56 us per launch on
+// layer1's shapes, a quarter of the step's weight-gradient time) where this one stages 16-byte pieces through LDS like
+// wgrad_lds_kernel.  A slice = the tile's 64 x 64 sub-tiles, one wave each (2 here), over its own stages; KS slices; the stage
+// loop, the branch-free fetch and the fold are wgrad_lds_kernel's.  A 128-wide cv tile may hold TWO taps of a 3x3 patch
+// (Ci = 64) -- the tap belongs to the thread's piece column -- and may end beyond Cv (9 x 64 = 4.5 tiles): such pieces are zeros
+// and their sub-tile is not stored.
+template <bool PATCH, int KS, int TCO, int TCV>
+__global__ __launch_bounds__(64 * (TCO / 64) * (TCV / 64) * KS) void wgrad_tile_kernel(
+    const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int64_t R, int Co, int Cv, int64_t ldy, int64_t ldx,
+    float *__restrict__ out, int64_t group_stride, int64_t rows_per_group, int cv_tiles, PatchGeom pg) {
+    constexpr int D = 2;
+    constexpr int WV = (TCO / 64) * (TCV / 64), TS = 64 * WV;            // waves / threads of a slice
+    constexpr int PRA = TCO / 8, PRB = TCV / 8;                           // 16-byte pieces per row
+    constexpr int NA = 32 * PRA / TS, NB = 32 * PRB / TS;                 // pieces per thread and stage
+    constexpr int RSA = TS / PRA, RSB = TS / PRB;                         // rows between a thread's pieces
+    constexpr int SLICE = 2 * 32 * (TCO + TCV);                           // ushorts of a slice's two buffers
+    static_assert(TS % PRA == 0 && TS % PRB == 0 && NA >= 1 && NB >= 1, "piece mapping");
+    static_assert(KS * SLICE * 2 >= (KS / 2) * 64 * TS * 4, "fold regions");
+    __shared__ __attribute__((aligned(16))) uint16_t lds_[KS * SLICE];
+    const int slice = threadIdx.x / TS, t = threadIdx.x % TS;
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int tile = blockIdx.x;
+    const int co0 = (tile / cv_tiles) * TCO, cv0 = (tile % cv_tiles) * TCV;
+    const int co_w = (wave / (TCV / 64)) * 64, cv_w = (wave % (TCV / 64)) * 64;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_group;
+    int64_t r1 = r0 + rows_per_group;
+    if (r1 > R) r1 = R;
+    const int ca = t % PRA, ra0 = t / PRA, cb = t % PRB, rb0 = t / PRB;
+    const int vb = cv0 + 8 * cb;                           // the B pieces' virtual column
+    const bool colb = vb < Cv;
+    int tap_dh = 0, tap_dw = 0, cinb = vb;
+    if (PATCH) {
+        const int tap = (colb ? vb : 0) / pg.Ci;
+        cinb = (colb ? vb : 0) - tap * pg.Ci;
+        tap_dh = tap / 3 - 1;
+        tap_dw = tap % 3 - 1;
+    } else if (!colb) {
+        cinb = 0;
+    }
+    uint16_t *sl = lds_ + slice * SLICE;                   // buffer b: A at sl + b * 32 * (TCO + TCV), B behind it
+    u32x4w ra[D][NA], rb[D][NB];
+    uint32_t okm[D];                                      // bit q: A piece q inside the slab; bit 8 + q: B piece q inside slab and image
+    int64_t a_off[NA], rowa[NA], b_off[NB], rowb[NB];
+    int pb_[NB], ph_[NB], pw_[NB];
+    int adv_w = 0, adv_h = 0, adv_b = 0;
+    const int64_t a_first = r0 * ldy + co0 + 8 * ca, b_first = PATCH ? cinb : r0 * ldx + cinb;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        rowa[q] = r0 + 32 * slice + ra0 + RSA * q;
+        a_off[q] = rowa[q] * ldy + co0 + 8 * ca;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        rowb[q] = r0 + 32 * slice + rb0 + RSB * q;
+        b_off[q] = rowb[q] * ldx + cinb;
+        pb_[q] = ph_[q] = pw_[q] = 0;
+        if (PATCH) {
+            const int64_t qd = rowb[q] / pg.Wo;
+            pw_[q] = (int)(rowb[q] - qd * pg.Wo);
+            pb_[q] = (int)(qd / pg.Ho);
+            ph_[q] = (int)(qd - (int64_t)pb_[q] * pg.Ho);
+        }
+    }
+    if (PATCH) {
+        adv_w = (32 * KS) % pg.Wo;
+        const int q_ = (32 * KS) / pg.Wo;
+        adv_h = q_ % pg.Ho;
+        adv_b = q_ / pg.Ho;
+    }
+    auto fetch = [&](u32x4w (&fa)[NA], u32x4w (&fb)[NB], uint32_t &ok_bits) {
+        ok_bits = 0;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const bool ok = rowa[q] < r1;
+            fa[q] = *reinterpret_cast<const u32x4w *>(dy + (ok ? a_off[q] : a_first));
+            ok_bits |= ok ? (1u << q) : 0u;
+            a_off[q] += 32 * KS * ldy;
+            rowa[q] += 32 * KS;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const bool ok = rowb[q] < r1 && colb;
+            if (!PATCH) {
+                fb[q] = *reinterpret_cast<const u32x4w *>(x + (ok ? b_off[q] : b_first));
+                ok_bits |= ok ? (0x100u << q) : 0u;
+                b_off[q] += 32 * KS * ldx;
+            } else {
+                const int hi = ph_[q] * pg.stride + tap_dh, wi = pw_[q] * pg.stride + tap_dw;
+                const bool in = ok && hi >= 0 && hi < pg.H && wi >= 0 && wi < pg.W;
+                const int64_t off = in ? (((int64_t)pb_[q] * pg.H + hi) * pg.W + wi) * ldx : 0;
+                fb[q] = *reinterpret_cast<const u32x4w *>(x + off + cinb);
+                ok_bits |= in ? (0x100u << q) : 0u;
+                pw_[q] += adv_w;
+                const int cw = pw_[q] >= pg.Wo;
+                pw_[q] -= cw ? pg.Wo : 0;
+                ph_[q] += adv_h + cw;
+                const int ch = ph_[q] >= pg.Ho;
+                ph_[q] -= ch ? pg.Ho : 0;
+                pb_[q] += adv_b + ch;
+            }
+            rowb[q] += 32 * KS;
+        }
+    };
+    auto stash = [&](int buf, const u32x4w (&fa)[NA], const u32x4w (&fb)[NB], uint32_t ok_bits) {
+        const u32x4w z = {0u, 0u, 0u, 0u};
+        uint16_t *sa = sl + buf * (32 * (TCO + TCV)), *sb = sa + 32 * TCO;
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            *reinterpret_cast<u32x4w *>(sa + (ra0 + RSA * q) * TCO + 8 * ca) = (ok_bits >> q) & 1u ? fa[q] : z;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            *reinterpret_cast<u32x4w *>(sb + (rb0 + RSB * q) * TCV + 8 * cb) = (ok_bits >> (8 + q)) & 1u ? fb[q] : z;
+    };
+    f32x16w acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc00[k] = acc01[k] = acc10[k] = acc11[k] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(ra[d], rb[d], okm[d]);
+    const int64_t rounds = (r1 - r0 + 32 * KS * D - 1) / (32 * KS * D);
+    for (int64_t it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int buf = d & 1;                         // (D = 2)
+            stash(buf, ra[d], rb[d], okm[d]);
+            fetch(ra[d], rb[d], okm[d]);
+            __syncthreads();
+            const uint16_t *sa = sl + buf * (32 * (TCO + TCV)), *sb = sa + 32 * TCO;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t wa[8], wb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    wa[j] = *reinterpret_cast<const uint32_t *>(sa + (16 * h + 8 * g + j) * TCO + co_w + 2 * i);
+                    wb[j] = *reinterpret_cast<const uint32_t *>(sb + (16 * h + 8 * g + j) * TCV + cv_w + 2 * i);
+                }
+                u32x4w a0, a1, b0, b1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    a0[p] = pair_lo(wa[2 * p], wa[2 * p + 1]);
+                    a1[p] = pair_hi(wa[2 * p], wa[2 * p + 1]);
+                    b0[p] = pair_lo(wb[2 * p], wb[2 * p + 1]);
+                    b1[p] = pair_hi(wb[2 * p], wb[2 * p + 1]);
+                }
+                const bf16x8w fa0 = __builtin_bit_cast(bf16x8w, a0), fa1 = __builtin_bit_cast(bf16x8w, a1);
+                const bf16x8w fb0 = __builtin_bit_cast(bf16x8w, b0), fb1 = __builtin_bit_cast(bf16x8w, b1);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
+            }
+        }
+    }
+    if (KS > 1) {
+        float *ex = reinterpret_cast<float *>(lds_);
+#pragma unroll
+        for (int h = KS / 2; h >= 1; h /= 2) {
+            __syncthreads();
+            if (slice >= h && slice < 2 * h) {
+                float *e = ex + (slice - h) * (64 * TS) + t;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    e[(k) * TS] = acc00[k];
+                    e[(16 + k) * TS] = acc01[k];
+                    e[(32 + k) * TS] = acc10[k];
+                    e[(48 + k) * TS] = acc11[k];
+                }
+            }
+            __syncthreads();
+            if (slice < h) {
+                const float *e = ex + slice * (64 * TS) + t;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    acc00[k] += e[(k) * TS];
+                    acc01[k] += e[(16 + k) * TS];
+                    acc10[k] += e[(32 + k) * TS];
+                    acc11[k] += e[(48 + k) * TS];
+                }
+            }
+        }
+        if (slice != 0) return;
+    }
+    if (cv0 + cv_w >= Cv) return;                          // (a sub-tile beyond the last virtual column)
+    float *o = out + (int64_t)blockIdx.y * group_stride;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * g;
+        float *p0 = o + (int64_t)(co0 + co_w + 2 * m) * Cv + cv0 + cv_w + 2 * i;
+        *reinterpret_cast<float2 *>(p0) = make_float2(acc00[reg], acc01[reg]);
+        *reinterpret_cast<float2 *>(p0 + Cv) = make_float2(acc10[reg], acc11[reg]);
+    }
+}
+
 // dw[...] = sum over the groups' partial tables (a fixed order: deterministic).  T9 = false: dw is [Co, Cv] like the partials, a
 // thread owns 4 consecutive outputs.  T9 = true: partial column v = tap * Ci + cin goes to the master's layout dw[co, cin, tap]
 // ([Co, Ci, 3, 3] contiguous); a thread owns the 9 taps of one (co, cin), the workgroup writes its 256 / S x 9 contiguous outputs
@@ -384,15 +578,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 struct WgradPlan {
-    int64_t rows_per_wave, groups;       // (wide: rows per GROUP -- one workgroup takes one slab)
+    int64_t rows_per_wave, groups;       // (wide / narrow LDS forms: rows per GROUP -- one workgroup takes one slab)
     int cv_tiles;
     int64_t tiles;
+    int narrow;                          // 0 none, 1 = 64 (co) x 128 (cv) tiles, 2 = 128 x 64 (wgrad_tile_kernel)
     bool wide;                           // the 128 x 128 LDS-staged kernel
 };
 
 static WgradPlan wgrad_plan(int64_t R, int Co, int Cv, int Ci_patch) {
     WgradPlan p;
     p.wide = !(Co & 127) && !(Cv & 127) && (Ci_patch == 0 || !(Ci_patch & 127));
+    p.narrow = 0;
+    if (!p.wide && Co == 64 && Cv >= 128 && !(Cv & 63)) p.narrow = 1;
+    else if (!p.wide && Cv == 64 && !(Co & 127) && Ci_patch == 0) p.narrow = 2;
+    if (p.narrow) {
+        const int tco = p.narrow == 1 ? 64 : 128, tcv = p.narrow == 1 ? 128 : 64;
+        constexpr int64_t RND = 32 * 4 * 2;               // rows x slices x depth of wgrad_tile_kernel
+        p.cv_tiles = (Cv + tcv - 1) / tcv;
+        p.tiles = (int64_t)(Co / tco) * p.cv_tiles;
+        int64_t groups = 256 / p.tiles;                   // one workgroup (8 waves, 96 KB of LDS) per compute unit: ONE wave of them
+        const int64_t by_rows = (R + RND - 1) / RND, by_bytes = (4LL << 20) / ((int64_t)Co * Cv);
+        if (groups > by_rows) groups = by_rows;
+        if (groups > by_bytes) groups = by_bytes;
+        if (groups < 1) groups = 1;
+        const int64_t rpg = (R + groups - 1) / groups;
+        p.rows_per_wave = (rpg + RND - 1) / RND * RND;
+        p.groups = (R + p.rows_per_wave - 1) / p.rows_per_wave;
+        return p;
+    }
     if (p.wide) {
         p.cv_tiles = Cv / 128;
         p.tiles = (int64_t)(Co / 128) * p.cv_tiles;
@@ -444,6 +657,18 @@ static int wgrad_launch(const void *dy, const void *x, int64_t R, int Co, int Cv
                                (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
     } else if (p.wide) {
         return DMM_ERR_UNSUPPORTED;                        // (16-byte pieces need 16-byte aligned rows)
+    } else if (p.narrow && (ldy & 7) == 0 && (ldx & 7) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0) {
+        if (p.narrow == 1 && patch)
+            hipLaunchKernelGGL((wgrad_tile_kernel<true, 4, 64, 128>), grid, dim3(512), 0, stream, (const uint16_t *)dy,
+                               (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+        else if (p.narrow == 1)
+            hipLaunchKernelGGL((wgrad_tile_kernel<false, 4, 64, 128>), grid, dim3(512), 0, stream, (const uint16_t *)dy,
+                               (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+        else
+            hipLaunchKernelGGL((wgrad_tile_kernel<false, 4, 128, 64>), grid, dim3(512), 0, stream, (const uint16_t *)dy,
+                               (const uint16_t *)x, R, Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);
+    } else if (p.narrow) {
+        return DMM_ERR_UNSUPPORTED;
     } else if (patch)
         hipLaunchKernelGGL((wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, (const uint16_t *)dy, (const uint16_t *)x, R,
                            Co, Cv, ldy, ldx, out, n, p.rows_per_wave, p.cv_tiles, pg);

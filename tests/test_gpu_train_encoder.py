@@ -80,7 +80,7 @@ def test_bn_entries_refuse_what_the_kernels_do_not_take():
 
 
 @pytest.mark.parametrize("R,co,ci", [(5376, 1024, 256), (86016, 256, 64), (1344, 2048, 512), (37, 64, 64), (1, 64, 128),
-                                     (21504, 128, 512), (4099, 192, 320)])
+                                     (21504, 128, 512), (4099, 192, 320), (86016, 64, 256), (777, 64, 192), (300, 384, 64)])
 def test_wgrad_1x1_against_the_fp32_product(R, co, ci):
     """dmm_wgrad_bf16: dW = dY^T X of bf16 operands with fp32 accumulation (products of bf16 values are exact in fp32: what
     differs from torch's fp32 product is the order of the sums) -- incl. row counts that are not a multiple of the 16-row
@@ -112,7 +112,8 @@ def test_wgrad_1x1_against_the_fp32_product(R, co, ci):
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,stride", [(2, 17, 23, 64, 128, 1), (3, 16, 28, 256, 256, 1), (2, 33, 56, 128, 128, 2),
-                                                (12, 8, 14, 512, 512, 1), (1, 1, 1, 64, 64, 1), (2, 5, 3, 64, 64, 2)])
+                                                (12, 8, 14, 512, 512, 1), (1, 1, 1, 64, 64, 1), (2, 5, 3, 64, 64, 2),
+                                                (12, 64, 112, 64, 64, 1), (3, 19, 31, 128, 64, 1), (2, 33, 41, 64, 64, 2)])
 def test_wgrad_3x3_against_torch_fp32(B, H, W, ci, co, stride):
     """dmm_wgrad3x3_bf16 (implicit patch matrix) against torch's fp32 weight gradient of the same bf16 values: borders (taps
     that fall outside the image), stride 2 with odd sizes, images of one pixel."""
